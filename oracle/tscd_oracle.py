@@ -1,0 +1,780 @@
+"""TEST INFRASTRUCTURE -- CPU (pure PyTorch, fp32) restatement of the reference's per-clip hot path.
+
+This file is the *oracle*: a functional re-statement of the algorithm in the reference files cited
+on every function below (paths relative to /root/reference).  It is NOT the product: only tests/,
+__graft_entry__.smoke() and bench.py's ``cpu_baseline`` leg may import it, and only as the checker /
+reported CPU baseline.  The product path (tscd_amd/ + yolox/) never imports anything from oracle/.
+
+Parity pin: oracle/make_golden.py imports the reference itself (build container only, with the
+third-party stubs of oracle/ref_loader.py) on seeded weights + synthetic clips, and commits inputs,
+weights and every reference output under tests/golden/.  tests/test_oracle_golden.py checks this
+restatement against those vectors (integer outputs bit-exact, floats 1e-5).  torchvision NMS is the
+one piece the reference cannot pin (absent dependency) -- see oracle/nms_ref.py.
+
+Model parameters travel as a flat ``dict name -> tensor`` using the reference's state_dict names
+(e.g. ``backbone.backbone.stem.conv.conv.weight``), so checkpoints interchange with the product.
+Only the flag combination used by exps/TSCD_OVIS/ovis_tscd_{base,large}.py and
+exps/TSCD_VID/vid_tscd_large.py is restated: agg_type='mca', decouple_reg, reconf,
+ota_mode, use_pre_nms=False, cat_ota_fg=False, cls_ota=True, vid_ota=False, ave=True, use_mask=False.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+
+from .nms_ref import batched_nms
+
+BN_EPS = 1e-3       # exps/TSCD_OVIS/ovis_tscd_large.py:109-113 (init_yolo)
+BN_MOMENTUM = 0.03
+
+
+@dataclass
+class TSCDConfig:
+    num_classes: int = 25
+    depth: float = 1.0
+    width: float = 1.0
+    strides: tuple = (8, 16, 32)
+    heads: int = 4                 # MCA heads          (tscd_base.py:41)
+    matcher_heads: int = 8         # CAFM / TaskAligned (tscd_head.py:120-129)
+    mca_scale: float = 25.0        # post_trans.py:558
+    sim_thresh: float = 0.75       # tscd_base.py:45
+    conf_sim_thresh: float = 0.99  # ovis_tscd_large.py:46
+    minimal_limit: int = 50        # ovis_tscd_large.py:45
+    maximal_limit: int = 500       # ovis_tscd_large.py:49 (0 = no upper clamp, vid_tscd_large.py)
+    conf_thresh: float = 0.001     # tscd_head.py:1546
+    vid_dk: int = 10               # tscd_head.py:1517
+
+    @property
+    def head_width(self):
+        return int(256 * self.width)
+
+
+def get_timing_signal_1d(index_sequence, channels, min_timescale=1.0, max_timescale=1.0e4):
+    """yolox/data/datasets/vid.py:1015-1023."""
+    num_timescales = channels // 2
+    log_time_incre = torch.tensor(math.log(max_timescale / min_timescale) / (num_timescales - 1))
+    inv_timescale = min_timescale * torch.exp(torch.arange(0, num_timescales) * -log_time_incre)
+    scaled_time = torch.unsqueeze(index_sequence, 1) * torch.unsqueeze(inv_timescale, 0)
+    return torch.cat([torch.sin(scaled_time), torch.cos(scaled_time)], dim=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# a1-a4: conv blocks, CSPDarknet, PAFPN
+# ----------------------------------------------------------------------------------------------
+def base_conv(sd, p, x, stride=1, training=False, act="silu"):
+    """BaseConv: Conv2d(no bias, same pad) -> BN(eps 1e-3, mom .03) -> SiLU (network_blocks.py:36-61)."""
+    w = sd[p + ".conv.weight"]
+    pad = (w.shape[-1] - 1) // 2
+    y = F.conv2d(x, w, None, stride, pad)
+    if training:
+        nbt = sd.get(p + ".bn.num_batches_tracked")
+        if nbt is not None:
+            nbt += 1
+    y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"],
+                     sd[p + ".bn.bias"], training, BN_MOMENTUM, BN_EPS)
+    return F.silu(y) if act == "silu" else y
+
+
+def focus(sd, p, x, training):
+    """Focus space-to-depth (tl, bl, tr, br) + 3x3 conv (network_blocks.py:267-289)."""
+    tl, tr = x[..., ::2, ::2], x[..., ::2, 1::2]
+    bl, br = x[..., 1::2, ::2], x[..., 1::2, 1::2]
+    return base_conv(sd, p + ".conv", torch.cat((tl, bl, tr, br), dim=1), 1, training)
+
+
+def bottleneck(sd, p, x, shortcut, training):
+    """Bottleneck 1x1 -> 3x3 (+x) (network_blocks.py:158-180)."""
+    y = base_conv(sd, p + ".conv2", base_conv(sd, p + ".conv1", x, 1, training), 1, training)
+    return y + x if shortcut else y
+
+
+def csp_layer(sd, p, x, n, shortcut, training):
+    """CSPLayer (network_blocks.py:226-264)."""
+    x1 = base_conv(sd, p + ".conv1", x, 1, training)
+    x2 = base_conv(sd, p + ".conv2", x, 1, training)
+    for i in range(n):
+        x1 = bottleneck(sd, f"{p}.m.{i}", x1, shortcut, training)
+    return base_conv(sd, p + ".conv3", torch.cat((x1, x2), dim=1), 1, training)
+
+
+def spp_bottleneck(sd, p, x, training):
+    """SPPBottleneck, max-pools 5/9/13 stride 1 (network_blocks.py:201-223)."""
+    x = base_conv(sd, p + ".conv1", x, 1, training)
+    x = torch.cat([x] + [F.max_pool2d(x, ks, 1, ks // 2) for ks in (5, 9, 13)], dim=1)
+    return base_conv(sd, p + ".conv2", x, 1, training)
+
+
+def csp_darknet(sd, p, x, depth, training):
+    """CSPDarknet.forward -> (dark3, dark4, dark5) (darknet.py:98-180)."""
+    bd = max(round(depth * 3), 1)
+    x = focus(sd, p + ".stem", x, training)
+    x = base_conv(sd, p + ".dark2.0", x, 2, training)
+    x = csp_layer(sd, p + ".dark2.1", x, bd, True, training)
+    x = base_conv(sd, p + ".dark3.0", x, 2, training)
+    d3 = csp_layer(sd, p + ".dark3.1", x, bd * 3, True, training)
+    x = base_conv(sd, p + ".dark4.0", d3, 2, training)
+    d4 = csp_layer(sd, p + ".dark4.1", x, bd * 3, True, training)
+    x = base_conv(sd, p + ".dark5.0", d4, 2, training)
+    x = spp_bottleneck(sd, p + ".dark5.1", x, training)
+    d5 = csp_layer(sd, p + ".dark5.2", x, bd, False, training)
+    return d3, d4, d5
+
+
+def yolo_pafpn(sd, x, cfg, training, p="backbone"):
+    """YOLOPAFPN.forward (yolo_pafpn.py:83-116)."""
+    n = round(3 * cfg.depth)
+    x2, x1, x0 = csp_darknet(sd, p + ".backbone", x, cfg.depth, training)
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    fpn_out0 = base_conv(sd, p + ".lateral_conv0", x0, 1, training)
+    f_out0 = csp_layer(sd, p + ".C3_p4", torch.cat([up(fpn_out0), x1], 1), n, False, training)
+    fpn_out1 = base_conv(sd, p + ".reduce_conv1", f_out0, 1, training)
+    pan_out2 = csp_layer(sd, p + ".C3_p3", torch.cat([up(fpn_out1), x2], 1), n, False, training)
+    p_out1 = base_conv(sd, p + ".bu_conv2", pan_out2, 2, training)
+    pan_out1 = csp_layer(sd, p + ".C3_n3", torch.cat([p_out1, fpn_out1], 1), n, False, training)
+    p_out0 = base_conv(sd, p + ".bu_conv1", pan_out1, 2, training)
+    pan_out0 = csp_layer(sd, p + ".C3_n4", torch.cat([p_out0, fpn_out0], 1), n, False, training)
+    return pan_out2, pan_out1, pan_out0
+
+
+# ----------------------------------------------------------------------------------------------
+# a6: Haar wavelet high-frequency block
+# ----------------------------------------------------------------------------------------------
+def haar_dwt(x):
+    """DWT_2D('haar') forward (surrounding_extraction.py:12-41,100-127): bands [ll, lh, hl, hh] on dim 1.
+
+    Taps after the reference's reversal (dec_lo=[s,s], dec_hi=[s,-s]; w_lh[i][j]=lo[j]*hi[i] ...):
+    with a=x[2y,2x], b=x[2y,2x+1], c=x[2y+1,2x], d=x[2y+1,2x+1]:
+    ll=(a+b+c+d)/2, lh=(a+b-c-d)/2, hl=(a-b+c-d)/2, hh=(a-b-c+d)/2.
+    """
+    a, b = x[..., 0::2, 0::2], x[..., 0::2, 1::2]
+    c, d = x[..., 1::2, 0::2], x[..., 1::2, 1::2]
+    return torch.cat([(a + b + c + d), (a + b - c - d), (a - b + c - d), (a - b - c + d)], dim=1) * 0.5
+
+
+def haar_idwt(x):
+    """IDWT_2D('haar') forward (surrounding_extraction.py:44-98). x: [B,4C,h,w] bands on dim 1."""
+    B, C4, h, w = x.shape
+    C = C4 // 4
+    ll, lh, hl, hh = x.view(B, 4, C, h, w).unbind(1)
+    out = x.new_empty(B, C, 2 * h, 2 * w)
+    out[..., 0::2, 0::2] = (ll + lh + hl + hh) * 0.5
+    out[..., 0::2, 1::2] = (ll + lh - hl - hh) * 0.5
+    out[..., 1::2, 0::2] = (ll - lh + hl - hh) * 0.5
+    out[..., 1::2, 1::2] = (ll - lh - hl + hh) * 0.5
+    return out
+
+
+def wavelets_hf_block(sd, p, x):
+    """WaveletsHFBlock.forward (surrounding_extraction.py:257-267)."""
+    C = x.shape[1]
+    x_dwt = haar_dwt(x)
+    hf = x_dwt[:, C:]
+    hf = F.relu(F.conv2d(hf, sd[p + ".filter1.0.weight"], sd[p + ".filter1.0.bias"]))
+    x_idwt = haar_idwt(torch.cat((torch.zeros_like(x_dwt[:, :C]), hf), dim=1))
+    x_content = F.relu(F.conv2d(x, sd[p + ".filter2.0.weight"], sd[p + ".filter2.0.bias"], 1, 1))
+    return x_content * x_idwt
+
+
+# ----------------------------------------------------------------------------------------------
+# a8: SimOTA
+# ----------------------------------------------------------------------------------------------
+def bboxes_iou_cxcywh(a, b):
+    """bboxes_iou(a, b, xyxy=False) (yolox/utils/boxes.py:131-154)."""
+    tl = torch.max(a[:, None, :2] - a[:, None, 2:] / 2, b[:, :2] - b[:, 2:] / 2)
+    br = torch.min(a[:, None, :2] + a[:, None, 2:] / 2, b[:, :2] + b[:, 2:] / 2)
+    area_a = torch.prod(a[:, 2:], 1)
+    area_b = torch.prod(b[:, 2:], 1)
+    en = (tl < br).type(tl.type()).prod(dim=2)
+    area_i = torch.prod(br - tl, 2) * en
+    return area_i / (area_a[:, None] + area_b - area_i)
+
+
+def get_in_boxes_info(gt, strides_a, xs, ys, num_gt):
+    """tscd_head.py:1428-1510. gt [G,4] cxcywh; strides_a/xs/ys [A]."""
+    xc = ((xs * strides_a) + 0.5 * strides_a)[None, :]
+    yc = ((ys * strides_a) + 0.5 * strides_a)[None, :]
+    gl = (gt[:, 0] - 0.5 * gt[:, 2])[:, None]
+    gr = (gt[:, 0] + 0.5 * gt[:, 2])[:, None]
+    gtop = (gt[:, 1] - 0.5 * gt[:, 3])[:, None]
+    gb = (gt[:, 1] + 0.5 * gt[:, 3])[:, None]
+    deltas = torch.stack([xc - gl, yc - gtop, gr - xc, gb - yc], 2)
+    is_in_boxes = deltas.min(dim=-1).values > 0.0
+    is_in_boxes_all = is_in_boxes.sum(dim=0) > 0
+    r = 4.5
+    cl = gt[:, 0][:, None] - r * strides_a[None, :]
+    cr = gt[:, 0][:, None] + r * strides_a[None, :]
+    ct = gt[:, 1][:, None] - r * strides_a[None, :]
+    cb = gt[:, 1][:, None] + r * strides_a[None, :]
+    cdel = torch.stack([xc - cl, yc - ct, cr - xc, cb - yc], 2)
+    is_in_centers = cdel.min(dim=-1).values > 0.0
+    is_in_centers_all = is_in_centers.sum(dim=0) > 0
+    anchor = is_in_boxes_all | is_in_centers_all
+    return anchor, (is_in_boxes[:, anchor] & is_in_centers[:, anchor])
+
+
+def dynamic_k_matching(cost, ious, gt_classes, num_gt, fg_mask, vid_dk=10):
+    """tscd_head.py:1512-1544."""
+    matching = torch.zeros_like(cost)
+    n_cand = min(vid_dk, ious.size(1))
+    topk_ious, _ = torch.topk(ious, n_cand, dim=1)
+    dynamic_ks = torch.clamp(topk_ious.sum(1).int(), min=1)
+    for g in range(num_gt):
+        _, pos = torch.topk(cost[g], k=int(dynamic_ks[g]), largest=False)
+        matching[g][pos] = 1.0
+    amg = matching.sum(0)
+    if (amg > 1).sum() > 0:
+        _, cost_argmin = torch.min(cost[:, amg > 1], dim=0)
+        matching[:, amg > 1] *= 0.0
+        matching[cost_argmin, amg > 1] = 1.0
+    fg_in = matching.sum(0) > 0.0
+    num_fg = int(fg_in.sum())
+    fg_mask = fg_mask.clone()
+    fg_mask[fg_mask.clone()] = fg_in
+    matched_gt_inds = matching[:, fg_in].argmax(0)
+    return num_fg, gt_classes[matched_gt_inds], (matching * ious).sum(0)[fg_in], matched_gt_inds, fg_mask
+
+
+@torch.no_grad()
+def simota_assign(outputs, labels, xs, ys, strides_a, cfg):
+    """get_fg_idx + get_assignments (tscd_head.py:1712-1851, 1330-1426).
+
+    outputs [B,A,5+NC]: decoded cxcywh boxes, raw obj / cls logits.  labels [B,L,5] (cls,cx,cy,w,h).
+    Returns per-image lists (fg_idx, cls_target, reg_target, obj_target, fg_mask), num_fg, num_gts.
+    """
+    B, A, _ = outputs.shape
+    nc = cfg.num_classes
+    nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
+    fg_ids, cls_t, reg_t, obj_t, fg_masks = [], [], [], [], []
+    num_fg, num_gts = 0.0, 0.0
+    for b in range(B):
+        G = int(nlabel[b])
+        num_gts += G
+        if G == 0:
+            fg_ids.append([])
+            cls_t.append(outputs.new_zeros((0, nc)))
+            reg_t.append(outputs.new_zeros((0, 4)))
+            obj_t.append(outputs.new_zeros((A, 1)))
+            fg_masks.append(outputs.new_zeros(A).bool())
+            continue
+        gt = labels[b, :G, 1:5]
+        gt_cls = labels[b, :G, 0]
+        fg_mask, in_bc = get_in_boxes_info(gt, strides_a, xs, ys, G)
+        boxes = outputs[b, :, :4][fg_mask]
+        cls_p = outputs[b, :, 5:][fg_mask]
+        obj_p = outputs[b, :, 4:5][fg_mask]
+        n_in = boxes.shape[0]
+        ious = bboxes_iou_cxcywh(gt, boxes)
+        gt_onehot = F.one_hot(gt_cls.to(torch.int64), nc).float().unsqueeze(1).repeat(1, n_in, 1)
+        iou_loss = -torch.log(ious + 1e-8)
+        p = (cls_p.float().unsqueeze(0).repeat(G, 1, 1).sigmoid_()
+             * obj_p.float().unsqueeze(0).repeat(G, 1, 1).sigmoid_())
+        cls_loss = F.binary_cross_entropy(p.sqrt_(), gt_onehot, reduction="none").sum(-1)
+        cost = cls_loss + 3.0 * iou_loss + 100000.0 * (~in_bc)
+        n_fg_img, matched_cls, pred_ious, matched_inds, fg_mask = dynamic_k_matching(
+            cost, ious, gt_cls, G, fg_mask, cfg.vid_dk)
+        num_fg += n_fg_img
+        fg_ids.append(torch.where(fg_mask)[0])
+        cls_t.append(F.one_hot(matched_cls.to(torch.int64), nc) * pred_ious.unsqueeze(-1))
+        obj_t.append(fg_mask.unsqueeze(-1).to(outputs.dtype))
+        reg_t.append(gt[matched_inds])
+        fg_masks.append(fg_mask)
+    return fg_ids, cls_t, reg_t, obj_t, fg_masks, max(num_fg, 1), num_gts
+
+
+# ----------------------------------------------------------------------------------------------
+# a9-a10: proposal selection + feature gather
+# ----------------------------------------------------------------------------------------------
+def select_proposals(decode_res, cfg, ota_idxs=None):
+    """postprocess_widx with use_pre_nms=False, cat_ota_fg=False (tscd_head.py:1546-1693).
+
+    decode_res [B,A,5+NC] (cx,cy,w,h,obj,cls...) is converted to xyxy IN PLACE (T2).
+    Returns pred_result[i] [n_i,7+NC], agg_idx[i] int64 ascending, refined_obj_masks [N,1],
+    reorder_cls[i] (positions inside ota_idxs[i] of the kept fg proposals) or None.
+    """
+    nc = cfg.num_classes
+    box = decode_res.new_empty(decode_res.shape)
+    box[:, :, 0] = decode_res[:, :, 0] - decode_res[:, :, 2] / 2
+    box[:, :, 1] = decode_res[:, :, 1] - decode_res[:, :, 3] / 2
+    box[:, :, 2] = decode_res[:, :, 0] + decode_res[:, :, 2] / 2
+    box[:, :, 3] = decode_res[:, :, 1] + decode_res[:, :, 3] / 2
+    decode_res[:, :, :4] = box[:, :, :4]
+    out, out_idx, reorder, masks = [], [], [], []
+    for i, pred in enumerate(decode_res):
+        conf, cls_id = torch.max(pred[:, 5:5 + nc], 1, keepdim=True)
+        det = torch.cat((pred[:, :5], conf, cls_id.float(), pred[:, 5:5 + nc]), 1)
+        score = det[:, 4] * det[:, 5]
+        mask = score >= cfg.conf_thresh
+        if cfg.minimal_limit != 0 and mask.sum() < cfg.minimal_limit:
+            _, top = torch.topk(score, cfg.minimal_limit)
+            mask[top] = True
+        if cfg.maximal_limit != 0 and mask.sum() > cfg.maximal_limit:
+            _, top = torch.topk(score, cfg.maximal_limit)
+            mask = torch.zeros_like(mask)
+            mask[top] = True
+        conf_idx = torch.where(mask)[0]
+        det = det[mask]
+        obj_mask = torch.zeros(conf_idx.shape[0], 1, dtype=torch.int64)
+        ro = None
+        if ota_idxs is not None and ota_idxs[i] is not None and len(ota_idxs[i]) > 0:
+            ro = []
+            for j in range(conf_idx.shape[0]):
+                hit = torch.where(ota_idxs[i] == conf_idx[j])[0]
+                if len(hit):
+                    obj_mask[j] = 1
+                    ro.append(hit[0])
+        out.append(det)
+        out_idx.append(conf_idx)
+        reorder.append(ro)
+        masks.append(obj_mask)
+    return out, out_idx, torch.cat(masks, 0), reorder
+
+
+# ----------------------------------------------------------------------------------------------
+# a11: MCA (global-to-local cosine attention)
+# ----------------------------------------------------------------------------------------------
+def _heads(t, h):
+    n, c = t.shape
+    return t.view(n, h, c // h).permute(1, 0, 2)  # [h, n, d]
+
+
+def attention_mca_g2l(sd, p, x_cls, x_reg, cls_score, n1, cfg, reconf=True, aux=None):
+    """Attention_mca_g2l.forward, ave=True, use_mask=False (post_trans.py:601-714, 581-599).
+
+    x_cls/x_reg [N2,W] with the local frame's n1 rows first; cls_score [N2].
+    Returns (cls_feature [n1,3W], reg_feature [n1,3W]).
+    """
+    h = cfg.heads
+    n2, C = x_cls.shape
+    q_c = _heads(F.linear(x_cls[:n1], sd[p + ".q_cls_local.weight"]), h)
+    kv_c = F.linear(x_cls, sd[p + ".kv_cls.weight"]).view(n2, 2, C)
+    k_c, v_c = _heads(kv_c[:, 0], h), _heads(kv_c[:, 1], h)
+    q_r = _heads(F.linear(x_reg[:n1], sd[p + ".q_reg_local.weight"]), h)
+    kv_r = F.linear(x_reg, sd[p + ".kv_reg.weight"]).view(n2, 2, C)
+    k_r, v_r = _heads(kv_r[:, 0], h), _heads(kv_r[:, 1], h)
+    nrm = lambda t: t / torch.norm(t, dim=-1, keepdim=True)
+    q_c, k_c, q_r, k_r = nrm(q_c), nrm(k_c), nrm(q_r), nrm(k_r)
+    v_cn, v_rn = nrm(v_c), nrm(v_r)
+    raw_c = v_cn[:, :n1] @ v_cn.transpose(-2, -1)
+    raw_r = v_rn[:, :n1] @ v_rn.transpose(-2, -1)
+    attn_c = (q_c @ k_c.transpose(-2, -1)) * cfg.mca_scale * cls_score.view(1, 1, -1)
+    attn_r = (q_r @ k_r.transpose(-2, -1)) * cfg.mca_scale
+    attn = (attn_r.softmax(dim=-1) + attn_c.softmax(dim=-1)) / 2
+    flat = lambda t: t.permute(1, 0, 2).reshape(t.shape[1], C)
+    x_c = torch.cat([flat(attn @ v_c), flat(v_c[:, :n1])], dim=-1)
+    x_r = torch.cat([flat(attn @ v_r), flat(v_r[:, :n1])], dim=-1)
+    x_c = F.linear(x_c, sd[p + ".linear.weight"], sd[p + ".linear.bias"])
+    if reconf:
+        x_r = F.linear(x_r, sd[p + ".linear_reg.weight"], sd[p + ".linear_reg.bias"])
+    raw_c = raw_c.sum(0) / h
+    raw_r = raw_r.sum(0) / h
+    sim_mask = (raw_c > cfg.sim_thresh).to(attn.dtype)
+    obj_mask = (raw_r > cfg.conf_sim_thresh).to(attn.dtype)
+    sim_round2 = torch.softmax(attn.sum(0) / h, dim=-1)
+    ave_c = sim_mask * sim_round2 / torch.sum(sim_mask * sim_round2, dim=-1, keepdim=True)
+    ave_r = obj_mask * sim_round2 / torch.sum(obj_mask * sim_round2, dim=-1, keepdim=True)
+    if aux is not None:
+        aux.setdefault("mca_attn", []).append(attn.detach())
+    cls_feature = torch.cat([ave_c @ flat(v_c), x_c], dim=-1)
+    reg_feature = torch.cat([ave_r @ flat(v_r), x_r], dim=-1) if reconf else None
+    return cls_feature, reg_feature
+
+
+def mca_tscd_g2l_reg(sd, p, x_cls, x_reg, cls_score, preds_per_frame, lframe, cfg, aux=None):
+    """MCA_tscd_g2l_reg.forward with reconf=True (post_trans.py:1127-1162). x_* [N,W]."""
+    nl = sum(preds_per_frame[:lframe])
+    xg_c, xg_r, sg = x_cls[nl:], x_reg[nl:], cls_score[nl:]
+    outs_c, outs_o, start = [], [], 0
+    for i in range(lframe):
+        n = preds_per_frame[i]
+        c, o = attention_mca_g2l(sd, p + ".mca",
+                                 torch.cat((x_cls[start:start + n], xg_c), 0),
+                                 torch.cat((x_reg[start:start + n], xg_r), 0),
+                                 torch.cat((cls_score[start:start + n], sg), 0), n, cfg, True, aux)
+        outs_c.append(c)
+        outs_o.append(o)
+        start += n
+    trans_cls = F.linear(torch.cat(outs_c, 0), sd[p + ".linear.weight"], sd[p + ".linear.bias"])
+    trans_obj = F.linear(torch.cat(outs_o, 0), sd[p + ".linear_obj.weight"], sd[p + ".linear_obj.bias"])
+    return trans_cls, trans_obj
+
+
+# ----------------------------------------------------------------------------------------------
+# a12: CAFM (AwarePositionRegMatcher) and a13: TaskAligned
+# ----------------------------------------------------------------------------------------------
+def se_module(sd, p, reg, edge):
+    """SEModule(2): per-(proposal,channel) 2->32->2 gate (tscd_matching.py:264-283). reg/edge [n,C]."""
+    f = torch.stack([reg, edge], dim=-1).reshape(-1, 2)
+    w = torch.sigmoid(F.linear(F.relu(F.linear(f, sd[p + ".fc.0.weight"])), sd[p + ".fc.2.weight"]))
+    w = w.view(*reg.shape, 2)
+    return reg * w[..., 0] + edge * w[..., 1]
+
+
+def cos_mh_attention(sd, p, q_in, k_in, v_in, heads):
+    """PositionMHAttention (boxes=None) / MHAttention: cosine q.k, softmax, @v
+    (tscd_matching.py:31-60, 140-181).  Inputs [n,C] -> [n,C]."""
+    n, C = q_in.shape
+    q = _heads(F.linear(q_in, sd[p + ".q_reg.weight"]), heads)
+    k = _heads(F.linear(k_in, sd[p + ".k_reg.weight"]), heads)
+    v = _heads(F.linear(v_in, sd[p + ".v_reg.weight"]), heads)
+    q = q / torch.norm(q, dim=-1, keepdim=True)
+    k = k / torch.norm(k, dim=-1, keepdim=True)
+    attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)
+    return (attn @ v).permute(1, 0, 2).reshape(n, C)
+
+
+def double_match(ref_a, cur_a, ref_b, cur_b):
+    """double_match_embds: Hungarian on 1 - mean cosine (tscd_matching.py:912-937). Inputs [n,C]."""
+    def nz(t):
+        t = t.detach()
+        return t / (t.norm(dim=1)[:, None] + 1e-6)
+    cost = 1 - ((nz(ref_a) @ nz(cur_a).t() + nz(ref_b) @ nz(cur_b).t()) / 2)
+    cost = cost.cpu()
+    cost = torch.where(torch.isnan(cost), torch.full_like(cost, 0), cost)
+    return linear_sum_assignment(cost)
+
+
+@dataclass
+class MatcherState:
+    """AwarePositionRegMatcher's cross-call memory (tscd_matching.py:708-715)."""
+    last_output: Optional[torch.Tensor] = None   # last_outputs[-1]  [n,C]
+    last_reg: Optional[torch.Tensor] = None
+    last_cls: Optional[torch.Tensor] = None
+    last_time: Optional[torch.Tensor] = None
+    last_edge: Optional[torch.Tensor] = None
+    last_n: int = 0                              # len(last_frame_embeds)
+
+
+def referring_cross_attention(sd, p, identity, tgt, memory, pos, query_pos, edge, query_edge, heads):
+    """ReferringCrossAttentionLayer.forward_post (tscd_matching.py:566-589)."""
+    q_in = se_module(sd, p + ".CA", tgt, query_edge) + query_pos
+    k_in = se_module(sd, p + ".CA", memory, edge) + pos
+    t2 = cos_mh_attention(sd, p + ".multihead_attn", q_in, k_in, memory, heads)
+    C = identity.shape[-1]
+    return F.layer_norm(identity + t2, (C,), sd[p + ".norm.weight"], sd[p + ".norm.bias"])
+
+
+def aware_position_reg_matcher(sd, p, feats, feats_reg, feats_cls, feats_edge, preds_per_frame,
+                               time_embedding, resume, state, cfg, aux=None):
+    """AwarePositionRegMatcher.forward, decoder_layer_num=1 (tscd_matching.py:722-888).
+
+    feats/feats_edge [N,W] (only the first sum(preds_per_frame) rows are consumed), feats_reg/feats_cls
+    [N_L,4W] (MCA outputs, only used -- detached -- as Hungarian cost), time_embedding [lframe,256].
+    Returns [N_L,W] (the reference's outputs[-1]) or None.
+    """
+    L = p + ".transformer_aware_cross_attention_layers.0"
+    H = cfg.matcher_heads
+    t_emb = F.linear(time_embedding, sd[p + ".absolute_position_embedding.weight"],
+                     sd[p + ".absolute_position_embedding.bias"])
+    outs, rets, raw, start = [], [], [], 0
+    for i, n in enumerate(preds_per_frame):
+        if n == 0:
+            if i == 0 and resume is False:
+                state.__init__()
+            continue
+        cur, cur_reg = feats[start:start + n], feats_reg[start:start + n]
+        cur_cls, cur_edge = feats_cls[start:start + n], feats_edge[start:start + n]
+        start += n
+        t_i = t_emb[i][None, :]
+        if (i == 0 and resume is False) or state.last_output is None:
+            state.last_reg, state.last_cls, state.last_n = cur_reg, cur_cls, n
+            ret = double_match(cur_reg, cur_reg, cur_cls, cur_cls)[1]
+            raw.append(np.asarray(ret))
+            out = referring_cross_attention(sd, L, cur, cur, cur, t_i, t_i, cur_edge, cur_edge, H)
+            new_edge = cur_edge
+        else:
+            row, col = double_match(state.last_reg, cur_reg, state.last_cls, cur_cls)
+            raw.append(np.asarray(col))
+            if state.last_n < n:
+                colset = set(int(c) for c in col)
+                nomatch = [j for j in range(n) if j not in colset]
+                col = np.append(col, nomatch).astype(np.int64)
+                last_feat = torch.cat((state.last_output, cur[nomatch]), 0)
+                last_edge = torch.cat((state.last_edge, cur_edge[nomatch]), 0)
+            elif state.last_n > n:
+                last_feat, last_edge = state.last_output[row], state.last_edge[row]
+            else:
+                last_feat, last_edge = state.last_output, state.last_edge
+            state.last_reg, state.last_cls, state.last_n = cur_reg[col], cur_cls[col], n
+            ret = col
+            out = referring_cross_attention(sd, L, cur[col], last_feat, cur, t_i, state.last_time,
+                                            cur_edge, last_edge, H)
+            new_edge = cur_edge[col]
+        state.last_output, state.last_time, state.last_edge = out, t_i, new_edge
+        rets.append(np.asarray(ret))
+        outs.append(out[np.argsort(ret)])
+    if aux is not None:
+        aux["hungarian"] = raw      # scipy's column assignment per local frame, as returned
+        aux["cafm_order"] = rets    # the permutation applied to the current frame (ret_indices)
+    if not outs:
+        return None
+    o = torch.cat(outs, 0)
+    return F.layer_norm(o, (o.shape[-1],), sd[p + ".decoder_norm.weight"], sd[p + ".decoder_norm.bias"])
+
+
+def task_aligned(sd, p, feats_reg, feats_obj, preds_per_frame, cfg):
+    """TaskAligned.forward, decoder_layer_num=1 (tscd_matching.py:1107-1139, 394-458)."""
+    L = p + ".transformer_cross_attention_layers.0"
+    outs, start = [], 0
+    C = feats_obj.shape[-1]
+    for n in preds_per_frame:
+        if n == 0:
+            continue
+        reg, obj = feats_reg[start:start + n], feats_obj[start:start + n]
+        start += n
+        t2 = cos_mh_attention(sd, L + ".multihead_attn", obj, reg, reg, cfg.matcher_heads)
+        outs.append(F.layer_norm(obj + t2, (C,), sd[L + ".norm.weight"], sd[L + ".norm.bias"]))
+    if not outs:
+        return None
+    return F.layer_norm(torch.cat(outs, 0), (C,), sd[p + ".decoder_norm.weight"], sd[p + ".decoder_norm.bias"])
+
+
+# ----------------------------------------------------------------------------------------------
+# a15-a16: losses and the eval tail
+# ----------------------------------------------------------------------------------------------
+def iou_loss(pred, target):
+    """IOUloss(reduction='none', loss_type='iou') (losses.py:9-53)."""
+    tl = torch.max(pred[:, :2] - pred[:, 2:] / 2, target[:, :2] - target[:, 2:] / 2)
+    br = torch.min(pred[:, :2] + pred[:, 2:] / 2, target[:, :2] + target[:, 2:] / 2)
+    area_p = torch.prod(pred[:, 2:], 1)
+    area_g = torch.prod(target[:, 2:], 1)
+    en = (tl < br).type(tl.type()).prod(dim=1)
+    area_i = torch.prod(br - tl, 1) * en
+    iou = area_i / (area_p + area_g - area_i + 1e-16)
+    return 1 - iou ** 2
+
+
+def encode_reg_preds(reg_targets, preds_xyxy, eps=1e-8):
+    """tscd_head.py:951-974: GT cxcywh vs base-detector xyxy -> (dx,dy,dw,dh)."""
+    w = preds_xyxy[:, 2] - preds_xyxy[:, 0]
+    hh = preds_xyxy[:, 3] - preds_xyxy[:, 1]
+    cx = preds_xyxy[:, 0] + 0.5 * w
+    cy = preds_xyxy[:, 1] + 0.5 * hh
+    return torch.stack(((reg_targets[:, 0] - cx) / w, (reg_targets[:, 1] - cy) / hh,
+                        torch.log(reg_targets[:, 2] / w + eps), torch.log(reg_targets[:, 3] / hh + eps)), dim=1)
+
+
+def decode_reg_preds5(reg_preds, preds_xyxy, clip=math.log(736.0 / 32)):
+    """tscd_head.py:914-949: deltas + base xyxy -> refined xyxy."""
+    w = preds_xyxy[:, 2] - preds_xyxy[:, 0]
+    hh = preds_xyxy[:, 3] - preds_xyxy[:, 1]
+    cx = preds_xyxy[:, 0] + 0.5 * w
+    cy = preds_xyxy[:, 1] + 0.5 * hh
+    dw = torch.clamp(reg_preds[:, 2], max=clip)
+    dh = torch.clamp(reg_preds[:, 3], max=clip)
+    pcx, pcy = reg_preds[:, 0] * w + cx, reg_preds[:, 1] * hh + cy
+    pw, ph = torch.exp(dw) * w, torch.exp(dh) * hh
+    return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=1)
+
+
+def final_postprocess(prediction, num_classes, fc_outputs, conf_output, reg_output,
+                      conf_thre=0.001, nms_thre=0.5, return_keep=False):
+    """post_process.postprocess (post_process.py:9-85).  prediction: list of [n_i,7+NC] (copied)."""
+    output = [None] * len(prediction)
+    output_ori = [None] * len(prediction)
+    keeps = [None] * len(prediction)
+    prediction = [p.clone() if p is not None else None for p in prediction]
+    prediction_ori = [p.clone() if p is not None else None for p in prediction]
+    for i, det in enumerate(prediction):
+        if det is None or not det.size(0):
+            continue
+        cls_conf, cls_pred = torch.max(fc_outputs[i], -1)
+        if conf_output is not None:
+            det[:, 4] = conf_output[i].sigmoid()
+        if reg_output is not None:
+            det[:, :4] = reg_output[i]
+        det[:, 5] = cls_conf.sigmoid()
+        det[:, 6] = cls_pred
+        score = fc_outputs[i].sigmoid()
+        loc = torch.where(score >= conf_thre)
+        scores = score[loc[0], loc[1]]
+        det[:, -num_classes:] = score
+        new = det[:, :7][loc[0]]
+        new[:, -1] = loc[1]
+        new[:, 5] = scores
+        high = new[(new[:, 4] * new[:, 5] >= conf_thre)]
+        if not high.shape[0]:
+            continue
+        keep = batched_nms(high[:, :4], high[:, 4] * high[:, 5], high[:, 6], nms_thre)
+        output[i] = high[keep]
+        keeps[i] = keep
+        ori = prediction_ori[i][:, :7]
+        ori = ori[ori[:, 4] * ori[:, 5] >= conf_thre]
+        output_ori[i] = ori[batched_nms(ori[:, :4], ori[:, 4] * ori[:, 5], ori[:, 6], nms_thre)]
+    if return_keep:
+        return output, output_ori, keeps
+    return output, output_ori
+
+
+# ----------------------------------------------------------------------------------------------
+# a5, a7, a17: the head and the model wrapper
+# ----------------------------------------------------------------------------------------------
+def make_grids(hw, strides, dtype=torch.float32):
+    """decode_outputs' grid/stride tables (tscd_head.py:755-770). Returns xs, ys, stride [A] each."""
+    xs, ys, ss = [], [], []
+    for (h, w), s in zip(hw, strides):
+        yv, xv = torch.meshgrid([torch.arange(h), torch.arange(w)], indexing="ij")
+        xs.append(xv.reshape(-1))
+        ys.append(yv.reshape(-1))
+        ss.append(torch.full((h * w,), s))
+    return torch.cat(xs).to(dtype), torch.cat(ys).to(dtype), torch.cat(ss).to(dtype)
+
+
+def tower(sd, p, x, training):
+    return base_conv(sd, p + ".1", base_conv(sd, p + ".0", x, 1, training), 1, training)
+
+
+def conv_pred(sd, p, x):
+    return F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"])
+
+
+def tscd_head(sd, cfg, xin, labels=None, imgs=None, time_embedding=None, nms_thresh=0.5, lframe=0,
+              gframe=32, resume=False, training=False, state=None, aux=None, p="head"):
+    """TSCDHead.forward (tscd_head.py:303-733)."""
+    nc = cfg.num_classes
+    aux = aux if aux is not None else {}
+    state = state if state is not None else MatcherState()
+    raw_out, dec_out, cls_f, reg_f, edge_f = [], [], [], [], []
+    for k, x in enumerate(xin):
+        x = base_conv(sd, f"{p}.stems.{k}", x, 1, training)
+        reg_feat = tower(sd, f"{p}.reg_convs.{k}", x, training)
+        cls_feat = tower(sd, f"{p}.cls_convs.{k}", x, training)
+        vid_feat = tower(sd, f"{p}.cls_convs2.{k}", x, training)
+        vid_feat_reg = tower(sd, f"{p}.reg_convs2.{k}", x, training)
+        obj_o = conv_pred(sd, f"{p}.obj_preds.{k}", reg_feat)
+        reg_o = conv_pred(sd, f"{p}.reg_preds.{k}", reg_feat)
+        cls_o = conv_pred(sd, f"{p}.cls_preds.{k}", cls_feat)
+        raw_out.append(torch.cat([reg_o, obj_o, cls_o], 1).flatten(2))
+        dec_out.append(torch.cat([reg_o, obj_o.sigmoid(), cls_o.sigmoid()], 1).flatten(2))
+        cls_f.append(vid_feat.flatten(2))
+        reg_f.append(vid_feat_reg.flatten(2))
+        edge_f.append(wavelets_hf_block(sd, f"{p}.edge_enhance_reg.{k}.0", vid_feat_reg).flatten(2))
+    hw = [t.shape[-2:] for t in xin]
+    xs, ys, ss = make_grids(hw, cfg.strides)
+    grid = torch.stack((xs, ys), 1)[None]
+    sst = ss[None, :, None]
+
+    def decode(t):  # get_output_and_grid / decode_outputs (tscd_head.py:735-770)
+        t = torch.cat(t, 2).permute(0, 2, 1)
+        return torch.cat(((t[..., :2] + grid) * sst, torch.exp(t[..., 2:4]) * sst, t[..., 4:]), -1)
+
+    decode_res = decode(dec_out)
+    ota_idxs = None
+    if training:
+        outputs = decode(raw_out)
+        (ota_idxs, cls_targets, reg_targets, obj_targets, fg_masks, num_fg, num_gts) = simota_assign(
+            outputs, labels, xs, ys, ss, cfg)
+        aux.update(outputs=outputs, fg_idx=ota_idxs, fg_masks=fg_masks)
+    cls_flat = torch.cat(cls_f, 2).permute(0, 2, 1)
+    reg_flat = torch.cat(reg_f, 2).permute(0, 2, 1)
+    edge_flat = torch.cat(edge_f, 2).permute(0, 2, 1)
+    aux.update(cls_flat=cls_flat, reg_flat=reg_flat, edge_flat=edge_flat)
+
+    decode_res = decode_res.clone()
+    pred_result, agg_idx, refine_obj_masks, cls_label_reorder = select_proposals(decode_res, cfg, ota_idxs)
+    aux.update(decode_res=decode_res, agg_idx=agg_idx, pred_result=pred_result)
+    ppf = [a.shape[0] for a in agg_idx]
+    if sum(ppf) == 0 and training:
+        return torch.tensor(0), 0, 0, 0, 0, 1, 0, 0, 0
+    if not training and xin[0].shape[0] == 1:
+        return pred_result, pred_result
+
+    # find_feature_score (tscd_head.py:976-1006)
+    f_cls = torch.cat([cls_flat[i][agg_idx[i]] for i in range(len(agg_idx))])
+    f_reg = torch.cat([reg_flat[i][agg_idx[i]] for i in range(len(agg_idx))])
+    f_edge = torch.cat([edge_flat[i][agg_idx[i]] for i in range(len(agg_idx))])
+    cls_scores = torch.cat([pr[:, 5] for pr in pred_result])
+    aux.update(f_cls=f_cls, f_reg=f_reg, f_edge=f_edge, cls_scores=cls_scores, preds_per_frame=ppf)
+
+    features_cls_matched, _ = mca_tscd_g2l_reg(sd, p + ".agg", f_cls, f_reg, cls_scores, ppf, lframe, cfg)
+    nl = sum(ppf[:lframe])
+    features_cls, features_reg = mca_tscd_g2l_reg(sd, p + ".agg_iou", f_cls, f_reg, cls_scores, ppf,
+                                                  lframe, cfg, aux)
+    aux.update(agg_cls=features_cls_matched, agg_iou_cls=features_cls, agg_iou_obj=features_reg)
+    matched = aware_position_reg_matcher(sd, p + ".local_reg_matcher", f_reg, features_reg, features_cls,
+                                         f_edge, ppf[:lframe], time_embedding[:lframe], resume, state, cfg,
+                                         aux)
+    if matched is None:
+        matched = f_reg[:nl]
+    aux.update(cafm=matched)
+    matched = F.linear(matched, sd[p + ".fc_reg_matcher.weight"], sd[p + ".fc_reg_matcher.bias"])
+    obj_refined = task_aligned(sd, p + ".task_aligned", matched, features_reg, ppf[:lframe], cfg)
+    if obj_refined is None:
+        obj_refined = features_reg
+    cls_preds = F.linear(features_cls_matched, sd[p + ".cls_pred.weight"], sd[p + ".cls_pred.bias"])
+    m_obj = F.linear(obj_refined, sd[p + ".matcher_obj_pred.weight"], sd[p + ".matcher_obj_pred.bias"])
+    m_reg = F.linear(matched, sd[p + ".matcher_reg_pred.weight"], sd[p + ".matcher_reg_pred.bias"])
+    aux.update(cls_preds=cls_preds, matcher_obj_preds=m_obj, matcher_reg_preds=m_reg)
+
+    if not training:
+        base = torch.cat([pred_result[i][:, :4] for i in range(lframe)], 0)
+        reg_xyxy = decode_reg_preds5(m_reg, base)
+        cls_pf, obj_pf, reg_pf, s = [], [], [], 0
+        for i in range(lframe):
+            cls_pf.append(cls_preds[s:s + ppf[i]])
+            obj_pf.append(m_obj[s:s + ppf[i]].squeeze(-1))
+            reg_pf.append(reg_xyxy[s:s + ppf[i]])
+            s += ppf[i]
+        res, res_ori, keeps = final_postprocess([pred_result[i] for i in range(lframe)], nc, cls_pf, obj_pf,
+                                                reg_pf, nms_thre=nms_thresh, return_keep=True)
+        aux.update(nms_keep=keeps)
+        return res, res_ori
+
+    # ---- training: targets for the refined heads (tscd_head.py:540-558, 611-657) ----
+    r_cls_t, r_reg_t = [], []
+    for i in range(lframe):
+        ro = cls_label_reorder[i]
+        if len(ota_idxs[i]) > 0 and ro is not None and len(ro):
+            r_cls_t.append(cls_targets[i][torch.stack(ro)])
+            r_reg_t.append(reg_targets[i][torch.stack(ro)])
+    if r_cls_t:
+        r_cls_t, r_reg_t = torch.cat(r_cls_t, 0), torch.cat(r_reg_t, 0)
+    else:
+        r_cls_t, r_reg_t = outputs.new_zeros(0, nc), outputs.new_zeros(0, 4)
+    cls_targets = torch.cat(cls_targets, 0)
+    reg_targets = torch.cat(reg_targets, 0)
+    obj_targets = torch.cat(obj_targets, 0)
+    fg_masks = torch.cat(fg_masks, 0)
+    r_obj_masks = refine_obj_masks[:nl, :]
+    num_fg_local = sum(len(ota_idxs[i]) for i in range(lframe))
+    base = torch.cat([pred_result[i][:, :4] for i in range(lframe)], 0).detach()
+    aux.update(refine_cls_targets=r_cls_t, refine_reg_targets=r_reg_t, refine_obj_masks=r_obj_masks,
+               num_fg=num_fg, num_fg_local=num_fg_local)
+
+    # get_matcher_refined_losses (tscd_head.py:1008-1203)
+    r_obj_t = r_obj_masks.type_as(obj_targets).view(-1, 1)
+    rmask = r_obj_masks.bool().squeeze(-1)
+    bce = lambda a, b: F.binary_cross_entropy_with_logits(a, b, reduction="none")
+    num_fg = max(num_fg, 1)
+    loss_iou = iou_loss(outputs[:, :, :4].reshape(-1, 4)[fg_masks], reg_targets).sum() / num_fg
+    loss_obj = bce(outputs[:, :, 4].reshape(-1, 1), obj_targets).sum() / num_fg
+    loss_cls = bce(outputs[:, :, 5:].reshape(-1, nc)[fg_masks], cls_targets).sum() / num_fg
+    loss_m_obj = bce(m_obj.view(-1, 1), r_obj_t).sum() / num_fg_local
+    m_reg_t = encode_reg_preds(r_reg_t, base[rmask])
+    loss_m_iou = F.smooth_l1_loss(m_reg.view(-1, 4)[rmask], m_reg_t, reduction="none").sum() / num_fg_local
+    loss_r_cls = bce(cls_preds.view(-1, nc)[rmask], r_cls_t).sum() / num_fg_local
+    if loss_m_obj > 15:
+        loss_m_obj = loss_m_obj / float(loss_m_obj) * 15
+    loss = 3.0 * loss_iou + loss_obj + 0.0 + loss_cls + loss_r_cls + loss_m_obj + 6.0 * loss_m_iou
+    return (loss, 3.0 * loss_iou, loss_obj, loss_cls, 0.0, num_fg / max(num_gts, 1), loss_r_cls, loss_m_obj,
+            6.0 * loss_m_iou)
+
+
+LOSS_KEYS = ("total_loss", "iou_loss", "conf_loss", "cls_loss", "l1_loss", "num_fg", "loss_matched_cls",
+             "loss_matched_obj", "loss_matched_iou")
+
+
+def tscd_forward(sd, cfg, x, targets=None, time_embedding=None, nms_thresh=0.5, lframe=0, gframe=32,
+                 resume=False, training=False, state=None, aux=None):
+    """TSCD.forward (tscd.py:23-50)."""
+    fpn = yolo_pafpn(sd, x, cfg, training)
+    if aux is not None:
+        aux["fpn"] = fpn
+    out = tscd_head(sd, cfg, fpn, targets, x, time_embedding, nms_thresh, lframe, gframe, resume, training,
+                    state, aux)
+    if training:
+        return dict(zip(LOSS_KEYS, out))
+    return out
