@@ -1,0 +1,141 @@
+"""GPU parity: MFMA implicit-GEMM conv + BN/SiLU + NHWC helpers vs the CPU oracle (oracle/tscd_oracle.py).
+
+Inputs/weights are rounded to fp16 first so both sides see identical operands; the kernel accumulates in fp32
+and stores fp16, so the tolerance is fp16 output rounding: |err| <= 2e-3 * max|ref| (+ 1e-3 abs).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tscd_oracle as O
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def assert_close(got, ref, rel=2e-3, abs_=1e-3):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    tol = rel * ref.abs().max().item() + abs_
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"max err {err} > tol {tol}"
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride
+    (2, 16, 16, 16, 64, 3, 1),      # Focus-like Cin=16 (K=144 -> pad 160)
+    (2, 18, 18, 64, 128, 3, 2),     # stride-2 downsample
+    (3, 9, 13, 128, 128, 1, 1),     # 1x1, ragged M
+    (2, 12, 12, 256, 256, 3, 1),    # head tower shape (W=256)
+    (1, 8, 8, 40, 25, 1, 1),        # Cin not multiple of 32, Cout=25 (cls pred)
+    (2, 7, 5, 8, 8, 3, 1),          # tiny golden-model width
+    (1, 1, 300, 96, 200, 1, 1),     # linear layer as 1x1 conv
+    (2, 6, 6, 1024, 512, 1, 1),     # deep K
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_raw_matches_oracle(case):
+    from tscd_amd import ops
+    B, H, W, Cin, Cout, k, s = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).half()
+    ref = F.conv2d(x.float(), w.float(), None, s, (k - 1) // 2)
+    xg = x.to(dev()).permute(0, 2, 3, 1).contiguous()
+    wpk = ops.pack_conv_weight(w.to(dev()))
+    y, _ = ops.conv2d(xg, wpk, Cout, k, s)
+    torch.cuda.synchronize()
+    assert_close(y.permute(0, 3, 1, 2), ref)
+
+
+def test_conv_channel_slices_and_bias_relu():
+    from tscd_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, H, W, Cin, Cout = 2, 10, 10, 32, 48
+    x = torch.randn(B, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 17).half()
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x.float(), w.float(), b, 1, 1))
+    big_in = torch.zeros(B, H, W, 80, dtype=torch.float16, device=dev())
+    big_in[..., 16:48] = x.to(dev()).permute(0, 2, 3, 1)
+    big_out = torch.full((B, H, W, 96), 7.0, dtype=torch.float16, device=dev())
+    ops.conv2d(big_in[..., 16:48], ops.pack_conv_weight(w.to(dev())), Cout, 3, 1, ops.EPI_BIAS_RELU, bias=b.to(dev()),
+               out=big_out[..., 8:56])
+    torch.cuda.synchronize()
+    assert_close(big_out[..., 8:56].permute(0, 3, 1, 2), ref)
+    assert (big_out[..., :8] == 7).all() and (big_out[..., 56:] == 7).all()  # neighbours untouched
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_base_conv_bn_silu(training):
+    """BaseConv (network_blocks.py:36-61) in train mode (batch stats + running-stat update) and eval (folded)."""
+    from tscd_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout = 4, 20, 20, 64, 96
+    x = torch.randn(B, Cin, H, W, generator=g).half()
+    sd = {"c.conv.weight": (torch.randn(Cout, Cin, 3, 3, generator=g) / 24).half().float(),
+          "c.bn.weight": 0.5 + torch.rand(Cout, generator=g), "c.bn.bias": 0.3 * torch.randn(Cout, generator=g),
+          "c.bn.running_mean": 0.1 * torch.randn(Cout, generator=g), "c.bn.running_var": 0.5 + torch.rand(Cout, generator=g)}
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    ref = O.base_conv(sd_ref, "c", x.float(), 1, training)
+    d = dev()
+    xg = x.to(d).permute(0, 2, 3, 1).contiguous()
+    wpk = ops.pack_conv_weight(sd["c.conv.weight"].to(d))
+    gam, bet = sd["c.bn.weight"].to(d), sd["c.bn.bias"].to(d)
+    rm, rv = sd["c.bn.running_mean"].to(d).clone(), sd["c.bn.running_var"].to(d).clone()
+    if training:
+        y, part = ops.conv2d(xg, wpk, Cout, 3, 1, ops.EPI_RAW, want_stats=True)
+        ss, mean, invstd = ops.bn_finalize(part, B * H * W, gam, bet, rm, rv)
+        ops.bn_act(y, ss, ops.ACT_SILU)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(rm.cpu().numpy(), sd_ref["c.bn.running_mean"].numpy(), atol=2e-4, rtol=1e-3)
+        np.testing.assert_allclose(rv.cpu().numpy(), sd_ref["c.bn.running_var"].numpy(), atol=2e-4, rtol=1e-3)
+    else:
+        ss = ops.bn_fold(gam, bet, rm, rv)
+        y, _ = ops.conv2d(xg, wpk, Cout, 3, 1, ops.EPI_BN_SILU, scale_shift=ss)
+        torch.cuda.synchronize()
+    assert_close(y.permute(0, 3, 1, 2), ref, rel=3e-3, abs_=2e-3)
+
+
+def test_focus_pool_upsample_haar():
+    from tscd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    d = dev()
+    img = torch.randint(0, 256, (2, 3, 16, 24), generator=g).float()
+    f = ops.focus_to_nhwc16(img.to(d))
+    tl, tr, bl, br = img[..., ::2, ::2], img[..., ::2, 1::2], img[..., 1::2, ::2], img[..., 1::2, 1::2]
+    ref = torch.cat((tl, bl, tr, br), 1)
+    torch.cuda.synchronize()
+    assert torch.equal(f[..., :12].permute(0, 3, 1, 2).float().cpu(), ref) and (f[..., 12:] == 0).all()
+
+    x = torch.randn(2, 16, 10, 14, generator=g).half()
+    xg = x.to(d).permute(0, 2, 3, 1).contiguous()
+    buf = torch.zeros(2, 10, 14, 64, dtype=torch.float16, device=d)
+    ops.copy_slice(xg, buf[..., :16])
+    ops.maxpool(buf[..., :16], buf[..., 16:32])
+    ops.maxpool(buf[..., 16:32], buf[..., 32:48])
+    ops.maxpool(buf[..., 32:48], buf[..., 48:64])
+    torch.cuda.synchronize()
+    for i, ks in enumerate((5, 9, 13)):   # SPP 5/9/13 == the 5-pool applied 1x/2x/3x (network_blocks.py:201-223)
+        ref = F.max_pool2d(x.float(), ks, 1, ks // 2)
+        assert torch.equal(buf[..., 16 * (i + 1):16 * (i + 2)].permute(0, 3, 1, 2).float().cpu(), ref)
+
+    up = torch.zeros(2, 20, 28, 16, dtype=torch.float16, device=d)
+    ops.copy_slice(xg, up, upsample=True)
+    torch.cuda.synchronize()
+    assert torch.equal(up.permute(0, 3, 1, 2).float().cpu(), F.interpolate(x.float(), scale_factor=2, mode="nearest"))
+
+    hf = ops.haar_hf(xg)
+    ref_dwt = O.haar_dwt(x.float())
+    torch.cuda.synchronize()
+    assert_close(hf.permute(0, 3, 1, 2), ref_dwt[:, 16:], rel=1e-3, abs_=1e-3)
+    content = torch.randn(2, 16, 10, 14, generator=g).half()
+    hf_in = ref_dwt[:, 16:].half()
+    out = ops.haar_idwt_mul(hf_in.to(d).permute(0, 2, 3, 1).contiguous(), content.to(d).permute(0, 2, 3, 1).contiguous())
+    ref = content.float() * O.haar_idwt(torch.cat((torch.zeros(2, 16, 5, 7), hf_in.float()), 1))
+    torch.cuda.synchronize()
+    assert_close(out.permute(0, 3, 1, 2), ref, rel=2e-3, abs_=2e-3)

@@ -1,0 +1,53 @@
+"""ctypes binding of the C-ABI in include/tscd_hip.h.  No fallback: a missing library is an ImportError."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtscd_hip.so")
+
+P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+# name -> argtypes (every entry point returns int status, 0 = ok)
+SIGNATURES = {
+    "tscd_conv2d_nhwc_f16": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "tscd_pack_conv_weight": [P, I, P, I, I, I, I, I, I, I, I, P],
+    "tscd_bn_finalize": [P, I, I, I, L, P, P, F, F, P, P, P, P, P, P],
+    "tscd_bn_fold": [P, P, P, P, F, I, P, P],
+    "tscd_bn_act_nhwc_f16": [P, I, P, I, P, P, I, L, I, I, P],
+    "tscd_focus_nchw_to_nhwc16": [P, I, P, I, I, I, P],
+    "tscd_copy_slice_nhwc_f16": [P, I, P, I, I, I, I, I, I, P],
+    "tscd_maxpool_nhwc_f16": [P, I, P, I, I, I, I, I, I, P],
+    "tscd_haar_hf_nhwc_f16": [P, I, P, I, I, I, I, P],
+    "tscd_haar_idwt_mul_nhwc_f16": [P, P, I, P, I, I, I, I, I, P],
+}
+PLAIN = {"tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
+         "tscd_last_error": ([], C.c_char_p)}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m tscd_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU / PyTorch fallback for the TSCD kernels.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = I
+    for name, (argtypes, restype) in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return lib
+
+
+lib = _load()
+
+
+def check(status, name):
+    if status != 0:
+        raise RuntimeError(f"{name} failed (status {status}): {lib.tscd_last_error().decode()}")
+
+
+def call(name, *args):
+    check(getattr(lib, name)(*args), name)

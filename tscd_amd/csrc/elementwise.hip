@@ -1,0 +1,358 @@
+// HBM-bound NHWC fp16 helpers around the conv kernel: weight packing, train-mode BatchNorm finalize/apply (+SiLU,
+// +residual), Focus space-to-depth, nearest 2x upsample / channel-slice copies (concat-free CSP/PAFPN buffers),
+// SPP max-pools and the Haar wavelet high-frequency block.  Every kernel moves 16 B (8 halves) per lane so a
+// wave reads/writes 1 KiB contiguous runs of channels.
+#include "common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+void tscd_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* tscd_last_error(void) { return g_err; }
+extern "C" int tscd_abi_version(void) { return 1; }
+
+#define EW_BLOCK 256
+static inline int ew_grid(long n) {
+  long g = (n + EW_BLOCK - 1) / EW_BLOCK;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Weight packing: torch [Cout][Cin][KH][KW] (f32 or f16) -> [CoutPad][Kpad] f16, k = (kh*KW+kw)*CinPad + cin.
+// mode 1 ("dgrad"): the packed matrix is the one that turns the SAME conv kernel into the data-gradient of a
+// stride-1 conv: rows = Cin, k = ((KH-1-kh)*KW + (KW-1-kw))*CoutAsCin + cout.
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const T* __restrict__ w, f16* __restrict__ out, int Cout, int Cin, int CinPad, int KH,
+                                   int KW, int rows_pad, int Kpad, int mode) {
+  long total = (long)rows_pad * Kpad;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int row = idx / Kpad, k = idx % Kpad;
+    float v = 0.f;
+    if (mode == 0) {
+      int tap = k / CinPad, ci = k % CinPad;
+      if (row < Cout && tap < KH * KW && ci < Cin) {
+        int kh = tap / KW, kw = tap % KW;
+        v = (float)w[(((long)row * Cin + ci) * KH + kh) * KW + kw];
+      }
+    } else {
+      // row = cin of the forward conv, inner channel = cout of the forward conv (CinPad carries Cout here)
+      int tap = k / CinPad, co = k % CinPad;
+      if (row < Cin && tap < KH * KW && co < Cout) {
+        int kh = KH - 1 - tap / KW, kw = KW - 1 - tap % KW;
+        v = (float)w[(((long)co * Cin + row) * KH + kh) * KW + kw];
+      }
+    }
+    out[idx] = (f16)v;
+  }
+}
+
+extern "C" int tscd_pack_conv_weight(const void* w, int src_is_f32, void* out, int Cout, int Cin, int CinPad, int KH, int KW,
+                                     int rows_pad, int Kpad, int mode, void* stream) {
+  TSCD_CHECK_ARG(w && out, "pack_conv_weight: null pointer");
+  TSCD_CHECK_ARG(mode == 0 || mode == 1, "pack_conv_weight: bad mode");
+  TSCD_CHECK_ARG(Kpad % 32 == 0 && Kpad >= KH * KW * CinPad, "pack_conv_weight: Kpad=%d too small", Kpad);
+  long total = (long)rows_pad * Kpad;
+  if (src_is_f32)
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       (const float*)w, (f16*)out, Cout, Cin, CinPad, KH, KW, rows_pad, Kpad, mode);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<f16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       (const f16*)w, (f16*)out, Cout, Cin, CinPad, KH, KW, rows_pad, Kpad, mode);
+  TSCD_CHECK_LAUNCH("pack_conv_weight");
+  return TSCD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Train-mode BatchNorm: reduce the conv kernel's per-M-tile partials in a fixed order (one wave per channel,
+// fp64 accumulation), emit scale/shift for the apply pass, the saved mean/invstd for backward, and update the
+// running statistics exactly like torch (momentum, unbiased variance) -- reference: network_blocks.py:52-58 with
+// eps=1e-3, momentum=0.03 (exps/TSCD_OVIS/ovis_tscd_large.py:109-113).
+// ------------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int mtiles, int cstride, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, float* scale_shift,
+                                   float* save_mean, float* save_invstd) {
+  int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = lane; t < mtiles; t += 64) {
+    s1 += (double)partial[((long)t * 2 + 0) * cstride + c];
+    s2 += (double)partial[((long)t * 2 + 1) * cstride + c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (lane == 0) {
+    double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0) var = 0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale_shift[c] = g * invstd;
+    scale_shift[C + c] = b - (float)mean * g * invstd;
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = invstd;
+    if (running_mean) {
+      double unbiased = count > 1 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+extern "C" int tscd_bn_finalize(const float* partial, int mtiles, int cstride, int C, long count, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                float* scale_shift, float* save_mean, float* save_invstd, void* stream) {
+  TSCD_CHECK_ARG(partial && scale_shift && C > 0 && mtiles > 0 && count > 0, "bn_finalize: bad args");
+  TSCD_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partial, mtiles, cstride, C,
+                     (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale_shift, save_mean,
+                     save_invstd);
+  TSCD_CHECK_LAUNCH("bn_finalize");
+  return TSCD_OK;
+}
+
+// Eval-mode fold: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale.
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                               float* scale_shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = gamma[c] / sqrtf(rv[c] + eps);
+  scale_shift[c] = s;
+  scale_shift[C + c] = beta[c] - rm[c] * s;
+}
+extern "C" int tscd_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                            float* scale_shift, void* stream) {
+  TSCD_CHECK_ARG(gamma && beta && rm && rv && scale_shift && C > 0, "bn_fold: bad args");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, rm, rv, eps, C,
+                     scale_shift);
+  TSCD_CHECK_LAUNCH("bn_fold");
+  return TSCD_OK;
+}
+
+// y = act(half(x*scale+shift)) (+ residual), 8 channels per lane.  act: 0 none, 1 SiLU, 2 ReLU.
+__global__ void bn_act_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy, const float* __restrict__ ss,
+                              const f16* __restrict__ res, int ldr, long M, int C, int act) {
+  const int cv = C >> 3;
+  const long total = M * cv;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long m = idx / cv;
+    int c = (int)(idx - m * cv) << 3;
+    f16x8 v = *(const f16x8*)(x + m * ldx + c);
+    f16x8 r;
+    if (res) r = *(const f16x8*)(res + m * ldr + c);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (float)(f16)((float)v[e] * ss[c + e] + ss[C + c + e]);
+      f16 h = act == 1 ? (f16)(t * sigmoidf_(t)) : (act == 2 ? (f16)fmaxf(t, 0.f) : (f16)t);
+      if (res) h = (f16)((float)h + (float)r[e]);
+      o[e] = h;
+    }
+    *(f16x8*)(y + m * ldy + c) = o;
+  }
+}
+
+extern "C" int tscd_bn_act_nhwc_f16(const void* x, int ldx, void* y, int ldy, const float* scale_shift, const void* residual,
+                                    int ldr, long M, int C, int act, void* stream) {
+  TSCD_CHECK_ARG(x && y && scale_shift, "bn_act: null pointer");
+  TSCD_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (residual == nullptr || ldr % 8 == 0),
+                 "bn_act: C / strides must be multiples of 8 (C=%d ldx=%d ldy=%d)", C, ldx, ldy);
+  TSCD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)residual & 15) == 0,
+                 "bn_act: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(bn_act_kernel, dim3(ew_grid(M * (C / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16*)x, ldx,
+                     (f16*)y, ldy, scale_shift, (const f16*)residual, ldr, M, C, act);
+  TSCD_CHECK_LAUNCH("bn_act");
+  return TSCD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Focus (network_blocks.py:267-289): NCHW image -> NHWC [B, H/2, W/2, 16] with channels
+// (tl c0..2, bl c0..2, tr c0..2, br c0..2, 0, 0, 0, 0); the 4 zero channels keep Cin a multiple of 8.
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void focus_kernel(const T* __restrict__ x, f16* __restrict__ y, int B, int H, int W) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long total = (long)B * Ho * Wo;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int wo = idx % Wo;
+    long t = idx / Wo;
+    int ho = t % Ho, b = t / Ho;
+    f16x8 o0, o1;
+    f16 v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // patch order tl, bl, tr, br  ->  (dy,dx) = (0,0),(1,0),(0,1),(1,1)
+      int dy = q & 1, dx = q >> 1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        v[q * 3 + c] = (f16)(float)x[(((long)b * 3 + c) * H + (2 * ho + dy)) * W + (2 * wo + dx)];
+    }
+    v[12] = v[13] = v[14] = v[15] = (f16)0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o0[e] = v[e]; o1[e] = v[8 + e]; }
+    *(f16x8*)(y + idx * 16) = o0;
+    *(f16x8*)(y + idx * 16 + 8) = o1;
+  }
+}
+extern "C" int tscd_focus_nchw_to_nhwc16(const void* x, int src_is_f32, void* y, int B, int H, int W, void* stream) {
+  TSCD_CHECK_ARG(x && y && B > 0 && H % 2 == 0 && W % 2 == 0, "focus: bad args");
+  long total = (long)B * (H / 2) * (W / 2);
+  if (src_is_f32)
+    hipLaunchKernelGGL(focus_kernel<float>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)x,
+                       (f16*)y, B, H, W);
+  else
+    hipLaunchKernelGGL(focus_kernel<f16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16*)x,
+                       (f16*)y, B, H, W);
+  TSCD_CHECK_LAUNCH("focus");
+  return TSCD_OK;
+}
+
+// Channel-slice copy with optional nearest 2x upsample: dst[b, h, w, :C] = src[b, h>>up, w>>up, :C].
+__global__ void copy_slice_kernel(const f16* __restrict__ src, int lds_, f16* __restrict__ dst, int ldd, int B, int H, int W,
+                                  int C, int up) {
+  const int cv = C >> 3;
+  const long total = (long)B * H * W * cv;
+  const int Hs = H >> up, Ws = W >> up;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int c = (int)(idx % cv) << 3;
+    long pix = idx / cv;
+    int w = pix % W;
+    long t = pix / W;
+    int h = t % H, b = t / H;
+    long spix = ((long)b * Hs + (h >> up)) * Ws + (w >> up);
+    *(f16x8*)(dst + pix * ldd + c) = *(const f16x8*)(src + spix * lds_ + c);
+  }
+}
+extern "C" int tscd_copy_slice_nhwc_f16(const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C,
+                                        int upsample, void* stream) {
+  TSCD_CHECK_ARG(src && dst && C % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0, "copy_slice: bad args C=%d", C);
+  TSCD_CHECK_ARG(upsample == 0 || (upsample == 1 && H % 2 == 0 && W % 2 == 0), "copy_slice: bad upsample");
+  hipLaunchKernelGGL(copy_slice_kernel, dim3(ew_grid((long)B * H * W * (C / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                     (const f16*)src, lds_, (f16*)dst, ldd, B, H, W, C, upsample);
+  TSCD_CHECK_LAUNCH("copy_slice");
+  return TSCD_OK;
+}
+
+// Stride-1 max-pool (kernel ks, pad ks/2, -inf padding) on a channel slice.  SPP's 5/9/13 pools are the 5-pool
+// applied 1x/2x/3x (max over nested windows), so the product calls this three times with ks=5.
+__global__ void maxpool_kernel(const f16* __restrict__ src, int lds_, f16* __restrict__ dst, int ldd, int B, int H, int W,
+                               int C, int ks) {
+  const int cv = C >> 3, r = ks >> 1;
+  const long total = (long)B * H * W * cv;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int c = (int)(idx % cv) << 3;
+    long pix = idx / cv;
+    int w = pix % W;
+    long t = pix / W;
+    int h = t % H, b = t / H;
+    f16x8 m;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+    for (int y = max(h - r, 0); y <= min(h + r, H - 1); ++y)
+      for (int x = max(w - r, 0); x <= min(w + r, W - 1); ++x) {
+        f16x8 v = *(const f16x8*)(src + (((long)b * H + y) * W + x) * lds_ + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+      }
+    *(f16x8*)(dst + pix * ldd + c) = m;
+  }
+}
+extern "C" int tscd_maxpool_nhwc_f16(const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, int ks,
+                                     void* stream) {
+  TSCD_CHECK_ARG(src && dst && C % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0 && (ks & 1), "maxpool: bad args");
+  hipLaunchKernelGGL(maxpool_kernel, dim3(ew_grid((long)B * H * W * (C / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                     (const f16*)src, lds_, (f16*)dst, ldd, B, H, W, C, ks);
+  TSCD_CHECK_LAUNCH("maxpool");
+  return TSCD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Haar wavelet high-frequency block (surrounding_extraction.py:12-127,257-267).
+// With a=x[2y,2x], b=x[2y,2x+1], c=x[2y+1,2x], d=x[2y+1,2x+1]:  lh=(a+b-c-d)/2, hl=(a-b+c-d)/2, hh=(a-b-c+d)/2
+// (the LL band is dropped by the block).  haar_hf writes [B,H/2,W/2,3C] (lh | hl | hh channel blocks), the
+// 1x1 conv + ReLU on it is the MFMA conv kernel, haar_idwt_mul reconstructs with LL = 0 and multiplies with the
+// 3x3 "content" branch:  out[2y,2x] = c*(lh+hl+hh)/2, out[2y,2x+1] = c*(lh-hl-hh)/2, out[2y+1,2x] = c*(-lh+hl-hh)/2,
+// out[2y+1,2x+1] = c*(-lh-hl+hh)/2.  Intermediates are rounded to fp16 where the reference's fp16 ops round.
+// ------------------------------------------------------------------------------------------------------
+__global__ void haar_hf_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ hf, int B, int H, int W, int C) {
+  const int cv = C >> 3, Ho = H >> 1, Wo = W >> 1;
+  const long total = (long)B * Ho * Wo * cv;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int c = (int)(idx % cv) << 3;
+    long pix = idx / cv;
+    int wo = pix % Wo;
+    long t = pix / Wo;
+    int ho = t % Ho, b = t / Ho;
+    const f16* p0 = x + (((long)b * H + 2 * ho) * W + 2 * wo) * ldx + c;
+    f16x8 a = *(const f16x8*)p0, bb = *(const f16x8*)(p0 + ldx);
+    f16x8 cc = *(const f16x8*)(p0 + (long)W * ldx), d = *(const f16x8*)(p0 + (long)W * ldx + ldx);
+    f16x8 lh, hl, hh;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float fa = a[e], fb = bb[e], fc = cc[e], fd = d[e];
+      lh[e] = (f16)(0.5f * (fa + fb - fc - fd));
+      hl[e] = (f16)(0.5f * (fa - fb + fc - fd));
+      hh[e] = (f16)(0.5f * (fa - fb - fc + fd));
+    }
+    f16* o = hf + pix * (3L * C) + c;
+    *(f16x8*)(o) = lh;
+    *(f16x8*)(o + C) = hl;
+    *(f16x8*)(o + 2 * C) = hh;
+  }
+}
+extern "C" int tscd_haar_hf_nhwc_f16(const void* x, int ldx, void* hf, int B, int H, int W, int C, void* stream) {
+  TSCD_CHECK_ARG(x && hf && C % 8 == 0 && ldx % 8 == 0 && H % 2 == 0 && W % 2 == 0, "haar_hf: bad args (H=%d W=%d C=%d)", H, W,
+                 C);
+  hipLaunchKernelGGL(haar_hf_kernel, dim3(ew_grid((long)B * (H / 2) * (W / 2) * (C / 8))), dim3(EW_BLOCK), 0,
+                     (hipStream_t)stream, (const f16*)x, ldx, (f16*)hf, B, H, W, C);
+  TSCD_CHECK_LAUNCH("haar_hf");
+  return TSCD_OK;
+}
+
+__global__ void haar_idwt_mul_kernel(const f16* __restrict__ hf, const f16* __restrict__ content, int ldc, f16* __restrict__ out,
+                                     int ldo, int B, int H, int W, int C) {
+  const int cv = C >> 3, Ho = H >> 1, Wo = W >> 1;
+  const long total = (long)B * Ho * Wo * cv;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int c = (int)(idx % cv) << 3;
+    long pix = idx / cv;
+    int wo = pix % Wo;
+    long t = pix / Wo;
+    int ho = t % Ho, b = t / Ho;
+    const f16* h = hf + pix * (3L * C) + c;
+    f16x8 lh = *(const f16x8*)h, hl = *(const f16x8*)(h + C), hh = *(const f16x8*)(h + 2 * C);
+    long p00 = ((long)b * H + 2 * ho) * W + 2 * wo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int dy = q >> 1, dx = q & 1;
+      long pp = p00 + (long)dy * W + dx;
+      f16x8 cc = *(const f16x8*)(content + pp * ldc + c);
+      f16x8 o;
+      float s_lh = dy ? -0.5f : 0.5f, s_hl = dx ? -0.5f : 0.5f, s_hh = (dx ^ dy) ? -0.5f : 0.5f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        f16 rec = (f16)(s_lh * (float)lh[e] + s_hl * (float)hl[e] + s_hh * (float)hh[e]);
+        o[e] = (f16)((float)cc[e] * (float)rec);
+      }
+      *(f16x8*)(out + pp * ldo + c) = o;
+    }
+  }
+}
+extern "C" int tscd_haar_idwt_mul_nhwc_f16(const void* hf, const void* content, int ldc, void* out, int ldo, int B, int H, int W,
+                                           int C, void* stream) {
+  TSCD_CHECK_ARG(hf && content && out && C % 8 == 0 && ldc % 8 == 0 && ldo % 8 == 0 && H % 2 == 0 && W % 2 == 0,
+                 "haar_idwt_mul: bad args");
+  hipLaunchKernelGGL(haar_idwt_mul_kernel, dim3(ew_grid((long)B * (H / 2) * (W / 2) * (C / 8))), dim3(EW_BLOCK), 0,
+                     (hipStream_t)stream, (const f16*)hf, (const f16*)content, ldc, (f16*)out, ldo, B, H, W, C);
+  TSCD_CHECK_LAUNCH("haar_idwt_mul");
+  return TSCD_OK;
+}
