@@ -1,0 +1,166 @@
+"""Autograd-aware building blocks on top of tscd_amd.ops.
+
+Forward passes are the HIP kernels.  Backward passes of the *trainable* head blocks are composed here; the
+convolution data/weight gradients currently go through ``aten.convolution_backward`` on the device (plumbing,
+listed as a pending HIP row in DESIGN.md) while BatchNorm/SiLU/ReLU gradients are written out explicitly.
+The frozen backbone / base head never build a graph (the reference freezes them: ovis_tscd_large.py:116-149).
+"""
+import torch
+
+from . import ops
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def _nchw(t):
+    """NHWC-logical tensor -> NCHW-logical view (channels_last memory), for aten conv backward."""
+    return t.permute(0, 3, 1, 2)
+
+
+def _conv_backward(dy, x, weight, stride, need_dx, need_dw):
+    k = weight.shape[-1]
+    pad = (k - 1) // 2
+    w16 = weight.detach().to(torch.float16)
+    dx, dw, _ = torch.ops.aten.convolution_backward(
+        _nchw(dy), _nchw(x), w16, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
+        [need_dx, need_dw, False])
+    if dx is not None:
+        dx = dx.permute(0, 2, 3, 1)
+    return dx, (dw.to(weight.dtype) if dw is not None else None)
+
+
+class _ConvBnSiluTrain(torch.autograd.Function):
+    """BaseConv in training mode: conv -> batch-stat BN (running stats updated) -> SiLU."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum):
+        wpk = ops.WEIGHTS.get(weight)
+        cout, k = weight.shape[0], weight.shape[-1]
+        raw, part = ops.conv2d(x, wpk, cout, k, stride, ops.EPI_RAW, want_stats=True)
+        B, Ho, Wo, _ = raw.shape
+        ss, mean, invstd = ops.bn_finalize(part, B * Ho * Wo, gamma, beta, running_mean, running_var, eps, momentum)
+        out = ops.bn_act(raw, ss, ops.ACT_SILU, out=ops.empty_nhwc(B, Ho, Wo, cout, x.device))
+        ctx.save_for_backward(x, weight, gamma, raw, ss, mean, invstd)
+        ctx.stride = stride
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, gamma, raw, ss, mean, invstd = ctx.saved_tensors
+        rawf = raw.float()
+        t = (rawf * ss[0] + ss[1]).half().float()          # BN output as the forward rounded it
+        sg = torch.sigmoid(t)
+        dt = dy.float() * (sg * (1 + t * (1 - sg)))         # SiLU'
+        xhat = (rawf - mean) * invstd
+        dbeta = dt.sum((0, 1, 2))
+        dgamma = (dt * xhat).sum((0, 1, 2))
+        n = rawf.shape[0] * rawf.shape[1] * rawf.shape[2]
+        draw = (gamma * invstd) * (dt - dbeta / n - xhat * (dgamma / n))
+        dx, dw = _conv_backward(draw.half(), x, weight, ctx.stride, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dw, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None
+
+
+def conv_bn_silu(x, weight, gamma, beta, running_mean, running_var, stride, training, out=None, residual=None,
+                 eps=ops.BN_EPS, momentum=ops.BN_MOMENTUM):
+    """BaseConv forward (network_blocks.py:36-61).  x NHWC fp16.  ``out`` / ``residual`` (channel slices) are only
+    allowed on the no-grad path."""
+    if training and _needs_grad(x, weight, gamma, beta):
+        assert out is None and residual is None
+        return _ConvBnSiluTrain.apply(x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum)
+    cout, k = weight.shape[0], weight.shape[-1]
+    cin_pad = x.shape[-1] if x.shape[-1] != weight.shape[1] else None   # Focus: 12 -> 16 channels
+    wpk = ops.WEIGHTS.get(weight, cin_pad)
+    if training:
+        y, part = ops.conv2d(x, wpk, cout, k, stride, ops.EPI_RAW, out=out, want_stats=True)
+        B, Ho, Wo, _ = y.shape
+        ss, _, _ = ops.bn_finalize(part, B * Ho * Wo, gamma, beta, running_mean, running_var, eps, momentum)
+        return ops.bn_act(y, ss, ops.ACT_SILU, residual=residual)
+    ss = ops.bn_fold(gamma, beta, running_mean, running_var, eps)
+    if residual is None:
+        y, _ = ops.conv2d(x, wpk, cout, k, stride, ops.EPI_BN_SILU, scale_shift=ss, out=out)
+        return y
+    y, _ = ops.conv2d(x, wpk, cout, k, stride, ops.EPI_RAW, out=out)
+    return ops.bn_act(y, ss, ops.ACT_SILU, residual=residual)
+
+
+class _ConvBias(torch.autograd.Function):
+    """nn.Conv2d with bias (+ optional ReLU): prediction 1x1 convs and the wavelet block's filters."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        wpk = ops.WEIGHTS.get(weight)
+        y, _ = ops.conv2d(x, wpk, weight.shape[0], weight.shape[-1], 1, ops.EPI_BIAS_RELU if relu else ops.EPI_BIAS,
+                          bias=bias.float())
+        ctx.save_for_backward(x, weight, y)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        if ctx.relu:
+            dy = dy * (y > 0)
+        dx, dw = _conv_backward(dy.contiguous(), x, weight, 1, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        db = dy.float().sum((0, 1, 2)) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+def conv_bias(x, weight, bias, relu=False):
+    if _needs_grad(x, weight, bias):
+        return _ConvBias.apply(x, weight, bias, relu)
+    wpk = ops.WEIGHTS.get(weight)
+    y, _ = ops.conv2d(x, wpk, weight.shape[0], weight.shape[-1], 1, ops.EPI_BIAS_RELU if relu else ops.EPI_BIAS,
+                      bias=bias.float())
+    return y
+
+
+class _HaarHF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.haar_hf(x)
+
+    @staticmethod
+    def backward(ctx, d):
+        # adjoint of the analysis step (DWT_Function.backward, surrounding_extraction.py:30-41)
+        B, h, w, C3 = d.shape
+        C = C3 // 3
+        lh, hl, hh = d[..., :C].float(), d[..., C:2 * C].float(), d[..., 2 * C:].float()
+        dx = d.new_empty(B, 2 * h, 2 * w, C)
+        dx[:, 0::2, 0::2] = (0.5 * (lh + hl + hh)).half()
+        dx[:, 0::2, 1::2] = (0.5 * (lh - hl - hh)).half()
+        dx[:, 1::2, 0::2] = (0.5 * (-lh + hl - hh)).half()
+        dx[:, 1::2, 1::2] = (0.5 * (-lh - hl + hh)).half()
+        return dx
+
+
+class _HaarIdwtMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hf, content):
+        ctx.save_for_backward(hf, content)
+        return ops.haar_idwt_mul(hf.contiguous(), content)
+
+    @staticmethod
+    def backward(ctx, d):
+        hf, content = ctx.saved_tensors
+        B, H, W, C = content.shape
+        lh, hl, hh = hf[..., :C].float(), hf[..., C:2 * C].float(), hf[..., 2 * C:].float()
+        rec = content.new_empty(B, H, W, C)
+        rec[:, 0::2, 0::2] = (0.5 * (lh + hl + hh)).half()
+        rec[:, 0::2, 1::2] = (0.5 * (lh - hl - hh)).half()
+        rec[:, 1::2, 0::2] = (0.5 * (-lh + hl - hh)).half()
+        rec[:, 1::2, 1::2] = (0.5 * (-lh - hl + hh)).half()
+        dcontent = d * rec
+        g = (d.float() * content.float())
+        a, b, c, e = g[:, 0::2, 0::2], g[:, 0::2, 1::2], g[:, 1::2, 0::2], g[:, 1::2, 1::2]
+        dhf = torch.cat((0.5 * (a + b - c - e), 0.5 * (a - b + c - e), 0.5 * (a - b - c + e)), -1).half()
+        return dhf, dcontent
+
+
+def haar_hf(x):
+    return _HaarHF.apply(x) if _needs_grad(x) else ops.haar_hf(x)
+
+
+def haar_idwt_mul(hf, content):
+    return _HaarIdwtMul.apply(hf, content) if _needs_grad(hf, content) else ops.haar_idwt_mul(hf.contiguous(), content)

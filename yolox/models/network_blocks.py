@@ -1,0 +1,117 @@
+"""Conv / CSP building blocks of CSPDarknet + PAFPN on the MI355X kernels.
+
+Interface mirror of the reference's yolox/models/network_blocks.py (BaseConv :36-61, Bottleneck :158-180,
+SPPBottleneck :201-223, CSPLayer :226-264, Focus :267-289): same submodule names (=> identical state_dict keys)
+and constructor arguments.  Differences are internal: activations flow as NHWC fp16 tensors
+([B,H,W,C] logical shape), every conv is tscd_amd's MFMA implicit GEMM with the BatchNorm statistics fused
+into its epilogue, and CSP / SPP concatenations are channel slices of one pre-allocated buffer that the producing
+kernels write into directly (no torch.cat copies).
+"""
+import torch
+import torch.nn as nn
+
+from tscd_amd import functional as TF
+from tscd_amd import ops
+
+
+def get_activation(name="silu", inplace=True):
+    if name in ("silu", "swish"):
+        return nn.SiLU(inplace=inplace)
+    if name == "relu":
+        return nn.ReLU(inplace=inplace)
+    if name == "lrelu":
+        return nn.LeakyReLU(0.1, inplace=inplace)
+    raise AttributeError("Unsupported act type: {}".format(name))
+
+
+class BaseConv(nn.Module):
+    """Conv2d(no bias, same pad) -> BatchNorm2d -> SiLU, one fused HIP pipeline."""
+
+    def __init__(self, in_channels, out_channels, ksize, stride, groups=1, bias=False, act="silu"):
+        super().__init__()
+        if groups != 1 or bias or act not in ("silu", "swish"):
+            raise NotImplementedError("TSCD path uses groups=1, bias=False, SiLU only")
+        pad = (ksize - 1) // 2
+        # nn.Conv2d / nn.BatchNorm2d only hold the parameters (state_dict compatibility); they are never called
+        self.conv = nn.Conv2d(in_channels, out_channels, ksize, stride, pad, groups=groups, bias=bias)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.act = get_activation(act, inplace=True)
+        self.stride = stride
+
+    def forward(self, x, out=None, residual=None):
+        bn = self.bn
+        training = self.training and bn.training
+        if training and bn.track_running_stats:
+            bn.num_batches_tracked += 1
+        y = TF.conv_bn_silu(x, self.conv.weight, bn.weight.float(), bn.bias.float(),
+                            bn.running_mean if bn.running_mean.dtype == torch.float32 else bn.running_mean.float(),
+                            bn.running_var if bn.running_var.dtype == torch.float32 else bn.running_var.float(),
+                            self.stride, training, out=out, residual=residual, eps=bn.eps, momentum=bn.momentum)
+        return y
+
+    fuseforward = forward
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, in_channels, out_channels, shortcut=True, expansion=0.5, depthwise=False, act="silu"):
+        super().__init__()
+        if depthwise:
+            raise NotImplementedError("depthwise convs are not on the TSCD path")
+        hidden = int(out_channels * expansion)
+        self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv2 = BaseConv(hidden, out_channels, 3, stride=1, act=act)
+        self.use_add = shortcut and in_channels == out_channels
+
+    def forward(self, x, out=None):
+        return self.conv2(self.conv1(x), out=out, residual=x if self.use_add else None)
+
+
+class SPPBottleneck(nn.Module):
+    """1x1 -> max-pools 5/9/13 (the 5-pool cascaded, written into slices of one buffer) -> 1x1."""
+
+    def __init__(self, in_channels, out_channels, kernel_sizes=(5, 9, 13), activation="silu"):
+        super().__init__()
+        assert tuple(kernel_sizes) == (5, 9, 13)
+        hidden = in_channels // 2
+        self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=activation)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=ks, stride=1, padding=ks // 2) for ks in kernel_sizes])
+        self.conv2 = BaseConv(hidden * (len(kernel_sizes) + 1), out_channels, 1, stride=1, act=activation)
+
+    def forward(self, x):
+        B, H, W, _ = x.shape
+        h = self.conv1.conv.out_channels
+        buf = ops.empty_nhwc(B, H, W, 4 * h, x.device)
+        self.conv1(x, out=buf[..., :h])
+        for i in range(3):
+            ops.maxpool(buf[..., i * h:(i + 1) * h], buf[..., (i + 1) * h:(i + 2) * h], 5)
+        return self.conv2(buf)
+
+
+class CSPLayer(nn.Module):
+    def __init__(self, in_channels, out_channels, n=1, shortcut=True, expansion=0.5, depthwise=False, act="silu"):
+        super().__init__()
+        hidden = int(out_channels * expansion)
+        self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv2 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv3 = BaseConv(2 * hidden, out_channels, 1, stride=1, act=act)
+        self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
+
+    def forward(self, x, out=None):
+        B, H, W, _ = x.shape
+        h = self.conv1.conv.out_channels
+        cat = ops.empty_nhwc(B, H, W, 2 * h, x.device)      # [m(conv1(x)) | conv2(x)]
+        self.conv2(x, out=cat[..., h:])
+        n = len(self.m)
+        x1 = self.conv1(x, out=cat[..., :h] if n == 0 else None)
+        for i, blk in enumerate(self.m):
+            x1 = blk(x1, out=cat[..., :h] if i == n - 1 else None)
+        return self.conv3(cat, out=out)
+
+
+class Focus(nn.Module):
+    def __init__(self, in_channels, out_channels, ksize=1, stride=1, act="silu"):
+        super().__init__()
+        self.conv = BaseConv(in_channels * 4, out_channels, ksize, stride, act=act)
+
+    def forward(self, img_nchw):
+        return self.conv(ops.focus_to_nhwc16(img_nchw))
