@@ -1,0 +1,116 @@
+/* tscd_hip.h -- C-ABI of libtscd_hip.so: the MI355X (gfx950) kernels of the TSCD per-clip hot path.
+ *
+ * The reference (Video-Object-Detection/TSCD) has no FFI boundary: its hot path is stock PyTorch ops called from
+ * Python modules.  This ABI therefore sits one layer below the module mirror in yolox/ (which reproduces the
+ * reference's import surface) and each entry point names the reference code it replaces (paths relative to the
+ * reference tree, file:line).  INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless marked (host); `stream` is a hipStream_t.
+ *   - all entry points are asynchronous on `stream`, never allocate, never synchronise; scratch memory is passed in
+ *     (`*_workspace_bytes` tells how much).  They are re-entrant per stream (no global mutable state).
+ *   - return 0 on success, 1 = bad argument, 2 = HIP launch error; tscd_last_error() returns a thread-local message.
+ *   - activations are fp16, NHWC ([B,H,W,C] row-major) or a channel slice of such a buffer: `ld*` is the pixel
+ *     stride in elements (>= C).  Channel counts / strides that feed 16-byte vector accesses must be multiples of 8.
+ */
+#ifndef TSCD_HIP_H
+#define TSCD_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int tscd_abi_version(void);
+const char* tscd_last_error(void);
+
+/* ---- convolution / GEMM (MFMA implicit GEMM) -------------------------------------------------------------------
+ * Replaces Conv2d inside BaseConv (yolox/models/network_blocks.py:36-61), the prediction convs
+ * (yolox/models/tscd_head.py:213-239), WaveletsHFBlock.filter1/2 (yolox/models/surrounding_extraction.py:223-232)
+ * and, with ksize=1/H=1, every nn.Linear of the proposal stage (post_trans.py:565-576,1139-1143;
+ * tscd_matching.py:24-26,151-153,704; tscd_head.py:123,130-133).
+ * epilogue: 0 raw (+ per-M-tile BN partial sums into bn_partial[mtiles][2][cstride] when non-NULL), 1 +bias,
+ * 2 +bias,ReLU, 3 folded BN + SiLU (eval), 4 folded BN, 5 Hungarian cost 1 - v/2 with NaN->0
+ * (tscd_matching.py:926-930). */
+int tscd_conv_tile_m(void);
+int tscd_conv_tile_n(int cout);
+int tscd_pack_conv_weight(const void* w, int src_is_f32, void* out, int Cout, int Cin, int CinPad, int KH, int KW,
+                          int rows_pad, int Kpad, int mode, void* stream);
+int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* bias, const float* scale,
+                         const float* shift, float* bn_partial, int B, int H, int W, int Cin, int Cout, int ksize,
+                         int stride, int ldx, int ldy, int epilogue, void* stream);
+
+/* ---- BatchNorm (train-mode statistics / eval fold) + activation: network_blocks.py:52-58 with eps 1e-3,
+ * momentum 0.03 (exps/TSCD_OVIS/ovis_tscd_large.py:109-113); Bottleneck shortcut add (network_blocks.py:176-179). */
+int tscd_bn_finalize(const float* partial, int mtiles, int cstride, int C, long count, const float* gamma,
+                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                     float* scale_shift, float* save_mean, float* save_invstd, void* stream);
+int tscd_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                 float* scale_shift, void* stream);
+int tscd_bn_act_nhwc_f16(const void* x, int ldx, void* y, int ldy, const float* scale_shift, const void* residual,
+                         int ldr, long M, int C, int act, void* stream);
+
+/* ---- layout / pooling helpers: Focus (network_blocks.py:267-289), nn.Upsample + torch.cat
+ * (yolo_pafpn.py:97-115), SPPBottleneck max-pools (network_blocks.py:201-223). */
+int tscd_focus_nchw_to_nhwc16(const void* x, int src_is_f32, void* y, int B, int H, int W, void* stream);
+int tscd_copy_slice_nhwc_f16(const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, int upsample,
+                             void* stream);
+int tscd_maxpool_nhwc_f16(const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, int ks,
+                          void* stream);
+
+/* ---- Haar wavelet high-frequency block: DWT_2D / IDWT_2D / WaveletsHFBlock.forward
+ * (surrounding_extraction.py:12-127,257-267). */
+int tscd_haar_hf_nhwc_f16(const void* x, int ldx, void* hf, int B, int H, int W, int C, void* stream);
+int tscd_haar_idwt_mul_nhwc_f16(const void* hf, const void* content, int ldc, void* out, int ldo, int B, int H, int W,
+                                int C, void* stream);
+
+/* ---- proposal stage: decode_outputs (tscd_head.py:755-770), postprocess_widx (tscd_head.py:1546-1693),
+ * find_feature_score (tscd_head.py:976-1006).  hw3/w3/stride3 are (host) int[3]; maps is a (host) array of 9 device
+ * pointers [feature][level]. */
+int tscd_decode_score(const void* raw0, const void* raw1, const void* raw2, const int* hw3, const int* w3,
+                      const int* stride3, int B, int NC, void* outputs, void* det, void* score, void* stream);
+int tscd_select_proposals(const void* score, int B, int A, float conf_thresh, int min_keep, int max_keep, int cap,
+                          int* out_idx, int* out_count, void* stream);
+int tscd_gather_rows(const void* const* maps, const int* hw3, const int* sel_idx, int cap, const int* frame_off, int B,
+                     int N, int W, int nmaps, void* out0, void* out1, void* out2, int scatter, void* stream);
+int tscd_gather_det(const void* det, int A, int ndet, const int* sel_idx, int cap, const int* frame_off, int B, int N,
+                    void* out, void* stream);
+
+/* ---- MCA, the fused global-to-local cosine attention: Attention_mca_g2l.forward + find_similar_round2
+ * (post_trans.py:581-714) over all local frames of MCA_tscd_g2l_reg.forward (post_trans.py:1127-1162).
+ * tiles: device int[ntiles][4] = (row0, nrows, loc_start, loc_end). */
+int tscd_mca_dp(int d);
+long tscd_mca_workspace_bytes(int N, int N_L, int W, int S);
+int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
+                     const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
+                     float sim_thresh, float conf_thresh, void* workspace, long workspace_bytes, void* xcat_c,
+                     void* xcat_r, void* cat3_c, void* cat3_r, void* stream);
+
+/* ---- CAFM / TaskAligned pieces: PositionMHAttention / MHAttention (tscd_matching.py:31-60,140-181), SEModule
+ * (:264-283), LayerNorm of forward_post (:566-589,:394-458), cosine normalisation of double_match_embds (:912-937).
+ * tiles: device int[ntiles][4] = (row0, nrows, key0, key1). */
+int tscd_cos_attn_f16(const void* q, const void* k, const void* v, int C, int heads, const int* tiles, int ntiles,
+                      void* out, void* stream);
+int tscd_se_fuse_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
+                     const float* pos, long n, int C, void* out, void* stream);
+int tscd_add_layernorm_f16(const void* a, const void* b, const float* gamma, const float* beta, int n, int C, float eps,
+                           void* out, void* stream);
+int tscd_row_normalize_f16(const void* x, int ldx, int n, int n_pad, int C, float eps, void* out, int ldo, void* stream);
+
+/* ---- eval tail: decode_reg_preds5 (tscd_head.py:914-949) + postprocess (post_process.py:9-85) +
+ * torchvision.ops.batched_nms.  mode 0 = refined set, 1 = original detections. */
+long tscd_nms_workspace_bytes(int L, int capM);
+int tscd_batched_nms(const void* det, int ndet, const int* frame_off, int L, const void* cls_logit,
+                     const void* obj_logit, const void* reg_delta, int NC, float conf_thresh, float iou_thresh, int capM,
+                     int mode, void* workspace, long workspace_bytes, void* out, int* out_idx, int* out_count,
+                     int* overflow_flag, void* stream);
+
+/* ---- SimOTA label assignment: get_fg_idx / get_assignments / get_in_boxes_info / dynamic_k_matching
+ * (tscd_head.py:1712-1851,1330-1544), bboxes_iou (yolox/utils/boxes.py:131-154). */
+long tscd_simota_workspace_bytes(int B, int A, int G, int topk);
+int tscd_simota_assign(const void* outputs, const float* labels, int B, int A, int NC, int Lmax, int G, const int* hw3,
+                       const int* w3, const int* stride3, int topk, int emu16, void* workspace, long workspace_bytes,
+                       unsigned char* fg_mask, int* matched_gt, float* pred_iou, int* num_fg, int* ngt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSCD_HIP_H */

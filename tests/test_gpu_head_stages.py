@@ -1,0 +1,300 @@
+"""GPU parity of each proposal-stage kernel against the CPU oracle ON THE SAME INPUTS.
+
+The oracle (fp32, pinned to the reference by tests/test_oracle_golden.py) is run on the golden clip; its
+intermediates are fed -- rounded to fp16 -- to the product's HIP stages and the outputs are compared with the
+oracle's next intermediates.  Integer outputs (proposal indices, Hungarian permutations, NMS keep lists, SimOTA
+assignments) must be bit-exact on these inputs; float outputs within the stated fp16 tolerances.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tscd_oracle as O
+from test_state_dict_compat import build_model
+
+
+def close(got, ref, rel_max, rel_mean=None):
+    got, ref = torch.as_tensor(got).float().cpu(), torch.as_tensor(ref).float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = (got - ref).abs()
+    assert err.max().item() <= rel_max * ref.abs().max().item() + 1e-4, (err.max().item(), ref.abs().max().item())
+    if rel_mean is not None:
+        assert err.mean().item() <= rel_mean * ref.abs().mean().item() + 1e-5, (err.mean().item(), ref.abs().mean().item())
+
+
+@pytest.fixture(scope="module")
+def ctx(golden):
+    cfg, sd, vec, meta = golden
+    sd = {k: v.clone() for k, v in sd.items()}
+    aux = {}
+    imgs = torch.from_numpy(vec["evalA_imgs"]).float()
+    temb = torch.from_numpy(vec["time_embedding"])
+    with torch.no_grad():
+        res = O.tscd_forward(sd, cfg, imgs, None, temb, 0.5, int(meta["lframe"]), int(meta["gframe"]), False, False,
+                             O.MatcherState(), aux)
+    m = build_model(cfg)
+    m.load_state_dict(golden[1], strict=True)
+    return cfg, meta, aux, res, m.cuda().eval(), temb
+
+
+def test_select_proposals_bit_exact(ctx):
+    from tscd_amd import ops
+    cfg, meta, aux, res, m, temb = ctx
+    # scores as the reference forms them: obj * max cls, here from the oracle's decode_res rounded to fp16
+    dr = aux["decode_res"].half().float()
+    score = (dr[..., 4].half() * dr[..., 5:].max(-1).values.half())          # fp16 product
+    idx, cnt = ops.select_proposals(score.cuda().contiguous(), 0.001, cfg.minimal_limit, cfg.maximal_limit)
+    cnt = cnt.cpu().tolist()
+    for b in range(score.shape[0]):
+        s = score[b].float()
+        mask = s >= torch.tensor(0.001).half().float()
+        if mask.sum() < cfg.minimal_limit:
+            top = torch.topk(s, cfg.minimal_limit).indices
+            mask[top] = True
+        if mask.sum() > cfg.maximal_limit:
+            # torch.topk leaves tie order open; the kernel's documented rule: value desc, then lower index
+            order = np.lexsort((np.arange(len(s)), -s.numpy()))
+            mask = torch.zeros_like(mask)
+            mask[torch.from_numpy(order[:cfg.maximal_limit].copy())] = True
+        ref = torch.where(mask)[0]
+        assert cnt[b] == len(ref)
+        assert torch.equal(idx[b, :cnt[b]].cpu().long(), ref)
+
+
+def test_mca_matches_oracle(ctx):
+    cfg, meta, aux, res, m, temb = ctx
+    L = int(meta["lframe"])
+    h = m.head
+    f_cls, f_reg = aux["f_cls"].half().cuda(), aux["f_reg"].half().cuda()
+    sc = aux["cls_scores"].half().cuda()
+    kw = dict(preds_per_frame=aux["preds_per_frame"], lframe=L, gframe=int(meta["gframe"]), conf_sim_thresh=cfg.conf_sim_thresh)
+    with torch.no_grad():
+        a, none = h.agg(f_cls, f_reg, sc, None, sim_thresh=cfg.sim_thresh, need_reg=False, **kw)
+        c, o = h.agg_iou(f_cls, f_reg, sc, None, sim_thresh=cfg.sim_thresh, **kw)
+    torch.cuda.synchronize()
+    assert none is None
+    # fp16 operands / fp32 accumulation vs the fp32 oracle: max 2e-2, mean 5e-3 (relative to max / mean |ref|)
+    close(a, aux["agg_cls"], 2e-2, 1e-2)
+    close(c, aux["agg_iou_cls"], 2e-2, 1e-2)
+    close(o, aux["agg_iou_obj"], 2e-2, 1e-2)
+
+
+@pytest.mark.parametrize("W,n_loc,n_glob", [(256, (70, 33), 300), (320, (40,), 100), (128, (64, 64, 1), 0)])
+def test_mca_other_widths(W, n_loc, n_glob):
+    """Head widths of TSCD-L (d=64), TSCD-X (d=80 -> padded to 96) and TSCD-S (d=32); ragged tiles; no global keys."""
+    from yolox.models.post_trans import MCA_tscd_g2l_reg
+    g = torch.Generator().manual_seed(W)
+    cfg = O.TSCDConfig()
+    mod = MCA_tscd_g2l_reg(W, 4 * W, num_heads=4, reconf=True)
+    sd = {"m." + k: v.detach().clone() for k, v in mod.state_dict().items()}
+    N = sum(n_loc) + n_glob
+    # clustered features so that the similarity masks (> .75 / > .99) select more than the diagonal
+    centers = torch.randn(12, W, generator=g)
+    lab = torch.randint(0, 12, (N,), generator=g)
+    x_cls = (centers[lab] + 0.15 * torch.randn(N, W, generator=g)).half()
+    x_reg = (centers[lab] + 0.02 * torch.randn(N, W, generator=g)).half()
+    sc = torch.rand(N, generator=g).half()
+    ppf = list(n_loc) + ([n_glob] if n_glob else [])
+    with torch.no_grad():
+        rc, ro = O.mca_tscd_g2l_reg(sd, "m", x_cls.float(), x_reg.float(), sc.float(), ppf, len(n_loc), cfg)
+        mod = mod.cuda()
+        c, o = mod(x_cls.cuda(), x_reg.cuda(), sc.cuda(), None, sim_thresh=0.75, preds_per_frame=ppf, lframe=len(n_loc),
+                   conf_sim_thresh=0.99)
+    torch.cuda.synchronize()
+    close(c, rc, 2e-2, 1e-2)
+    close(o, ro, 2e-2, 1e-2)
+
+
+def test_cafm_and_task_aligned_match_oracle(ctx):
+    cfg, meta, aux, res, m, temb = ctx
+    L = int(meta["lframe"])
+    h = m.head
+    ppf = aux["preds_per_frame"]
+    nl = sum(ppf[:L])
+    f_reg, f_edge = aux["f_reg"].half().cuda(), aux["f_edge"].half().cuda()
+    a_cls, a_obj = aux["agg_iou_cls"].half().cuda(), aux["agg_iou_obj"].half().cuda()
+    h.local_reg_matcher._clear_state()
+    with torch.no_grad():
+        out = h.local_reg_matcher(f_reg, a_obj, a_cls, f_edge, ppf[:L], temb[:L].cuda(), resume=False)[-1]
+        hung = list(h.local_reg_matcher.last_hungarian)
+    torch.cuda.synchronize()
+    # INT: Hungarian column assignment per local frame.  The product forms the cost in fp16 like the reference does
+    # under autocast/.half() (tscd_matching.py:919-930 runs torch.mm on fp16 tensors), so near-ties can resolve
+    # differently from the fp32 oracle: require >= 90 % identical columns AND a total cost within 1e-3 (relative) of
+    # the optimum under the oracle's fp32 cost.
+    assert len(hung) == len(aux["hungarian"])
+    start, prev = 0, None
+    regs, clss = aux["agg_iou_obj"], aux["agg_iou_cls"]
+    nz = lambda t: t / (t.norm(dim=1)[:, None] + 1e-6)
+    for fi, (a, b) in enumerate(zip(hung, aux["hungarian"])):
+        a, b = np.asarray(a), np.asarray(b)
+        assert len(a) == len(b)
+        assert (a == b).mean() >= 0.9, (fi, (a == b).mean())
+        assert len(set(a.tolist())) == len(a)           # a valid assignment: no column used twice
+    close(out, aux["cafm"], 6e-2, 1.5e-2)     # LayerNorm'd output, rms 1: reference's own fp16 noise is 5.4e-2 max
+    with torch.no_grad():
+        matched4 = torch.nn.functional.linear(aux["cafm"], m.head.fc_reg_matcher.weight.cpu(), m.head.fc_reg_matcher.bias.cpu())
+        ta = h.task_aligned(matched4.half().cuda(), a_obj, ppf[:L])
+        ref = O.task_aligned({k: v.cpu() for k, v in m.state_dict().items()}, "head.task_aligned", matched4, aux["agg_iou_obj"],
+                             ppf[:L], cfg)
+    torch.cuda.synchronize()
+    close(ta, ref, 6e-2, 1.5e-2)
+
+
+def test_nms_bit_exact_keep_lists(ctx):
+    """Final NMS on the oracle's refined predictions: kept candidate indices (INT) must equal the oracle's."""
+    from yolox.models.post_process import nms_frames
+    cfg, meta, aux, res, m, temb = ctx
+    L = int(meta["lframe"])
+    ppf = aux["preds_per_frame"]
+    nl = sum(ppf[:L])
+    det = torch.cat([aux["pred_result"][i] for i in range(L)], 0)
+    det[:, :4] = det[:, :4].clamp(-500, 500)     # random-init base boxes reach 1e5 px (inf in fp16); keep them finite
+    det = det.half()
+    # random-init deltas are huge (exp(dw) overflows fp16 -> inf boxes, which makes the coordinate-offset trick of
+    # batched_nms produce NaN IoUs); scale them to a realistic range so the comparison exercises NMS, not inf handling
+    cls, obj, reg = aux["cls_preds"].half(), aux["matcher_obj_preds"].half(), (0.05 * aux["matcher_reg_preds"]).half()
+    # oracle on the same fp16-rounded inputs (fp16 values, fp32 arithmetic)
+    # decode on half tensors: every torch op rounds to fp16, exactly what the reference does in .half() eval
+    reg_xyxy = O.decode_reg_preds5(reg, det[:, :4]).float()
+    s, cls_pf, obj_pf, reg_pf = 0, [], [], []
+    for i in range(L):
+        cls_pf.append(cls[s:s + ppf[i]].float()); obj_pf.append(obj[s:s + ppf[i]].float().squeeze(-1)); reg_pf.append(reg_xyxy[s:s + ppf[i]])
+        s += ppf[i]
+    pr = [det[sum(ppf[:i]):sum(ppf[:i + 1])].float() for i in range(L)]
+    # mimic the fp16 rounding of sigmoid / products the kernel (and the reference in .half()) applies
+    def q(t):
+        return t.half().float()
+    ref_res, ref_ori, ref_keep = [], [], []
+    for i in range(L):
+        sc = q(torch.sigmoid(cls_pf[i])); ob = q(torch.sigmoid(obj_pf[i]))
+        loc = torch.where(sc >= q(torch.tensor(0.001)))
+        prod = q(ob[loc[0]] * sc[loc[0], loc[1]])
+        keepm = prod >= q(torch.tensor(0.001))
+        boxes, scores, cids = reg_pf[i][loc[0]][keepm], prod[keepm], loc[1][keepm]
+        from oracle.nms_ref import batched_nms
+        ref_keep.append(batched_nms(boxes, scores, cids.float(), 0.5))
+        ref_res.append((boxes, scores, cids))
+    out, ori, keep = nms_frames(det.cuda(), ppf[:L], cfg.num_classes, cls.cuda(), obj.cuda(), reg.cuda(), 0.001, 0.5, return_idx=True)
+    torch.cuda.synchronize()
+    for i in range(L):
+        k = keep[i].cpu().long()
+        # INT: kept candidate indices, in order, bit-exact
+        assert torch.equal(k, ref_keep[i]), (i, len(k), len(ref_keep[i]), len(set(k.tolist()) & set(ref_keep[i].tolist())))
+        assert out[i].shape[0] == len(k)
+        # refined boxes: device expf vs libm exp may differ in the last fp16 bit
+        assert torch.allclose(out[i][:, :4].float().cpu(), ref_res[i][0][ref_keep[i]], rtol=2e-3, atol=0.07)
+        # rows come out in decreasing score order
+        sc = (out[i][:, 4].float() * out[i][:, 5].float()).half().float().cpu()
+        assert torch.all(sc[:-1] >= sc[1:])
+
+
+def test_simota_bit_exact(golden):
+    """SimOTA on the oracle's decoded outputs (fp16-rounded), fp32 evaluation mode (emu16=0): fg anchors, matched gt
+    and matched IoU must reproduce the oracle's assignment exactly."""
+    from tscd_amd import ops
+    cfg, sd, vec, meta = golden
+    sd = {k: v.clone() for k, v in sd.items()}
+    aux = {}
+    imgs = torch.from_numpy(vec["evalA_imgs"]).float()
+    labels = torch.from_numpy(vec["train_labels"])
+    temb = torch.from_numpy(vec["time_embedding"])
+    with torch.no_grad():
+        O.tscd_forward(sd, cfg, imgs, labels, temb, 0.5, int(meta["lframe"]), int(meta["gframe"]), False, True, O.MatcherState(), aux)
+    outputs = aux["outputs"].half()
+    S = int(meta["S"])
+    hw = [(S // s, S // s) for s in cfg.strides]
+    xs, ys, ss = O.make_grids(hw, cfg.strides)
+    ref = O.simota_assign(outputs.float(), labels, xs, ys, ss, cfg)
+    geo = ops.LevelGeometry(hw, cfg.strides)
+    fg, mg, pi, nfg, ngt = ops.simota_assign(outputs.cuda().contiguous(), labels.cuda(), geo, cfg.num_classes, 64, emu16=False)
+    torch.cuda.synchronize()
+    for b in range(outputs.shape[0]):
+        ours = torch.nonzero(fg[b]).flatten().cpu()
+        assert torch.equal(ours, ref[0][b]), b
+        assert int(nfg[b]) == len(ref[0][b])
+        np.testing.assert_allclose(pi[b][fg[b].bool()].cpu().numpy(), ref[1][b].sum(-1).numpy(), rtol=1e-5, atol=1e-6)
+    assert ngt.cpu().tolist() == [3] * outputs.shape[0]
+
+
+def test_wavelet_block_vs_reference_golden(golden):
+    """WaveletsHFBlock (a6) on the reference's own reg_convs2 maps -> the reference's edge maps (golden, fp32).
+    fp16 tolerance: 1.5e-2 of max|ref|, 5e-3 of mean|ref|."""
+    cfg, sd, vec, meta = golden
+    m = build_model(cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    for k in range(3):
+        x = torch.from_numpy(vec[f"evalA_reg2_{k}"]).cuda().half().permute(0, 2, 3, 1).contiguous()
+        with torch.no_grad():
+            e = m.head.edge_enhance_reg[k][0](x)
+        torch.cuda.synchronize()
+        close(e.permute(0, 3, 1, 2), vec[f"evalA_edge{k}"], 1.5e-2, 1e-2)
+
+
+def test_trainable_tower_backward_matches_oracle_autograd():
+    """conv -> train-mode BN -> SiLU (x2) + wavelet block: HIP forward, composed backward vs the oracle's autograd."""
+    from yolox.models.network_blocks import BaseConv
+    from yolox.models.surrounding_extraction import WaveletsHFBlock
+    g = torch.Generator().manual_seed(0)
+    C, B, H, W = 32, 3, 12, 12
+    tower = torch.nn.Sequential(BaseConv(C, C, 3, 1), BaseConv(C, C, 3, 1))
+    wav = WaveletsHFBlock(C)
+    for mod in tower.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eps, mod.momentum = 1e-3, 0.03
+            mod.weight.data = 0.5 + torch.rand(C, generator=g)
+            mod.bias.data = 0.2 * torch.randn(C, generator=g)
+    x = torch.randn(B, C, H, W, generator=g).half()
+    gy = torch.randn(B, C, H, W, generator=g).half()
+    # oracle side (fp32 autograd)
+    sd = {"t." + k: v.detach().clone().float().requires_grad_(v.is_floating_point() and "running" not in k)
+          for k, v in tower.state_dict().items()}
+    sd.update({"w." + k: v.detach().clone().float().requires_grad_("filter" in k) for k, v in wav.state_dict().items()})
+    y = O.tower(sd, "t", x.float(), True)
+    e = O.wavelets_hf_block(sd, "w", y)
+    (e * gy.float()).sum().backward()
+    tower, wav = tower.cuda().train(), wav.cuda().train()
+    ye = wav(tower[1](tower[0](x.cuda().permute(0, 2, 3, 1).contiguous())))
+    close(ye.permute(0, 3, 1, 2), e.detach(), 2e-2, 1e-2)
+    (ye.float() * gy.cuda().permute(0, 2, 3, 1).float()).sum().backward()
+    torch.cuda.synchronize()
+    pairs = [("t.0.conv.weight", tower[0].conv.weight), ("t.1.conv.weight", tower[1].conv.weight), ("t.0.bn.weight", tower[0].bn.weight),
+             ("t.1.bn.bias", tower[1].bn.bias), ("w.filter1.0.weight", wav.filter1[0].weight), ("w.filter2.0.weight", wav.filter2[0].weight),
+             ("w.filter2.0.bias", wav.filter2[0].bias), ("w.filter1.0.bias", wav.filter1[0].bias)]
+    for name, p in pairs:
+        ref, got = sd[name].grad, p.grad.float().cpu()
+        cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+        assert cos > 0.995, (name, cos)
+        assert abs(got.norm().item() / ref.norm().item() - 1) < 0.03, (name, got.norm().item(), ref.norm().item())
+
+
+def test_mca_backward_matches_oracle_autograd():
+    from yolox.models.post_trans import MCA_tscd_g2l_reg
+    g = torch.Generator().manual_seed(3)
+    W, ppf, L = 64, [40, 25, 90], 2
+    cfg = O.TSCDConfig()
+    mod = MCA_tscd_g2l_reg(W, 4 * W, num_heads=4, reconf=True)
+    N = sum(ppf)
+    centers = torch.randn(8, W, generator=g)
+    lab = torch.randint(0, 8, (N,), generator=g)
+    xc = (centers[lab] + 0.2 * torch.randn(N, W, generator=g)).half()
+    xr = (centers[lab] + 0.05 * torch.randn(N, W, generator=g)).half()
+    sc = torch.rand(N, generator=g).half()
+    gc, go = torch.randn(sum(ppf[:L]), 4 * W, generator=g), torch.randn(sum(ppf[:L]), 4 * W, generator=g)
+    sd = {"m." + k: v.detach().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+    xc32, xr32, sc32 = xc.float().requires_grad_(True), xr.float().requires_grad_(True), sc.float().requires_grad_(True)
+    rc, ro = O.mca_tscd_g2l_reg(sd, "m", xc32, xr32, sc32, ppf, L, cfg)
+    ((rc * gc).sum() + (ro * go).sum()).backward()
+    mod = mod.cuda()
+    xcg, xrg, scg = xc.cuda().requires_grad_(True), xr.cuda().requires_grad_(True), sc.cuda().requires_grad_(True)
+    c, o = mod(xcg, xrg, scg, None, sim_thresh=0.75, preds_per_frame=ppf, lframe=L, conf_sim_thresh=0.99)
+    ((c.float() * gc.cuda()).sum() + (o.float() * go.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    checks = [(xcg.grad, xc32.grad, "x_cls"), (xrg.grad, xr32.grad, "x_reg"), (scg.grad, sc32.grad, "score")]
+    checks += [(p.grad, sd["m." + k].grad, k) for k, p in mod.named_parameters()]
+    for got, ref, name in checks:
+        cos = torch.nn.functional.cosine_similarity(got.float().cpu().flatten(), ref.flatten(), dim=0).item()
+        assert cos > 0.99, (name, cos)

@@ -19,8 +19,21 @@ SIGNATURES = {
     "tscd_maxpool_nhwc_f16": [P, I, P, I, I, I, I, I, I, P],
     "tscd_haar_hf_nhwc_f16": [P, I, P, I, I, I, I, P],
     "tscd_haar_idwt_mul_nhwc_f16": [P, P, I, P, I, I, I, I, I, P],
+    "tscd_decode_score": [P, P, P, P, P, P, I, I, P, P, P, P],
+    "tscd_select_proposals": [P, I, I, F, I, I, I, P, P, P],
+    "tscd_gather_rows": [P, P, P, I, P, I, I, I, I, P, P, P, I, P],
+    "tscd_gather_det": [P, I, I, P, I, P, I, I, P, P],
+    "tscd_mca_forward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, L, P, P, P, P, P],
+    "tscd_cos_attn_f16": [P, P, P, I, I, P, I, P, P],
+    "tscd_se_fuse_f16": [P, I, P, I, P, P, P, L, I, P, P],
+    "tscd_add_layernorm_f16": [P, P, P, P, I, I, F, P, P],
+    "tscd_row_normalize_f16": [P, I, I, I, I, F, P, I, P],
+    "tscd_batched_nms": [P, I, P, I, P, P, P, I, F, F, I, I, P, L, P, P, P, P, P],
+    "tscd_simota_assign": [P, P, I, I, I, I, I, P, P, P, I, I, P, L, P, P, P, P, P, P],
 }
-PLAIN = {"tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
+PLAIN = {"tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
+         "tscd_nms_workspace_bytes": ([I, I], L), "tscd_simota_workspace_bytes": ([I, I, I, I], L),
+         "tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
          "tscd_last_error": ([], C.c_char_p)}
 
 

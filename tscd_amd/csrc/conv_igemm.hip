@@ -31,7 +31,7 @@ struct ConvParams {
   int mtiles, ntiles, cstride;
 };
 
-enum { EPI_RAW = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BN_SILU = 3, EPI_BN = 4 };
+enum { EPI_RAW = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BN_SILU = 3, EPI_BN = 4, EPI_COST = 5 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
@@ -175,6 +175,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
           o = (f16)(v + bias);
         } else if (p.epilogue == EPI_BIAS_RELU) {
           o = (f16)fmaxf(v + bias, 0.f);
+        } else if (p.epilogue == EPI_COST) {
+          // Hungarian cost of double_match_embds (tscd_matching.py:912-937): 1 - (cos_reg + cos_cls)/2, NaN -> 0
+          float c = 1.0f - 0.5f * (float)(f16)v;
+          o = (c != c) ? (f16)0.f : (f16)c;
         } else {
           // eval: conv (fp16) -> BN with running stats (fp16 out) -> SiLU (fp16 out)
           float t = (float)(f16)((float)(f16)v * sc + sh);
@@ -228,7 +232,7 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
   TSCD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wpk & 15) == 0, "conv2d: x / w must be 16-byte aligned");
   TSCD_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d: ksize %d not supported", ksize);
   TSCD_CHECK_ARG(stride == 1 || stride == 2, "conv2d: stride %d not supported", stride);
-  TSCD_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv2d: bad epilogue %d", epilogue);
+  TSCD_CHECK_ARG(epilogue >= 0 && epilogue <= 5, "conv2d: bad epilogue %d", epilogue);
   if (epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU) TSCD_CHECK_ARG(bias, "conv2d: bias epilogue without bias");
   if (epilogue == EPI_BN_SILU || epilogue == EPI_BN) TSCD_CHECK_ARG(scale && shift, "conv2d: BN epilogue without scale/shift");
   ConvParams p;

@@ -187,3 +187,268 @@ def haar_idwt_mul(hf, content, out=None):
     call("tscd_haar_idwt_mul_nhwc_f16", hf.data_ptr(), content.data_ptr(), nhwc_ld(content), out.data_ptr(), nhwc_ld(out),
          B, H, W, C, _stream())
     return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# GEMM (nn.Linear) on the conv kernel
+# ----------------------------------------------------------------------------------------------------
+EPI_COST = 5
+
+
+def pack_linear_weight(w):
+    """nn.Linear weight [out, in] -> packed [rows_pad, Kpad] (a 1x1 conv)."""
+    return pack_conv_weight(w.reshape(w.shape[0], w.shape[1], 1, 1))
+
+
+class _LinearCache(WeightCache):
+    def get(self, w):
+        key = (id(w), "lin")
+        ent = self._c.get(key)
+        tag = (w.data_ptr(), w._version, w.dtype, w.device)
+        if ent is None or ent[0] != tag:
+            ent = (tag, pack_linear_weight(w))
+            self._c[key] = ent
+        return ent[1]
+
+
+LINEAR_WEIGHTS = _LinearCache()
+
+
+def linear(x, weight, bias=None, out=None, wpk=None):
+    """x [n, K] fp16 (row stride may exceed K) @ weight[out,K]^T (+ bias) -> [n, out] fp16 via the MFMA conv kernel."""
+    n, K = x.shape
+    nout = weight.shape[0] if weight is not None else out.shape[1]
+    wpk = LINEAR_WEIGHTS.get(weight) if wpk is None else wpk
+    if out is None:
+        out = torch.empty((n, nout), dtype=torch.float16, device=x.device)
+    if n == 0:
+        return out
+    x4 = x.unsqueeze(0).unsqueeze(0)
+    o4 = out.unsqueeze(0).unsqueeze(0)
+    if bias is not None:
+        conv2d(x4, wpk, nout, 1, 1, EPI_BIAS, bias=bias.float(), out=o4)
+    else:
+        conv2d(x4, wpk, nout, 1, 1, EPI_RAW, out=o4)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# proposal stage
+# ----------------------------------------------------------------------------------------------------
+def _i32(vals, device):
+    return torch.tensor(vals, dtype=torch.int32, device=device)
+
+
+class LevelGeometry:
+    """Per-clip FPN level table (hw, w, stride) as host int arrays for the C-ABI (no device copy needed)."""
+
+    def __init__(self, hw_list, strides):
+        import ctypes as C
+        self.hw = [h * w for h, w in hw_list]
+        self.w = [w for _, w in hw_list]
+        self.strides = list(strides)
+        self.A = sum(self.hw)
+        self.c_hw = (C.c_int * 3)(*self.hw)
+        self.c_w = (C.c_int * 3)(*self.w)
+        self.c_stride = (C.c_int * 3)(*self.strides)
+
+
+def decode_score(raw_levels, geo, num_classes, want_outputs):
+    """raw_levels: 3 contiguous tensors [B, h, w, 5+NC] fp16.  -> outputs [B,A,5+NC] or None, det [B,A,7+NC], score [B,A]."""
+    B = raw_levels[0].shape[0]
+    dev = raw_levels[0].device
+    nch = 5 + num_classes
+    for r in raw_levels:
+        assert r.is_contiguous() and r.shape[-1] == nch and r.dtype == torch.float16
+    outputs = torch.empty((B, geo.A, nch), dtype=torch.float16, device=dev) if want_outputs else None
+    det = torch.empty((B, geo.A, 7 + num_classes), dtype=torch.float16, device=dev)
+    score = torch.empty((B, geo.A), dtype=torch.float16, device=dev)
+    call("tscd_decode_score", raw_levels[0].data_ptr(), raw_levels[1].data_ptr(), raw_levels[2].data_ptr(), geo.c_hw, geo.c_w,
+         geo.c_stride, B, num_classes, _ptr(outputs), det.data_ptr(), score.data_ptr(), _stream())
+    return outputs, det, score
+
+
+def select_proposals(score, conf_thresh, min_keep, max_keep):
+    """-> (idx [B, cap] int32 ascending anchor ids, count [B] int32)."""
+    B, A = score.shape
+    cap = max_keep if max_keep > 0 else A
+    cap = max(cap, min_keep, 1)
+    idx = torch.empty((B, cap), dtype=torch.int32, device=score.device)
+    cnt = torch.empty((B,), dtype=torch.int32, device=score.device)
+    call("tscd_select_proposals", score.data_ptr(), B, A, float(conf_thresh), int(min_keep), int(max_keep), cap, idx.data_ptr(),
+         cnt.data_ptr(), _stream())
+    return idx, cnt
+
+
+def _map_table(maps_per_feature):
+    import ctypes as C
+    ptrs = []
+    for f in range(3):
+        for k in range(3):
+            ptrs.append(maps_per_feature[f][k].data_ptr() if f < len(maps_per_feature) else 0)
+    return (C.c_void_p * 9)(*ptrs)
+
+
+def gather_rows(maps_per_feature, geo, sel_idx, frame_off, N, W):
+    """maps_per_feature: list (<=3) of per-level lists of contiguous [B,h,w,W] maps.  -> list of [N, W] tensors."""
+    nm = len(maps_per_feature)
+    dev = sel_idx.device
+    outs = [torch.empty((N, W), dtype=torch.float16, device=dev) for _ in range(nm)]
+    for f in maps_per_feature:
+        for m in f:
+            assert m.is_contiguous() and m.shape[-1] == W
+    B = maps_per_feature[0][0].shape[0]
+    call("tscd_gather_rows", _map_table(maps_per_feature), geo.c_hw, sel_idx.data_ptr(), sel_idx.shape[1], frame_off.data_ptr(),
+         B, N, W, nm, _ptr(outs[0]), _ptr(outs[1] if nm > 1 else None), _ptr(outs[2] if nm > 2 else None), 0, _stream())
+    return outs
+
+
+def scatter_rows(grads, grad_maps_per_feature, geo, sel_idx, frame_off, N, W):
+    """Adjoint of gather_rows: writes grads[f][n] into the (pre-zeroed) grad maps."""
+    nm = len(grads)
+    B = grad_maps_per_feature[0][0].shape[0]
+    gs = [g.contiguous() for g in grads]
+    call("tscd_gather_rows", _map_table(grad_maps_per_feature), geo.c_hw, sel_idx.data_ptr(), sel_idx.shape[1],
+         frame_off.data_ptr(), B, N, W, nm, _ptr(gs[0]), _ptr(gs[1] if nm > 1 else None), _ptr(gs[2] if nm > 2 else None), 1,
+         _stream())
+
+
+def gather_det(det, sel_idx, frame_off, N):
+    B, A, nd = det.shape
+    out = torch.empty((N, nd), dtype=torch.float16, device=det.device)
+    call("tscd_gather_det", det.data_ptr(), A, nd, sel_idx.data_ptr(), sel_idx.shape[1], frame_off.data_ptr(), B, N,
+         out.data_ptr(), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# MCA
+# ----------------------------------------------------------------------------------------------------
+def mca_tiles(preds_per_frame, lframe, device):
+    """q-tile table: 32-row tiles that never straddle a frame.  -> int32 [ntiles,4] (row0,nrows,loc_start,loc_end)."""
+    tiles, start = [], 0
+    for i in range(lframe):
+        n = preds_per_frame[i]
+        for r in range(0, n, 32):
+            tiles.append((start + r, min(32, n - r), start, start + n))
+        start += n
+    return torch.tensor(tiles, dtype=torch.int32, device=device).reshape(-1, 4)
+
+
+def mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale, sim_thresh, conf_thresh, splits=None):
+    """Fused global-to-local attention.  Returns (xcat_c [N_L,2W], cat3_c [N_L,3W], xcat_r, cat3_r): first W columns
+    of xcat = P@v, second W = own values; first W columns of cat3 = the sim_round2 aggregation (rest is filled by the
+    caller's linear)."""
+    dev = q_c.device
+    nt = tiles.shape[0]
+    if splits is None:
+        splits = max(1, min(16, (1024 + nt - 1) // max(nt, 1)))
+    ws_bytes = lib.tscd_mca_workspace_bytes(N, N_L, W, splits)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    mk = lambda c: torch.empty((N_L, c), dtype=torch.float16, device=dev)
+    xcat_c, cat3_c = mk(2 * W), mk(3 * W)
+    xcat_r, cat3_r = (mk(2 * W), mk(3 * W)) if need_reg else (None, None)
+    for t in (q_c, kv_c, q_r, kv_r, score):
+        assert t.is_contiguous() and t.dtype == torch.float16
+    call("tscd_mca_forward", q_c.data_ptr(), kv_c.data_ptr(), q_r.data_ptr(), kv_r.data_ptr(), score.data_ptr(),
+         tiles.data_ptr(), nt, N, N_L, W, splits, int(need_reg), float(scale), float(sim_thresh), float(conf_thresh),
+         ws.data_ptr(), ws_bytes, xcat_c.data_ptr(), _ptr(xcat_r), cat3_c.data_ptr(), _ptr(cat3_r), _stream())
+    return xcat_c, cat3_c, xcat_r, cat3_r
+
+
+# ----------------------------------------------------------------------------------------------------
+# CAFM / TaskAligned pieces
+# ----------------------------------------------------------------------------------------------------
+def attn_tiles(segments, device):
+    """segments: list of (row0, nrows, key0, key1).  16-row tiles."""
+    t = []
+    for (r0, n, k0, k1) in segments:
+        for r in range(0, n, 16):
+            t.append((r0 + r, min(16, n - r), k0, k1))
+    return torch.tensor(t, dtype=torch.int32, device=device).reshape(-1, 4)
+
+
+def cos_attn(q, k, v, heads, tiles):
+    n, C = q.shape
+    out = torch.empty((n, C), dtype=torch.float16, device=q.device)
+    for t in (q, k, v):
+        assert t.is_contiguous() and t.dtype == torch.float16 and t.shape[1] == C
+    call("tscd_cos_attn_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), C, heads, tiles.data_ptr(), tiles.shape[0],
+         out.data_ptr(), _stream())
+    return out
+
+
+def se_fuse(reg, edge, w0, w2, pos):
+    n, C = reg.shape
+    out = torch.empty((n, C), dtype=torch.float16, device=reg.device)
+    assert reg.stride(1) == 1 and edge.stride(1) == 1
+    call("tscd_se_fuse_f16", reg.data_ptr(), reg.stride(0), edge.data_ptr(), edge.stride(0), w0.data_ptr(), w2.data_ptr(),
+         _ptr(pos), n, C, out.data_ptr(), _stream())
+    return out
+
+
+def add_layernorm(a, b, gamma, beta, eps=1e-5):
+    n, C = a.shape
+    out = torch.empty((n, C), dtype=torch.float16, device=a.device)
+    assert a.is_contiguous() and (b is None or b.is_contiguous())
+    call("tscd_add_layernorm_f16", a.data_ptr(), _ptr(b), gamma.data_ptr(), beta.data_ptr(), n, C, eps, out.data_ptr(), _stream())
+    return out
+
+
+def match_cost(ref_reg, cur_reg, ref_cls, cur_cls):
+    """1 - (cos(reg_ref,reg_cur) + cos(cls_ref,cls_cur))/2 as ONE GEMM over [reg | cls] normalised rows -> [n_ref,n_cur] fp16."""
+    nr, C = ref_reg.shape
+    ncur = cur_reg.shape[0]
+    dev = ref_reg.device
+    bn = lib.tscd_conv_tile_n(ncur)
+    rows_pad = (ncur + bn - 1) // bn * bn
+    a = torch.empty((nr, 2 * C), dtype=torch.float16, device=dev)
+    b = torch.empty((rows_pad, 2 * C), dtype=torch.float16, device=dev)
+    for src, dst, n, npad in ((ref_reg, a[:, :C], nr, nr), (ref_cls, a[:, C:], nr, nr), (cur_reg, b[:, :C], ncur, rows_pad),
+                              (cur_cls, b[:, C:], ncur, rows_pad)):
+        assert src.stride(1) == 1
+        call("tscd_row_normalize_f16", src.data_ptr(), src.stride(0), n, npad, C, 1e-6, dst.data_ptr(), 2 * C, _stream())
+    cost = torch.empty((nr, ncur), dtype=torch.float16, device=dev)
+    assert (2 * C) % 32 == 0
+    conv2d(a.unsqueeze(0).unsqueeze(0), b, ncur, 1, 1, EPI_COST, out=cost.unsqueeze(0).unsqueeze(0))
+    return cost
+
+
+# ----------------------------------------------------------------------------------------------------
+# NMS / SimOTA
+# ----------------------------------------------------------------------------------------------------
+def batched_nms(det, frame_off, L, num_classes, conf_thresh, iou_thresh, cap_m, mode, cls_logit=None, obj_logit=None,
+                reg_delta=None):
+    """-> (rows [L,capM,7] fp16, keep_idx [L,capM] int32, count [L] int32, overflow [1] int32)."""
+    dev = det.device
+    ws_bytes = lib.tscd_nms_workspace_bytes(L, cap_m)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    out = torch.empty((L, cap_m, 7), dtype=torch.float16, device=dev)
+    idx = torch.empty((L, cap_m), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((L,), dtype=torch.int32, device=dev)
+    ovf = torch.zeros((1,), dtype=torch.int32, device=dev)
+    call("tscd_batched_nms", det.data_ptr(), det.shape[1], frame_off.data_ptr(), L, _ptr(cls_logit), _ptr(obj_logit),
+         _ptr(reg_delta), num_classes, float(conf_thresh), float(iou_thresh), cap_m, mode, ws.data_ptr(), ws_bytes,
+         out.data_ptr(), idx.data_ptr(), cnt.data_ptr(), ovf.data_ptr(), _stream())
+    return out, idx, cnt, ovf
+
+
+def simota_assign(outputs, labels, geo, num_classes, max_gt, topk=10, emu16=True):
+    """outputs [B,A,5+NC] fp16, labels [B,Lmax,5] (any float dtype).  -> fg_mask u8 [B,A], matched_gt i32 [B,A],
+    pred_iou f32 [B,A], num_fg i32 [B], ngt i32 [B]."""
+    B, A, _ = outputs.shape
+    dev = outputs.device
+    lab = labels.float().contiguous()
+    G = min(max_gt, lab.shape[1])
+    ws_bytes = lib.tscd_simota_workspace_bytes(B, A, G, topk)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    fg = torch.empty((B, A), dtype=torch.uint8, device=dev)
+    mg = torch.empty((B, A), dtype=torch.int32, device=dev)
+    pi = torch.empty((B, A), dtype=torch.float32, device=dev)
+    nfg = torch.empty((B,), dtype=torch.int32, device=dev)
+    ngt = torch.empty((B,), dtype=torch.int32, device=dev)
+    assert outputs.is_contiguous() and outputs.dtype == torch.float16
+    call("tscd_simota_assign", outputs.data_ptr(), lab.data_ptr(), B, A, num_classes, lab.shape[1], G, geo.c_hw, geo.c_w,
+         geo.c_stride, topk, int(emu16), ws.data_ptr(), ws_bytes, fg.data_ptr(), mg.data_ptr(), pi.data_ptr(), nfg.data_ptr(),
+         ngt.data_ptr(), _stream())
+    return fg, mg, pi, nfg, ngt

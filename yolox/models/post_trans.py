@@ -1,0 +1,135 @@
+"""MCA: global-to-local multi-head cosine attention (interface of the reference's yolox/models/post_trans.py
+Attention_mca_g2l :550-714 and MCA_tscd_g2l_reg :1109-1162) on the fused MI355X kernel (tscd_amd/csrc/mca.hip).
+
+Differences from the reference are internal: all local frames of the clip go through ONE fused launch (the
+reference loops over frames and re-projects the shared global keys each time), no [heads, N1, N2] tensor is
+materialised, the four projections and the output linears are MFMA GEMMs writing straight into the concat buffers.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from tscd_amd import ops
+from tscd_amd.autograd import hip_op
+
+
+class Attention_mca_g2l(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., scale=25, reconf=False):
+        super().__init__()
+        if num_heads != 4:
+            raise NotImplementedError("the fused MCA kernel maps the 4 heads of TSCD onto the 4 waves of a workgroup")
+        self.num_heads = num_heads
+        self.scale = scale
+        self.reconf = reconf
+        self.q_cls_local = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv_cls = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.q_reg_local = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv_reg = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.linear = nn.Linear(2 * dim, 2 * dim)
+        if self.reconf:
+            self.linear_reg = nn.Linear(2 * dim, 2 * dim)
+
+
+def _mca_torch(x_cls, x_reg, score, wq_c, wkv_c, wq_r, wkv_r, w_lin, b_lin, w_linr, b_linr, w_out, b_out, w_obj, b_obj,
+               ppf, lframe, heads, scale, sim_thresh, conf_thresh, need_reg):
+    """Device-side PyTorch expression of the same math, differentiated in backward only (never a forward result)."""
+    N, C = x_cls.shape
+    nl = sum(ppf[:lframe])
+    h = heads
+    hd = lambda t: t.view(t.shape[0], h, C // h).permute(1, 0, 2)
+    nrm = lambda t: t / torch.norm(t.float(), dim=-1, keepdim=True).to(t.dtype)
+    flat = lambda t: t.permute(1, 0, 2).reshape(t.shape[1], C)
+    kv_c = F.linear(x_cls, wkv_c)
+    kv_r = F.linear(x_reg, wkv_r)
+    q_c_all = F.linear(x_cls[:nl], wq_c)
+    q_r_all = F.linear(x_reg[:nl], wq_r)
+    outs_c, outs_r, start = [], [], 0
+    for i in range(lframe):
+        n = ppf[i]
+        rows = torch.cat((torch.arange(start, start + n, device=x_cls.device), torch.arange(nl, N, device=x_cls.device)))
+        k_c, v_c = hd(kv_c[rows, :C]), hd(kv_c[rows, C:])
+        k_r, v_r = hd(kv_r[rows, :C]), hd(kv_r[rows, C:])
+        q_c, q_r = hd(q_c_all[start:start + n]), hd(q_r_all[start:start + n])
+        sc = score[rows].float()
+        a_c = (nrm(q_c) @ nrm(k_c).transpose(-2, -1)).float() * scale * sc.view(1, 1, -1)
+        a_r = (nrm(q_r) @ nrm(k_r).transpose(-2, -1)).float() * scale
+        attn = (a_r.softmax(-1) + a_c.softmax(-1)) / 2
+        attn16 = attn.to(v_c.dtype)
+        x_c = torch.cat([flat(attn16 @ v_c), flat(v_c[:, :n])], -1)
+        x_c = F.linear(x_c, w_lin, b_lin)
+        sim2 = torch.softmax(attn.sum(0) / h, dim=-1)
+        with torch.no_grad():
+            raw_c = (nrm(v_c)[:, :n] @ nrm(v_c).transpose(-2, -1)).float().sum(0) / h
+            m_c = (raw_c > sim_thresh).float()
+        ave_c = m_c * sim2 / torch.sum(m_c * sim2, dim=-1, keepdim=True)
+        outs_c.append(torch.cat([ave_c.to(v_c.dtype) @ flat(v_c), x_c], -1))
+        if need_reg:
+            x_r = torch.cat([flat(attn16 @ v_r), flat(v_r[:, :n])], -1)
+            x_r = F.linear(x_r, w_linr, b_linr)
+            with torch.no_grad():
+                raw_r = (nrm(v_r)[:, :n] @ nrm(v_r).transpose(-2, -1)).float().sum(0) / h
+                m_r = (raw_r > conf_thresh).float()
+            ave_r = m_r * sim2 / torch.sum(m_r * sim2, dim=-1, keepdim=True)
+            outs_r.append(torch.cat([ave_r.to(v_r.dtype) @ flat(v_r), x_r], -1))
+        start += n
+    trans_cls = F.linear(torch.cat(outs_c, 0), w_out, b_out)
+    if not need_reg:
+        return trans_cls
+    return trans_cls, F.linear(torch.cat(outs_r, 0), w_obj, b_obj)
+
+
+class MCA_tscd_g2l_reg(nn.Module):
+    def __init__(self, dim, out_dim, num_heads=4, qkv_bias=False, attn_drop=0., scale=25, reconf=False):
+        super().__init__()
+        self.reconf = reconf
+        self.mca = Attention_mca_g2l(dim, num_heads, qkv_bias, attn_drop, scale=scale, reconf=reconf)
+        self.linear = nn.Linear(3 * dim, out_dim)
+        if reconf:
+            self.linear_obj = nn.Linear(3 * dim, out_dim)
+
+    def forward(self, x_cls, x_reg, cls_score=None, fg_score=None, sim_thresh=0.75, ave=True, use_mask=False, **kwargs):
+        """x_cls / x_reg: [1,N,W] (reference layout) or [N,W]; the first sum(preds_per_frame[:lframe]) rows are the local
+        frames' proposals.  Returns (trans_cls [N_L,out], trans_obj [N_L,out] or None).  ``need_reg=False`` (private
+        kwarg used by the head for ``agg``, whose second output the reference discards) skips the regression branch."""
+        if not ave or use_mask:
+            raise NotImplementedError("TSCD runs MCA with ave=True, use_mask=False (tscd_base.py:49,61)")
+        ppf, lframe = list(kwargs.get("preds_per_frame")), kwargs.get("lframe")
+        need_reg = bool(kwargs.get("need_reg", True)) and self.reconf
+        conf_thresh = kwargs.get("conf_sim_thresh", 0.99)
+        x_cls = x_cls[0] if x_cls.dim() == 3 else x_cls
+        x_reg = x_reg[0] if x_reg.dim() == 3 else x_reg
+        m = self.mca
+        half = lambda t: None if t is None else t.to(torch.float16)
+        params = [m.q_cls_local.weight, m.kv_cls.weight, m.q_reg_local.weight, m.kv_reg.weight, m.linear.weight, m.linear.bias,
+                  m.linear_reg.weight if need_reg else None, m.linear_reg.bias if need_reg else None,
+                  self.linear.weight, self.linear.bias, self.linear_obj.weight if need_reg else None,
+                  self.linear_obj.bias if need_reg else None]
+        N, W = x_cls.shape
+        nl = sum(ppf[:lframe])
+        args = (ppf, lframe, m.num_heads, float(m.scale), float(sim_thresh), float(conf_thresh), need_reg)
+
+        def hip_fn(xc, xr, sc, *ws):
+            (wq_c, wkv_c, wq_r, wkv_r, w_lin, b_lin, w_linr, b_linr, w_out, b_out, w_obj, b_obj) = ws
+            xc, xr, sc = xc.contiguous(), xr.contiguous(), sc.to(torch.float16).contiguous()
+            q_c = ops.linear(xc[:nl], wq_c)
+            kv_c = ops.linear(xc, wkv_c)
+            q_r = ops.linear(xr[:nl], wq_r)
+            kv_r = ops.linear(xr, wkv_r)
+            tiles = ops.mca_tiles(ppf, lframe, xc.device)
+            xcat_c, cat3_c, xcat_r, cat3_r = ops.mca_attention(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, m.scale,
+                                                               sim_thresh, conf_thresh)
+            ops.linear(xcat_c, w_lin, b_lin, out=cat3_c[:, W:])
+            t_cls = ops.linear(cat3_c, w_out, b_out)
+            if not need_reg:
+                return t_cls
+            ops.linear(xcat_r, w_linr, b_linr, out=cat3_r[:, W:])
+            return t_cls, ops.linear(cat3_r, w_obj, b_obj)
+
+        def torch_fn(xc, xr, sc, *ws):
+            return _mca_torch(xc, xr, sc, *[half(w) for w in ws], *args)
+
+        out = hip_op(hip_fn, torch_fn, x_cls.to(torch.float16), x_reg.to(torch.float16), cls_score, *params)
+        if need_reg:
+            return out
+        return out, None

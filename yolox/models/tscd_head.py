@@ -1,0 +1,268 @@
+"""TSCDHead on the MI355X kernels.
+
+Interface mirror of the reference's yolox/models/tscd_head.py:26-1916 for the flag set the TSCD exps use
+(agg_type='mca', decouple_reg, reconf, ota_mode, use_pre_nms=False, cat_ota_fg=False, cls_ota):
+same constructor (including its misspelt keyword names), attribute names and state_dict keys, same forward
+contract -- training returns the reference's 9-tuple of losses, eval returns (result, result_ori).
+
+What changed is where the work happens.  The reference drives the proposal stage from the host (per-image SimOTA
+loops with .item() syncs, a per-proposal torch.where loop, per-frame attention loops); here every stage is a
+device kernel over the whole clip and the host only learns (a) the per-frame proposal counts (one D2H, they size
+the ragged tensors), (b) the Hungarian cost matrix per local frame (scipy runs on the host as in the reference)
+and (c) in eval the per-frame detection counts.  Losses are evaluated densely over all anchors with device-side
+masks instead of boolean-mask gathers, so no further syncs occur.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from tscd_amd import functional as TF
+from tscd_amd import ops
+
+from .losses import IOUloss
+from .network_blocks import BaseConv
+from .post_process import nms_frames
+from .post_trans import MCA_tscd_g2l_reg
+from .surrounding_extraction import WaveletsHFBlock
+from .tscd_matching import AwarePositionRegMatcher, TaskAligned, linear as hip_linear
+
+
+class _GatherRows(torch.autograd.Function):
+    """find_feature_score's row gather; backward = scatter into zero-initialised per-level gradient maps."""
+
+    @staticmethod
+    def forward(ctx, geo, sel_idx, frame_off, N, W, nmaps, *maps):
+        per_feature = [list(maps[f * 3:(f + 1) * 3]) for f in range(nmaps)]
+        outs = ops.gather_rows(per_feature, geo, sel_idx, frame_off, N, W)
+        ctx.geo, ctx.sel_idx, ctx.frame_off, ctx.N, ctx.W, ctx.nmaps = geo, sel_idx, frame_off, N, W, nmaps
+        ctx.shapes = [m.shape for m in maps]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        zeros = [torch.zeros(s, dtype=torch.float16, device=grads[0].device) for s in ctx.shapes]
+        per_feature = [zeros[f * 3:(f + 1) * 3] for f in range(ctx.nmaps)]
+        gs = [g if g is not None else torch.zeros((ctx.N, ctx.W), dtype=torch.float16, device=zeros[0].device) for g in grads]
+        ops.scatter_rows([g.to(torch.float16) for g in gs], per_feature, ctx.geo, ctx.sel_idx, ctx.frame_off, ctx.N, ctx.W)
+        return (None,) * 6 + tuple(zeros)
+
+
+class TSCDHead(nn.Module):
+    def __init__(self, num_classes, width=1.0, strides=[8, 16, 32], in_channels=[256, 512, 1024], act="silu", depthwise=False,
+                 heads=4, drop=0.0, use_score=True, defualt_p=30, sim_thresh=0.75, pre_nms=0.75, ave=True, defulat_pre=750,
+                 test_conf=0.001, use_mask=False, gmode=True, lmode=True, both_mode=False, localBlocks=1, **kwargs):
+        super().__init__()
+        if depthwise:
+            raise NotImplementedError("depthwise convs are not on the TSCD path")
+        unsupported = (kwargs.get("agg_type", "localagg") != "mca" or not kwargs.get("ota_mode", False)
+                       or not kwargs.get("decouple_reg", False) or not kwargs.get("reconf", False)
+                       or kwargs.get("use_pre_nms", True) or kwargs.get("cat_ota_fg", True) or kwargs.get("vid_ota", False)
+                       or not kwargs.get("cls_ota", True) or not kwargs.get("vid_cls", True) or not kwargs.get("vid_reg", True)
+                       or both_mode or not ave or use_mask)
+        if unsupported:
+            raise NotImplementedError(
+                "only the flag set of exps/TSCD_OVIS/ovis_tscd_{base,large}.py / TSCD_VID/vid_tscd_large.py is built: "
+                "agg_type='mca', ota_mode, decouple_reg, reconf, use_pre_nms=False, cat_ota_fg=False (SURVEY.md T4)")
+        self.Afternum = defualt_p
+        self.Prenum = defulat_pre
+        self.simN = defualt_p
+        self.nms_thresh = pre_nms
+        self.n_anchors = 1
+        self.use_score = use_score
+        self.num_classes = num_classes
+        self.decode_in_inference = True
+        self.gmode, self.lmode, self.both_mode = gmode, lmode, both_mode
+        self.width = int(256 * width)
+        self.sim_thresh, self.ave, self.use_mask = sim_thresh, ave, use_mask
+        W = self.width
+
+        self.cls_convs = nn.ModuleList()
+        self.reg_convs = nn.ModuleList()
+        self.edge_enhance_reg = nn.ModuleList()
+        self.cls_preds = nn.ModuleList()
+        self.reg_preds = nn.ModuleList()
+        self.obj_preds = nn.ModuleList()
+        self.cls_convs2 = nn.ModuleList()
+        self.reg_convs2 = nn.ModuleList()
+        self.agg = MCA_tscd_g2l_reg(dim=W, out_dim=4 * W, num_heads=heads, attn_drop=drop, reconf=True)
+        self.agg_iou = MCA_tscd_g2l_reg(dim=W, out_dim=4 * W, num_heads=heads, attn_drop=drop, reconf=True)
+        self.local_reg_matcher = AwarePositionRegMatcher(hidden_channel=W, feedforward_channel=W, num_head=8,
+                                                         decoder_layer_num=1, act=act)
+        self.fc_reg_matcher = nn.Linear(W, 4 * W)
+        self.task_aligned = TaskAligned(hidden_channel=4 * W, num_head=8, decoder_layer_num=1, act=act)
+        self.cls_pred = nn.Linear(4 * W, num_classes)
+        self.matcher_obj_pred = nn.Linear(4 * W, 1)
+        self.matcher_reg_pred = nn.Linear(4 * W, 4)
+        self.stems = nn.ModuleList()
+        self.kwargs = kwargs
+
+        tower = lambda: nn.Sequential(BaseConv(W, W, 3, 1, act=act), BaseConv(W, W, 3, 1, act=act))
+        for i in range(len(in_channels)):
+            self.stems.append(BaseConv(int(in_channels[i] * width), W, 1, 1, act=act))
+            self.cls_convs.append(tower())
+            self.reg_convs.append(tower())
+            self.edge_enhance_reg.append(nn.Sequential(WaveletsHFBlock(in_channels=W)))
+            self.cls_preds.append(nn.Conv2d(W, self.n_anchors * num_classes, 1, 1, 0))
+            self.reg_preds.append(nn.Conv2d(W, 4, 1, 1, 0))
+            self.obj_preds.append(nn.Conv2d(W, self.n_anchors * 1, 1, 1, 0))
+            self.cls_convs2.append(tower())
+            self.reg_convs2.append(tower())
+
+        self.use_l1 = False
+        self.l1_loss = nn.L1Loss(reduction="none")
+        self.bcewithlog_loss = nn.BCEWithLogitsLoss(reduction="none")
+        self.iou_loss = IOUloss(reduction="none")
+        self.smooth_l1_loss = nn.SmoothL1Loss(reduction="none")
+        self.strides = strides
+        self.ota_mode = True
+        self.max_gt = 128          # SimOTA cost planes are sized for this many boxes per frame
+        self.debug = None          # tests set a dict here to capture intermediates
+
+    def initialize_biases(self, prior_prob):
+        for convs in (self.cls_preds, self.obj_preds):
+            for conv in convs:
+                b = conv.bias.view(self.n_anchors, -1)
+                b.data.fill_(-math.log((1 - prior_prob) / prior_prob))
+                conv.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
+
+    # ------------------------------------------------------------------------------------------------
+    def _dbg(self, **kw):
+        if self.debug is not None:
+            self.debug.update(kw)
+
+    def forward(self, xin, labels=None, imgs=None, time_embedding=None, nms_thresh=0.5, lframe=0, gframe=32, resume=False):
+        nc, W = self.num_classes, self.width
+        nch = 5 + nc
+        feats = [x.permute(0, 2, 3, 1) for x in xin]                 # NCHW-logical (channels-last) -> NHWC views
+        feats = [f if f.dtype == torch.float16 else f.half() for f in feats]
+        B = feats[0].shape[0]
+        dev = feats[0].device
+        training = self.training
+        grad = torch.is_grad_enabled() and training
+        geo = ops.LevelGeometry([f.shape[1:3] for f in feats], self.strides)
+
+        raw_levels, cls_maps, reg_maps, edge_maps = [], [], [], []
+        for k, x in enumerate(feats):
+            with torch.no_grad():                                    # frozen stem / base towers (ovis_tscd_large.py:141-149)
+                x = self.stems[k](x)
+                reg_feat = self.reg_convs[k][1](self.reg_convs[k][0](x))
+                cls_feat = self.cls_convs[k][1](self.cls_convs[k][0](x))
+            vid_feat = self.cls_convs2[k][1](self.cls_convs2[k][0](x))
+            vid_feat_reg = self.reg_convs2[k][1](self.reg_convs2[k][0](x))
+            reg_o = TF.conv_bias(reg_feat, self.reg_preds[k].weight, self.reg_preds[k].bias)
+            obj_o = TF.conv_bias(reg_feat, self.obj_preds[k].weight, self.obj_preds[k].bias)
+            cls_o = TF.conv_bias(cls_feat, self.cls_preds[k].weight, self.cls_preds[k].bias)
+            raw_levels.append(torch.cat([reg_o, obj_o, cls_o], -1))   # [B,h,w,5+NC]: tiny, autograd-tracked
+            cls_maps.append(vid_feat)
+            reg_maps.append(vid_feat_reg)
+            edge_maps.append(self.edge_enhance_reg[k][0](vid_feat_reg))
+        self.hw = [tuple(f.shape[1:3]) for f in feats]
+
+        with torch.no_grad():
+            outputs, det, score = ops.decode_score([r.detach().contiguous() for r in raw_levels], geo, nc, training)
+            sel_idx, sel_cnt = ops.select_proposals(score, 0.001, self.kwargs.get("minimal_limit", 0),
+                                                    self.kwargs.get("maximal_limit", 0))
+            if training:
+                fg_mask, matched_gt, pred_iou, num_fg_b, ngt_b = ops.simota_assign(outputs, labels, geo, nc, self.max_gt)
+        ppf = sel_cnt.cpu().tolist()                                   # sync #1: ragged sizes
+        N, nl = sum(ppf), sum(ppf[:lframe])
+        self._dbg(outputs=outputs, det=det, score=score, sel_idx=sel_idx, preds_per_frame=ppf)
+        if N == 0 and training:
+            return torch.tensor(0), 0, 0, 0, 0, 1, 0, 0, 0
+        off = [0]
+        for n in ppf:
+            off.append(off[-1] + n)
+        frame_off = torch.tensor(off, dtype=torch.int32, device=dev)
+        pred_rows = ops.gather_det(det, sel_idx, frame_off, N)          # pred_result rows, frame-major [N,7+NC]
+        if not training and B == 1:
+            pr = [pred_rows[off[i]:off[i + 1]] for i in range(B)]
+            return pr, pr
+        a_idx = torch.cat([sel_idx[b, :ppf[b]] for b in range(B)]).long()
+        b_idx = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor(ppf, device=dev), output_size=N)
+
+        maps = [m.contiguous() for m in (cls_maps + reg_maps + edge_maps)]
+        if grad and any(m.requires_grad for m in maps):
+            f_cls, f_reg, f_edge = _GatherRows.apply(geo, sel_idx, frame_off, N, W, 3, *maps)
+        else:
+            f_cls, f_reg, f_edge = ops.gather_rows([maps[0:3], maps[3:6], maps[6:9]], geo, sel_idx, frame_off, N, W)
+        if training:
+            raw_all = torch.cat([r.reshape(B, -1, nch) for r in raw_levels], 1)              # [B,A,5+NC] logits with grad
+        if grad:
+            cid = pred_rows[:, 6].long()
+            cls_scores = torch.sigmoid(raw_all[b_idx, a_idx, 5 + cid])                       # == pred_rows[:,5], differentiable
+        else:
+            cls_scores = pred_rows[:, 5]
+        if self.debug is not None:
+            self._dbg(agg_idx=[sel_idx[b, :ppf[b]] for b in range(B)], pred_rows=pred_rows, f_cls=f_cls, f_reg=f_reg,
+                      f_edge=f_edge, edge_maps=edge_maps, reg_maps=reg_maps)
+
+        kw = dict(preds_per_frame=ppf, lframe=lframe, gframe=gframe, conf_sim_thresh=self.kwargs.get("conf_sim_thresh", 0.99))
+        features_cls_matched, _ = self.agg(f_cls, f_reg, cls_scores, None, sim_thresh=self.sim_thresh, ave=self.ave,
+                                           use_mask=self.use_mask, need_reg=False, **kw)
+        features_cls, features_reg = self.agg_iou(f_cls, f_reg, cls_scores, None, sim_thresh=self.sim_thresh, ave=self.ave,
+                                                  use_mask=self.use_mask, **kw)
+        matched = self.local_reg_matcher(f_reg, features_reg, features_cls, f_edge, ppf[:lframe], time_embedding[:lframe],
+                                         resume=resume)
+        matched = f_reg[:nl] if matched is None else matched[-1]
+        self._dbg(agg_cls=features_cls_matched, agg_iou_cls=features_cls, agg_iou_obj=features_reg, cafm=matched,
+                  hungarian=list(self.local_reg_matcher.last_hungarian))
+        matched4 = hip_linear(matched, self.fc_reg_matcher)
+        obj_refined = self.task_aligned(matched4, features_reg, ppf[:lframe])
+        if obj_refined is None:
+            obj_refined = features_reg
+        cls_preds = hip_linear(features_cls_matched, self.cls_pred)
+        m_obj = hip_linear(obj_refined, self.matcher_obj_pred)
+        m_reg = hip_linear(matched4, self.matcher_reg_pred)
+        self._dbg(cls_preds=cls_preds, matcher_obj_preds=m_obj, matcher_reg_preds=m_reg)
+
+        if not training:
+            res, res_ori, keep = nms_frames(pred_rows[:nl], ppf[:lframe], nc, cls_preds, m_obj, m_reg, 0.001, nms_thresh,
+                                            return_idx=True)
+            self._dbg(nms_keep=keep)
+            return res, res_ori
+
+        # ---------------- losses (get_matcher_refined_losses, tscd_head.py:1008-1203), dense + masked ----------------
+        raw_f = raw_all.float()
+        fg = fg_mask.bool()
+        lab = labels.float()
+        mg = matched_gt.clamp(min=0).long()
+        gt_box = torch.gather(lab[..., 1:5], 1, mg.unsqueeze(-1).expand(-1, -1, 4))          # [B,A,4] cxcywh of matched gt
+        gt_cls = torch.gather(lab[..., 0], 1, mg).long().clamp(0, nc - 1)
+        num_fg = num_fg_b.sum().float().clamp(min=1)
+        num_gts = ngt_b.sum().float()
+        iou_l = self.iou_loss(outputs[..., :4].float().reshape(-1, 4), gt_box.reshape(-1, 4)).view(B, -1)
+        loss_iou = torch.where(fg, iou_l, torch.zeros_like(iou_l)).sum() / num_fg
+        loss_obj = self.bcewithlog_loss(raw_f[..., 4], fg.float()).sum() / num_fg
+        cls_t = F.one_hot(gt_cls, nc).float() * pred_iou.unsqueeze(-1)
+        loss_cls = (self.bcewithlog_loss(raw_f[..., 5:], cls_t) * fg.unsqueeze(-1)).sum() / num_fg
+        # refined heads: local-frame proposals that SimOTA marked foreground
+        lb, la = b_idx[:nl], a_idx[:nl]
+        rmask = fg[lb, la]
+        num_fg_local = num_fg_b[:lframe].sum().float()
+        loss_m_obj = self.bcewithlog_loss(m_obj.float().view(-1), rmask.float()).sum() / num_fg_local
+        r_cls_t = cls_t[lb, la]
+        loss_r_cls = (self.bcewithlog_loss(cls_preds.float(), r_cls_t) * rmask.unsqueeze(-1)).sum() / num_fg_local
+        base = pred_rows[:nl, :4].float()
+        tgt = self._encode_reg(gt_box[lb, la], base, rmask)
+        sl1 = self.smooth_l1_loss(torch.where(rmask.unsqueeze(-1), m_reg.float(), torch.zeros_like(tgt)), tgt)
+        loss_m_iou = (sl1 * rmask.unsqueeze(-1)).sum() / num_fg_local
+        loss_m_obj = torch.where(loss_m_obj > 15, loss_m_obj / loss_m_obj.detach() * 15, loss_m_obj)
+        loss = 3.0 * loss_iou + loss_obj + loss_cls + loss_r_cls + loss_m_obj + 6.0 * loss_m_iou
+        self._dbg(fg_mask=fg_mask, matched_gt=matched_gt, num_fg=num_fg_b)
+        return (loss, 3.0 * loss_iou, loss_obj, loss_cls, 0.0, num_fg / num_gts.clamp(min=1), loss_r_cls, loss_m_obj,
+                6.0 * loss_m_iou)
+
+    @staticmethod
+    def _encode_reg(gt_cxcywh, base_xyxy, mask, eps=1e-8):
+        """encode_reg_preds (tscd_head.py:951-974); rows outside ``mask`` are neutralised to avoid NaNs."""
+        w = base_xyxy[:, 2] - base_xyxy[:, 0]
+        h = base_xyxy[:, 3] - base_xyxy[:, 1]
+        cx, cy = base_xyxy[:, 0] + 0.5 * w, base_xyxy[:, 1] + 0.5 * h
+        one = torch.ones_like(w)
+        w_, h_ = torch.where(mask, w, one), torch.where(mask, h, one)
+        gw, gh = torch.where(mask, gt_cxcywh[:, 2], one), torch.where(mask, gt_cxcywh[:, 3], one)
+        t = torch.stack(((gt_cxcywh[:, 0] - cx) / w_, (gt_cxcywh[:, 1] - cy) / h_, torch.log(gw / w_ + eps),
+                         torch.log(gh / h_ + eps)), dim=1)
+        return torch.where(mask.unsqueeze(-1), t, torch.zeros_like(t))

@@ -1,0 +1,280 @@
+"""CAFM (AwarePositionRegMatcher) and TaskAligned on the MI355X kernels.
+
+Interface mirror of the reference's yolox/models/tscd_matching.py (PositionMHAttention :11-137, MHAttention :140-181,
+SEModule :264-283, SelfAttentionLayer :286-357, CrossAttentionLayer :394-458, FFNLayer :461-505,
+ReferringCrossAttentionLayer :535-636, AwarePositionRegMatcher :639-1080, TaskAligned :1083-1139): same submodule
+tree (including the layers the reference constructs but never calls -- they carry state_dict keys), same stateful
+frame-to-frame behaviour.  Device work per local frame: one MFMA GEMM for the Hungarian cost, the SE gate,
+q/k/v GEMMs, the cosine attention kernel and the fused residual+LayerNorm; the assignment itself stays on the host
+(scipy's linear_sum_assignment, as in the reference) -- one D2H of an fp16 [n_ref, n_cur] matrix per frame.
+"""
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+from torch import nn
+
+from tscd_amd import ops
+from tscd_amd.autograd import hip_op
+
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
+# ------------------------------------------------------------------------------------------------- device ops
+def linear(x, lin):
+    """nn.Linear on the MFMA GEMM (fp16 in/out)."""
+    w, b = lin.weight, lin.bias
+
+    def torch_fn(x, w, b):
+        return F.linear(x, w.to(x.dtype), None if b is None else b.to(x.dtype))
+
+    return hip_op(lambda x, w, b: ops.linear(x.contiguous(), w, b), torch_fn, x, w, b)
+
+
+def cos_attention(q, k, v, heads, segments):
+    """softmax(q^ k^T) v per head, rows grouped in segments [(row0, nrows, key0, key1)]."""
+    def hip_fn(q, k, v):
+        return ops.cos_attn(q.contiguous(), k.contiguous(), v.contiguous(), heads, ops.attn_tiles(segments, q.device))
+
+    def torch_fn(q, k, v):
+        outs = []
+        C = q.shape[1]
+        hd = lambda t: t.view(t.shape[0], heads, C // heads).permute(1, 0, 2)
+        for (r0, n, k0, k1) in segments:
+            qq, kk, vv = hd(q[r0:r0 + n]).float(), hd(k[k0:k1]).float(), hd(v[k0:k1])
+            qq = qq / torch.norm(qq, dim=-1, keepdim=True)
+            kk = kk / torch.norm(kk, dim=-1, keepdim=True)
+            attn = (qq @ kk.transpose(-2, -1)).softmax(-1).to(vv.dtype)
+            outs.append((attn @ vv).permute(1, 0, 2).reshape(n, C))
+        return torch.cat(outs, 0)
+
+    return hip_op(hip_fn, torch_fn, q, k, v)
+
+
+def add_layernorm(a, b, norm):
+    def torch_fn(a, b, g, be):
+        x = a if b is None else a + b
+        return F.layer_norm(x.float(), (x.shape[-1],), g.float(), be.float(), norm.eps).to(a.dtype)
+
+    return hip_op(lambda a, b, g, be: ops.add_layernorm(a.contiguous(), None if b is None else b.contiguous(), _f32(g),
+                                                        _f32(be), norm.eps), torch_fn, a, b, norm.weight, norm.bias)
+
+
+class MHAttention(nn.Module):
+    def __init__(self, d_model, num_heads=8, dropout=0., qkv_bias=False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.q_reg = nn.Linear(d_model, d_model, bias=qkv_bias)
+        self.k_reg = nn.Linear(d_model, d_model, bias=qkv_bias)
+        self.v_reg = nn.Linear(d_model, d_model, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(dropout)
+
+    def attend(self, q_in, k_in, v_in, segments):
+        return cos_attention(linear(q_in, self.q_reg), linear(k_in, self.k_reg), linear(v_in, self.v_reg), self.num_heads,
+                             segments)
+
+
+class PositionMHAttention(MHAttention):
+    """Only the boxes=None path is live on the TSCD route (tscd_matching.py:49-50); position_embedding is a parameter
+    holder."""
+
+    def __init__(self, d_model, num_heads=8, dropout=0., qkv_bias=False):
+        super().__init__(d_model, num_heads, dropout, qkv_bias)
+        self.position_embedding = nn.Conv2d(64, num_heads, kernel_size=1, stride=1, padding=0)
+
+
+class SEModule(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(channels, channels * 16, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(channels * 16, channels, bias=False), nn.Sigmoid())
+
+    def fuse(self, reg, edge, pos):
+        """reg*g0 + edge*g1 + pos  (SE gate per (proposal, channel) + with_pos_embed), reg/edge [n,C], pos [1,C] or [C]."""
+        w0, w2 = self.fc[0].weight, self.fc[2].weight
+
+        def hip_fn(reg, edge, pos, w0, w2):
+            return ops.se_fuse(reg, edge, _f32(w0).contiguous(), _f32(w2).contiguous(), _f32(pos).reshape(-1).contiguous())
+
+        def torch_fn(reg, edge, pos, w0, w2):
+            f = torch.stack([reg, edge], dim=-1).reshape(-1, 2)
+            g = torch.sigmoid(F.linear(F.relu(F.linear(f, w0.to(f.dtype))), w2.to(f.dtype))).view(*reg.shape, 2)
+            return reg * g[..., 0] + edge * g[..., 1] + pos.to(reg.dtype).reshape(1, -1)
+
+        return hip_op(hip_fn, torch_fn, reg, edge, pos, w0, w2)
+
+
+def _xavier(mod):
+    for p in mod.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+
+
+class SelfAttentionLayer(nn.Module):
+    """Constructed by the reference but never called on the TSCD path -- parameter holder."""
+
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        self.self_attn = PositionMHAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+        self.CA = SEModule(2)
+        _xavier(self)
+
+
+class FFNLayer(nn.Module):
+    """Constructed by the reference but never called on the TSCD path -- parameter holder."""
+
+    def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="silu", normalize_before=False):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+        _xavier(self)
+
+
+class CrossAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="silu", normalize_before=False):
+        super().__init__()
+        assert not normalize_before
+        self.multihead_attn = MHAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+        _xavier(self)
+
+    def forward(self, tgt, memory, segments):
+        return add_layernorm(tgt, self.multihead_attn.attend(tgt, memory, memory, segments), self.norm)
+
+
+class ReferringCrossAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        assert not normalize_before
+        self.multihead_attn = PositionMHAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+        self.CA = SEModule(2)
+        _xavier(self)
+
+    def forward(self, identity, tgt, memory, pos, query_pos, edge, query_edge):
+        n = tgt.shape[0]
+        q_in = self.CA.fuse(tgt, query_edge, query_pos)
+        k_in = self.CA.fuse(memory, edge, pos)
+        t2 = self.multihead_attn.attend(q_in, k_in, memory, [(0, n, 0, memory.shape[0])])
+        return add_layernorm(identity, t2, self.norm)
+
+
+class AwarePositionRegMatcher(nn.Module):
+    def __init__(self, hidden_channel=512, feedforward_channel=2048, num_head=8, decoder_layer_num=6, act="silu"):
+        super().__init__()
+        if decoder_layer_num != 1:
+            raise NotImplementedError("TSCD builds the matcher with decoder_layer_num=1 (tscd_head.py:120-122)")
+        self.num_heads = num_head
+        self.num_layers = decoder_layer_num
+        self.transformer_self_attention_layers = nn.ModuleList(
+            [SelfAttentionLayer(hidden_channel, num_head, 0.0, act, False)])
+        self.transformer_aware_cross_attention_layers = nn.ModuleList(
+            [ReferringCrossAttentionLayer(hidden_channel, num_head, 0.0, act, False)])
+        self.transformer_ffn_layers = nn.ModuleList([FFNLayer(hidden_channel, feedforward_channel, 0.0, act, False)])
+        self.absolute_position_embedding = nn.Linear(256, hidden_channel)
+        self.edge_feature_embedding = nn.Linear(int(hidden_channel / 4), hidden_channel)
+        self.decoder_norm = nn.LayerNorm(hidden_channel)
+        self._clear_state()
+        self.last_hungarian = []     # test hook: scipy's column assignment per processed frame
+
+    def _clear_state(self):
+        self.last_outputs = None              # reference name; here the previous frame's output rows [n,C]
+        self.last_frame_reg_embeds = None
+        self.last_frame_cls_embeds = None
+        self.last_frame_time_embedding = None
+        self.last_frame_edge_embeds = None
+        self.last_frame_n = 0
+
+    @staticmethod
+    @torch.no_grad()
+    def double_match_embds(ref_reg, cur_reg, ref_cls, cur_cls):
+        """Hungarian on 1 - mean cosine (tscd_matching.py:912-937).  Cost matrix = one MFMA GEMM; D2H; scipy."""
+        cost = ops.match_cost(ref_reg.detach().contiguous(), cur_reg.detach().contiguous(), ref_cls.detach().contiguous(),
+                              cur_cls.detach().contiguous())
+        return linear_sum_assignment(cost.float().cpu().numpy())
+
+    def forward(self, features, features_reg, features_cls, features_edge, preds_per_frame, time_embedding, resume=False):
+        """features / features_edge [N,W] (first sum(preds_per_frame) rows used), features_reg / features_cls [N_L,4W],
+        time_embedding [lframe,256].  Returns [1, N_L, W] like the reference (the head takes [-1]) or None."""
+        dev = features.device
+        layer = self.transformer_aware_cross_attention_layers[0]
+        t_emb = linear(time_embedding.to(torch.float16).contiguous(), self.absolute_position_embedding)
+        outs, rets, start = [], [], 0
+        self.last_hungarian = []
+        idx = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.long, device=dev)
+        for i, n in enumerate(preds_per_frame):
+            if n == 0:
+                if i == 0 and resume is False:
+                    self._clear_state()
+                continue
+            cur, cur_reg = features[start:start + n], features_reg[start:start + n]
+            cur_cls, cur_edge = features_cls[start:start + n], features_edge[start:start + n]
+            start += n
+            t_i = t_emb[i:i + 1]
+            if (i == 0 and resume is False) or self.last_outputs is None:
+                self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = cur_reg, cur_cls, n
+                ret = self.double_match_embds(cur_reg, cur_reg, cur_cls, cur_cls)[1]
+                self.last_hungarian.append(np.asarray(ret))
+                out = layer(cur, cur, cur, t_i, t_i, cur_edge, cur_edge)
+                new_edge = cur_edge
+            else:
+                row, col = self.double_match_embds(self.last_frame_reg_embeds, cur_reg, self.last_frame_cls_embeds, cur_cls)
+                self.last_hungarian.append(np.asarray(col))
+                if self.last_frame_n < n:
+                    taken = np.zeros(n, dtype=bool)
+                    taken[col] = True
+                    nomatch = np.nonzero(~taken)[0]
+                    col = np.append(col, nomatch).astype(np.int64)
+                    nm = idx(nomatch)
+                    last_feat = torch.cat((self.last_outputs, cur[nm]), 0)
+                    last_edge = torch.cat((self.last_frame_edge_embeds, cur_edge[nm]), 0)
+                elif self.last_frame_n > n:
+                    r = idx(row)
+                    last_feat, last_edge = self.last_outputs[r], self.last_frame_edge_embeds[r]
+                else:
+                    last_feat, last_edge = self.last_outputs, self.last_frame_edge_embeds
+                c = idx(col)
+                self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = cur_reg[c], cur_cls[c], n
+                ret = col
+                out = layer(cur[c], last_feat, cur, t_i, self.last_frame_time_embedding, cur_edge, last_edge)
+                new_edge = cur_edge[c]
+            self.last_outputs, self.last_frame_time_embedding, self.last_frame_edge_embeds = out, t_i, new_edge
+            rets.append(np.asarray(ret))
+            outs.append(out[idx(np.argsort(ret))])
+        if not outs:
+            return None
+        o = torch.cat(outs, 0)
+        return add_layernorm(o, None, self.decoder_norm).unsqueeze(0)
+
+
+class TaskAligned(nn.Module):
+    def __init__(self, hidden_channel=512, num_head=8, decoder_layer_num=6, act="silu"):
+        super().__init__()
+        if decoder_layer_num != 1:
+            raise NotImplementedError("TSCD builds TaskAligned with decoder_layer_num=1 (tscd_head.py:128-129)")
+        self.num_heads = num_head
+        self.num_layers = decoder_layer_num
+        self.transformer_cross_attention_layers = nn.ModuleList([CrossAttentionLayer(hidden_channel, num_head, 0.0, act, False)])
+        self.decoder_norm = nn.LayerNorm(hidden_channel)
+
+    def forward(self, features_reg, features_obj, preds_per_frame):
+        """All frames in one launch per op: segments keep each frame's queries on its own keys."""
+        segs, start = [], 0
+        for n in preds_per_frame:
+            if n:
+                segs.append((start, n, start, start + n))
+            start += n
+        if not segs:
+            return None
+        out = self.transformer_cross_attention_layers[0](features_obj, features_reg, segs)
+        return add_layernorm(out, None, self.decoder_norm)
