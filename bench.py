@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""TSCD hot-path benchmark: clips/s of one TRAIN step (fwd + bwd + SGD + EMA) of TSCD-L on synthetic 16-frame 576x576
+clips (BASELINE.json metric, configs[2]), one process per GPU, clips sharded data-parallel (weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the keys below).  `roofline` times the dominant kernel (the MFMA implicit-GEMM
+conv at the head-tower shape, 33 % of all FLOPs) with device events on the stream it runs on; `cpu_baseline` times
+the CPU oracle (oracle/tscd_oracle.py, the fp32 PyTorch restatement of the reference -- kind "port") on one clip of
+the same workload on the host cores of this box.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--lframe", type=int, default=4)
+    ap.add_argument("--size", type=int, default=576)
+    ap.add_argument("--depth", type=float, default=1.0)
+    ap.add_argument("--width", type=float, default=1.0)
+    ap.add_argument("--props", type=str, default="500", choices=["500", "50"], help="proposal regime (SURVEY 8d)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-only-baseline", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+NUM_CLASSES = 25
+
+
+def build_model(depth, width, props):
+    """Same construction as exps/TSCD_OVIS/ovis_tscd_large.py:52-159 (reference): freeze backbone + base head,
+    BN eps/momentum, prior bias; then the synthetic proposal-count control of SURVEY 8d."""
+    from yolox.models import TSCD, TSCDHead, YOLOPAFPN
+    torch.manual_seed(0)
+    in_channels = [256, 512, 1024]
+    backbone = YOLOPAFPN(depth, width, in_channels=in_channels)
+    for p in backbone.parameters():
+        p.requires_grad = False
+    more = dict(use_ffn=True, use_time_emd=False, use_loc_emd=True, loc_fuse_type="identity", use_qkv=True, local_mask=False,
+                local_mask_branch="", pure_pos_emb=False, loc_conf=False, iou_base=False, reconf=True, ota_mode=True, ota_cls=False,
+                traj_linking=False, iou_window=0, globalBlocks=1, use_pre_nms=False, cat_ota_fg=False, agg_type="mca",
+                minimal_limit=50, maximal_limit=500, conf_sim_thresh=0.99, decouple_reg=True)
+    head = TSCDHead(NUM_CLASSES, width, in_channels=in_channels, heads=4, drop=0.0, use_score=True, defualt_p=30, sim_thresh=0.75,
+                    pre_nms=0.75, ave=True, defulat_pre=750, test_conf=0.001, use_mask=False, gmode=True, lmode=True,
+                    both_mode=False, localBlocks=1, **more)
+    for mod in (head.stems, head.reg_convs, head.cls_convs, head.reg_preds):
+        for p in mod.parameters():
+            p.requires_grad = False
+    model = TSCD(backbone, head)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    model.head.initialize_biases(1e-2)
+    if props == "500":
+        for c in model.head.obj_preds:
+            c.bias.data.fill_(2.0)
+        for c in model.head.cls_preds:
+            c.bias.data.fill_(0.0)
+    # 27 parameter tensors never receive a gradient; a static set, so exclude them from DDP's reducer
+    dead = ("transformer_self_attention_layers", "transformer_ffn_layers", "edge_feature_embedding", "position_embedding",
+            "agg.linear_obj", "agg.mca.linear_reg", "agg_iou.linear.", "agg_iou.mca.linear.")
+    for k, p in model.named_parameters():
+        if any(d in k for d in dead):
+            p.requires_grad = False
+    return model
+
+
+def make_optimizer(model, lr=0.002 / 64 * 16, momentum=0.9, weight_decay=5e-4, stem_lr_ratio=0.1):
+    """4 parameter groups as ovis_tscd_large.py:164-197."""
+    pg0, pg1, pg2, pg3 = [], [], [], []
+    for k, v in model.named_modules():
+        if hasattr(v, "bias") and isinstance(v.bias, torch.nn.Parameter):
+            pg2.append(v.bias)
+        if isinstance(v, torch.nn.BatchNorm2d) or "bn" in k:
+            pg0.append(v.weight)
+        elif hasattr(v, "weight") and isinstance(v.weight, torch.nn.Parameter):
+            (pg3 if ("head.stem" in k or "head.reg_convs" in k or "head.cls_convs" in k) else pg1).append(v.weight)
+    tr = lambda ps: [p for p in ps if p.requires_grad]
+    opt = torch.optim.SGD(tr(pg0), lr=lr, momentum=momentum, nesterov=True)
+    opt.add_param_group({"params": tr(pg1), "weight_decay": weight_decay})
+    opt.add_param_group({"params": tr(pg2)})
+    if tr(pg3):
+        opt.add_param_group({"params": tr(pg3), "lr": lr * stem_lr_ratio, "weight_decay": weight_decay})
+    return opt
+
+
+class FusedEMA:
+    """ModelEMA.update (yolox/utils/ema.py:48-60) over every floating state tensor, as two multi-tensor launches."""
+
+    def __init__(self, model, decay=0.9998):
+        self.src = [v for v in model.state_dict().values() if v.dtype.is_floating_point]
+        self.ema = [v.detach().clone() for v in self.src]
+        self.updates = 0
+        self.decay = lambda x: decay * (1 - math.exp(-x / 2000))
+
+    @torch.no_grad()
+    def update(self):
+        self.updates += 1
+        d = self.decay(self.updates)
+        torch._foreach_mul_(self.ema, d)
+        torch._foreach_add_(self.ema, self.src, alpha=1.0 - d)
+
+
+def synth_clip(B, S, device, seed=0):
+    """SURVEY 8d synthetic inputs: uniform 0..255 images (fp16), 6 boxes per frame, sinusoidal time embedding."""
+    g = torch.Generator().manual_seed(seed)
+    imgs = (torch.rand(B, 3, S, S, generator=g) * 255).half()
+    targets = torch.zeros(B, 100, 5)
+    sc = S / 576.0
+    for j in range(6):
+        targets[:, j] = torch.tensor([float(j), (80 + 60 * j) * sc, (100 + 50 * j) * sc, (60 + 10 * j) * sc, (90 + 5 * j) * sc])
+    num_timescales = 128
+    inc = math.log(1.0e4) / (num_timescales - 1)
+    inv = torch.exp(torch.arange(0, num_timescales) * -inc)
+    st = torch.arange(B).float().unsqueeze(1) * inv.unsqueeze(0)
+    temb = torch.cat([torch.sin(st), torch.cos(st)], dim=1)
+    return imgs.to(device), targets.half().to(device), temb.half().to(device)
+
+
+def cpu_baseline(args, state_dict):
+    """The CPU oracle (fp32 PyTorch restatement of the reference, kind 'port') on ONE clip of the same workload."""
+    from oracle import tscd_oracle as O
+    ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("TSCD_CPU_THREADS", "16")))
+    torch.set_num_threads(ncores)
+    cfg = O.TSCDConfig(num_classes=NUM_CLASSES, depth=args.depth, width=args.width, minimal_limit=50, maximal_limit=500)
+    sd = {}
+    for k, v in state_dict.items():
+        v = v.detach().cpu()
+        v = v.float().clone() if v.is_floating_point() else v.clone()
+        if v.is_floating_point() and "running_" not in k and ("head.cls_convs2" in k or "head.reg_convs2" in k or "agg" in k
+                                                              or "matcher" in k or "task_aligned" in k or "_pred" in k
+                                                              or "edge_enhance" in k):
+            v.requires_grad_(True)
+        sd[k] = v
+    # bounded sample: a quarter clip (lframe/4 local + gframe/4 global frames) of the same workload, time scaled x4
+    div = 4 if args.frames % 4 == 0 and args.lframe % 4 == 0 else 1
+    nf, nl = args.frames // div, args.lframe // div
+    imgs, targets, temb = synth_clip(nf, args.size, "cpu")
+    t0 = time.time()
+    out = O.tscd_forward(sd, cfg, imgs.float(), targets.float(), temb.float(), 0.5, nl, nf - nl, False, True, O.MatcherState(), None)
+    out["total_loss"].backward()
+    dt = (time.time() - t0) * div
+    return {"value": 1.0 / dt, "unit": "clips/s", "cores": ncores, "kind": "port",
+            "sample": f"{nf} of {args.frames} frames ({nl} local + {nf - nl} global) @{args.size}^2, TSCD d{args.depth}/w{args.width}, "
+                      f"fwd+bwd, {args.props} props/frame, measured {dt / div:.1f} s x{div} = {dt:.1f} s per clip; "
+                      f"oracle/tscd_oracle.py, torch {torch.__version__} fp32, {ncores} threads"}
+
+
+def roofline_dominant_kernel(args, device):
+    """Head-tower conv (3x3, W->W, stride-8 level, all frames): conv_igemm_kernel<128,128,2,2>, MFMA-bound.
+    Algorithmic FLOPs per launch = 2 * (B*h*w) * W * (9*W)."""
+    from tscd_amd import ops
+    W = int(256 * args.width)
+    B, h = args.frames, args.size // 8
+    x = torch.randn(B, h, h, W, device=device).half()
+    w = (torch.randn(W, W, 3, 3, device=device) / math.sqrt(9 * W)).half()
+    wpk = ops.pack_conv_weight(w)
+    out = ops.empty_nhwc(B, h, h, W, device)
+    for _ in range(5):
+        ops.conv2d(x, wpk, W, 3, 1, out=out, want_stats=True)
+    torch.cuda.synchronize()
+    n = 30
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        ops.conv2d(x, wpk, W, 3, 1, out=out, want_stats=True)
+    e.record()
+    torch.cuda.synchronize()
+    t = s.elapsed_time(e) / n * 1e-3
+    flops = 2.0 * B * h * h * W * 9 * W
+    peak = 2500.0
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel<128,128,2,2>", "shape": f"B{B} {h}x{h} {W}->{W} 3x3", "achieved": flops / t / 1e12,
+            "peak": peak, "unit": "TFLOP/s", "frac": flops / t / 1e12 / peak, "traffic": None, "launch_us": t * 1e6}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    model = build_model(args.depth, args.width, args.props).to(device).train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    opt = make_optimizer(model)
+    scaler = torch.amp.GradScaler("cuda")
+    ema = FusedEMA(model)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
+                                                        gradient_as_bucket_view=True)
+    imgs, targets, temb = synth_clip(args.frames, args.size, device, seed=rank)
+    gframe = args.frames - args.lframe
+
+    def step():
+        out = net(imgs, targets, temb, lframe=args.lframe, gframe=gframe, resume=False)
+        loss = out["total_loss"]
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        ema.update()
+        return loss
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    verbose = bool(os.environ.get("TSCD_BENCH_VERBOSE"))
+    for i in range(args.warmup):
+        t1 = time.perf_counter()
+        l = step()
+        if verbose:
+            torch.cuda.synchronize()
+            print(f"[bench] warmup {i}: {time.perf_counter() - t1:.3f} s loss {float(l):.3f}", file=sys.stderr, flush=True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        ppf = model.head.debug["preds_per_frame"] if model.head.debug else None
+        roof = roofline_dominant_kernel(args, device)
+        line = {
+            "metric": "clips/s (16f 576^2, TSCD-L train step)", "value": world * args.steps / dt, "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"TSCD d{args.depth}/w{args.width} train step (fwd+bwd+SGD+EMA), {args.frames}-frame {args.size}^2 clip per GPU, "
+                                   f"lframe {args.lframe}+gframe {gframe}, {args.props} proposals/frame, {NUM_CLASSES} classes, random init",
+                       "clips_per_step": world, "parallelism": f"dp{world}"},
+            "loss": float(loss), "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args, sd0)
+            except Exception as ex:  # the baseline must never take the GPU number down with it
+                line["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,20 @@ int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* b
                          const float* shift, float* bn_partial, int B, int H, int W, int Cin, int Cout, int ksize,
                          int stride, int ldx, int ldy, int epilogue, void* stream);
 
+/* ---- backward of the trainable head convs (autograd of network_blocks.py:36-61 / surrounding_extraction.py:223-232
+ * under tscd_trainer.py:171-176).  Weight gradient of a stride-1 "same" conv as a pixel-axis GEMM with
+ * ds_read_b64_tr_b16 operand fetch and a deterministic split-K reduction; dw is fp32 in torch layout
+ * [Cout][Cin][KH][KW].  The data gradient is tscd_conv2d_nhwc_f16 on dY with tscd_pack_conv_weight(mode=1).
+ * tscd_bn_silu_bwd_f16: gradient of SiLU(BatchNorm_train(raw)); sums_out = [dbeta | dgamma]. */
+int tscd_conv_wgrad_splits(long M);
+long tscd_conv_wgrad_workspace_bytes(long M, int Cout, int Cin, int ksize);
+int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
+                             int ldx, int lddy, void* workspace, long workspace_bytes, void* stream);
+long tscd_bn_silu_bwd_workspace_bytes(long M, int C);
+int tscd_bn_silu_bwd_f16(const void* dy, const void* raw, const float* scale_shift, const float* mean,
+                         const float* invstd, const float* gamma, long M, int C, void* draw, float* sums_out,
+                         void* workspace, long workspace_bytes, void* stream);
+
 /* ---- BatchNorm (train-mode statistics / eval fold) + activation: network_blocks.py:52-58 with eps 1e-3,
  * momentum 0.03 (exps/TSCD_OVIS/ovis_tscd_large.py:109-113); Bottleneck shortcut add (network_blocks.py:176-179). */
 int tscd_bn_finalize(const float* partial, int mtiles, int cstride, int C, long count, const float* gamma,

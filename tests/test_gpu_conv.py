@@ -139,3 +139,24 @@ def test_focus_pool_upsample_haar():
     ref = content.float() * O.haar_idwt(torch.cat((torch.zeros(2, 16, 5, 7), hf_in.float()), 1))
     torch.cuda.synchronize()
     assert_close(out.permute(0, 3, 1, 2), ref, rel=2e-3, abs_=2e-3)
+
+
+@pytest.mark.parametrize("case", [(5, 16, 16, 32, 32, 1), (5, 4, 4, 32, 8, 1), (3, 12, 12, 32, 32, 3), (2, 20, 20, 256, 256, 3),
+                                  (1, 1, 300, 96, 200, 1), (2, 9, 7, 128, 96, 3)])
+def test_conv_wgrad_and_dgrad(case):
+    """Backward kernels of the trainable head convs vs PyTorch autograd of F.conv2d on the same fp16 operands (fp32
+    math): weight gradient (pixel-axis GEMM with ds_read_b64_tr_b16) 1e-3 relative, data gradient 2e-3."""
+    from tscd_amd import ops
+    B, H, W, Ci, Co, k = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Ci, generator=g).half()
+    dy = torch.randn(B, H, W, Co, generator=g).half()
+    wt = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).half()
+    xr = x.permute(0, 3, 1, 2).float().requires_grad_(True)
+    w = wt.float().requires_grad_(True)
+    F.conv2d(xr, w, None, 1, (k - 1) // 2).backward(dy.permute(0, 3, 1, 2).float())
+    dw = ops.conv_wgrad(x.to(dev()), dy.to(dev()), Ci, Co, k)
+    dx = ops.conv_dgrad(dy.to(dev()), wt.to(dev()))
+    torch.cuda.synchronize()
+    assert_close(dw, w.grad, rel=1e-3, abs_=1e-3)
+    assert_close(dx.permute(0, 3, 1, 2), xr.grad, rel=2e-3, abs_=2e-3)

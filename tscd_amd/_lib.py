@@ -2,6 +2,8 @@
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- load PyTorch-ROCm's bundled libamdhip64.so.7 FIRST so this library binds to the same HIP runtime
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtscd_hip.so")
 
@@ -29,9 +31,13 @@ SIGNATURES = {
     "tscd_add_layernorm_f16": [P, P, P, P, I, I, F, P, P],
     "tscd_row_normalize_f16": [P, I, I, I, I, F, P, I, P],
     "tscd_batched_nms": [P, I, P, I, P, P, P, I, F, F, I, I, P, L, P, P, P, P, P],
+    "tscd_conv_wgrad_nhwc_f16": [P, P, P, I, I, I, I, I, I, I, I, P, L, P],
+    "tscd_bn_silu_bwd_f16": [P, P, P, P, P, P, L, I, P, P, P, L, P],
     "tscd_simota_assign": [P, P, I, I, I, I, I, P, P, P, I, I, P, L, P, P, P, P, P, P],
 }
-PLAIN = {"tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
+PLAIN = {"tscd_conv_wgrad_splits": ([L], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
+         "tscd_bn_silu_bwd_workspace_bytes": ([L, I], L),
+         "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
          "tscd_nms_workspace_bytes": ([I, I], L), "tscd_simota_workspace_bytes": ([I, I, I, I], L),
          "tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
          "tscd_last_error": ([], C.c_char_p)}

@@ -1,0 +1,286 @@
+// Backward kernels of the trainable head convs (cls_convs2 / reg_convs2 towers, WaveletsHFBlock filters; reference:
+// autograd of network_blocks.py:36-61 and surrounding_extraction.py:223-232 under tscd_trainer.py:171-176).
+//
+// conv_wgrad  dW[cout][tap,cin] = sum_pixels dY[pix][cout] * X[pix shifted by tap][cin]  (stride-1, "same" padding)
+//   GEMM with the PIXEL axis as K: both operands are stored pixel-major ([pix][channel], NHWC), i.e. K is the slow
+//   index of both.  Tiles are staged into LDS as they lie in memory (coalesced 16-B rows) and the MFMA fragments are
+//   fetched with gfx950's hardware-transposing LDS read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group,
+//   returned column-major): two of them give a lane its 8 consecutive k (pixels) for its channel.  LDS rows are
+//   128 + 32 halves (320 B = 80 dwords = 16 mod 64 banks) so the 4 rows of a transposed read hit disjoint bank
+//   quarters.  Split-K over pixel ranges (gridDim.y) writes fp32 slabs that a second kernel reduces in a fixed order
+//   (deterministic, no float atomics) into the torch weight layout [Cout][Cin][KH][KW].
+// The data gradient of these stride-1 convs needs no kernel of its own: it is conv_igemm.hip run on dY with the
+// weights packed in "dgrad" order (flipped taps, in/out swapped).
+//
+// bn_silu_bwd_*  gradient of SiLU(BatchNorm_train(raw)) w.r.t. raw, gamma, beta in two passes over [M,C]:
+//   pass 1: dt = dy * silu'(t), per-channel partial sums of dt and dt*xhat (fixed-order reduction via bn_bwd_reduce);
+//   pass 2: draw = gamma*invstd * (dt - mean(dt) - xhat*mean(dt*xhat)).
+#include "common.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+  const f16* x;
+  const f16* dy;
+  float* part;   // [S][Cout][Ncols]
+  int B, H, W, Cin, Cout, KH, KW, pad;
+  int ldx, lddy;
+  int M, Ncols, S, ktiles_per_split, mtiles, ntiles;
+};
+
+__device__ __forceinline__ f16x8 tr_frag(const f16* tile_row0_col0, int ldst, int lane) {
+  // 16-lane group: lane i = 4q+p supplies &tile[q][4p]; receives column i of rows 0..3
+  const int i = lane & 15, q = i >> 2, p = i & 3;
+  auto a0 = (__attribute__((address_space(3))) s16x4*)(tile_row0_col0 + q * ldst + 4 * p);
+  auto a1 = (__attribute__((address_space(3))) s16x4*)(tile_row0_col0 + (q + 4) * ldst + 4 * p);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(a0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(a1);
+  // reinterpret the 64-bit results as whole vectors (per-element bit_cast of the builtin's result is miscompiled
+  // by hipcc 7.2: it broadcasts element 0)
+  f16x4 lo4 = __builtin_bit_cast(f16x4, lo), hi4 = __builtin_bit_cast(f16x4, hi);
+  f16x8 r = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+  constexpr int BM = 128, BN = 128, BK = 32, LDST = 160;
+  __shared__ __attribute__((aligned(16))) f16 Ys[2][BK][LDST];
+  __shared__ __attribute__((aligned(16))) f16 Xs[2][BK][LDST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int mt = blockIdx.x / p.ntiles, nt = blockIdx.x % p.ntiles;
+  const int c0 = mt * BM, n0 = nt * BN;
+  const int s = blockIdx.y;
+  const int kt0 = s * p.ktiles_per_split;
+  int kt1 = kt0 + p.ktiles_per_split;
+  const int ktotal = (p.M + BK - 1) / BK;
+  if (kt1 > ktotal) kt1 = ktotal;
+
+  // staging assignment: 2 (pixel row, 8-channel chunk) pairs per thread and operand
+  const int chunk = tid & 15, prow = tid >> 4;   // prow 0..15 (+16)
+  const int ych = c0 + chunk * 8;                // dY channels
+  const bool y_ok = ych < p.Cout;
+  const int ncol = n0 + chunk * 8;               // (tap, cin) column of X
+  const bool n_ok = ncol < p.Ncols;
+  const int tap = n_ok ? ncol / p.Cin : 0, cin = n_ok ? ncol - tap * p.Cin : 0;
+  const int dh = tap / p.KW - p.pad, dw = tap % p.KW - p.pad;
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f16x8 yreg[2], xreg[2];
+
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int m = kt * BK + prow + 16 * i;
+      bool mok = m < p.M;
+      int mm = mok ? m : 0;
+      yreg[i] = (mok && y_ok) ? *(const f16x8*)(p.dy + (long)mm * p.lddy + ych) : zero8;
+      int b = mm / (p.H * p.W);
+      int rem = mm - b * (p.H * p.W);
+      int ho = rem / p.W, wo = rem - ho * p.W;
+      int hi = ho + dh, wi = wo + dw;
+      bool ok = mok && n_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      xreg[i] = ok ? *(const f16x8*)(p.x + (((long)b * p.H + hi) * p.W + wi) * p.ldx + cin) : zero8;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *(f16x8*)(&Ys[buf][prow + 16 * i][chunk * 8]) = yreg[i];
+      *(f16x8*)(&Xs[buf][prow + 16 * i][chunk * 8]) = xreg[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (kt0 < kt1) {
+    load_tiles(kt0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  // fragment geometry (see tr_frag): 16-lane group g -> channel block 16*(g&1), k block 8*(g>>1)
+  const int g = lane >> 4;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    if (kt + 1 < kt1) load_tiles(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kb = ks * 16 + 8 * (g >> 1);
+      f16x8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = tr_frag(&Ys[buf][kb][wm * 64 + i * 32 + 16 * (g & 1)], LDST, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = tr_frag(&Xs[buf][kb][wn * 64 + j * 32 + 16 * (g & 1)], LDST, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < kt1) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = c0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < p.Cout && col < p.Ncols) p.part[((long)s * p.Cout + row) * p.Ncols + col] = acc[i][j][e];
+      }
+    }
+}
+
+// dW[cout][cin][kh][kw] (fp32, torch layout) = sum_s part[s][cout][(kh*KW+kw)*Cin + cin]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int S, int Cout, int Cin, int KH, int KW, float* __restrict__ dw) {
+  const long total = (long)Cout * Cin * KH * KW;
+  const int Ncols = KH * KW * Cin;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int kw = idx % KW;
+    long t = idx / KW;
+    int kh = t % KH;
+    t /= KH;
+    int ci = t % Cin, co = t / Cin;
+    long src = (long)co * Ncols + (kh * KW + kw) * Cin + ci;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[(long)s * Cout * Ncols + src];
+    dw[idx] = a;
+  }
+}
+
+extern "C" int tscd_conv_wgrad_splits(long M) {
+  long kt = (M + 31) / 32;
+  int s = (int)(kt / 96);   // >= ~96 k-tiles per split
+  if (s < 1) s = 1;
+  if (s > 32) s = 32;
+  return s;
+}
+extern "C" long tscd_conv_wgrad_workspace_bytes(long M, int Cout, int Cin, int ksize) {
+  return 4L * tscd_conv_wgrad_splits(M) * Cout * ksize * ksize * Cin + 256;
+}
+
+extern "C" int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
+                                        int ldx, int lddy, void* workspace, long workspace_bytes, void* stream) {
+  TSCD_CHECK_ARG(x && dy && dw && workspace, "conv_wgrad: null pointer");
+  TSCD_CHECK_ARG(ksize == 1 || ksize == 3, "conv_wgrad: ksize %d", ksize);
+  TSCD_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, "conv_wgrad: channels / strides must be multiples of 8");
+  TSCD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv_wgrad: pointers must be 16-byte aligned");
+  WgradParams p;
+  p.x = (const f16*)x; p.dy = (const f16*)dy; p.part = (float*)workspace;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = ksize; p.KW = ksize; p.pad = (ksize - 1) / 2;
+  p.ldx = ldx; p.lddy = lddy;
+  long M = (long)B * H * W;
+  TSCD_CHECK_ARG(M < (1L << 31), "conv_wgrad: M too large");
+  p.M = (int)M; p.Ncols = ksize * ksize * Cin;
+  p.S = tscd_conv_wgrad_splits(M);
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_conv_wgrad_workspace_bytes(M, Cout, Cin, ksize), "conv_wgrad: workspace too small");
+  int ktotal = (p.M + 31) / 32;
+  p.ktiles_per_split = (ktotal + p.S - 1) / p.S;
+  p.mtiles = cdiv(Cout, 128); p.ntiles = cdiv(p.Ncols, 128);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.mtiles * p.ntiles, p.S), dim3(256), 0, st, p);
+  TSCD_CHECK_LAUNCH("conv_wgrad");
+  long total = (long)Cout * p.Ncols;
+  int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, st, p.part, p.S, Cout, Cin, ksize, ksize, dw);
+  TSCD_CHECK_LAUNCH("wgrad_reduce");
+  return TSCD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- BN + SiLU backward
+#define BNB_ROWS 128
+// partial [nblk][2][C]: sum dt, sum dt*xhat over the block's rows
+__global__ void bn_silu_bwd_stats_kernel(const f16* __restrict__ dy, const f16* __restrict__ raw, const float* __restrict__ ss,
+                                         const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C,
+                                         float* __restrict__ partial) {
+  const int cv = C >> 3;
+  const long r0 = (long)blockIdx.x * BNB_ROWS;
+  for (int c8 = threadIdx.x; c8 < cv; c8 += blockDim.x) {
+    const int c = c8 << 3;
+    float s1[8], s2[8], sc[8], sh[8], mu[8], iv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = s2[e] = 0.f; sc[e] = ss[c + e]; sh[e] = ss[C + c + e]; mu[e] = mean[c + e]; iv[e] = invstd[c + e]; }
+    for (long r = r0; r < r0 + BNB_ROWS && r < M; ++r) {
+      f16x8 g = *(const f16x8*)(dy + r * C + c), x = *(const f16x8*)(raw + r * C + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float xr = (float)x[e];
+        float t = (float)(f16)(xr * sc[e] + sh[e]);
+        float sg = sigmoidf_(t);
+        float dt = (float)g[e] * (sg * (1.f + t * (1.f - sg)));
+        s1[e] += dt;
+        s2[e] += dt * ((xr - mu[e]) * iv[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      partial[((long)blockIdx.x * 2 + 0) * C + c + e] = s1[e];
+      partial[((long)blockIdx.x * 2 + 1) * C + c + e] = s2[e];
+    }
+  }
+}
+// sums [2][C] (fp32) from the partials, one wave per channel, fixed order, fp64 accumulation
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums) {
+  int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int t = lane; t < nblk; t += 64) {
+    a += (double)partial[((long)t * 2 + 0) * C + c];
+    b += (double)partial[((long)t * 2 + 1) * C + c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  if (lane == 0) { sums[c] = (float)a; sums[C + c] = (float)b; }
+}
+__global__ void bn_silu_bwd_apply_kernel(const f16* __restrict__ dy, const f16* __restrict__ raw, const float* __restrict__ ss,
+                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                         const float* __restrict__ gamma, const float* __restrict__ sums, long M, int C,
+                                         f16* __restrict__ draw) {
+  const int cv = C >> 3;
+  const long total = M * cv;
+  const float invn = 1.0f / (float)M;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx / cv;
+    int c = (int)(idx - r * cv) << 3;
+    f16x8 g = *(const f16x8*)(dy + r * C + c), x = *(const f16x8*)(raw + r * C + c), o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float xr = (float)x[e];
+      float t = (float)(f16)(xr * ss[c + e] + ss[C + c + e]);
+      float sg = sigmoidf_(t);
+      float dt = (float)g[e] * (sg * (1.f + t * (1.f - sg)));
+      float xh = (xr - mean[c + e]) * invstd[c + e];
+      o[e] = (f16)(gamma[c + e] * invstd[c + e] * (dt - sums[c + e] * invn - xh * sums[C + c + e] * invn));
+    }
+    *(f16x8*)(draw + r * C + c) = o;
+  }
+}
+
+// dy, raw, draw: contiguous [M, C] fp16.  sums_out [2][C] = (dbeta, dgamma).  workspace: floats [nblk][2][C].
+extern "C" long tscd_bn_silu_bwd_workspace_bytes(long M, int C) { return 4L * ((M + BNB_ROWS - 1) / BNB_ROWS) * 2 * C + 256; }
+extern "C" int tscd_bn_silu_bwd_f16(const void* dy, const void* raw, const float* scale_shift, const float* mean, const float* invstd,
+                                    const float* gamma, long M, int C, void* draw, float* sums_out, void* workspace,
+                                    long workspace_bytes, void* stream) {
+  TSCD_CHECK_ARG(dy && raw && scale_shift && mean && invstd && gamma && draw && sums_out && workspace, "bn_silu_bwd: null pointer");
+  TSCD_CHECK_ARG(C % 8 == 0 && M > 0, "bn_silu_bwd: C must be a multiple of 8");
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_bn_silu_bwd_workspace_bytes(M, C), "bn_silu_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = (int)((M + BNB_ROWS - 1) / BNB_ROWS);
+  int threads = (C / 8) < 64 ? 64 : ((C / 8) > 256 ? 256 : (C / 8 + 63) / 64 * 64);
+  hipLaunchKernelGGL(bn_silu_bwd_stats_kernel, dim3(nblk), dim3(threads), 0, st, (const f16*)dy, (const f16*)raw, scale_shift, mean,
+                     invstd, M, C, (float*)workspace);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, nblk, C, sums_out);
+  long total = M * (C / 8);
+  int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, st, (const f16*)dy, (const f16*)raw,
+                     scale_shift, mean, invstd, gamma, sums_out, M, C, (f16*)draw);
+  TSCD_CHECK_LAUNCH("bn_silu_bwd");
+  return TSCD_OK;
+}

@@ -1,8 +1,9 @@
 """Autograd-aware building blocks on top of tscd_amd.ops.
 
-Forward passes are the HIP kernels.  Backward passes of the *trainable* head blocks are composed here; the
-convolution data/weight gradients currently go through ``aten.convolution_backward`` on the device (plumbing,
-listed as a pending HIP row in DESIGN.md) while BatchNorm/SiLU/ReLU gradients are written out explicitly.
+Forward AND backward of the trainable head conv blocks are HIP kernels (conv_igemm.hip, conv_wgrad.hip): data
+gradients reuse the forward MFMA kernel with dgrad-packed weights, weight gradients use the pixel-axis GEMM,
+BatchNorm+SiLU backward is a fused two-pass kernel.
+
 The frozen backbone / base head never build a graph (the reference freezes them: ovis_tscd_large.py:116-149).
 """
 import torch
@@ -20,15 +21,22 @@ def _nchw(t):
 
 
 def _conv_backward(dy, x, weight, stride, need_dx, need_dw):
-    k = weight.shape[-1]
-    pad = (k - 1) // 2
-    w16 = weight.detach().to(torch.float16)
-    dx, dw, _ = torch.ops.aten.convolution_backward(
-        _nchw(dy), _nchw(x), w16, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
-        [need_dx, need_dw, False])
-    if dx is not None:
-        dx = dx.permute(0, 2, 3, 1)
-    return dx, (dw.to(weight.dtype) if dw is not None else None)
+    """Stride-1 'same' conv gradients on the HIP kernels: dgrad = the forward MFMA kernel with dgrad-packed weights,
+    wgrad = conv_wgrad.hip (pixel-axis GEMM, transposing LDS reads, deterministic split-K)."""
+    assert stride == 1, "only stride-1 convs are trainable on the TSCD path"
+    cout, cin, k, _ = weight.shape
+    dy = dy.to(torch.float16)
+    dx = ops.conv_dgrad(dy, weight) if need_dx else None
+    dw = None
+    if need_dw:
+        if cout % 8:   # prediction convs (Cout = 25 / 4 / 1): zero-pad dY's channels so rows stay 16-byte aligned
+            cp = (cout + 7) // 8 * 8
+            dyp = dy.new_zeros(dy.shape[:-1] + (cp,))
+            dyp[..., :cout] = dy
+            dw = ops.conv_wgrad(x, dyp, cin, cp, k)[:cout].to(weight.dtype)
+        else:
+            dw = ops.conv_wgrad(x, dy.contiguous(), cin, cout, k).to(weight.dtype)
+    return dx, dw
 
 
 class _ConvBnSiluTrain(torch.autograd.Function):
@@ -49,16 +57,8 @@ class _ConvBnSiluTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, gamma, raw, ss, mean, invstd = ctx.saved_tensors
-        rawf = raw.float()
-        t = (rawf * ss[0] + ss[1]).half().float()          # BN output as the forward rounded it
-        sg = torch.sigmoid(t)
-        dt = dy.float() * (sg * (1 + t * (1 - sg)))         # SiLU'
-        xhat = (rawf - mean) * invstd
-        dbeta = dt.sum((0, 1, 2))
-        dgamma = (dt * xhat).sum((0, 1, 2))
-        n = rawf.shape[0] * rawf.shape[1] * rawf.shape[2]
-        draw = (gamma * invstd) * (dt - dbeta / n - xhat * (dgamma / n))
-        dx, dw = _conv_backward(draw.half(), x, weight, ctx.stride, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        draw, dgamma, dbeta = ops.bn_silu_bwd(dy.to(torch.float16), raw, ss, mean, invstd, gamma.float())
+        dx, dw = _conv_backward(draw, x, weight, ctx.stride, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dx, dw, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None
 
 

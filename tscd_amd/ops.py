@@ -5,6 +5,8 @@ contiguous NHWC buffer (``stride(-1) == 1``, pixel stride ``ld = stride(-2)``) -
 buffers are plain torch views.  Kernels run on ``torch.cuda.current_stream()`` and only borrow ``data_ptr()``s.
 PyTorch is plumbing here (allocation, streams, autograd bookkeeping); all arithmetic is in the HIP kernels.
 """
+import weakref
+
 import torch
 
 from ._lib import call, lib
@@ -75,14 +77,22 @@ class WeightCache:
     def __init__(self):
         self._c = {}
 
-    def get(self, w, cin_pad=None, mode=0):
-        key = (id(w), mode, cin_pad)
+    @staticmethod
+    def _tag(w):
+        return (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape))
+
+    def _lookup(self, key, w, make):
+        # id() values are recycled once a tensor dies, so an entry is only valid while its weakref still points at `w`
         ent = self._c.get(key)
-        tag = (w.data_ptr(), w._version, w.dtype, w.device)
-        if ent is None or ent[0] != tag:
-            ent = (tag, pack_conv_weight(w, cin_pad, mode))
+        if ent is None or ent[2]() is not w or ent[0] != self._tag(w):
+            if len(self._c) > 4096:
+                self._c = {k: v for k, v in self._c.items() if v[2]() is not None}
+            ent = (self._tag(w), make(), weakref.ref(w))
             self._c[key] = ent
         return ent[1]
+
+    def get(self, w, cin_pad=None, mode=0):
+        return self._lookup((id(w), mode, cin_pad), w, lambda: pack_conv_weight(w, cin_pad, mode))
 
 
 WEIGHTS = WeightCache()
@@ -202,13 +212,7 @@ def pack_linear_weight(w):
 
 class _LinearCache(WeightCache):
     def get(self, w):
-        key = (id(w), "lin")
-        ent = self._c.get(key)
-        tag = (w.data_ptr(), w._version, w.dtype, w.device)
-        if ent is None or ent[0] != tag:
-            ent = (tag, pack_linear_weight(w))
-            self._c[key] = ent
-        return ent[1]
+        return self._lookup((id(w), "lin"), w, lambda: pack_linear_weight(w))
 
 
 LINEAR_WEIGHTS = _LinearCache()
@@ -452,3 +456,41 @@ def simota_assign(outputs, labels, geo, num_classes, max_gt, topk=10, emu16=True
          geo.c_stride, topk, int(emu16), ws.data_ptr(), ws_bytes, fg.data_ptr(), mg.data_ptr(), pi.data_ptr(), nfg.data_ptr(),
          ngt.data_ptr(), _stream())
     return fg, mg, pi, nfg, ngt
+
+
+# ----------------------------------------------------------------------------------------------------
+# backward kernels of the trainable head convs
+# ----------------------------------------------------------------------------------------------------
+def conv_wgrad(x, dy, cin, cout, ksize):
+    """dW [cout,cin,k,k] fp32 of a stride-1 'same' conv; x [B,H,W,cin], dy [B,H,W,cout] fp16 NHWC(-slices)."""
+    B, H, W, _ = x.shape
+    M = B * H * W
+    ws_bytes = lib.tscd_conv_wgrad_workspace_bytes(M, cout, cin, ksize)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    call("tscd_conv_wgrad_nhwc_f16", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, cin, cout, ksize, nhwc_ld(x), nhwc_ld(dy),
+         ws.data_ptr(), ws_bytes, _stream())
+    return dw
+
+
+def conv_dgrad(dy, weight):
+    """dX of a stride-1 'same' conv = the forward MFMA kernel on dY with the weights packed in dgrad order."""
+    cout, cin, k, _ = weight.shape
+    wpk = WEIGHTS.get(weight, None, 1)
+    dx, _ = conv2d(dy, wpk, cin, k, 1, EPI_RAW)
+    return dx
+
+
+def bn_silu_bwd(dy, raw, scale_shift, mean, invstd, gamma):
+    """-> (draw fp16 like raw, dgamma [C], dbeta [C]) for y = SiLU(BN_train(raw))."""
+    B, H, W, C = raw.shape
+    M = B * H * W
+    dy = dy.contiguous()
+    assert raw.is_contiguous()
+    ws_bytes = lib.tscd_bn_silu_bwd_workspace_bytes(M, C)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=raw.device)
+    draw = torch.empty_like(raw)
+    sums = torch.empty((2, C), dtype=torch.float32, device=raw.device)
+    call("tscd_bn_silu_bwd_f16", dy.data_ptr(), raw.data_ptr(), scale_shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+         gamma.data_ptr(), M, C, draw.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+    return draw, sums[1], sums[0]

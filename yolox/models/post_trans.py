@@ -33,50 +33,55 @@ class Attention_mca_g2l(nn.Module):
 
 def _mca_torch(x_cls, x_reg, score, wq_c, wkv_c, wq_r, wkv_r, w_lin, b_lin, w_linr, b_linr, w_out, b_out, w_obj, b_obj,
                ppf, lframe, heads, scale, sim_thresh, conf_thresh, need_reg):
-    """Device-side PyTorch expression of the same math, differentiated in backward only (never a forward result)."""
+    """Device-side PyTorch expression of the same math, differentiated in backward only (never a forward result).
+    All local frames are evaluated as one padded batch [L, heads, n_max, n_max + N_G] (invalid keys masked to -inf,
+    padded query rows dropped at the end) so the op count does not grow with lframe."""
     N, C = x_cls.shape
-    nl = sum(ppf[:lframe])
-    h = heads
-    hd = lambda t: t.view(t.shape[0], h, C // h).permute(1, 0, 2)
+    dev = x_cls.device
+    L, h = lframe, heads
+    nl = sum(ppf[:L])
+    nmax = max(ppf[:L])
+    ng = N - nl
+    K = nmax + ng
+    # row index tables: queries [L, nmax], keys [L, K]; padded slots point at row 0 and are masked
+    qrow = torch.zeros((L, nmax), dtype=torch.long)
+    qok = torch.zeros((L, nmax), dtype=torch.bool)
+    start = 0
+    for i in range(L):
+        qrow[i, :ppf[i]] = torch.arange(start, start + ppf[i])
+        qok[i, :ppf[i]] = True
+        start += ppf[i]
+    krow = torch.cat((qrow, torch.arange(nl, N).unsqueeze(0).expand(L, -1)), 1).to(dev)
+    kok = torch.cat((qok, torch.ones((L, ng), dtype=torch.bool)), 1).to(dev)
+    qrow, qok = qrow.to(dev), qok.to(dev)
+    hd = lambda t: t.view(L, t.shape[1], h, C // h).permute(0, 2, 1, 3)          # [L,h,n,d]
     nrm = lambda t: t / torch.norm(t.float(), dim=-1, keepdim=True).to(t.dtype)
-    flat = lambda t: t.permute(1, 0, 2).reshape(t.shape[1], C)
-    kv_c = F.linear(x_cls, wkv_c)
-    kv_r = F.linear(x_reg, wkv_r)
-    q_c_all = F.linear(x_cls[:nl], wq_c)
-    q_r_all = F.linear(x_reg[:nl], wq_r)
-    outs_c, outs_r, start = [], [], 0
-    for i in range(lframe):
-        n = ppf[i]
-        rows = torch.cat((torch.arange(start, start + n, device=x_cls.device), torch.arange(nl, N, device=x_cls.device)))
-        k_c, v_c = hd(kv_c[rows, :C]), hd(kv_c[rows, C:])
-        k_r, v_r = hd(kv_r[rows, :C]), hd(kv_r[rows, C:])
-        q_c, q_r = hd(q_c_all[start:start + n]), hd(q_r_all[start:start + n])
-        sc = score[rows].float()
-        a_c = (nrm(q_c) @ nrm(k_c).transpose(-2, -1)).float() * scale * sc.view(1, 1, -1)
-        a_r = (nrm(q_r) @ nrm(k_r).transpose(-2, -1)).float() * scale
-        attn = (a_r.softmax(-1) + a_c.softmax(-1)) / 2
-        attn16 = attn.to(v_c.dtype)
-        x_c = torch.cat([flat(attn16 @ v_c), flat(v_c[:, :n])], -1)
-        x_c = F.linear(x_c, w_lin, b_lin)
-        sim2 = torch.softmax(attn.sum(0) / h, dim=-1)
+    flat = lambda t: t.permute(0, 2, 1, 3).reshape(L, t.shape[2], C)              # [L,n,C]
+    kv_c, kv_r = F.linear(x_cls, wkv_c), F.linear(x_reg, wkv_r)
+    q_c, q_r = hd(F.linear(x_cls[:nl], wq_c)[qrow]), hd(F.linear(x_reg[:nl], wq_r)[qrow])
+    k_c, v_c = hd(kv_c[krow][..., :C]), hd(kv_c[krow][..., C:])
+    k_r, v_r = hd(kv_r[krow][..., :C]), hd(kv_r[krow][..., C:])
+    neg = torch.where(kok, 0.0, float("-inf")).view(L, 1, 1, K)
+    sc = score[krow].float().view(L, 1, 1, K)
+    a_c = (nrm(q_c) @ nrm(k_c).transpose(-2, -1)).float() * scale * sc + neg
+    a_r = (nrm(q_r) @ nrm(k_r).transpose(-2, -1)).float() * scale + neg
+    attn = (a_r.softmax(-1) + a_c.softmax(-1)) / 2
+    attn16 = attn.to(v_c.dtype)
+    sim2 = torch.softmax(attn.sum(1) / h + neg[:, 0], dim=-1)                      # [L,n,K]
+    def branch(v, w_l, b_l, thresh, w_o, b_o):
+        x = torch.cat([flat(attn16 @ v), flat(v[:, :, :nmax])], -1)
+        x = F.linear(x, w_l, b_l)
         with torch.no_grad():
-            raw_c = (nrm(v_c)[:, :n] @ nrm(v_c).transpose(-2, -1)).float().sum(0) / h
-            m_c = (raw_c > sim_thresh).float()
-        ave_c = m_c * sim2 / torch.sum(m_c * sim2, dim=-1, keepdim=True)
-        outs_c.append(torch.cat([ave_c.to(v_c.dtype) @ flat(v_c), x_c], -1))
-        if need_reg:
-            x_r = torch.cat([flat(attn16 @ v_r), flat(v_r[:, :n])], -1)
-            x_r = F.linear(x_r, w_linr, b_linr)
-            with torch.no_grad():
-                raw_r = (nrm(v_r)[:, :n] @ nrm(v_r).transpose(-2, -1)).float().sum(0) / h
-                m_r = (raw_r > conf_thresh).float()
-            ave_r = m_r * sim2 / torch.sum(m_r * sim2, dim=-1, keepdim=True)
-            outs_r.append(torch.cat([ave_r.to(v_r.dtype) @ flat(v_r), x_r], -1))
-        start += n
-    trans_cls = F.linear(torch.cat(outs_c, 0), w_out, b_out)
+            vn = nrm(v)
+            raw = (vn[:, :, :nmax] @ vn.transpose(-2, -1)).float().sum(1) / h
+            m = ((raw > thresh) & kok.view(L, 1, K)).float()
+        ave = m * sim2 / torch.sum(m * sim2, dim=-1, keepdim=True).clamp(min=1e-30)
+        out = torch.cat([ave.to(v.dtype) @ flat(v), x], -1)                       # [L,nmax,3C]
+        return F.linear(out[qok], w_o, b_o)                                        # valid rows, frame-major
+    trans_cls = branch(v_c, w_lin, b_lin, sim_thresh, w_out, b_out)
     if not need_reg:
         return trans_cls
-    return trans_cls, F.linear(torch.cat(outs_r, 0), w_obj, b_obj)
+    return trans_cls, branch(v_r, w_linr, b_linr, conf_thresh, w_obj, b_obj)
 
 
 class MCA_tscd_g2l_reg(nn.Module):

@@ -101,9 +101,12 @@ class SEModule(nn.Module):
             return ops.se_fuse(reg, edge, _f32(w0).contiguous(), _f32(w2).contiguous(), _f32(pos).reshape(-1).contiguous())
 
         def torch_fn(reg, edge, pos, w0, w2):
-            f = torch.stack([reg, edge], dim=-1).reshape(-1, 2)
-            g = torch.sigmoid(F.linear(F.relu(F.linear(f, w0.to(f.dtype))), w2.to(f.dtype))).view(*reg.shape, 2)
-            return reg * g[..., 0] + edge * g[..., 1] + pos.to(reg.dtype).reshape(1, -1)
+            # elementwise form of Linear(2->32) / Linear(32->2): K=2 GEMMs pick pathological hipBLASLt tiles
+            w0, w2 = w0.to(reg.dtype), w2.to(reg.dtype)
+            hid = F.relu(reg.unsqueeze(-1) * w0[:, 0] + edge.unsqueeze(-1) * w0[:, 1])          # [n,C,32]
+            g0 = torch.sigmoid((hid * w2[0]).sum(-1))
+            g1 = torch.sigmoid((hid * w2[1]).sum(-1))
+            return reg * g0 + edge * g1 + pos.to(reg.dtype).reshape(1, -1)
 
         return hip_op(hip_fn, torch_fn, reg, edge, pos, w0, w2)
 
