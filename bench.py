@@ -72,7 +72,7 @@ def build_model(depth, width, props):
         for c in model.head.cls_preds:
             c.bias.data.fill_(0.0)
     # 27 parameter tensors never receive a gradient; a static set, so exclude them from DDP's reducer
-    dead = ("transformer_self_attention_layers", "transformer_ffn_layers", "edge_feature_embedding", "position_embedding",
+    dead = ("transformer_self_attention_layers", "transformer_ffn_layers", "edge_feature_embedding", "attn.position_embedding",
             "agg.linear_obj", "agg.mca.linear_reg", "agg_iou.linear.", "agg_iou.mca.linear.")
     for k, p in model.named_parameters():
         if any(d in k for d in dead):

@@ -1,0 +1,65 @@
+"""N>1 path on CPU: two gloo ranks wrap the product model the way bench.py does (frozen backbone/base head, the 27
+never-used parameter tensors of SURVEY F5 frozen so DDP's bucket set is static) and all-reduce gradients.
+
+The HIP kernels cannot run without a GPU, so the forward is replaced by a surrogate that touches exactly the trainable
+parameters; what is covered is the distributed plumbing: rendezvous on 127.0.0.1, DDP construction over the mirror's
+module tree, gradient averaging, and that the trainable set equals the set of parameters that receive gradients in the
+reference (golden ``train_grad_names``) -- the condition for DDP not to hang on unused parameters.
+"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ref_names, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = bench.build_model(0.33, 0.125, "500")
+    trainable = {k for k, p in model.named_parameters() if p.requires_grad}
+    ddp = torch.nn.parallel.DistributedDataParallel(model, broadcast_buffers=False)
+    # surrogate "step": every trainable parameter contributes, scaled by (rank + 1)
+    loss = sum(p.sum() for p in model.parameters() if p.requires_grad) * float(rank + 1)
+    ddp.reducer.prepare_for_backward([])   # forward of the wrapped module is bypassed on CPU
+    loss.backward()
+    g = next(p for p in model.parameters() if p.requires_grad).grad
+    opt = bench.make_optimizer(model)
+    ema = bench.FusedEMA(model)
+    opt.step()
+    ema.update()
+    q.put((rank, sorted(trainable) == sorted(ref_names), float(g.flatten()[0]), len(opt.param_groups)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce(golden):
+    cfg, sd, vec, meta = golden
+    ref_names = ["backbone." + k[len("backbone."):] if k.startswith("backbone.") else k for k in vec["train_grad_names"].tolist()]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ref_names, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same_set, g0, ngroups in res:
+        assert same_set, "trainable set differs from the reference's set of parameters with gradients"
+        assert abs(g0 - 1.5) < 1e-6          # mean of (1, 2) over the two ranks
+        assert ngroups == 3                   # bn weights / decayed weights / biases (pg3 is fully frozen)
