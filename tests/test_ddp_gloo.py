@@ -62,4 +62,6 @@ def test_two_rank_gloo_gradient_allreduce(golden):
     for rank, same_set, g0, ngroups in res:
         assert same_set, "trainable set differs from the reference's set of parameters with gradients"
         assert abs(g0 - 1.5) < 1e-6          # mean of (1, 2) over the two ranks
-        assert ngroups == 3                   # bn weights / decayed weights / biases (pg3 is fully frozen)
+        # bn weights / decayed weights / biases / pg3: the reference's substring test "head.cls_convs" in k also matches
+        # head.cls_convs2.* (ovis_tscd_large.py:177), so the trainable cls_convs2 weights train at lr * stem_lr_ratio
+        assert ngroups == 4
