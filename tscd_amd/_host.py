@@ -1,0 +1,46 @@
+"""ctypes binding of libtscd_host.so (tscd_amd/csrc_host/lap.cpp): the host-side linear-sum-assignment solver."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtscd_host.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} not found: run `python -m tscd_amd.build`")
+_lib = C.CDLL(LIB_PATH)
+_lib.tscd_lap_solve_f64.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+_lib.tscd_lap_solve_f64.restype = C.c_int
+_lib.tscd_lap_solve_f16.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+_lib.tscd_lap_solve_f16.restype = C.c_int
+
+
+def lap_f64(cost):
+    """Same contract as scipy.optimize.linear_sum_assignment(cost) (minimisation), bit-identical result."""
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    nr, nc = cost.shape
+    k = min(nr, nc)
+    a, b = np.empty(k, np.int64), np.empty(k, np.int64)
+    st = _lib.tscd_lap_solve_f64(cost.ctypes.data, nr, nc, a.ctypes.data, b.ctypes.data)
+    if st:
+        raise ValueError("cost matrix is infeasible" if st == 2 else "matrix contains invalid numeric entries")
+    return a, b
+
+
+def lap_f16(cost_u16, row_map=None):
+    """cost_u16: C-contiguous uint16 view of an fp16 [R, nc] matrix; row_map (int64 [nr]) selects/permutes its rows.
+    NaNs count as 0 (tscd_matching.py:929-930)."""
+    assert cost_u16.dtype == np.uint16 and cost_u16.flags.c_contiguous
+    nc = cost_u16.shape[1]
+    if row_map is not None:
+        row_map = np.ascontiguousarray(row_map, dtype=np.int64)
+        nr = row_map.shape[0]
+    else:
+        nr = cost_u16.shape[0]
+    k = min(nr, nc)
+    a, b = np.empty(k, np.int64), np.empty(k, np.int64)
+    st = _lib.tscd_lap_solve_f16(cost_u16.ctypes.data, nc, None if row_map is None else row_map.ctypes.data, nr, nc,
+                                 a.ctypes.data, b.ctypes.data)
+    if st:
+        raise ValueError("assignment failed (status %d)" % st)
+    return a, b

@@ -13,6 +13,22 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-Wno-unused-result", "-I", CSRC]
 
 
+HOST_SRC = os.path.join(HERE, "csrc_host", "lap.cpp")
+HOST_LIB = os.path.join(LIBDIR, "libtscd_host.so")
+
+
+def build_host(force=False, verbose=True):
+    """g++ build of the host-side assignment solver (no -march flags: SIMD variants are selected at run time)."""
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) > os.path.getmtime(HOST_SRC):
+        return HOST_LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", HOST_SRC, "-o", HOST_LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -22,6 +38,7 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
+    build_host(force, verbose)
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)

@@ -5,18 +5,19 @@ SEModule :264-283, SelfAttentionLayer :286-357, CrossAttentionLayer :394-458, FF
 ReferringCrossAttentionLayer :535-636, AwarePositionRegMatcher :639-1080, TaskAligned :1083-1139): same submodule
 tree (including the layers the reference constructs but never calls -- they carry state_dict keys), same stateful
 frame-to-frame behaviour.  Device work per local frame: one MFMA GEMM for the Hungarian cost, the SE gate,
-q/k/v GEMMs, the cosine attention kernel and the fused residual+LayerNorm; the assignment itself stays on the host
-(scipy's linear_sum_assignment, as in the reference) -- one D2H of an fp16 [n_ref, n_cur] matrix per frame.
+q/k/v GEMMs, the cosine attention kernel and the fused residual+LayerNorm; the assignment itself stays on the host like
+the reference's scipy call, solved by tscd_amd/csrc_host/lap.cpp (same algorithm and tie rules, SIMD inner loop) -- all
+cost matrices of a clip reach the host with ONE D2H.
 """
 from typing import Optional
 
 import numpy as np
 import torch
 import torch.nn.functional as F
-from scipy.optimize import linear_sum_assignment
 from torch import nn
 
 from tscd_amd import ops
+from tscd_amd._host import lap_f16
 from tscd_amd.autograd import hip_op
 
 
@@ -200,38 +201,83 @@ class AwarePositionRegMatcher(nn.Module):
 
     @staticmethod
     @torch.no_grad()
-    def double_match_embds(ref_reg, cur_reg, ref_cls, cur_cls):
-        """Hungarian on 1 - mean cosine (tscd_matching.py:912-937).  Cost matrix = one MFMA GEMM; D2H; scipy."""
-        cost = ops.match_cost(ref_reg.detach().contiguous(), cur_reg.detach().contiguous(), ref_cls.detach().contiguous(),
-                              cur_cls.detach().contiguous())
-        return linear_sum_assignment(cost.float().cpu().numpy())
+    def _cost_matrices(pairs):
+        """pairs: list of (ref_reg, cur_reg, ref_cls, cur_cls).  One MFMA GEMM each (1 - mean cosine, fp16 like the
+        reference's torch.mm under autocast/.half(), tscd_matching.py:919-930), all copied to the host with ONE sync."""
+        costs = [ops.match_cost(a.detach().contiguous(), b.detach().contiguous(), c.detach().contiguous(), d.detach().contiguous())
+                 for (a, b, c, d) in pairs]
+        if not costs:
+            return []
+        flat = torch.cat([c.reshape(-1) for c in costs])
+        host = flat.cpu().numpy().view(np.uint16)        # the only device->host transfer of the matcher
+        out, o = [], 0
+        for c in costs:
+            n = c.numel()
+            out.append(np.ascontiguousarray(host[o:o + n].reshape(c.shape)))
+            o += n
+        return out
 
     def forward(self, features, features_reg, features_cls, features_edge, preds_per_frame, time_embedding, resume=False):
         """features / features_edge [N,W] (first sum(preds_per_frame) rows used), features_reg / features_cls [N_L,4W],
-        time_embedding [lframe,256].  Returns [1, N_L, W] like the reference (the head takes [-1]) or None."""
+        time_embedding [lframe,256].  Returns [1, N_L, W] like the reference (the head takes [-1]) or None.
+
+        The Hungarian cost of frame i is a row permutation of cost(MCA features of frame i-1, frame i): the reference's
+        ``last_frame_*_embeds`` are the previous frame's MCA rows re-ordered by the previous assignment.  So every cost
+        matrix of the clip is computed up front (no dependence on the attention outputs), copied to the host once, and
+        the assignments are solved by the host solver (tscd_amd/csrc_host/lap.cpp, bit-identical to the scipy call of the
+        reference) on the permuted rows while the device runs the previous frame's attention."""
         dev = features.device
         layer = self.transformer_aware_cross_attention_layers[0]
         t_emb = linear(time_embedding.to(torch.float16).contiguous(), self.absolute_position_embedding)
-        outs, rets, start = [], [], 0
         self.last_hungarian = []
         idx = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.long, device=dev)
+
+        # ---- plan: which (reference, current) pair each non-empty frame is matched against ----
+        spans, start = [], 0
+        for n in preds_per_frame:
+            spans.append((start, start + n))
+            start += n
+        plan, prev, have_state = [], None, self.last_outputs is not None
         for i, n in enumerate(preds_per_frame):
             if n == 0:
                 if i == 0 and resume is False:
-                    self._clear_state()
+                    have_state, prev = False, None
                 continue
-            cur, cur_reg = features[start:start + n], features_reg[start:start + n]
-            cur_cls, cur_edge = features_cls[start:start + n], features_edge[start:start + n]
-            start += n
+            first = (i == 0 and resume is False) or (prev is None and not have_state)
+            plan.append((i, "self" if first else ("state" if prev is None else "prev"), prev))
+            prev = i
+        pairs = []
+        for (i, kind, pi) in plan:
+            s0, s1 = spans[i]
+            cur_reg, cur_cls = features_reg[s0:s1], features_cls[s0:s1]
+            if kind == "self":
+                pairs.append((cur_reg, cur_reg, cur_cls, cur_cls))
+            elif kind == "state":
+                pairs.append((self.last_frame_reg_embeds, cur_reg, self.last_frame_cls_embeds, cur_cls))
+            else:
+                p0, p1 = spans[pi]
+                pairs.append((features_reg[p0:p1], cur_reg, features_cls[p0:p1], cur_cls))
+        costs = self._cost_matrices(pairs)
+
+        outs, prev_perm = [], None
+        for (i, kind, pi), cost in zip(plan, costs):
+            n = preds_per_frame[i]
+            s0, s1 = spans[i]
+            if i == 0 and resume is False:
+                self._clear_state()
+            cur, cur_edge = features[s0:s1], features_edge[s0:s1]
+            cur_reg, cur_cls = features_reg[s0:s1], features_cls[s0:s1]
             t_i = t_emb[i:i + 1]
-            if (i == 0 and resume is False) or self.last_outputs is None:
+            if kind == "self":
                 self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = cur_reg, cur_cls, n
-                ret = self.double_match_embds(cur_reg, cur_reg, cur_cls, cur_cls)[1]
+                ret = lap_f16(cost)[1]
                 self.last_hungarian.append(np.asarray(ret))
                 out = layer(cur, cur, cur, t_i, t_i, cur_edge, cur_edge)
                 new_edge = cur_edge
+                perm = np.arange(n)
             else:
-                row, col = self.double_match_embds(self.last_frame_reg_embeds, cur_reg, self.last_frame_cls_embeds, cur_cls)
+                # rows of the reference frame in the order the reference holds them (previous assignment applied)
+                row, col = lap_f16(cost, prev_perm if kind == "prev" else None)
                 self.last_hungarian.append(np.asarray(col))
                 if self.last_frame_n < n:
                     taken = np.zeros(n, dtype=bool)
@@ -251,9 +297,12 @@ class AwarePositionRegMatcher(nn.Module):
                 ret = col
                 out = layer(cur[c], last_feat, cur, t_i, self.last_frame_time_embedding, cur_edge, last_edge)
                 new_edge = cur_edge[c]
+                perm = np.asarray(col)
             self.last_outputs, self.last_frame_time_embedding, self.last_frame_edge_embeds = out, t_i, new_edge
-            rets.append(np.asarray(ret))
+            prev_perm = perm
             outs.append(out[idx(np.argsort(ret))])
+        if not plan and len(preds_per_frame) and preds_per_frame[0] == 0 and resume is False:
+            self._clear_state()
         if not outs:
             return None
         o = torch.cat(outs, 0)
