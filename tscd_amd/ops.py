@@ -101,6 +101,10 @@ WEIGHTS = WeightCache()
 # ----------------------------------------------------------------------------------------------------
 # conv / BN / elementwise
 # ----------------------------------------------------------------------------------------------------
+# bench.py sets this to a list to time every conv launch with device events on the launch stream
+CONV_PROFILE = None
+
+
 def conv_out_hw(H, W, ksize, stride):
     pad = (ksize - 1) // 2
     return (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
@@ -125,8 +129,15 @@ def conv2d(x, wpk, cout, ksize, stride=1, epilogue=EPI_RAW, bias=None, scale_shi
     scale = shift = None
     if scale_shift is not None:
         scale, shift = scale_shift[0], scale_shift[1]
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("tscd_conv2d_nhwc_f16", x.data_ptr(), wpk.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(scale), _ptr(shift),
          _ptr(partial), B, H, W, Cin, cout, ksize, stride, ldx, ldy, epilogue, _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((lib.tscd_conv_tile_n(cout), 2.0 * B * Ho * Wo * cout * ksize * ksize * Cin, e0, e1))
     return out, partial
 
 

@@ -1,0 +1,128 @@
+"""TSCD training / evaluation driver (contract of the reference's yolox/core/tscd_trainer.py:90-468).
+
+Same per-iteration order as the reference's ``train_one_iter`` (:153-192): clip from the loader, fp16 cast (T1),
+multiscale ``exp.preprocess``, forward, ``GradScaler``-scaled backward, SGD step, EMA (decay .9998), LR update.  The
+model computes in fp16 inside the HIP kernels, so no autocast context is needed.  DDP: gradients all-reduced over
+RCCL, the parameters that never get a gradient are frozen so the bucket set is static, buffers are not
+broadcast (BN statistics stay per rank until ``all_reduce_norm`` before evaluation, as in the reference)."""
+import os
+import time
+
+import torch
+from torch.nn.parallel import DistributedDataParallel as DDP
+
+from yolox.utils import ModelEMA, all_reduce_norm, get_local_rank, get_rank, get_world_size, is_parallel, synchronize
+
+DEAD_PARAMS = ("transformer_self_attention_layers", "transformer_ffn_layers", "edge_feature_embedding", "attn.position_embedding",
+               "agg.linear_obj", "agg.mca.linear_reg", "agg_iou.linear.", "agg_iou.mca.linear.")
+
+
+class Trainer:
+    def __init__(self, exp, args, val_loader=None, val=False):
+        self.exp, self.args, self.val_loader, self.val = exp, args, val_loader, val
+        self.max_epoch = exp.max_epoch
+        self.amp_training = getattr(args, "fp16", True)
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp_training)
+        self.is_distributed = get_world_size() > 1
+        self.rank, self.local_rank = get_rank(), get_local_rank()
+        self.device = "cuda:{}".format(self.local_rank)
+        self.use_model_ema = exp.ema
+        self.input_size = exp.input_size
+        self.best_ap = 0
+        self.file_name = os.path.join(exp.output_dir, getattr(args, "experiment_name", None) or exp.exp_name)
+        self.lframe, self.gframe = exp.lframe, exp.gframe
+        self.history = []
+        if self.rank == 0:
+            os.makedirs(self.file_name, exist_ok=True)
+
+    # ------------------------------------------------------------------ setup
+    def before_train(self):
+        torch.cuda.set_device(self.local_rank)
+        model = self.exp.get_model()
+        for k, p in model.named_parameters():
+            if any(d in k for d in DEAD_PARAMS):
+                p.requires_grad = False
+        model.to(self.device)
+        self.optimizer = self.exp.get_optimizer(self.args.batch_size)
+        model = self.resume_train(model)
+        self.train_loader = self.exp.get_data_loader(batch_size=self.args.batch_size, is_distributed=self.is_distributed)
+        self.prefetcher = self.train_loader          # tensor contract: next() -> (imgs, targets, time_embedding)
+        self.max_iter = len(self.train_loader)
+        self.lr_scheduler = self.exp.get_lr_scheduler(self.exp.basic_lr_per_img * self.args.batch_size, self.max_iter)
+        if self.is_distributed:
+            model = DDP(model, device_ids=[self.local_rank], broadcast_buffers=False)
+        if self.use_model_ema:
+            self.ema_model = ModelEMA(model, 0.9998)
+            self.ema_model.updates = self.max_iter * self.start_epoch
+        self.model = model
+        self.model.train()
+
+    def resume_train(self, model):
+        self.start_epoch = 0
+        ckpt_file = getattr(self.args, "ckpt", None)
+        if getattr(self.args, "resume", False):
+            ckpt_file = ckpt_file or os.path.join(self.file_name, "latest_ckpt.pth")
+            ckpt = torch.load(ckpt_file, map_location=self.device, weights_only=True)
+            model.load_state_dict(ckpt["model"])
+            self.optimizer.load_state_dict(ckpt["optimizer"])
+            self.start_epoch = ckpt.get("start_epoch", 0)
+        elif ckpt_file:
+            ckpt = torch.load(ckpt_file, map_location=self.device, weights_only=True)["model"]
+            own = model.state_dict()      # shape-tolerant fine-tune load (yolox/utils/checkpoint.py:11-33)
+            model.load_state_dict({k: v for k, v in ckpt.items() if k in own and own[k].shape == v.shape}, strict=False)
+        return model
+
+    # ------------------------------------------------------------------ loop
+    def train(self):
+        self.before_train()
+        try:
+            for self.epoch in range(self.start_epoch, self.max_epoch):
+                for self.iter in range(self.max_iter):
+                    self.train_one_iter()
+                    if (self.progress_in_iter + 1) % 10 == 0 and getattr(self.exp, "multiscale_range", 0) > 0:
+                        self.input_size = self.exp.random_resize(self.train_loader, self.epoch, self.rank, self.is_distributed)
+                self.save_ckpt("latest")
+        finally:
+            pass
+
+    @property
+    def progress_in_iter(self):
+        return self.epoch * self.max_iter + self.iter
+
+    def train_one_iter(self):
+        t0 = time.time()
+        inps, targets, time_embedding = self.prefetcher.next()
+        inps, targets, time_embedding = inps.half(), targets.half(), time_embedding.half()      # tscd_trainer.py:159-161
+        targets.requires_grad = False
+        inps, targets = self.exp.preprocess(inps, targets, self.input_size)
+        outputs = self.model(inps, targets, time_embedding, lframe=self.exp.lframe, gframe=self.exp.gframe, resume=False)
+        loss = outputs["total_loss"]
+        self.optimizer.zero_grad()
+        self.scaler.scale(loss).backward()
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        if self.use_model_ema:
+            self.ema_model.update(self.model)
+        lr = self.lr_scheduler.update_lr(self.progress_in_iter + 1)
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr
+        self.history.append({"iter_time": time.time() - t0, "lr": lr, **{k: float(v) for k, v in outputs.items()}})
+        return outputs
+
+    # ------------------------------------------------------------------ eval / checkpoints
+    def evaluate(self):
+        model = self.ema_model.ema if self.use_model_ema else self.model
+        model = model.module if is_parallel(model) else model
+        all_reduce_norm(model)
+        evaluator = self.exp.get_evaluator(self.val_loader)
+        res = self.exp.eval(model, evaluator, self.is_distributed)
+        synchronize()
+        return res
+
+    def save_ckpt(self, ckpt_name, update_best_ckpt=False):
+        if self.rank != 0:
+            return
+        model = self.ema_model.ema if self.use_model_ema else self.model
+        model = model.module if is_parallel(model) else model
+        state = {"start_epoch": self.epoch + 1, "model": model.state_dict(), "optimizer": self.optimizer.state_dict()}
+        torch.save(state, os.path.join(self.file_name, ckpt_name + "_ckpt.pth"))

@@ -1,0 +1,5 @@
+from .dist import (all_reduce_norm, get_local_rank, get_local_size, get_num_devices, get_rank, get_world_size,
+                   is_main_process, synchronize, time_synchronized)
+from .ema import ModelEMA, is_parallel
+from .lr_scheduler import LRScheduler
+from .setup_env import configure_nccl, configure_omp

@@ -1,0 +1,34 @@
+"""ModelEMA with the reference's contract (yolox/utils/ema.py:22-60): EMA over every floating tensor of the
+state_dict (parameters AND buffers, so the frozen backbone's BN running stats are tracked), decay ramp
+d = decay * (1 - exp(-n/2000)).  The update is two multi-tensor launches instead of ~1200 small ones."""
+import math
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+
+
+def is_parallel(model):
+    return isinstance(model, (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel))
+
+
+class ModelEMA:
+    def __init__(self, model, decay=0.9999, updates=0):
+        self.ema = deepcopy(model.module if is_parallel(model) else model).eval()
+        self.updates = updates
+        self.decay = lambda x: decay * (1 - math.exp(-x / 2000))
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+
+    @torch.no_grad()
+    def update(self, model):
+        self.updates += 1
+        d = self.decay(self.updates)
+        msd = (model.module if is_parallel(model) else model).state_dict()
+        dst, src = [], []
+        for k, v in self.ema.state_dict().items():
+            if v.dtype.is_floating_point:
+                dst.append(v)
+                src.append(msd[k].detach().to(v.dtype))
+        torch._foreach_mul_(dst, d)
+        torch._foreach_add_(dst, src, alpha=1.0 - d)
