@@ -96,7 +96,16 @@ long tscd_mca_workspace_bytes(int N, int N_L, int W, int S);
 int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
                      const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
                      float sim_thresh, float conf_thresh, void* workspace, long workspace_bytes, void* xcat_c,
-                     void* xcat_r, void* cat3_c, void* cat3_r, void* stream);
+                     void* xcat_r, void* cat3_c, void* cat3_r, float* stats_out, void* stream);
+/* Backward of the fused attention (autograd of post_trans.py:601-714 under tscd_trainer.py:171-176): gradients w.r.t. the
+ * projected q / (k|v) rows and the key scores.  stats = stats_out of the forward call; dxcat_* [N_L,2W], dsoft_* / soft_* the
+ * first W columns of the [N_L,3W] concat (row strides ld_dsoft / ld_soft). */
+long tscd_mca_backward_workspace_bytes(int N, int N_L, int W, int S, int ntiles);
+int tscd_mca_backward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
+                      const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale, float sim_thresh,
+                      float conf_thresh, const float* stats, const void* dxcat_c, const void* dxcat_r, const void* dsoft_c,
+                      const void* dsoft_r, int ld_dsoft, const void* soft_c, const void* soft_r, int ld_soft, void* workspace,
+                      long workspace_bytes, void* dq_c, void* dkv_c, void* dq_r, void* dkv_r, float* dscore, void* stream);
 
 /* ---- CAFM / TaskAligned pieces: PositionMHAttention / MHAttention (tscd_matching.py:31-60,140-181), SEModule
  * (:264-283), LayerNorm of forward_post (:566-589,:394-458), cosine normalisation of double_match_embds (:912-937).

@@ -25,7 +25,8 @@ SIGNATURES = {
     "tscd_select_proposals": [P, I, I, F, I, I, I, P, P, P],
     "tscd_gather_rows": [P, P, P, I, P, I, I, I, I, P, P, P, I, P],
     "tscd_gather_det": [P, I, I, P, I, P, I, I, P, P],
-    "tscd_mca_forward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, L, P, P, P, P, P],
+    "tscd_mca_forward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, L, P, P, P, P, P, P],
+    "tscd_mca_backward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, P, P, P, P, I, P, P, I, P, L, P, P, P, P, P, P],
     "tscd_cos_attn_f16": [P, P, P, I, I, P, I, P, P],
     "tscd_se_fuse_f16": [P, I, P, I, P, P, P, L, I, P, P],
     "tscd_add_layernorm_f16": [P, P, P, P, I, I, F, P, P],
@@ -38,6 +39,7 @@ SIGNATURES = {
 PLAIN = {"tscd_conv_wgrad_splits": ([L], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
          "tscd_bn_silu_bwd_workspace_bytes": ([L, I], L),
          "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
+         "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),
          "tscd_nms_workspace_bytes": ([I, I], L), "tscd_simota_workspace_bytes": ([I, I, I, I], L),
          "tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
          "tscd_last_error": ([], C.c_char_p)}

@@ -23,11 +23,7 @@
 // ~N_L/32 * splits workgroups fill the chip.  All local frames of a clip run in ONE launch: a q-tile belongs to one
 // frame and its key blocks are [own frame rows] then [global rows]; the reference's per-frame recomputation of the
 // global keys' K/V projections disappears (they are shared).
-#include "common.h"
-
-#define MCA_HEADS 4
-
-struct McaTile { int row0, nrows, loc_start, loc_end; };
+#include "mca_common.h"
 
 struct McaParams {
   // prepared operands
@@ -94,18 +90,6 @@ __global__ void mca_prep_kernel(const f16* __restrict__ q_c, const f16* __restri
         }
       }
     }
-  }
-}
-
-// -------------------------------------------------------------------------------------------------- helpers
-__device__ __forceinline__ void block_range(const McaTile& t, int N_L, int N, int j, int& key0, int& lo, int& hi,
-                                            int n_local) {
-  if (j < n_local) {
-    key0 = ((t.loc_start >> 5) + j) << 5;
-    lo = t.loc_start; hi = t.loc_end;
-  } else {
-    key0 = ((N_L >> 5) + (j - n_local)) << 5;
-    lo = N_L; hi = N;
   }
 }
 
@@ -339,8 +323,23 @@ __global__ __launch_bounds__(256) void mca_aggregate_kernel(McaParams p) {
 // -------------------------------------------------------------------------------------------------- finalize
 __global__ void mca_finalize_kernel(const float* __restrict__ part_oc, const float* __restrict__ part_or,
                                     const float* __restrict__ part_sc, const float* __restrict__ part_sr,
-                                    const float* __restrict__ part_den, int S, int N_L, int W, int d, int DP, int need_reg,
-                                    f16* xcat_c, f16* xcat_r, f16* cat3_c, f16* cat3_r) {
+                                    const float* __restrict__ part_den, const float* __restrict__ lsum, float* __restrict__ stats_out,
+                                    int S, int N_L, int W, int d, int DP, int need_reg, f16* xcat_c, f16* xcat_r, f16* cat3_c,
+                                    f16* cat3_r) {
+  // stats_out (optional, for backward): [HEADS][2][N_L] softmax row sums, then [2][N_L] sim_round2 denominators
+  if (stats_out) {
+    long nst = (long)MCA_HEADS * 2 * N_L + 2L * N_L;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nst; i += (long)gridDim.x * blockDim.x) {
+      float a = 0.f;
+      if (i < (long)MCA_HEADS * 2 * N_L) {
+        for (int s = 0; s < S; ++s) a += lsum[(long)s * MCA_HEADS * 2 * N_L + i];
+      } else {
+        long j = i - (long)MCA_HEADS * 2 * N_L;
+        for (int s = 0; s < S; ++s) a += part_den[(long)s * 2 * N_L + j];
+      }
+      stats_out[i] = a;
+    }
+  }
   const int WP = MCA_HEADS * DP;
   long total = (long)N_L * W;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -367,6 +366,15 @@ __global__ void mca_finalize_kernel(const float* __restrict__ part_oc, const flo
   }
 }
 
+// host launcher of the prep kernel, shared with mca_bwd.hip (kernels cannot be launched across translation units)
+void mca_launch_prep(hipStream_t st, const f16* q_c, const f16* kv_c, const f16* q_r, const f16* kv_r, int N, int N_L, int Npad, int W,
+                     int d, int DP, f16* qn_c, f16* kn_c, f16* vn_c, f16* vt_c, f16* qn_r, f16* kn_r, f16* vn_r, f16* vt_r, f16* xcat_c,
+                     f16* xcat_r) {
+  long waves = 2L * Npad;
+  hipLaunchKernelGGL(mca_prep_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st, q_c, kv_c, q_r, kv_r, N, N_L, Npad,
+                     W, d, DP, qn_c, kn_c, vn_c, vt_c, qn_r, kn_r, vn_r, vt_r, xcat_c, xcat_r);
+}
+
 // -------------------------------------------------------------------------------------------------- C-ABI
 extern "C" int tscd_mca_dp(int d) { return (d + 31) / 32 * 32; }
 
@@ -382,7 +390,7 @@ extern "C" long tscd_mca_workspace_bytes(int N, int N_L, int W, int S) {
 extern "C" int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
                                 const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
                                 float sim_thresh, float conf_thresh, void* workspace, long workspace_bytes, void* xcat_c,
-                                void* xcat_r, void* cat3_c, void* cat3_r, void* stream) {
+                                void* xcat_r, void* cat3_c, void* cat3_r, float* stats_out, void* stream) {
   TSCD_CHECK_ARG(q_c && kv_c && q_r && kv_r && score && tiles && workspace && xcat_c && cat3_c, "mca_forward: null pointer");
   TSCD_CHECK_ARG(!need_reg || (xcat_r && cat3_r), "mca_forward: reg outputs requested without buffers");
   TSCD_CHECK_ARG(W % MCA_HEADS == 0 && W % 8 == 0, "mca_forward: W=%d must be a multiple of 8 (4 heads)", W);
@@ -443,7 +451,8 @@ extern "C" int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q
   long total = (long)N_L * W;
   int fg = (int)((total + 255) / 256);
   hipLaunchKernelGGL(mca_finalize_kernel, dim3(fg > 2048 ? 2048 : fg), dim3(256), 0, st, part_oc, part_or, part_sc, part_sr,
-                     part_den, S, N_L, W, d, DP, need_reg, (f16*)xcat_c, (f16*)xcat_r, (f16*)cat3_c, (f16*)cat3_r);
+                     part_den, lsum, stats_out, S, N_L, W, d, DP, need_reg, (f16*)xcat_c, (f16*)xcat_r, (f16*)cat3_c,
+                     (f16*)cat3_r);
   TSCD_CHECK_LAUNCH("mca_finalize");
   return TSCD_OK;
 }

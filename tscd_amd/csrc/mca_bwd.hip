@@ -1,0 +1,525 @@
+// MCA backward: gradient of the fused global-to-local cosine attention of mca.hip w.r.t. the projected q / k / v rows
+// and the key confidence scores (reference: autograd of Attention_mca_g2l.forward, yolox/models/post_trans.py:601-714,
+// inside MCA_tscd_g2l_reg.forward :1127-1162; trained through tscd_trainer.py:171-176).
+//
+// Forward (per head h, query row r, key k; see mca.hip):
+//   Pc = softmax_k(25*score_k*qc^.kc^)   Pr = softmax_k(25*qr^.kr^)   P = (Pc+Pr)/2
+//   Oc = P vc   Or = P vr             M = mean_h P   E = exp(M)   Ac = [Rc>.75] E / Dc   Ar = [Rr>.99] E / Dr
+//   softc = Ac Vc(all heads)   softr = Ar Vr            (the R masks are constants: no gradient through v^)
+// Backward, given dOc, dOr, dsoftc, dsoftr (two passes over (query tile, key block), nothing of size N1 x N2 in HBM):
+//   dA_c[r,k] = dsoftc_r . Vc_k (all heads)        dM = Ac (dA_c - dsoftc_r.softc_r) + Ar (dA_r - dsoftr_r.softr_r)
+//   dP_h = dOc_h . vc_h + dOr_h . vr_h + dM/4
+//   pass 1: delta_c[h,r] = sum_k Pc dP/2, delta_r[h,r] = sum_k Pr dP/2
+//   pass 2: dSc = Pc (dP/2 - delta_c), dSr = Pr (dP/2 - delta_r)
+//           dq^c += (25 score dSc) k^c        dk^c += (25 score dSc)^T q^c        dscore += sum_{h,r} 25 dSc (q^c.k^c)
+//           dq^r += (25 dSr) k^r              dk^r += (25 dSr)^T q^r
+//           dvc  += P^T dOc + Ac^T dsoftc     dvr  += P^T dOr + Ar^T dsoftr
+// Workgroup = one 32-query tile x 4 heads (one wave per head) as in the forward; key blocks strided over gridDim.y.
+// Products that reduce over keys use A-fragments read row-wise from LDS fp16 tiles; products that reduce over query rows
+// (dk, dv) read the same tiles with ds_read_b64_tr_b16 (hardware transpose) and take their B operands from per-tile
+// transposed copies prepared once (q^T, dO^T, dsoft^T: [tile][4*DP][32], 16-byte aligned rows).  dq accumulates in
+// registers; dk / dv / dscore are summed over query tiles with fp32 atomics (two 128-byte segments per wave instruction).
+#include "mca_common.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct McaBwdParams {
+  const f16 *qn_c, *qn_r, *kn_c, *kn_r, *vn_c, *vn_r;   // normalised, padded [rows][WP]
+  const f16 *vraw_c, *vraw_r;                           // raw v, padded [Npad][WP]
+  const f16 *kt_c, *kt_r;                               // k^ transposed [WP][Npad]
+  const f16 *qT_c, *qT_r;                               // per tile [ntiles][WP][32]
+  const f16 *gO_c, *gO_r, *gS_c, *gS_r;                 // upstream grads, padded row-major [N_L][WP]
+  const f16 *gOT_c, *gOT_r, *gST_c, *gST_r;             // per tile transposed [ntiles][WP][32]
+  const f16* score;
+  const McaTile* tiles;
+  const float* stats;        // [HEADS][2][N_L] softmax row sums, then [2][N_L] sim_round2 denominators
+  const float* gdot;         // [2][N_L]: dsoftc.softc, dsoftr.softr
+  float* delta_part;         // [S][HEADS][2][N_L]
+  float *dqn_c, *dqn_r;      // [N_L][WP]   (atomic accumulate)
+  float *dkn_c, *dkn_r, *dv_c, *dv_r;   // [Npad][WP]
+  float* dscore;             // [N]
+  int N, N_L, Npad, WP, S;
+  float scale, sim_thresh, conf_thresh;
+};
+
+__device__ __forceinline__ f16x8 tr_frag16(const f16* tile_row0_col0, int ldst, int lane) {
+  const int i = lane & 15, q = i >> 2, p = i & 3;
+  auto a0 = (__attribute__((address_space(3))) s16x4*)(tile_row0_col0 + q * ldst + 4 * p);
+  auto a1 = (__attribute__((address_space(3))) s16x4*)(tile_row0_col0 + (q + 4) * ldst + 4 * p);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(a0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(a1);
+  f16x4 lo4 = __builtin_bit_cast(f16x4, lo), hi4 = __builtin_bit_cast(f16x4, hi);   // whole-vector casts (see conv_wgrad.hip)
+  return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ------------------------------------------------------------------------------------------------ layouts for backward
+// One wave per (row, branch): extra operand layouts that the forward prep does not produce (raw v padded, k^ transposed,
+// per-tile transposed q^) -- rows follow mca_prep_kernel's conventions.
+__global__ void mca_bwd_layout_kernel(const f16* __restrict__ kn_c, const f16* __restrict__ kn_r, const f16* __restrict__ kv_c,
+                                      const f16* __restrict__ kv_r, int N, int Npad, int W, int d, int DP, f16* vraw_c,
+                                      f16* vraw_r, f16* kt_c, f16* kt_r) {
+  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  int n = wave >> 1, br = wave & 1;
+  if (n >= Npad) return;
+  const int WP = MCA_HEADS * DP;
+  const f16* kn = br ? kn_r : kn_c;
+  const f16* kv = br ? kv_r : kv_c;
+  f16* vraw = br ? vraw_r : vraw_c;
+  f16* kt = br ? kt_r : kt_c;
+  for (int c = lane; c < WP; c += 64) {
+    int h = c / DP, j = c % DP;
+    f16 v = (n < N && j < d) ? kv[(long)n * 2 * W + W + h * d + j] : (f16)0.f;
+    vraw[(long)n * WP + c] = v;
+    kt[(long)c * Npad + n] = kn[(long)n * WP + c];
+  }
+}
+
+// Per q-tile: padded row-major + transposed copies of q^ and of the upstream gradients, and gdot = dsoft . soft.
+__global__ void mca_bwd_tiles_kernel(const McaTile* __restrict__ tiles, int ntiles, const f16* __restrict__ qn_c,
+                                     const f16* __restrict__ qn_r, const f16* __restrict__ dO_c, int ld_dO,
+                                     const f16* __restrict__ dO_r, const f16* __restrict__ dS_c, int ld_dS,
+                                     const f16* __restrict__ dS_r, const f16* __restrict__ soft_c, const f16* __restrict__ soft_r,
+                                     int ld_soft, int N_L, int W, int d, int DP, int need_reg, f16* qT_c, f16* qT_r, f16* gO_c,
+                                     f16* gO_r, f16* gS_c, f16* gS_r, f16* gOT_c, f16* gOT_r, f16* gST_c, f16* gST_r,
+                                     float* gdot) {
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const McaTile tl = tiles[t];
+  const int WP = MCA_HEADS * DP;
+  for (int i = tid; i < 32 * WP; i += blockDim.x) {
+    int j = i / WP, c = i % WP;          // j = row inside the tile, c = padded column
+    int h = c / DP, jj = c % DP;
+    bool ok = j < tl.nrows && jj < d;
+    long row = tl.row0 + j;
+    f16 z = (f16)0.f;
+    f16 a = ok ? dO_c[row * ld_dO + h * d + jj] : z;
+    f16 b = ok ? dS_c[row * ld_dS + h * d + jj] : z;
+    f16 ar = (ok && need_reg) ? dO_r[row * ld_dO + h * d + jj] : z;
+    f16 br = (ok && need_reg) ? dS_r[row * ld_dS + h * d + jj] : z;
+    if (j < tl.nrows) {
+      gO_c[row * WP + c] = a; gS_c[row * WP + c] = b; gO_r[row * WP + c] = ar; gS_r[row * WP + c] = br;
+    }
+    long o = ((long)t * WP + c) * 32 + j;
+    gOT_c[o] = a; gST_c[o] = b; gOT_r[o] = ar; gST_r[o] = br;
+    qT_c[o] = j < tl.nrows ? qn_c[row * WP + c] : z;
+    qT_r[o] = j < tl.nrows ? qn_r[row * WP + c] : z;
+  }
+  // gdot: one wave per row
+  int wv = tid >> 6, lane = tid & 63;
+  for (int j = wv; j < tl.nrows; j += (blockDim.x >> 6)) {
+    long row = tl.row0 + j;
+    float gc = 0.f, gr = 0.f;
+    for (int c = lane; c < W; c += 64) {
+      gc += (float)dS_c[row * ld_dS + c] * (float)soft_c[row * ld_soft + c];
+      if (need_reg) gr += (float)dS_r[row * ld_dS + c] * (float)soft_r[row * ld_soft + c];
+    }
+    gc = wave_sum(gc); gr = wave_sum(gr);
+    if (lane == 0) { gdot[row] = gc; gdot[N_L + row] = gr; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ core
+template <int DP, bool NEED_REG, int PASS>
+__global__ __launch_bounds__(256) void mca_bwd_core_kernel(McaBwdParams p) {
+  constexpr int KS = DP / 16, NT = DP / 32;
+  constexpr int PST = 33, HST = 40;
+  __shared__ float X[3][MCA_HEADS][32][PST];          // cross-head exchange (round 1: P, Rc, Rr; round 2: -, dAc, dAr)
+  __shared__ float A32[2][32][PST];                   // Ac, Ar (fp32)
+  __shared__ __attribute__((aligned(16))) f16 A16[2][32][HST];              // Ac, Ar (fp16 MFMA operands)
+  __shared__ __attribute__((aligned(16))) f16 T16[3][MCA_HEADS][32][HST];   // per head: Tc, Tr, P
+  __shared__ float invl[MCA_HEADS][2][32];
+  __shared__ float dlt[MCA_HEADS][2][32];
+  __shared__ float dinv[2][32];
+  __shared__ float gdt[2][32];
+
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int tile = blockIdx.x;
+  const McaTile t = p.tiles[tile];
+  const int s = blockIdx.y;
+  const int n_local = ((t.loc_end + 31) >> 5) - (t.loc_start >> 5);
+  const int n_glob = ((p.N + 31) >> 5) - (p.N_L >> 5);
+  const int nblk = n_local + n_glob;
+  {
+    int hh = tid >> 6, rem = tid & 63, br = rem >> 5, row = rem & 31;
+    bool ok = row < t.nrows;
+    float l = ok ? p.stats[((long)hh * 2 + br) * p.N_L + t.row0 + row] : 0.f;
+    invl[hh][br][row] = l > 0.f ? 1.0f / l : 0.f;
+    float dsum = 0.f;
+    if (PASS == 2 && ok)
+      for (int ss = 0; ss < p.S; ++ss) dsum += p.delta_part[(((long)ss * MCA_HEADS + hh) * 2 + br) * p.N_L + t.row0 + row];
+    dlt[hh][br][row] = dsum;
+    if (tid < 64) {
+      float dn = ok ? p.stats[(long)MCA_HEADS * 2 * p.N_L + (long)br * p.N_L + t.row0 + row] : 0.f;
+      dinv[br][row] = dn > 0.f ? 1.0f / dn : 0.f;
+      gdt[br][row] = ok ? p.gdot[(long)br * p.N_L + t.row0 + row] : 0.f;
+    }
+  }
+  int qrow = t.row0 + (lane & 31);
+  if (qrow >= t.row0 + t.nrows) qrow = t.row0;
+  f16x8 qc[KS], qr[KS], vlc[KS], vlr[KS], gOc[KS], gOr[KS], gSc[KS], gSr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    long o = (long)qrow * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
+    qc[ks] = *(const f16x8*)(p.qn_c + o);
+    qr[ks] = *(const f16x8*)(p.qn_r + o);
+    vlc[ks] = *(const f16x8*)(p.vn_c + o);
+    gOc[ks] = *(const f16x8*)(p.gO_c + o);
+    gSc[ks] = *(const f16x8*)(p.gS_c + o);
+    if (NEED_REG) {
+      vlr[ks] = *(const f16x8*)(p.vn_r + o);
+      gOr[ks] = *(const f16x8*)(p.gO_r + o);
+      gSr[ks] = *(const f16x8*)(p.gS_r + o);
+    }
+  }
+  f32x16 dqc[NT], dqr[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dqc[n][e] = dqr[n][e] = 0.f;
+  float dl_c[16], dl_r[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dl_c[e] = dl_r[e] = 0.f;
+  __syncthreads();
+
+  const int col = lane & 31, half = lane >> 5, g = lane >> 4;
+  for (int j = s; j < nblk; j += p.S) {
+    int key0, lo, hi;
+    block_range(t, p.N_L, p.N, j, key0, lo, hi, n_local);
+    const int key = key0 + col;
+    const bool valid = key >= lo && key < hi;
+    const float kscore = valid ? (float)p.score[key] : 0.f;
+    f32x16 sc, sr, rc, rr, gvc, gvr, gac, gar;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sc[e] = sr[e] = rc[e] = rr[e] = gvc[e] = gvr[e] = gac[e] = gar[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      long o = (long)key * p.WP + h * DP + ks * 16 + half * 8;
+      f16x8 kc = *(const f16x8*)(p.kn_c + o), kr = *(const f16x8*)(p.kn_r + o);
+      f16x8 vnc = *(const f16x8*)(p.vn_c + o), vrc = *(const f16x8*)(p.vraw_c + o);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qc[ks], kc, sc, 0, 0, 0);
+      sr = __builtin_amdgcn_mfma_f32_32x32x16_f16(qr[ks], kr, sr, 0, 0, 0);
+      rc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlc[ks], vnc, rc, 0, 0, 0);
+      gvc = __builtin_amdgcn_mfma_f32_32x32x16_f16(gOc[ks], vrc, gvc, 0, 0, 0);
+      gac = __builtin_amdgcn_mfma_f32_32x32x16_f16(gSc[ks], vrc, gac, 0, 0, 0);
+      if (NEED_REG) {
+        f16x8 vnr = *(const f16x8*)(p.vn_r + o), vrr = *(const f16x8*)(p.vraw_r + o);
+        rr = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlr[ks], vnr, rr, 0, 0, 0);
+        gvr = __builtin_amdgcn_mfma_f32_32x32x16_f16(gOr[ks], vrr, gvr, 0, 0, 0);
+        gar = __builtin_amdgcn_mfma_f32_32x32x16_f16(gSr[ks], vrr, gar, 0, 0, 0);
+      }
+    }
+    float pc[16], pr[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+      pc[e] = valid ? __expf(p.scale * kscore * sc[e] - p.scale) * invl[h][0][row] : 0.f;
+      pr[e] = valid ? __expf(p.scale * sr[e] - p.scale) * invl[h][1][row] : 0.f;
+      X[0][h][row][col] = 0.5f * (pc[e] + pr[e]);
+      X[1][h][row][col] = valid ? rc[e] : -2.f;
+      X[2][h][row][col] = (valid && NEED_REG) ? rr[e] : -2.f;
+    }
+    __syncthreads();
+    {
+      const int row = tid >> 3, c0 = (tid & 7) * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        int cc = c0 + c;
+        float mp = 0.25f * (X[0][0][row][cc] + X[0][1][row][cc] + X[0][2][row][cc] + X[0][3][row][cc]);
+        float mc = 0.25f * (X[1][0][row][cc] + X[1][1][row][cc] + X[1][2][row][cc] + X[1][3][row][cc]);
+        float mr = 0.25f * (X[2][0][row][cc] + X[2][1][row][cc] + X[2][2][row][cc] + X[2][3][row][cc]);
+        float ex = __expf(mp);
+        float ac = mc > p.sim_thresh ? ex * dinv[0][row] : 0.f;
+        float ar = (NEED_REG && mr > p.conf_thresh) ? ex * dinv[1][row] : 0.f;
+        A32[0][row][cc] = ac; A32[1][row][cc] = ar;
+        A16[0][row][cc] = (f16)ac; A16[1][row][cc] = (f16)ar;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+      X[1][h][row][col] = gac[e];
+      X[2][h][row][col] = NEED_REG ? gar[e] : 0.f;
+    }
+    __syncthreads();
+    {
+      const int row = tid >> 3, c0 = (tid & 7) * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        int cc = c0 + c;
+        float dac = X[1][0][row][cc] + X[1][1][row][cc] + X[1][2][row][cc] + X[1][3][row][cc];
+        float dar = X[2][0][row][cc] + X[2][1][row][cc] + X[2][2][row][cc] + X[2][3][row][cc];
+        X[0][0][row][cc] = A32[0][row][cc] * (dac - gdt[0][row]) + A32[1][row][cc] * (dar - gdt[1][row]);   // dM
+      }
+    }
+    __syncthreads();
+    float dsco = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+      float hdp = 0.5f * (gvc[e] + gvr[e] + 0.25f * X[0][0][row][col]);
+      if (PASS == 1) {
+        dl_c[e] += pc[e] * hdp;
+        dl_r[e] += pr[e] * hdp;
+      } else {
+        float dsc = pc[e] * (hdp - dlt[h][0][row]);
+        float dsr = pr[e] * (hdp - dlt[h][1][row]);
+        dsco += dsc * p.scale * sc[e];
+        T16[0][h][row][col] = (f16)(dsc * p.scale * kscore);
+        T16[1][h][row][col] = (f16)(dsr * p.scale);
+        T16[2][h][row][col] = (f16)(0.5f * (pc[e] + pr[e]));
+      }
+    }
+    if (PASS == 2) {
+      dsco += __shfl_xor(dsco, 32, 64);
+      if (half == 0 && valid) atomicAdd(p.dscore + key, dsco);
+      __syncthreads();
+      // ---- products that reduce over keys: dq^ += T K^  (A rows from LDS, B from the transposed k^) ----
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ko = ks * 16 + half * 8;
+        f16x8 atc = *(const f16x8*)(&T16[0][h][col][ko]);
+        f16x8 atr = *(const f16x8*)(&T16[1][h][col][ko]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          long o = (long)(h * DP + n * 32 + col) * p.Npad + key0 + ko;
+          dqc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(atc, *(const f16x8*)(p.kt_c + o), dqc[n], 0, 0, 0);
+          dqr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(atr, *(const f16x8*)(p.kt_r + o), dqr[n], 0, 0, 0);
+        }
+      }
+      // ---- products that reduce over query rows: dk^ = T^T q^,  dv = P^T dO + A^T dsoft  (transposing LDS reads) ----
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x16 akc, akr, avc, avr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) akc[e] = akr[e] = avc[e] = avr[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int kb = ks * 16 + 8 * (g >> 1), mb = 16 * (g & 1);
+          long ob = ((long)tile * p.WP + h * DP + n * 32 + col) * 32 + ks * 16 + half * 8;
+          f16x8 tcT = tr_frag16(&T16[0][h][kb][mb], HST, lane);
+          f16x8 trT = tr_frag16(&T16[1][h][kb][mb], HST, lane);
+          f16x8 pT = tr_frag16(&T16[2][h][kb][mb], HST, lane);
+          f16x8 acT = tr_frag16(&A16[0][kb][mb], HST, lane);
+          akc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tcT, *(const f16x8*)(p.qT_c + ob), akc, 0, 0, 0);
+          akr = __builtin_amdgcn_mfma_f32_32x32x16_f16(trT, *(const f16x8*)(p.qT_r + ob), akr, 0, 0, 0);
+          avc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pT, *(const f16x8*)(p.gOT_c + ob), avc, 0, 0, 0);
+          avc = __builtin_amdgcn_mfma_f32_32x32x16_f16(acT, *(const f16x8*)(p.gST_c + ob), avc, 0, 0, 0);
+          if (NEED_REG) {
+            f16x8 arT = tr_frag16(&A16[1][kb][mb], HST, lane);
+            avr = __builtin_amdgcn_mfma_f32_32x32x16_f16(pT, *(const f16x8*)(p.gOT_r + ob), avr, 0, 0, 0);
+            avr = __builtin_amdgcn_mfma_f32_32x32x16_f16(arT, *(const f16x8*)(p.gST_r + ob), avr, 0, 0, 0);
+          }
+        }
+        // result rows = keys of this block, columns = channels of head h
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int krow = key0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (krow >= lo && krow < hi) {
+            long o = (long)krow * p.WP + h * DP + n * 32 + col;
+            atomicAdd(p.dkn_c + o, akc[e]);
+            atomicAdd(p.dkn_r + o, akr[e]);
+            atomicAdd(p.dv_c + o, avc[e]);
+            if (NEED_REG) atomicAdd(p.dv_r + o, avr[e]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (PASS == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        dl_c[e] += __shfl_xor(dl_c[e], o, 64);
+        dl_r[e] += __shfl_xor(dl_r[e], o, 64);
+      }
+    }
+    if (col == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row < t.nrows) {
+          long o = (((long)s * MCA_HEADS + h) * 2) * p.N_L + t.row0 + row;
+          p.delta_part[o] = dl_c[e];
+          p.delta_part[o + p.N_L] = dl_r[e];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row < t.nrows) {
+          long o = (long)(t.row0 + row) * p.WP + h * DP + n * 32 + col;
+          atomicAdd(p.dqn_c + o, dqc[n][e]);
+          atomicAdd(p.dqn_r + o, dqr[n][e]);
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ normalisation backward
+// One wave per (row, branch): x^ = x/||x||  =>  dx = (dx^ - x^ (x^.dx^)) / ||x||  per head, for q and k; v passes through
+// (+ the gradient of the "x_ori" rows, i.e. d xcat[:, W:2W], for local rows).  Outputs fp16 dq [N_L,W], dkv [N,2W].
+__global__ void mca_bwd_finish_kernel(const f16* __restrict__ q_c, const f16* __restrict__ kv_c, const f16* __restrict__ q_r,
+                                      const f16* __restrict__ kv_r, const float* __restrict__ dqn_c, const float* __restrict__ dqn_r,
+                                      const float* __restrict__ dkn_c, const float* __restrict__ dkn_r, const float* __restrict__ dv_c,
+                                      const float* __restrict__ dv_r, const f16* __restrict__ dvloc_c, const f16* __restrict__ dvloc_r,
+                                      int ld_dvloc, int N, int N_L, int W, int d, int DP, int need_reg, f16* dq_c, f16* dkv_c,
+                                      f16* dq_r, f16* dkv_r) {
+  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  int n = wave >> 1, br = wave & 1;
+  if (n >= N) return;
+  const int WP = MCA_HEADS * DP;
+  const f16* q = br ? q_r : q_c;
+  const f16* kv = br ? kv_r : kv_c;
+  const float* dqn = br ? dqn_r : dqn_c;
+  const float* dkn = br ? dkn_r : dkn_c;
+  const float* dv = br ? dv_r : dv_c;
+  const f16* dvloc = br ? dvloc_r : dvloc_c;
+  f16* dq = br ? dq_r : dq_c;
+  f16* dkv = br ? dkv_r : dkv_c;
+  const bool vgrad = (br == 0) || need_reg;
+  for (int h = 0; h < MCA_HEADS; ++h) {
+    float kx[2] = {0.f, 0.f}, qx[2] = {0.f, 0.f}, dk[2] = {0.f, 0.f}, dqq[2] = {0.f, 0.f};
+    float sk = 0.f, sq = 0.f, kd = 0.f, qd = 0.f;
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      int j = lane + rnd * 64;
+      if (j < d) {
+        kx[rnd] = (float)kv[(long)n * 2 * W + h * d + j];
+        dk[rnd] = dkn[(long)n * WP + h * DP + j];
+        if (n < N_L) {
+          qx[rnd] = (float)q[(long)n * W + h * d + j];
+          dqq[rnd] = dqn[(long)n * WP + h * DP + j];
+        }
+      }
+      sk += kx[rnd] * kx[rnd]; sq += qx[rnd] * qx[rnd];
+      kd += kx[rnd] * dk[rnd]; qd += qx[rnd] * dqq[rnd];
+    }
+    sk = wave_sum(sk); sq = wave_sum(sq); kd = wave_sum(kd); qd = wave_sum(qd);
+    float ik = 1.0f / sqrtf(sk), iq = 1.0f / sqrtf(sq);
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      int j = lane + rnd * 64;
+      if (j < d) {
+        // x^.dx^ = (x.dx^)/||x||  =>  dx = dx^/||x|| - x (x.dx^)/||x||^3
+        dkv[(long)n * 2 * W + h * d + j] = (f16)(dk[rnd] * ik - kx[rnd] * kd * ik * ik * ik);
+        float g = vgrad ? dv[(long)n * WP + h * DP + j] : 0.f;
+        if (n < N_L && vgrad) g += (float)dvloc[(long)n * ld_dvloc + h * d + j];
+        dkv[(long)n * 2 * W + W + h * d + j] = (f16)g;
+        if (n < N_L) dq[(long)n * W + h * d + j] = (f16)(dqq[rnd] * iq - qx[rnd] * qd * iq * iq * iq);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI
+extern "C" long tscd_mca_backward_workspace_bytes(int N, int N_L, int W, int S, int ntiles) {
+  int d = W / MCA_HEADS, DP = (d + 31) / 32 * 32, WP = MCA_HEADS * DP;
+  long Npad = (N + 31) / 32 * 32 + 32;
+  long halves = 2L * N_L * WP + 4L * Npad * WP + 2L * WP * Npad          // forward prep layouts
+                + 2L * Npad * WP + 2L * WP * Npad                       // vraw, kt
+                + 4L * N_L * WP + 6L * ntiles * WP * 32;                // gO/gS padded, qT/gOT/gST per tile
+  long floats = 2L * N_L + (long)S * MCA_HEADS * 2 * N_L + 2L * N_L * WP + 4L * Npad * WP;
+  return halves * 2 + floats * 4 + 8192;
+}
+
+// defined in mca.hip
+void mca_launch_prep(hipStream_t st, const f16* q_c, const f16* kv_c, const f16* q_r, const f16* kv_r, int N, int N_L, int Npad, int W,
+                     int d, int DP, f16* qn_c, f16* kn_c, f16* vn_c, f16* vt_c, f16* qn_r, f16* kn_r, f16* vn_r, f16* vt_r, f16* xcat_c,
+                     f16* xcat_r);
+
+// dxcat_* : gradient w.r.t. the [N_L, 2W] concat (first W = attention output, second W = own value rows);
+// dsoft_* : gradient w.r.t. the first W columns of the [N_L, 3W] concat (row stride ld_dsoft); soft_* the forward values.
+// Outputs: dq_* [N_L, W], dkv_* [N, 2W] fp16; dscore [N] fp32 (zeroed here).
+extern "C" int tscd_mca_backward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
+                                 const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
+                                 float sim_thresh, float conf_thresh, const float* stats, const void* dxcat_c,
+                                 const void* dxcat_r, const void* dsoft_c, const void* dsoft_r, int ld_dsoft, const void* soft_c,
+                                 const void* soft_r, int ld_soft, void* workspace, long workspace_bytes, void* dq_c, void* dkv_c,
+                                 void* dq_r, void* dkv_r, float* dscore, void* stream) {
+  TSCD_CHECK_ARG(q_c && kv_c && q_r && kv_r && score && tiles && stats && dxcat_c && dsoft_c && soft_c && workspace && dq_c &&
+                     dkv_c && dq_r && dkv_r && dscore, "mca_backward: null pointer");
+  TSCD_CHECK_ARG(!need_reg || (dxcat_r && dsoft_r && soft_r), "mca_backward: reg gradients missing");
+  TSCD_CHECK_ARG(W % MCA_HEADS == 0 && W % 8 == 0 && N_L > 0 && N >= N_L && ntiles > 0 && S > 0 && S <= 64, "mca_backward: bad sizes");
+  const int d = W / MCA_HEADS, DP = (d + 31) / 32 * 32, WP = MCA_HEADS * DP;
+  TSCD_CHECK_ARG(DP <= 96, "mca_backward: head dim %d not supported (max 96)", d);
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_mca_backward_workspace_bytes(N, N_L, W, S, ntiles), "mca_backward: workspace too small");
+  const int Npad = (N + 31) / 32 * 32 + 32;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  auto take = [&](long bytes) { char* r = ws; ws += (bytes + 255) / 256 * 256; return r; };
+  f16* qn_c = (f16*)take(2L * N_L * WP); f16* qn_r = (f16*)take(2L * N_L * WP);
+  f16* kn_c = (f16*)take(2L * Npad * WP); f16* kn_r = (f16*)take(2L * Npad * WP);
+  f16* vn_c = (f16*)take(2L * Npad * WP); f16* vn_r = (f16*)take(2L * Npad * WP);
+  f16* vt_c = (f16*)take(2L * WP * Npad); f16* vt_r = (f16*)take(2L * WP * Npad);
+  f16* vraw_c = (f16*)take(2L * Npad * WP); f16* vraw_r = (f16*)take(2L * Npad * WP);
+  f16* kt_c = (f16*)take(2L * WP * Npad); f16* kt_r = (f16*)take(2L * WP * Npad);
+  f16* gO_c = (f16*)take(2L * N_L * WP); f16* gO_r = (f16*)take(2L * N_L * WP);
+  f16* gS_c = (f16*)take(2L * N_L * WP); f16* gS_r = (f16*)take(2L * N_L * WP);
+  long tb = 2L * ntiles * WP * 32;
+  f16* qT_c = (f16*)take(tb); f16* qT_r = (f16*)take(tb);
+  f16* gOT_c = (f16*)take(tb); f16* gOT_r = (f16*)take(tb); f16* gST_c = (f16*)take(tb); f16* gST_r = (f16*)take(tb);
+  float* gdot = (float*)take(4L * 2 * N_L);
+  float* delta_part = (float*)take(4L * S * MCA_HEADS * 2 * N_L);
+  // atomic targets (one contiguous region, zeroed together with dscore)
+  long acc_floats = 2L * N_L * WP + 4L * Npad * WP;
+  float* acc = (float*)take(4L * acc_floats);
+  TSCD_CHECK_ARG(ws - (char*)workspace <= workspace_bytes, "mca_backward: workspace carve-out overflow");
+  float* dqn_c = acc; float* dqn_r = dqn_c + (long)N_L * WP;
+  float* dkn_c = dqn_r + (long)N_L * WP; float* dkn_r = dkn_c + (long)Npad * WP;
+  float* dv_c = dkn_r + (long)Npad * WP; float* dv_r = dv_c + (long)Npad * WP;
+  (void)hipMemsetAsync(acc, 0, 4L * acc_floats, st);
+  (void)hipMemsetAsync(dscore, 0, 4L * N, st);
+
+  {
+    long waves = 2L * Npad;
+    unsigned grid = (unsigned)((waves * 64 + 255) / 256);
+    mca_launch_prep(st, (const f16*)q_c, (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, N, N_L, Npad, W, d, DP, qn_c, kn_c, vn_c,
+                    vt_c, qn_r, kn_r, vn_r, vt_r, nullptr, nullptr);
+    hipLaunchKernelGGL(mca_bwd_layout_kernel, dim3(grid), dim3(256), 0, st, kn_c, kn_r, (const f16*)kv_c, (const f16*)kv_r, N, Npad,
+                       W, d, DP, vraw_c, vraw_r, kt_c, kt_r);
+    hipLaunchKernelGGL(mca_bwd_tiles_kernel, dim3(ntiles), dim3(256), 0, st, (const McaTile*)tiles, ntiles, qn_c, qn_r,
+                       (const f16*)dxcat_c, 2 * W, (const f16*)dxcat_r, (const f16*)dsoft_c, ld_dsoft, (const f16*)dsoft_r,
+                       (const f16*)soft_c, (const f16*)soft_r, ld_soft, N_L, W, d, DP, need_reg, qT_c, qT_r, gO_c, gO_r, gS_c, gS_r,
+                       gOT_c, gOT_r, gST_c, gST_r, gdot);
+    TSCD_CHECK_LAUNCH("mca_backward prep");
+  }
+  McaBwdParams p;
+  p.qn_c = qn_c; p.qn_r = qn_r; p.kn_c = kn_c; p.kn_r = kn_r; p.vn_c = vn_c; p.vn_r = vn_r;
+  p.vraw_c = vraw_c; p.vraw_r = vraw_r; p.kt_c = kt_c; p.kt_r = kt_r; p.qT_c = qT_c; p.qT_r = qT_r;
+  p.gO_c = gO_c; p.gO_r = gO_r; p.gS_c = gS_c; p.gS_r = gS_r; p.gOT_c = gOT_c; p.gOT_r = gOT_r; p.gST_c = gST_c; p.gST_r = gST_r;
+  p.score = (const f16*)score; p.tiles = (const McaTile*)tiles; p.stats = stats; p.gdot = gdot; p.delta_part = delta_part;
+  p.dqn_c = dqn_c; p.dqn_r = dqn_r; p.dkn_c = dkn_c; p.dkn_r = dkn_r; p.dv_c = dv_c; p.dv_r = dv_r; p.dscore = dscore;
+  p.N = N; p.N_L = N_L; p.Npad = Npad; p.WP = WP; p.S = S;
+  p.scale = scale; p.sim_thresh = sim_thresh; p.conf_thresh = conf_thresh;
+  dim3 grid(ntiles, S), block(256);
+#define MCAB(DPV)                                                                            \
+  do {                                                                                       \
+    if (need_reg) {                                                                          \
+      hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, true, 1>), grid, block, 0, st, p);        \
+      hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, true, 2>), grid, block, 0, st, p);        \
+    } else {                                                                                 \
+      hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, false, 1>), grid, block, 0, st, p);       \
+      hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, false, 2>), grid, block, 0, st, p);       \
+    }                                                                                        \
+  } while (0)
+  if (DP == 32) MCAB(32);
+  else if (DP == 64) MCAB(64);
+  else MCAB(96);
+#undef MCAB
+  TSCD_CHECK_LAUNCH("mca_backward core");
+  {
+    long waves = 2L * N;
+    hipLaunchKernelGGL(mca_bwd_finish_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st, (const f16*)q_c,
+                       (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, dqn_c, dqn_r, dkn_c, dkn_r, dv_c, dv_r,
+                       (const f16*)dxcat_c + W, need_reg ? (const f16*)dxcat_r + W : (const f16*)dxcat_c + W, 2 * W, N, N_L, W, d, DP,
+                       need_reg, (f16*)dq_c, (f16*)dkv_c, (f16*)dq_r, (f16*)dkv_r);
+    TSCD_CHECK_LAUNCH("mca_backward finish");
+  }
+  return TSCD_OK;
+}

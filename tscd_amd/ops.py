@@ -250,8 +250,17 @@ def linear(x, weight, bias=None, out=None, wpk=None):
 # ----------------------------------------------------------------------------------------------------
 # proposal stage
 # ----------------------------------------------------------------------------------------------------
+def h2d(data, dtype, device):
+    """Small host table -> device WITHOUT a stream-blocking pageable copy: stage through (cached) pinned memory and copy
+    asynchronously on the current stream.  Every index / tile / offset table of the proposal stage goes through here."""
+    t = torch.as_tensor(data, dtype=dtype)
+    if device is None or torch.device(device).type != "cuda":
+        return t
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def _i32(vals, device):
-    return torch.tensor(vals, dtype=torch.int32, device=device)
+    return h2d(vals, torch.int32, device)
 
 
 class LevelGeometry:
@@ -347,28 +356,75 @@ def mca_tiles(preds_per_frame, lframe, device):
         for r in range(0, n, 32):
             tiles.append((start + r, min(32, n - r), start, start + n))
         start += n
-    return torch.tensor(tiles, dtype=torch.int32, device=device).reshape(-1, 4)
+    return h2d(tiles, torch.int32, device).reshape(-1, 4)
 
 
-def mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale, sim_thresh, conf_thresh, splits=None):
-    """Fused global-to-local attention.  Returns (xcat_c [N_L,2W], cat3_c [N_L,3W], xcat_r, cat3_r): first W columns
+def mca_splits(ntiles):
+    return max(1, min(16, (1024 + ntiles - 1) // max(ntiles, 1)))
+
+
+def mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale, sim_thresh, conf_thresh, splits=None,
+                  want_stats=False):
+    """Fused global-to-local attention.  Returns (xcat_c [N_L,2W], cat3_c [N_L,3W], xcat_r, cat3_r, stats): first W columns
     of xcat = P@v, second W = own values; first W columns of cat3 = the sim_round2 aggregation (rest is filled by the
-    caller's linear)."""
+    caller's linear); stats (for backward) = softmax row sums [4,2,N_L] ++ sim_round2 denominators [2,N_L]."""
     dev = q_c.device
     nt = tiles.shape[0]
     if splits is None:
-        splits = max(1, min(16, (1024 + nt - 1) // max(nt, 1)))
+        splits = mca_splits(nt)
     ws_bytes = lib.tscd_mca_workspace_bytes(N, N_L, W, splits)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     mk = lambda c: torch.empty((N_L, c), dtype=torch.float16, device=dev)
     xcat_c, cat3_c = mk(2 * W), mk(3 * W)
     xcat_r, cat3_r = (mk(2 * W), mk(3 * W)) if need_reg else (None, None)
+    stats = torch.empty((10 * N_L,), dtype=torch.float32, device=dev) if want_stats else None
     for t in (q_c, kv_c, q_r, kv_r, score):
         assert t.is_contiguous() and t.dtype == torch.float16
     call("tscd_mca_forward", q_c.data_ptr(), kv_c.data_ptr(), q_r.data_ptr(), kv_r.data_ptr(), score.data_ptr(),
          tiles.data_ptr(), nt, N, N_L, W, splits, int(need_reg), float(scale), float(sim_thresh), float(conf_thresh),
-         ws.data_ptr(), ws_bytes, xcat_c.data_ptr(), _ptr(xcat_r), cat3_c.data_ptr(), _ptr(cat3_r), _stream())
-    return xcat_c, cat3_c, xcat_r, cat3_r
+         ws.data_ptr(), ws_bytes, xcat_c.data_ptr(), _ptr(xcat_r), cat3_c.data_ptr(), _ptr(cat3_r), _ptr(stats), _stream())
+    return xcat_c, cat3_c, xcat_r, cat3_r, stats
+
+
+def mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale, sim_thresh, conf_thresh, stats, dxcat_c, dxcat_r,
+                 dcat3_c, dcat3_r, cat3_c, cat3_r):
+    """Gradients of the fused attention w.r.t. the projected rows: -> (dq_c [N_L,W], dkv_c [N,2W], dq_r, dkv_r, dscore [N]).
+    dxcat_* [N_L,2W] contiguous fp16; dcat3_* / cat3_* [N_L,3W] (only their first W columns are read)."""
+    dev = q_c.device
+    nt = tiles.shape[0]
+    S = mca_splits(nt)
+    ws_bytes = lib.tscd_mca_backward_workspace_bytes(N, N_L, W, S, nt)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    dq_c = torch.empty((N_L, W), dtype=torch.float16, device=dev)
+    dq_r = torch.empty((N_L, W), dtype=torch.float16, device=dev)
+    dkv_c = torch.empty((N, 2 * W), dtype=torch.float16, device=dev)
+    dkv_r = torch.empty((N, 2 * W), dtype=torch.float16, device=dev)
+    dscore = torch.empty((N,), dtype=torch.float32, device=dev)
+    for t in (dxcat_c, dcat3_c, cat3_c) + ((dxcat_r, dcat3_r, cat3_r) if need_reg else ()):
+        assert t.is_contiguous() and t.dtype == torch.float16
+    call("tscd_mca_backward", q_c.data_ptr(), kv_c.data_ptr(), q_r.data_ptr(), kv_r.data_ptr(), score.data_ptr(), tiles.data_ptr(), nt,
+         N, N_L, W, S, int(need_reg), float(scale), float(sim_thresh), float(conf_thresh), stats.data_ptr(), dxcat_c.data_ptr(),
+         _ptr(dxcat_r), dcat3_c.data_ptr(), _ptr(dcat3_r), 3 * W, cat3_c.data_ptr(), _ptr(cat3_r), 3 * W, ws.data_ptr(), ws_bytes,
+         dq_c.data_ptr(), dkv_c.data_ptr(), dq_r.data_ptr(), dkv_r.data_ptr(), dscore.data_ptr(), _stream())
+    return dq_c, dkv_c, dq_r, dkv_r, dscore
+
+
+def linear_dgrad(dy, weight):
+    """dX = dY @ W for y = x @ W^T (W [out, in]); the same MFMA GEMM with W^T as the 'weight'."""
+    return linear(dy.contiguous(), weight.detach().t().contiguous())
+
+
+def linear_wgrad(x, dy):
+    """dW [out, in] fp32 = dY^T @ X  (the pixel-axis GEMM of conv_wgrad.hip with 1x1 taps)."""
+    n, cin = x.shape
+    cout = dy.shape[1]
+    cp = (cout + 7) // 8 * 8
+    if cp != cout or not dy.is_contiguous():
+        d2 = dy.new_zeros((n, cp))
+        d2[:, :cout] = dy
+        dy = d2
+    dw = conv_wgrad(x.unsqueeze(0).unsqueeze(0), dy.unsqueeze(0).unsqueeze(0), cin, cp, 1)
+    return dw[:cout, :, 0, 0]
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -380,7 +436,7 @@ def attn_tiles(segments, device):
     for (r0, n, k0, k1) in segments:
         for r in range(0, n, 16):
             t.append((r0 + r, min(16, n - r), k0, k1))
-    return torch.tensor(t, dtype=torch.int32, device=device).reshape(-1, 4)
+    return h2d(t, torch.int32, device).reshape(-1, 4)
 
 
 def cos_attn(q, k, v, heads, tiles):

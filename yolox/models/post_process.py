@@ -20,7 +20,7 @@ def nms_frames(det_rows, frame_counts, num_classes, cls_logits=None, obj_logits=
     off = [0]
     for n in frame_counts:
         off.append(off[-1] + n)
-    frame_off = torch.tensor(off, dtype=torch.int32, device=dev)
+    frame_off = ops.h2d(off, torch.int32, dev)
     nmax = max(frame_counts) if frame_counts else 0
     if nmax == 0:
         return [None] * L, [None] * L

@@ -51,9 +51,9 @@ def _mca_torch(x_cls, x_reg, score, wq_c, wkv_c, wq_r, wkv_r, w_lin, b_lin, w_li
         qrow[i, :ppf[i]] = torch.arange(start, start + ppf[i])
         qok[i, :ppf[i]] = True
         start += ppf[i]
-    krow = torch.cat((qrow, torch.arange(nl, N).unsqueeze(0).expand(L, -1)), 1).to(dev)
-    kok = torch.cat((qok, torch.ones((L, ng), dtype=torch.bool)), 1).to(dev)
-    qrow, qok = qrow.to(dev), qok.to(dev)
+    krow = ops.h2d(torch.cat((qrow, torch.arange(nl, N).unsqueeze(0).expand(L, -1)), 1), torch.long, dev)
+    kok = ops.h2d(torch.cat((qok, torch.ones((L, ng), dtype=torch.bool)), 1), torch.bool, dev)
+    qrow, qok = ops.h2d(qrow, torch.long, dev), ops.h2d(qok, torch.bool, dev)
     hd = lambda t: t.view(L, t.shape[1], h, C // h).permute(0, 2, 1, 3)          # [L,h,n,d]
     nrm = lambda t: t / torch.norm(t.float(), dim=-1, keepdim=True).to(t.dtype)
     flat = lambda t: t.permute(0, 2, 1, 3).reshape(L, t.shape[2], C)              # [L,n,C]
@@ -82,6 +82,73 @@ def _mca_torch(x_cls, x_reg, score, wq_c, wkv_c, wq_r, wkv_r, w_lin, b_lin, w_li
     if not need_reg:
         return trans_cls
     return trans_cls, branch(v_r, w_linr, b_linr, conf_thresh, w_obj, b_obj)
+
+
+class _MCAFunction(torch.autograd.Function):
+    """Forward and backward of MCA_tscd_g2l_reg on the HIP kernels (mca.hip / mca_bwd.hip + MFMA GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x_cls, x_reg, score, wq_c, wkv_c, wq_r, wkv_r, w_lin, b_lin, w_linr, b_linr, w_out, b_out, w_obj, b_obj):
+        ppf, lframe, scale, sim_thresh, conf_thresh, need_reg = cfg
+        ctx.set_materialize_grads(False)     # an unused output (agg_iou's cls branch is only used detached) gives None
+        N, W = x_cls.shape
+        nl = sum(ppf[:lframe])
+        xc, xr, sc = x_cls.contiguous(), x_reg.contiguous(), score.to(torch.float16).contiguous()
+        q_c, kv_c = ops.linear(xc[:nl], wq_c), ops.linear(xc, wkv_c)
+        q_r, kv_r = ops.linear(xr[:nl], wq_r), ops.linear(xr, wkv_r)
+        tiles = ops.mca_tiles(ppf, lframe, xc.device)
+        want = any(ctx.needs_input_grad)
+        xcat_c, cat3_c, xcat_r, cat3_r, stats = ops.mca_attention(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, scale, sim_thresh,
+                                                                  conf_thresh, want_stats=want)
+        ops.linear(xcat_c, w_lin, b_lin, out=cat3_c[:, W:])
+        t_cls = ops.linear(cat3_c, w_out, b_out)
+        t_obj = None
+        if need_reg:
+            ops.linear(xcat_r, w_linr, b_linr, out=cat3_r[:, W:])
+            t_obj = ops.linear(cat3_r, w_obj, b_obj)
+        if want:
+            ctx.cfg = cfg
+            ctx.save_for_backward(xc, xr, sc, q_c, kv_c, q_r, kv_r, tiles, stats, xcat_c, cat3_c, xcat_r, cat3_r, wq_c, wkv_c, wq_r, wkv_r,
+                                  w_lin, w_linr, w_out, w_obj)
+        return (t_cls, t_obj) if need_reg else t_cls
+
+    @staticmethod
+    def backward(ctx, g_cls, g_obj=None):
+        ppf, lframe, scale, sim_thresh, conf_thresh, need_reg = ctx.cfg
+        (xc, xr, sc, q_c, kv_c, q_r, kv_r, tiles, stats, xcat_c, cat3_c, xcat_r, cat3_r, wq_c, wkv_c, wq_r, wkv_r, w_lin, w_linr, w_out,
+         w_obj) = ctx.saved_tensors
+        N, W = xc.shape
+        nl = q_c.shape[0]
+        z16 = lambda *shape: torch.zeros(shape, dtype=torch.float16, device=xc.device)
+
+        def head(g, cat3, xcat, w_o, w_l):
+            """through linear(3W->4W) and mca.linear(2W->2W): -> d cat3 [nl,3W], d xcat [nl,2W], dW_o, db_o, dW_l, db_l"""
+            if g is None:      # this output was not used downstream: no gradient for its two linears (SURVEY F5)
+                return z16(nl, 3 * W), z16(nl, 2 * W), None, None, None, None
+            g = g.to(torch.float16).contiguous()
+            d_cat3 = ops.linear_dgrad(g, w_o)
+            d_x = d_cat3[:, W:]
+            d_xcat = ops.linear_dgrad(d_x, w_l)
+            return (d_cat3, d_xcat, ops.linear_wgrad(cat3, g), g.float().sum(0), ops.linear_wgrad(xcat, d_x), d_x.float().sum(0))
+
+        dc3_c, dxc_c, dw_out, db_out, dw_lin, db_lin = head(g_cls, cat3_c, xcat_c, w_out, w_lin)
+        if need_reg:
+            dc3_r, dxc_r, dw_obj, db_obj, dw_linr, db_linr = head(g_obj, cat3_r, xcat_r, w_obj, w_linr)
+        else:
+            dc3_r = dxc_r = dw_obj = db_obj = dw_linr = db_linr = None
+        dq_c, dkv_c, dq_r, dkv_r, dscore = ops.mca_backward(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, scale, sim_thresh,
+                                                            conf_thresh, stats, dxc_c, dxc_r, dc3_c, dc3_r, cat3_c, cat3_r)
+        dx_c = ops.linear_dgrad(dkv_c, wkv_c)
+        dx_c[:nl] += ops.linear_dgrad(dq_c, wq_c)
+        dx_r = ops.linear_dgrad(dkv_r, wkv_r)
+        dx_r[:nl] += ops.linear_dgrad(dq_r, wq_r)
+        like = lambda g, w: None if g is None else g.to(w.dtype).reshape(w.shape)
+        grads = (None, dx_c, dx_r, dscore.to(sc.dtype),
+                 like(ops.linear_wgrad(xc[:nl], dq_c), wq_c), like(ops.linear_wgrad(xc, dkv_c), wkv_c),
+                 like(ops.linear_wgrad(xr[:nl], dq_r), wq_r), like(ops.linear_wgrad(xr, dkv_r), wkv_r),
+                 like(dw_lin, w_lin), db_lin, like(dw_linr, w_linr) if need_reg else None, db_linr,
+                 like(dw_out, w_out), db_out, like(dw_obj, w_obj) if need_reg else None, db_obj)
+        return grads
 
 
 class MCA_tscd_g2l_reg(nn.Module):
@@ -114,6 +181,12 @@ class MCA_tscd_g2l_reg(nn.Module):
         nl = sum(ppf[:lframe])
         args = (ppf, lframe, m.num_heads, float(m.scale), float(sim_thresh), float(conf_thresh), need_reg)
 
+        if kwargs.get("backward", "hip") == "hip" or not torch.is_grad_enabled():
+            cfg = (ppf, lframe, float(m.scale), float(sim_thresh), float(conf_thresh), need_reg)
+            out = _MCAFunction.apply(cfg, x_cls.to(torch.float16), x_reg.to(torch.float16), cls_score, *params)
+            return out if need_reg else (out, None)
+
+        # ---- reference path for gradient checks: HIP forward, backward by differentiating the PyTorch expression ----
         def hip_fn(xc, xr, sc, *ws):
             (wq_c, wkv_c, wq_r, wkv_r, w_lin, b_lin, w_linr, b_linr, w_out, b_out, w_obj, b_obj) = ws
             xc, xr, sc = xc.contiguous(), xr.contiguous(), sc.to(torch.float16).contiguous()
@@ -122,8 +195,8 @@ class MCA_tscd_g2l_reg(nn.Module):
             q_r = ops.linear(xr[:nl], wq_r)
             kv_r = ops.linear(xr, wkv_r)
             tiles = ops.mca_tiles(ppf, lframe, xc.device)
-            xcat_c, cat3_c, xcat_r, cat3_r = ops.mca_attention(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, m.scale,
-                                                               sim_thresh, conf_thresh)
+            xcat_c, cat3_c, xcat_r, cat3_r, _ = ops.mca_attention(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, m.scale,
+                                                                  sim_thresh, conf_thresh)
             ops.linear(xcat_c, w_lin, b_lin, out=cat3_c[:, W:])
             t_cls = ops.linear(cat3_c, w_out, b_out)
             if not need_reg:

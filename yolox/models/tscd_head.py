@@ -174,13 +174,13 @@ class TSCDHead(nn.Module):
         off = [0]
         for n in ppf:
             off.append(off[-1] + n)
-        frame_off = torch.tensor(off, dtype=torch.int32, device=dev)
+        frame_off = ops.h2d(off, torch.int32, dev)
         pred_rows = ops.gather_det(det, sel_idx, frame_off, N)          # pred_result rows, frame-major [N,7+NC]
         if not training and B == 1:
             pr = [pred_rows[off[i]:off[i + 1]] for i in range(B)]
             return pr, pr
         a_idx = torch.cat([sel_idx[b, :ppf[b]] for b in range(B)]).long()
-        b_idx = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor(ppf, device=dev), output_size=N)
+        b_idx = torch.repeat_interleave(torch.arange(B, device=dev), ops.h2d(ppf, torch.long, dev), output_size=N)
 
         maps = [m.contiguous() for m in (cls_maps + reg_maps + edge_maps)]
         if grad and any(m.requires_grad for m in maps):

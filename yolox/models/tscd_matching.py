@@ -230,7 +230,7 @@ class AwarePositionRegMatcher(nn.Module):
         layer = self.transformer_aware_cross_attention_layers[0]
         t_emb = linear(time_embedding.to(torch.float16).contiguous(), self.absolute_position_embedding)
         self.last_hungarian = []
-        idx = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.long, device=dev)
+        idx = lambda a: ops.h2d(np.ascontiguousarray(a), torch.long, dev)
 
         # ---- plan: which (reference, current) pair each non-empty frame is matched against ----
         spans, start = [], 0
