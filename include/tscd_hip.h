@@ -116,6 +116,17 @@ int tscd_se_fuse_f16(const void* reg, int ldr, const void* edge, int lde, const 
                      const float* pos, long n, int C, void* out, void* stream);
 int tscd_add_layernorm_f16(const void* a, const void* b, const float* gamma, const float* beta, int n, int C, float eps,
                            void* out, void* stream);
+/* Backward of the three kernels above (autograd under tscd_trainer.py:171-176).  cos_attn_bwd: gradients w.r.t. the raw
+ * q/k (normalisation backward included) and v; q/dO/dq [n,C], k/v/dk/dv [nk,C]; workspace >= 8*nk*C bytes.  se_fuse_bwd / add_layernorm_bwd: parameter
+ * gradients are fp32 atomics into buffers the caller zeroes (dpos[C], dw0[32*2], dw2[2*32]; dgamma[C], dbeta[C]). */
+int tscd_cos_attn_bwd_f16(const void* q, const void* k, const void* v, const void* dO, int n, int nk, int C, int heads,
+                          const int* tiles, int ntiles, void* workspace, long workspace_bytes, void* dq, void* dk, void* dv,
+                          void* stream);
+int tscd_se_fuse_bwd_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
+                         const void* dout, long n, int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2,
+                         void* stream);
+int tscd_add_layernorm_bwd_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
+                               void* dx, float* dgamma, float* dbeta, void* stream);
 int tscd_row_normalize_f16(const void* x, int ldx, int n, int n_pad, int C, float eps, void* out, int ldo, void* stream);
 
 /* ---- eval tail: decode_reg_preds5 (tscd_head.py:914-949) + postprocess (post_process.py:9-85) +

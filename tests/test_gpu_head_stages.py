@@ -301,3 +301,87 @@ def test_mca_backward_matches_oracle_autograd(W, ppf, L, mode):
         cos = torch.nn.functional.cosine_similarity(got.float().cpu().flatten(), ref.flatten(), dim=0).item()
         ratio = (got.float().cpu().norm() / ref.norm()).item()
         assert cos > 0.999 and abs(ratio - 1) < 0.01, (name, cos, ratio)     # measured: 1.0000 / 1.000 on every tensor
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("C,heads,nq,nk", [(256, 8, 150, 150), (1024, 8, 77, 77), (64, 8, 40, 130), (320, 8, 33, 90)])
+def test_cafm_attention_pieces_backward_match_oracle_autograd(C, heads, nq, nk):
+    """cos_attn / se_fuse / add_layernorm / linear backward kernels vs. autograd of the oracle's fp32 expressions
+    (oracle cos_mh_attention, se_module, referring_cross_attention: the reference's tscd_matching.py:140-181, 264-283, 535-636)."""
+    from yolox.models import tscd_matching as M
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + nq)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    # --- cosine attention, two segments over different key ranges
+    q, k, v, go = rnd(nq, C), rnd(nk, C), rnd(nk, C), rnd(nq, C)
+    h1, k1 = nq // 3, nk // 2
+    segs = [(0, h1, 0, k1), (h1, nq - h1, k1, nk)]
+    qd, kd, vd = (t.half().to(dev).requires_grad_() for t in (q, k, v))
+    out = M.cos_attention(qd, kd, vd, heads, segs)
+    out.backward(go.half().to(dev))
+    qr, kr, vr = (t.half().float().requires_grad_() for t in (q, k, v))
+    outs = []
+    eye = {"a.%s_reg.weight" % n: torch.eye(C) for n in "qkv"}        # the projections are tested with `linear` below
+    for (r0, n, a, b) in segs:
+        outs.append(O.cos_mh_attention(eye, "a", qr[r0:r0 + n], kr[a:b], vr[a:b], heads))
+    ref = torch.cat(outs, 0)
+    ref.backward(go.half().float())
+    assert close(out, ref, 2e-2)
+    for name, got, want in (("dq", qd.grad, qr.grad), ("dk", kd.grad, kr.grad), ("dv", vd.grad, vr.grad)):
+        c = _cos(got.cpu(), want)
+        assert c > 0.9995, (name, c)
+        assert abs(float(got.float().norm().cpu() / want.norm()) - 1) < 2e-2, name
+    # --- SE gate
+    se = M.SEModule(2).to(dev)
+    reg, edge, pos = rnd(nq, C), rnd(nq, C), rnd(1, C)
+    rd, ed = (t.half().to(dev).requires_grad_() for t in (reg, edge))
+    pd = pos.to(dev).requires_grad_()
+    o = se.fuse(rd, ed, pd)
+    o.backward(go.half().to(dev))
+    rr, er, pr = reg.half().float().requires_grad_(), edge.half().float().requires_grad_(), pos.clone().requires_grad_()
+    w0, w2 = se.fc[0].weight.detach().cpu().clone().requires_grad_(), se.fc[2].weight.detach().cpu().clone().requires_grad_()
+    oref = O.se_module({"se.fc.0.weight": w0, "se.fc.2.weight": w2}, "se", rr, er) + pr
+    oref.backward(go.half().float())
+    assert close(o, oref, 2e-2)
+    for name, got, want in (("dreg", rd.grad, rr.grad), ("dedge", ed.grad, er.grad), ("dpos", pd.grad, pr.grad),
+                            ("dw0", se.fc[0].weight.grad, w0.grad), ("dw2", se.fc[2].weight.grad, w2.grad)):
+        c = _cos(got.cpu(), want)
+        assert c > 0.999, (name, c)
+    # --- residual + LayerNorm
+    norm = torch.nn.LayerNorm(C).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * rnd(C)); norm.bias.copy_(0.1 * rnd(C))
+    for with_b in (True, False):
+        norm.zero_grad()
+        ad, bd = reg.half().to(dev).requires_grad_(), edge.half().to(dev).requires_grad_()
+        y = M.add_layernorm(ad, bd if with_b else None, norm)
+        y.backward(go.half().to(dev))
+        ar, br = reg.half().float().requires_grad_(), edge.half().float().requires_grad_()
+        gw, gb = norm.weight.detach().cpu().clone().requires_grad_(), norm.bias.detach().cpu().clone().requires_grad_()
+        x = ar + br if with_b else ar
+        yr = F.layer_norm(x, (C,), gw, gb, norm.eps)
+        yr.backward(go.half().float())
+        assert close(y, yr, 2e-2)
+        pairs = [("da", ad.grad, ar.grad), ("dgamma", norm.weight.grad, gw.grad), ("dbeta", norm.bias.grad, gb.grad)]
+        if with_b:
+            pairs.append(("db", bd.grad, br.grad))
+        for name, got, want in pairs:
+            c = _cos(got.cpu(), want)
+            assert c > 0.9995, (name, with_b, c)
+    # --- linear
+    lin = torch.nn.Linear(C, 2 * C + 8).to(dev)
+    xd = reg.half().to(dev).requires_grad_()
+    gl = rnd(nq, 2 * C + 8)
+    yl = M.linear(xd, lin)
+    yl.backward(gl.half().to(dev))
+    xr = reg.half().float().requires_grad_()
+    wl, bl = lin.weight.detach().cpu().clone().requires_grad_(), lin.bias.detach().cpu().clone().requires_grad_()
+    F.linear(xr, wl, bl).backward(gl.half().float())
+    for name, got, want in (("dx", xd.grad, xr.grad), ("dw", lin.weight.grad, wl.grad), ("db", lin.bias.grad, bl.grad)):
+        c = _cos(got.cpu(), want)
+        assert c > 0.9995, (name, c)

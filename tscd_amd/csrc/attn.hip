@@ -225,3 +225,304 @@ extern "C" int tscd_row_normalize_f16(const void* x, int ldx, int n, int n_pad, 
   TSCD_CHECK_LAUNCH("row_normalize");
   return TSCD_OK;
 }
+
+// ====================================================================================================================
+// Backward kernels (autograd of the modules above under tscd_trainer.py:171-176).
+// ====================================================================================================================
+
+// cos_attn backward.  O = softmax(q^ k^T) v per head.  One workgroup = 16 query rows x one head, two passes over the
+// segment's keys (64 per tile, staged through LDS):
+//   pass 1: l = sum_k exp(s-1), delta = sum_k P (dO.v)
+//   pass 2: dS = P (dO.v - delta);  dq^ += dS k^;  dk^ += dS^T q^;  dv += P^T dO   (dk^, dv: fp32 atomics over query tiles)
+// then the q normalisation backward in place (dq = (dq^ - q^ (q^.dq^)) / ||q||).  k's normalisation backward runs in
+// cos_attn_bwd_finish once all tiles have added their share.
+template <int D>
+__global__ __launch_bounds__(256) void cos_attn_bwd_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                          const f16* __restrict__ v, const f16* __restrict__ dO, int C,
+                                                          const AttnTile* __restrict__ tiles, f16* __restrict__ dq,
+                                                          float* __restrict__ dkn, float* __restrict__ dv) {
+  constexpr int R = 16, KT = 64, DS = D + 1, NC = (D + 15) / 16, NJ = (D + 31) / 32;
+  __shared__ float qs[R][DS], gs[R][DS], ks[KT][DS], vs[KT][DS];
+  __shared__ float ps[R][KT + 1], dss[R][KT + 1];
+  __shared__ float qinv[R], lrow[R], drow[R];
+  const int tid = threadIdx.x, h = blockIdx.y;
+  const AttnTile t = tiles[blockIdx.x];
+  const int r = tid >> 4, c16 = tid & 15;
+  for (int i = tid; i < R * D; i += 256) {
+    int rr = i / D, j = i % D;
+    bool ok = rr < t.nrows;
+    qs[rr][j] = ok ? (float)q[(long)(t.row0 + rr) * C + h * D + j] : 0.f;
+    gs[rr][j] = ok ? (float)dO[(long)(t.row0 + rr) * C + h * D + j] : 0.f;
+  }
+  __syncthreads();
+  {
+    float ss = 0.f;
+    for (int j = c16; j < D; j += 16) ss += qs[r][j] * qs[r][j];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    float inv = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
+    if (c16 == 0) qinv[r] = inv;
+    __syncthreads();
+    for (int j = c16; j < D; j += 16) qs[r][j] *= inv;
+  }
+  float accq[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) accq[i] = 0.f;
+  float lsum = 0.f, dsum = 0.f;
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int kb = t.key0; kb < t.key1; kb += KT) {
+      const int nk = min(KT, t.key1 - kb);
+      for (int i = tid; i < KT * D; i += 256) {
+        int kk = i / D, j = i % D;
+        ks[kk][j] = kk < nk ? (float)k[(long)(kb + kk) * C + h * D + j] : 0.f;
+        vs[kk][j] = kk < nk ? (float)v[(long)(kb + kk) * C + h * D + j] : 0.f;
+      }
+      __syncthreads();
+      {
+        int kk = tid >> 2, part = tid & 3;
+        float ss = 0.f;
+        for (int j = part; j < D; j += 4) ss += ks[kk][j] * ks[kk][j];
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        float inv = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
+        __syncthreads();
+        for (int j = part; j < D; j += 4) ks[kk][j] *= inv;   // k^ in place
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < KT / 16; ++i) {
+        int kk = c16 + 16 * i;
+        float s = 0.f, g = 0.f;
+        for (int j = 0; j < D; ++j) { s += qs[r][j] * ks[kk][j]; g += gs[r][j] * vs[kk][j]; }
+        float pv = kk < nk ? __expf(s - 1.0f) : 0.f;
+        if (pass == 0) {
+          lsum += pv;
+          dsum += pv * g;
+        } else {
+          float pn = pv * lrow[r];
+          ps[r][kk] = pn;
+          dss[r][kk] = pn * (g - drow[r]);
+        }
+      }
+      if (pass == 1) {
+        __syncthreads();
+        for (int kk = 0; kk < nk; ++kk) {
+          float d = dss[r][kk];
+#pragma unroll
+          for (int i = 0; i < NC; ++i)
+            if (c16 + 16 * i < D) accq[i] += d * ks[kk][c16 + 16 * i];
+        }
+        // dk^[kk][c] += sum_r dS[r][kk] q^[r][c];  dv[kk][c] += sum_r P[r][kk] dO[r][c]   (2 keys x 32 channels per wave)
+        for (int i = 0; i < KT / 8; ++i) {
+          int kk = (tid >> 5) + 8 * i;
+          if (kk >= nk) continue;
+#pragma unroll
+          for (int jn = 0; jn < NJ; ++jn) {
+            int c = (tid & 31) + 32 * jn;
+            if (c >= D) continue;
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) { a += dss[rr][kk] * qs[rr][c]; b += ps[rr][kk] * gs[rr][c]; }
+            long o = (long)(kb + kk) * C + h * D + c;
+            atomicAdd(dkn + o, a);
+            atomicAdd(dv + o, b);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (pass == 0) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { lsum += __shfl_xor(lsum, o, 64); dsum += __shfl_xor(dsum, o, 64); }
+      if (c16 == 0) {
+        float il = lsum > 0.f ? 1.0f / lsum : 0.f;
+        lrow[r] = il;
+        drow[r] = dsum * il;
+      }
+      __syncthreads();
+    }
+  }
+  // q normalisation backward: dq = (dq^ - q^ (q^.dq^)) * (1/||q||)
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+    if (c16 + 16 * i < D) dot += accq[i] * qs[r][c16 + 16 * i];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+  if (r < t.nrows) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      if (c16 + 16 * i < D)
+        dq[(long)(t.row0 + r) * C + h * D + c16 + 16 * i] = (f16)((accq[i] - qs[r][c16 + 16 * i] * dot) * qinv[r]);
+  }
+}
+
+// one wave per (key row, head): dk = (dk^ - k^ (k^.dk^)) / ||k||, dv passes through; fp32 accumulators -> fp16 grads
+__global__ void cos_attn_bwd_finish_kernel(const f16* __restrict__ k, const float* __restrict__ dkn, const float* __restrict__ dvacc,
+                                           int n, int C, int heads, f16* __restrict__ dk, f16* __restrict__ dv) {
+  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  int row = wave / heads, h = wave % heads;
+  if (row >= n) return;
+  const int D = C / heads;
+  float ss = 0.f, dot = 0.f;
+  for (int j = lane; j < D; j += 64) {
+    float x = (float)k[(long)row * C + h * D + j];
+    ss += x * x;
+    dot += x * dkn[(long)row * C + h * D + j];
+  }
+  ss = wave_sum(ss); dot = wave_sum(dot);
+  float inv = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
+  for (int j = lane; j < D; j += 64) {
+    long o = (long)row * C + h * D + j;
+    float x = (float)k[o];
+    dk[o] = (f16)(dkn[o] * inv - x * dot * inv * inv * inv);
+    dv[o] = (f16)dvacc[o];
+  }
+}
+
+// q/dO/dq [n,C], k/v/dk/dv [nk,C]; workspace: 2 * nk * C floats (dk^ and dv accumulators, zeroed here)
+extern "C" int tscd_cos_attn_bwd_f16(const void* q, const void* k, const void* v, const void* dO, int n, int nk, int C, int heads,
+                                     const int* tiles, int ntiles, void* workspace, long workspace_bytes, void* dq, void* dk,
+                                     void* dv, void* stream) {
+  TSCD_CHECK_ARG(q && k && v && dO && tiles && workspace && dq && dk && dv && heads > 0 && C % heads == 0, "cos_attn_bwd: bad args");
+  TSCD_CHECK_ARG(workspace_bytes >= 8L * nk * C, "cos_attn_bwd: workspace too small");
+  if (nk == 0) return TSCD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  float* dkn = (float*)workspace;
+  float* dva = dkn + (long)nk * C;
+  (void)hipMemsetAsync(workspace, 0, 8L * nk * C, st);
+  const int D = C / heads;
+  dim3 grid(ntiles, heads), block(256);
+#define CAB(DV)                                                                                                           \
+  hipLaunchKernelGGL((cos_attn_bwd_kernel<DV>), grid, block, 0, st, (const f16*)q, (const f16*)k, (const f16*)v, (const f16*)dO, C, \
+                     (const AttnTile*)tiles, (f16*)dq, dkn, dva)
+  if (ntiles > 0) switch (D) {
+    case 4: CAB(4); break;
+    case 8: CAB(8); break;
+    case 16: CAB(16); break;
+    case 32: CAB(32); break;
+    case 40: CAB(40); break;
+    case 48: CAB(48); break;
+    case 64: CAB(64); break;
+    case 80: CAB(80); break;
+    case 128: CAB(128); break;
+    case 160: CAB(160); break;
+    default:
+      tscd_set_error("cos_attn_bwd: head dim %d not instantiated", D);
+      return TSCD_ERR_ARG;
+  }
+#undef CAB
+  long waves = (long)nk * heads;
+  hipLaunchKernelGGL(cos_attn_bwd_finish_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st, (const f16*)k, dkn, dva,
+                     nk, C, heads, (f16*)dk, (f16*)dv);
+  TSCD_CHECK_LAUNCH("cos_attn_bwd");
+  return TSCD_OK;
+}
+
+// se_fuse backward: d reg, d edge (fp16), d pos [C], d w0 [32][2], d w2 [2][32] (fp32 atomics; caller zeroes them).
+__global__ void se_fuse_bwd_kernel(const f16* __restrict__ reg, int ldr, const f16* __restrict__ edge, int lde,
+                                   const float* __restrict__ w0, const float* __restrict__ w2, const f16* __restrict__ dout, long n,
+                                   int C, f16* __restrict__ dreg, f16* __restrict__ dedge, float* __restrict__ dpos,
+                                   float* __restrict__ dw0, float* __restrict__ dw2) {
+  __shared__ float sw0[64], sw2[64], acc[128];
+  if (threadIdx.x < 64) { sw0[threadIdx.x] = w0[threadIdx.x]; sw2[threadIdx.x] = w2[threadIdx.x]; }
+  if (threadIdx.x < 128) acc[threadIdx.x] = 0.f;
+  __syncthreads();
+  float g0w[32], g1w[32];   // per-thread partial sums of dw2[0][j], dw2[1][j]
+  float h0w[32], h1w[32];   // dw0[j][0], dw0[j][1]
+#pragma unroll
+  for (int j = 0; j < 32; ++j) g0w[j] = g1w[j] = h0w[j] = h1w[j] = 0.f;
+  long total = n * C;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long row = idx / C;
+    int c = idx % C;
+    float a = (float)reg[row * ldr + c], b = (float)edge[row * lde + c], go = (float)dout[idx];
+    float hid[32], z0 = 0.f, z1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      hid[j] = fmaxf(sw0[2 * j] * a + sw0[2 * j + 1] * b, 0.f);
+      z0 += sw2[j] * hid[j];
+      z1 += sw2[32 + j] * hid[j];
+    }
+    float g0 = sigmoidf_(z0), g1 = sigmoidf_(z1);
+    float dz0 = go * a * g0 * (1.f - g0), dz1 = go * b * g1 * (1.f - g1);
+    float da = go * g0, db = go * g1;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      float dh = hid[j] > 0.f ? dz0 * sw2[j] + dz1 * sw2[32 + j] : 0.f;
+      da += dh * sw0[2 * j];
+      db += dh * sw0[2 * j + 1];
+      g0w[j] += dz0 * hid[j];
+      g1w[j] += dz1 * hid[j];
+      h0w[j] += dh * a;
+      h1w[j] += dh * b;
+    }
+    dreg[idx] = (f16)da;
+    dedge[idx] = (f16)db;
+    atomicAdd(dpos + c, go);
+  }
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    float a = wave_sum(g0w[j]), b = wave_sum(g1w[j]), c = wave_sum(h0w[j]), d = wave_sum(h1w[j]);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&acc[j], a); atomicAdd(&acc[32 + j], b); atomicAdd(&acc[64 + 2 * j], c); atomicAdd(&acc[64 + 2 * j + 1], d);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) atomicAdd(dw2 + threadIdx.x, acc[threadIdx.x]);
+  else if (threadIdx.x < 128) atomicAdd(dw0 + threadIdx.x - 64, acc[threadIdx.x]);
+}
+extern "C" int tscd_se_fuse_bwd_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
+                                    const void* dout, long n, int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2,
+                                    void* stream) {
+  TSCD_CHECK_ARG(reg && edge && w0 && w2 && dout && dreg && dedge && dpos && dw0 && dw2, "se_fuse_bwd: null pointer");
+  if (n == 0) return TSCD_OK;
+  long total = n * C;
+  int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(se_fuse_bwd_kernel, dim3(grid > 512 ? 512 : grid), dim3(256), 0, (hipStream_t)stream, (const f16*)reg, ldr,
+                     (const f16*)edge, lde, w0, w2, (const f16*)dout, n, C, (f16*)dreg, (f16*)dedge, dpos, dw0, dw2);
+  TSCD_CHECK_LAUNCH("se_fuse_bwd");
+  return TSCD_OK;
+}
+
+// add_layernorm backward: y = LN(a (+ b)) * gamma + beta.  dx (= da = db) fp16; dgamma / dbeta fp32 atomics (zeroed by caller).
+__global__ void add_layernorm_bwd_kernel(const f16* __restrict__ a, const f16* __restrict__ b, const float* __restrict__ gamma,
+                                         const f16* __restrict__ dy, int n, int C, float eps, f16* __restrict__ dx,
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= n) return;
+  float s = 0.f, s2 = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    float x = (float)a[(long)row * C + c];
+    if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
+    s += x; s2 += x * x;
+  }
+  s = wave_sum(s); s2 = wave_sum(s2);
+  float mean = s / C, var = fmaxf(s2 / C - mean * mean, 0.f), inv = 1.0f / sqrtf(var + eps);
+  float m1 = 0.f, m2 = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    float x = (float)a[(long)row * C + c];
+    if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
+    float xh = (x - mean) * inv, g = (float)dy[(long)row * C + c] * gamma[c];
+    m1 += g; m2 += g * xh;
+  }
+  m1 = wave_sum(m1) / C; m2 = wave_sum(m2) / C;
+  for (int c = lane; c < C; c += 64) {
+    float x = (float)a[(long)row * C + c];
+    if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
+    float xh = (x - mean) * inv, d = (float)dy[(long)row * C + c];
+    dx[(long)row * C + c] = (f16)(inv * (d * gamma[c] - m1 - xh * m2));
+    atomicAdd(dgamma + c, d * xh);
+    atomicAdd(dbeta + c, d);
+  }
+}
+extern "C" int tscd_add_layernorm_bwd_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
+                                          void* dx, float* dgamma, float* dbeta, void* stream) {
+  TSCD_CHECK_ARG(a && gamma && dy && dx && dgamma && dbeta && C > 0, "add_layernorm_bwd: bad args");
+  if (n == 0) return TSCD_OK;
+  hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const f16*)a,
+                     (const f16*)b, gamma, (const f16*)dy, n, C, eps, (f16*)dx, dgamma, dbeta);
+  TSCD_CHECK_LAUNCH("add_layernorm_bwd");
+  return TSCD_OK;
+}

@@ -466,6 +466,48 @@ def add_layernorm(a, b, gamma, beta, eps=1e-5):
     return out
 
 
+def cos_attn_bwd(q, k, v, d_out, heads, tiles):
+    """-> (dq, dk, dv) fp16 [n,C]: backward of cos_attn w.r.t. the raw (pre-normalisation) q / k and v."""
+    n, C = q.shape
+    nk = k.shape[0]
+    dev = q.device
+    for t in (q, k, v, d_out):
+        assert t.is_contiguous() and t.dtype == torch.float16 and t.shape[1] == C
+    assert d_out.shape == q.shape and v.shape == k.shape
+    ws = torch.empty((2 * nk * C,), dtype=torch.float32, device=dev)
+    dq = torch.zeros((n, C), dtype=torch.float16, device=dev)        # rows outside every tile keep a zero gradient
+    dk, dv = (torch.empty((nk, C), dtype=torch.float16, device=dev) for _ in range(2))
+    call("tscd_cos_attn_bwd_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), d_out.data_ptr(), n, nk, C, heads, tiles.data_ptr(),
+         tiles.shape[0], ws.data_ptr(), ws.numel() * 4, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _stream())
+    return dq, dk, dv
+
+
+def se_fuse_bwd(reg, edge, w0, w2, d_out):
+    """-> (d_reg, d_edge fp16 [n,C], d_pos [C], d_w0 [32,2], d_w2 [2,32] fp32)."""
+    n, C = reg.shape
+    dev = reg.device
+    assert reg.stride(1) == 1 and edge.stride(1) == 1 and d_out.is_contiguous() and d_out.dtype == torch.float16
+    d_reg = torch.empty((n, C), dtype=torch.float16, device=dev)
+    d_edge = torch.empty((n, C), dtype=torch.float16, device=dev)
+    acc = torch.zeros((C + 128,), dtype=torch.float32, device=dev)
+    call("tscd_se_fuse_bwd_f16", reg.data_ptr(), reg.stride(0), edge.data_ptr(), edge.stride(0), w0.data_ptr(), w2.data_ptr(),
+         d_out.data_ptr(), n, C, d_reg.data_ptr(), d_edge.data_ptr(), acc.data_ptr(), acc[C:].data_ptr(), acc[C + 64:].data_ptr(),
+         _stream())
+    return d_reg, d_edge, acc[:C], acc[C:C + 64].view(32, 2), acc[C + 64:].view(2, 32)
+
+
+def add_layernorm_bwd(a, b, gamma, d_out, eps=1e-5):
+    """-> (dx fp16 [n,C] (= da = db), d_gamma [C], d_beta [C] fp32)."""
+    n, C = a.shape
+    dev = a.device
+    assert a.is_contiguous() and (b is None or b.is_contiguous()) and d_out.is_contiguous() and d_out.dtype == torch.float16
+    dx = torch.empty((n, C), dtype=torch.float16, device=dev)
+    acc = torch.zeros((2, C), dtype=torch.float32, device=dev)
+    call("tscd_add_layernorm_bwd_f16", a.data_ptr(), _ptr(b), gamma.data_ptr(), d_out.data_ptr(), n, C, eps, dx.data_ptr(),
+         acc[0].data_ptr(), acc[1].data_ptr(), _stream())
+    return dx, acc[0], acc[1]
+
+
 def match_cost(ref_reg, cur_reg, ref_cls, cur_cls):
     """1 - (cos(reg_ref,reg_cur) + cos(cls_ref,cls_cur))/2 as ONE GEMM over [reg | cls] normalised rows -> [n_ref,n_cur] fp16."""
     nr, C = ref_reg.shape

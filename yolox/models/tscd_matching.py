@@ -26,43 +26,97 @@ def _f32(t):
 
 
 # ------------------------------------------------------------------------------------------------- device ops
+class _Linear(torch.autograd.Function):
+    """nn.Linear on the MFMA GEMM, forward and backward: dX = dY W (same kernel, transposed weight), dW = dY^T X (pixel-axis
+    GEMM of conv_wgrad.hip), db = column sums."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return ops.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.to(torch.float16).contiguous()
+        dx = ops.linear_dgrad(g, w) if ctx.needs_input_grad[0] else None
+        dw = ops.linear_wgrad(x, g).to(w.dtype).reshape(w.shape) if ctx.needs_input_grad[1] else None
+        db = g.float().sum(0).to(w.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
 def linear(x, lin):
     """nn.Linear on the MFMA GEMM (fp16 in/out)."""
     w, b = lin.weight, lin.bias
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        return _Linear.apply(x, w, b)
+    return ops.linear(x.contiguous(), w, b)
 
-    def torch_fn(x, w, b):
-        return F.linear(x, w.to(x.dtype), None if b is None else b.to(x.dtype))
 
-    return hip_op(lambda x, w, b: ops.linear(x.contiguous(), w, b), torch_fn, x, w, b)
+class _CosAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads, tiles):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        ctx.save_for_backward(q, k, v, tiles)
+        ctx.heads = heads
+        return ops.cos_attn(q, k, v, heads, tiles)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, tiles = ctx.saved_tensors
+        dq, dk, dv = ops.cos_attn_bwd(q, k, v, g.to(torch.float16).contiguous(), ctx.heads, tiles)
+        return dq, dk, dv, None, None
 
 
 def cos_attention(q, k, v, heads, segments):
     """softmax(q^ k^T) v per head, rows grouped in segments [(row0, nrows, key0, key1)]."""
-    def hip_fn(q, k, v):
-        return ops.cos_attn(q.contiguous(), k.contiguous(), v.contiguous(), heads, ops.attn_tiles(segments, q.device))
+    tiles = ops.attn_tiles(segments, q.device)
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        return _CosAttention.apply(q, k, v, heads, tiles)
+    return ops.cos_attn(q.contiguous(), k.contiguous(), v.contiguous(), heads, tiles)
 
-    def torch_fn(q, k, v):
-        outs = []
-        C = q.shape[1]
-        hd = lambda t: t.view(t.shape[0], heads, C // heads).permute(1, 0, 2)
-        for (r0, n, k0, k1) in segments:
-            qq, kk, vv = hd(q[r0:r0 + n]).float(), hd(k[k0:k1]).float(), hd(v[k0:k1])
-            qq = qq / torch.norm(qq, dim=-1, keepdim=True)
-            kk = kk / torch.norm(kk, dim=-1, keepdim=True)
-            attn = (qq @ kk.transpose(-2, -1)).softmax(-1).to(vv.dtype)
-            outs.append((attn @ vv).permute(1, 0, 2).reshape(n, C))
-        return torch.cat(outs, 0)
 
-    return hip_op(hip_fn, torch_fn, q, k, v)
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps):
+        a = a.contiguous()
+        b = None if b is None else b.contiguous()
+        g32 = _f32(gamma).contiguous()
+        ctx.save_for_backward(a, b, g32)
+        ctx.eps, ctx.pdtype = eps, gamma.dtype
+        return ops.add_layernorm(a, b, g32, _f32(beta).contiguous(), eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, g32 = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.add_layernorm_bwd(a, b, g32, g.to(torch.float16).contiguous(), ctx.eps)
+        need = ctx.needs_input_grad
+        return (dx if need[0] else None, dx if b is not None and need[1] else None,
+                dgamma.to(ctx.pdtype) if need[2] else None, dbeta.to(ctx.pdtype) if need[3] else None, None)
 
 
 def add_layernorm(a, b, norm):
-    def torch_fn(a, b, g, be):
-        x = a if b is None else a + b
-        return F.layer_norm(x.float(), (x.shape[-1],), g.float(), be.float(), norm.eps).to(a.dtype)
+    return _AddLayerNorm.apply(a, b, norm.weight, norm.bias, norm.eps)
 
-    return hip_op(lambda a, b, g, be: ops.add_layernorm(a.contiguous(), None if b is None else b.contiguous(), _f32(g),
-                                                        _f32(be), norm.eps), torch_fn, a, b, norm.weight, norm.bias)
+
+class _SEFuse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, reg, edge, pos, w0, w2):
+        w0f, w2f = _f32(w0).contiguous(), _f32(w2).contiguous()
+        ctx.save_for_backward(reg, edge, w0f, w2f)
+        ctx.pos_shape, ctx.pos_dtype, ctx.wdtype = pos.shape, pos.dtype, w0.dtype
+        return ops.se_fuse(reg, edge, w0f, w2f, _f32(pos).reshape(-1).contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        reg, edge, w0f, w2f = ctx.saved_tensors
+        d_reg, d_edge, d_pos, d_w0, d_w2 = ops.se_fuse_bwd(reg, edge, w0f, w2f, g.to(torch.float16).contiguous())
+        need = ctx.needs_input_grad
+        return (d_reg if need[0] else None, d_edge if need[1] else None,
+                d_pos.reshape(ctx.pos_shape).to(ctx.pos_dtype) if need[2] else None,
+                d_w0.to(ctx.wdtype) if need[3] else None, d_w2.to(ctx.wdtype) if need[4] else None)
 
 
 class MHAttention(nn.Module):
@@ -96,20 +150,7 @@ class SEModule(nn.Module):
 
     def fuse(self, reg, edge, pos):
         """reg*g0 + edge*g1 + pos  (SE gate per (proposal, channel) + with_pos_embed), reg/edge [n,C], pos [1,C] or [C]."""
-        w0, w2 = self.fc[0].weight, self.fc[2].weight
-
-        def hip_fn(reg, edge, pos, w0, w2):
-            return ops.se_fuse(reg, edge, _f32(w0).contiguous(), _f32(w2).contiguous(), _f32(pos).reshape(-1).contiguous())
-
-        def torch_fn(reg, edge, pos, w0, w2):
-            # elementwise form of Linear(2->32) / Linear(32->2): K=2 GEMMs pick pathological hipBLASLt tiles
-            w0, w2 = w0.to(reg.dtype), w2.to(reg.dtype)
-            hid = F.relu(reg.unsqueeze(-1) * w0[:, 0] + edge.unsqueeze(-1) * w0[:, 1])          # [n,C,32]
-            g0 = torch.sigmoid((hid * w2[0]).sum(-1))
-            g1 = torch.sigmoid((hid * w2[1]).sum(-1))
-            return reg * g0 + edge * g1 + pos.to(reg.dtype).reshape(1, -1)
-
-        return hip_op(hip_fn, torch_fn, reg, edge, pos, w0, w2)
+        return _SEFuse.apply(reg, edge, pos, self.fc[0].weight, self.fc[2].weight)
 
 
 def _xavier(mod):
