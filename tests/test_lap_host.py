@@ -47,3 +47,50 @@ def test_lap_large_and_nan():
         r0, c0 = linear_sum_assignment(ref)
         r1, c1 = lap_f16(h.view(np.uint16))
         assert np.array_equal(r0, r1) and np.array_equal(c0, c1)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_lap_fixed_point_fp16_variant_matches_scipy(seed):
+    """The int32 fixed-point AVX-512 path taken for fp16 matrices (and its fall-back to the double solver outside the
+    fixed-point range) returns scipy's indices on the cost shapes CAFM produces: 1 - cos of near-identical rows (dense
+    ties), self-match (zero diagonal), slightly negative entries, rectangular, plus out-of-range / inf entries."""
+    from tscd_amd._host import lap_f16
+    rng = np.random.default_rng(100 + seed)
+    for trial in range(60):
+        nr, nc = rng.integers(1, 140, 2)
+        kind = trial % 6
+        if kind == 0:       # near-identical unit rows: costs ~1e-3 with heavy fp16 ties
+            base = rng.standard_normal((1, 32))
+            a = base + 0.02 * rng.standard_normal((nr, 32)); b = base + 0.02 * rng.standard_normal((nc, 32))
+            a /= np.linalg.norm(a, axis=1, keepdims=True); b /= np.linalg.norm(b, axis=1, keepdims=True)
+            h = (1 - a @ b.T).astype(np.float16)
+        elif kind == 1:     # self-match
+            a = rng.standard_normal((nr, 16)); a /= np.linalg.norm(a, axis=1, keepdims=True)
+            h = (1 - (a @ a.T).astype(np.float16).astype(np.float32)).astype(np.float16)
+        elif kind == 2:
+            h = (0.01 * rng.standard_normal((nr, nc))).astype(np.float16)          # both signs
+        elif kind == 3:
+            h = rng.integers(0, 3, (nr, nc)).astype(np.float16)
+        elif kind == 4:     # leaves the fixed-point range -> double solver
+            h = (20 * rng.random((nr, nc))).astype(np.float16)
+        else:
+            h = (1 + 0.05 * rng.standard_normal((nr, nc))).astype(np.float16)
+            h[rng.integers(0, nr), rng.integers(0, nc)] = np.nan
+        ref = h.astype(float)
+        ref[np.isnan(ref)] = 0
+        perm = rng.permutation(h.shape[0])
+        r0, c0 = linear_sum_assignment(ref[perm])
+        r1, c1 = lap_f16(np.ascontiguousarray(h).view(np.uint16), perm)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1), (seed, trial, kind, h.shape)
+
+
+def test_lap_on_device_cost_sample():
+    """A 192x160 crop of a CAFM cost matrix the MI355X GEMM produced on the bench clip (random-init regime: hundreds of
+    exactly tied fp16 entries per row) with the indices scipy returns for it."""
+    import os
+    from tscd_amd._host import lap_f16
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cafm_cost_device_sample.npz"))
+    r, c = lap_f16(np.ascontiguousarray(z["cost_f16_bits"]))
+    assert np.array_equal(r, z["scipy_rows"]) and np.array_equal(c, z["scipy_cols"])
+    r0, c0 = linear_sum_assignment(z["cost_f16_bits"].view(np.float16).astype(float))
+    assert np.array_equal(c0, z["scipy_cols"])

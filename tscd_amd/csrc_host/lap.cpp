@@ -207,6 +207,164 @@ int solve(int64_t nr, int64_t nc, const double* cost_in, int64_t* a, int64_t* b)
   return 0;
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// Fixed-point variant for fp16 cost matrices (what the device GEMM hands over).  Every fp16 value below 8.0 is an exact
+// multiple of 2^-24, so costs, dual variables and path lengths are exact int32 in that unit; the double-precision
+// sequence above is exact on the same inputs too (all intermediate magnitudes < 2^10 with 2^-24 granularity fit 53 bits),
+// hence both variants -- and scipy -- walk through identical states.  16 columns per AVX-512 op, branch-free relaxation and
+// tie rule, int16 predecessor stores.  Any magnitude reaching 2^27 units (8.0) aborts
+// with status 3 and the caller falls back to the double solver.
+#if defined(__x86_64__)
+constexpr int32_t QLIM = 1 << 27, QINF = 1 << 30;
+static int64_t g_steps = 0;        // relaxation passes of the last solves (diagnostics)
+struct WorkQ {
+  std::vector<int32_t> u, v, spc, col4row, row4col, remaining, pos, sr_list;
+  std::vector<int16_t> path;
+  std::vector<uint16_t> live, freec;
+  std::vector<uint8_t> SR;
+};
+
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static int32_t relax_row_q32(const int32_t* crow, const int32_t* v, int32_t* spc, int16_t* path, const uint16_t* live, int64_t ncp,
+                             int32_t base, int16_t id) {
+  const __m512i vbase = _mm512_set1_epi32(base);
+  const __m256i vid = _mm256_set1_epi16(id);
+  __m512i low = _mm512_set1_epi32(QINF);
+  for (int64_t j = 0, b = 0; j < ncp; j += 16, ++b) {     // branch-free: data-dependent branches here mispredict
+    const __mmask16 lv = live[b];
+    __m512i r = _mm512_sub_epi32(_mm512_add_epi32(_mm512_loadu_si512(crow + j), vbase), _mm512_loadu_si512(v + j));
+    __m512i sp = _mm512_loadu_si512(spc + j);
+    __mmask16 m = _mm512_mask_cmplt_epi32_mask(lv, r, sp);
+    sp = _mm512_mask_mov_epi32(sp, m, r);
+    _mm512_storeu_si512(spc + j, sp);
+    _mm256_mask_storeu_epi16(path + j, m, vid);
+    low = _mm512_mask_min_epi32(low, lv, low, sp);
+  }
+  return _mm512_reduce_min_epi32(low);
+}
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static void convert_q32(const uint16_t* src, int32_t* dst, int64_t n) {   // n % 16 == 0
+  const __m512 scale = _mm512_set1_ps(16777216.0f);
+  for (int64_t j = 0; j < n; j += 16)
+    _mm512_storeu_si512(dst + j, _mm512_cvtps_epi32(_mm512_mul_ps(_mm512_cvtph_ps(_mm256_loadu_si256((const __m256i*)(src + j))), scale)));
+}
+// cost: fp16 bits, [nr][ncp] with ncp % 32 == 0 (padding columns are never live), nr <= nc.  0 ok, 2 infeasible, 3 overflow.
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static int solve_q(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int32_t* col4row_out) {
+  WorkQ w;
+  std::vector<int32_t> c32((size_t)nr * ncp);        // 2^-24 units, converted once
+  convert_q32(cost, c32.data(), nr * ncp);
+  const int64_t nb = ncp / 16;
+  w.u.assign(nr, 0); w.v.assign(ncp, 0); w.spc.resize(ncp); w.path.assign(ncp, -1); w.col4row.assign(nr, -1);
+  w.row4col.assign(ncp, -1); w.remaining.resize(nc); w.pos.resize(ncp); w.live.resize(nb); w.SR.assign(nr, 0);
+  w.sr_list.reserve(nr);
+  w.freec.assign(nb, 0xffff);
+  for (int64_t curRow = 0; curRow < nr; ++curRow) {
+    int32_t minVal = 0;
+    int64_t i = curRow, num_remaining = nc, sink = -1;
+    for (int64_t it = 0; it < nc; ++it) {
+      w.remaining[it] = (int32_t)(nc - it - 1);
+      w.pos[nc - it - 1] = (int32_t)it;
+    }
+    for (int64_t b = 0; b < nb; ++b) {
+      int64_t left = nc - b * 16;
+      w.live[b] = left >= 16 ? 0xffff : (left > 0 ? (uint16_t)((1u << left) - 1) : 0);
+    }
+    for (int32_t r : w.sr_list) w.SR[r] = 0;
+    w.sr_list.clear();
+    std::fill(w.spc.begin(), w.spc.end(), QINF);
+    while (sink == -1) {
+      w.SR[i] = 1;
+      w.sr_list.push_back((int32_t)i);
+      ++g_steps;
+      int32_t lowest = relax_row_q32(c32.data() + i * ncp, w.v.data(), w.spc.data(), w.path.data(), w.live.data(), ncp,
+                                     minVal - w.u[i], (int16_t)i);
+      if (lowest == QINF) return 2;
+      if (lowest >= QLIM || lowest <= -QLIM) return 3;
+      // tie rule, vectorised: smallest `remaining` position among the tied columns, and the largest one among tied
+      // columns that have no row yet (w.freec: bit set while row4col[j] == -1)
+      int64_t first_pos, last_free_pos;
+      {
+        const __m512i vlow = _mm512_set1_epi32(lowest);
+        __m512i pmin = _mm512_set1_epi32(std::numeric_limits<int32_t>::max()), pmax = _mm512_set1_epi32(-1);
+        for (int64_t b = 0; b < nb; ++b) {
+          __mmask16 m = _mm512_mask_cmpeq_epi32_mask(w.live[b], _mm512_loadu_si512(w.spc.data() + b * 16), vlow);
+          if (!m) continue;
+          __m512i pv = _mm512_loadu_si512(w.pos.data() + b * 16);
+          pmin = _mm512_mask_min_epi32(pmin, m, pmin, pv);
+          pmax = _mm512_mask_max_epi32(pmax, m & w.freec[b], pmax, pv);
+        }
+        first_pos = _mm512_reduce_min_epi32(pmin);
+        last_free_pos = _mm512_reduce_max_epi32(pmax);
+      }
+      int64_t index = (last_free_pos > first_pos) ? last_free_pos : first_pos;
+      minVal = lowest;
+      int64_t j = w.remaining[index];
+      if (w.row4col[j] == -1) sink = j; else i = w.row4col[j];
+      w.live[j >> 4] &= (uint16_t)~(1u << (j & 15));
+      --num_remaining;
+      int32_t moved = w.remaining[num_remaining];
+      w.remaining[index] = moved;
+      w.pos[moved] = (int32_t)index;
+    }
+    w.u[curRow] += minVal;
+    bool over = false;
+    for (int32_t r : w.sr_list)
+      if (r != curRow) {
+        w.u[r] += minVal - w.spc[w.col4row[r]];
+        over |= (w.u[r] >= QLIM || w.u[r] <= -QLIM);
+      }
+    over |= (w.u[curRow] >= QLIM || w.u[curRow] <= -QLIM);
+    for (int64_t b = 0; b < nb; ++b) {
+      int64_t left = nc - b * 16;
+      uint32_t full = left >= 16 ? 0xffffu : (left > 0 ? ((1u << left) - 1) : 0u);
+      uint32_t dead = full & ~(uint32_t)w.live[b];
+      while (dead) {
+        int64_t j = b * 16 + __builtin_ctz(dead);
+        dead &= dead - 1;
+        w.v[j] -= minVal - w.spc[j];
+        over |= (w.v[j] >= QLIM || w.v[j] <= -QLIM);
+      }
+    }
+    if (over) return 3;
+    int64_t j = sink;
+    while (true) {
+      int64_t r = w.path[j];
+      w.row4col[j] = (int32_t)r;
+      w.freec[j >> 4] &= (uint16_t)~(1u << (j & 15));
+      int32_t t = w.col4row[r];
+      w.col4row[r] = (int32_t)j;
+      j = t;
+      if (r == curRow) break;
+    }
+  }
+  for (int64_t r = 0; r < nr; ++r) col4row_out[r] = w.col4row[r];
+  return 0;
+}
+static const bool g_have_q = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
+                             __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("f16c");
+
+// gathers (and transposes when nc < nr) the fp16 matrix into the padded layout solve_q wants; false when an entry is
+// outside the fixed-point range (|x| >= 8, inf).  NaN -> 0 like the reference.
+static bool prepare_q(const uint16_t* cost, int64_t ld, const int64_t* row_map, int64_t nr, int64_t nc, bool transpose, int64_t ncp,
+                      std::vector<uint16_t>& out) {
+  const int64_t R = transpose ? nc : nr;
+  out.assign((size_t)R * ncp, 0);
+  bool ok = true;
+  for (int64_t i = 0; i < nr; ++i) {
+    const uint16_t* src = cost + (row_map ? row_map[i] : i) * ld;
+    for (int64_t j = 0; j < nc; ++j) {
+      uint16_t h = src[j];
+      uint32_t e = (h >> 10) & 0x1f;
+      if (e == 31) { if (h & 0x3ff) h = 0; else ok = false; }
+      else if (e >= 18) ok = false;               // |x| >= 8
+      if (transpose) out[(size_t)j * ncp + i] = h; else out[(size_t)i * ncp + j] = h;
+    }
+  }
+  return ok;
+}
+#endif
+
 inline double half_to_double(uint16_t h) {
   uint32_t sign = (h >> 15) & 1, exp = (h >> 10) & 0x1f, man = h & 0x3ff;
   double val;
@@ -228,6 +386,31 @@ int tscd_lap_solve_f64(const double* cost, int64_t nr, int64_t nc, int64_t* row_
 // is cost[row_map[r]] (row_map may be NULL).  NaN entries are replaced by 0 like the reference does.
 int tscd_lap_solve_f16(const uint16_t* cost, int64_t ld, const int64_t* row_map, int64_t nr, int64_t nc, int64_t* row_ind,
                        int64_t* col_ind) {
+  if (nr == 0 || nc == 0) return 0;
+#if defined(__x86_64__)
+  if (g_have_q && nr < 32000 && nc < 32000) {
+    const bool transpose = nc < nr;
+    const int64_t R = transpose ? nc : nr, Cc = transpose ? nr : nc, ncp = (Cc + 31) / 32 * 32;
+    std::vector<uint16_t> q;
+    if (prepare_q(cost, ld, row_map, nr, nc, transpose, ncp, q)) {
+      std::vector<int32_t> c4r(R);
+      int st = solve_q(R, Cc, ncp, q.data(), c4r.data());
+      if (st == 0) {
+        if (transpose) {
+          std::vector<int64_t> order(R);
+          std::iota(order.begin(), order.end(), 0);
+          std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return c4r[x] < c4r[y]; });
+          for (int64_t i = 0; i < R; ++i) { row_ind[i] = c4r[order[i]]; col_ind[i] = order[i]; }
+        } else {
+          for (int64_t i = 0; i < R; ++i) { row_ind[i] = i; col_ind[i] = c4r[i]; }
+        }
+        return 0;
+      }
+      if (st == 2) return 2;
+      // st == 3: magnitudes left the fixed-point range -> double solver below
+    }
+  }
+#endif
   std::vector<double> c((size_t)nr * nc);
   for (int64_t i = 0; i < nr; ++i) {
     const uint16_t* src = cost + (row_map ? row_map[i] : i) * ld;
@@ -237,5 +420,22 @@ int tscd_lap_solve_f16(const uint16_t* cost, int64_t ld, const int64_t* row_map,
     }
   }
   return solve(nr, nc, c.data(), row_ind, col_ind);
+}
+int64_t tscd_lap_debug_steps(int reset) {
+#if defined(__x86_64__)
+  int64_t s = g_steps;
+  if (reset) g_steps = 0;
+  return s;
+#else
+  return 0;
+#endif
+}
+// 1 when tscd_lap_solve_f16 runs the fixed-point AVX-512 variant on this host
+int tscd_lap_fixed_point_available(void) {
+#if defined(__x86_64__)
+  return g_have_q ? 1 : 0;
+#else
+  return 0;
+#endif
 }
 }
