@@ -12,6 +12,7 @@
 // costs: ~1 ms vs 8-12 ms.
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -215,32 +216,50 @@ int solve(int64_t nr, int64_t nc, const double* cost_in, int64_t* a, int64_t* b)
 // tie rule, int16 predecessor stores.  Any magnitude reaching 2^27 units (8.0) aborts
 // with status 3 and the caller falls back to the double solver.
 #if defined(__x86_64__)
-constexpr int32_t QLIM = 1 << 27, QINF = 1 << 30;
-static int64_t g_steps = 0;        // relaxation passes of the last solves (diagnostics)
-struct WorkQ {
-  std::vector<int32_t> u, v, spc, col4row, row4col, remaining, pos, sr_list;
-  std::vector<int16_t> path;
-  std::vector<uint16_t> live, freec;
-  std::vector<uint8_t> SR;
-};
-
-__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
-static int32_t relax_row_q32(const int32_t* crow, const int32_t* v, int32_t* spc, int16_t* path, const uint16_t* live, int64_t ncp,
-                             int32_t base, int16_t id) {
-  const __m512i vbase = _mm512_set1_epi32(base);
-  const __m256i vid = _mm256_set1_epi16(id);
-  __m512i low = _mm512_set1_epi32(QINF);
-  for (int64_t j = 0, b = 0; j < ncp; j += 16, ++b) {     // branch-free: data-dependent branches here mispredict
-    const __mmask16 lv = live[b];
-    __m512i r = _mm512_sub_epi32(_mm512_add_epi32(_mm512_loadu_si512(crow + j), vbase), _mm512_loadu_si512(v + j));
-    __m512i sp = _mm512_loadu_si512(spc + j);
-    __mmask16 m = _mm512_mask_cmplt_epi32_mask(lv, r, sp);
-    sp = _mm512_mask_mov_epi32(sp, m, r);
-    _mm512_storeu_si512(spc + j, sp);
-    _mm256_mask_storeu_epi16(path + j, m, vid);
-    low = _mm512_mask_min_epi32(low, lv, low, sp);
+// 64-byte aligned storage: every 512-bit access below stays inside one cache line (no split loads / failed store forwarding)
+template <typename T>
+struct AlignedBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  AlignedBuf(size_t count, T fill) : n(count) {
+    p = (T*)std::aligned_alloc(64, (count * sizeof(T) + 63) / 64 * 64);
+    for (size_t i = 0; i < count; ++i) p[i] = fill;
   }
-  return _mm512_reduce_min_epi32(low);
+  explicit AlignedBuf(size_t count) : n(count) { p = (T*)std::aligned_alloc(64, (count * sizeof(T) + 63) / 64 * 64); }
+  ~AlignedBuf() { std::free(p); }
+  AlignedBuf(const AlignedBuf&) = delete;
+  AlignedBuf& operator=(const AlignedBuf&) = delete;
+  T* data() { return p; }
+  T& operator[](size_t i) { return p[i]; }
+  T* begin() { return p; }
+  T* end() { return p + n; }
+};
+constexpr int32_t QLIM = 1 << 27, QINF = 1 << 30, QDEADV = -(QINF + (QINF >> 1));
+static int64_t g_steps = 0;        // relaxation passes of the last solves (diagnostics)
+
+// One relaxation pass from row i, mask-free: columns already in SC carry veff = QDEADV (so their candidate exceeds QINF)
+// and spc = QINF (their real spc is parked in spcsave), which removes them from the update, the minimum and the tie test
+// without predicate loads.  Branch-free on purpose: data-dependent branches here mispredict.
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static int32_t relax_row_q32(const int32_t* crow, const int32_t* veff, int32_t* spc, int16_t* path, int64_t ncp, int32_t base,
+                             int16_t id) {
+  const __m512i vbase = _mm512_set1_epi32(base);
+  const __m512i vid = _mm512_set1_epi16(id);
+  __m512i low0 = _mm512_set1_epi32(QINF), low1 = low0;
+  for (int64_t j = 0; j < ncp; j += 32) {
+    __m512i r0 = _mm512_sub_epi32(_mm512_add_epi32(_mm512_loadu_si512(crow + j), vbase), _mm512_loadu_si512(veff + j));
+    __m512i r1 = _mm512_sub_epi32(_mm512_add_epi32(_mm512_loadu_si512(crow + j + 16), vbase), _mm512_loadu_si512(veff + j + 16));
+    __m512i s0 = _mm512_loadu_si512(spc + j), s1 = _mm512_loadu_si512(spc + j + 16);
+    __mmask16 m0 = _mm512_cmplt_epi32_mask(r0, s0), m1 = _mm512_cmplt_epi32_mask(r1, s1);
+    s0 = _mm512_min_epi32(s0, r0);
+    s1 = _mm512_min_epi32(s1, r1);
+    _mm512_storeu_si512(spc + j, s0);
+    _mm512_storeu_si512(spc + j + 16, s1);
+    _mm512_mask_storeu_epi16(path + j, (__mmask32)m0 | ((__mmask32)m1 << 16), vid);
+    low0 = _mm512_min_epi32(low0, s0);
+    low1 = _mm512_min_epi32(low1, s1);
+  }
+  return _mm512_reduce_min_epi32(_mm512_min_epi32(low0, low1));
 }
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
 static void convert_q32(const uint16_t* src, int32_t* dst, int64_t n) {   // n % 16 == 0
@@ -251,94 +270,92 @@ static void convert_q32(const uint16_t* src, int32_t* dst, int64_t n) {   // n %
 // cost: fp16 bits, [nr][ncp] with ncp % 32 == 0 (padding columns are never live), nr <= nc.  0 ok, 2 infeasible, 3 overflow.
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
 static int solve_q(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int32_t* col4row_out) {
-  WorkQ w;
-  std::vector<int32_t> c32((size_t)nr * ncp);        // 2^-24 units, converted once
+  // 2^-24 units, converted once; the 1 MB buffer is kept per thread (fresh pages cost more than the solve's first rows)
+  static thread_local int32_t* c32_buf = nullptr;
+  static thread_local size_t c32_cap = 0;
+  if (c32_cap < (size_t)nr * ncp) {
+    std::free(c32_buf);
+    c32_cap = (size_t)nr * ncp;
+    c32_buf = (int32_t*)std::aligned_alloc(64, (c32_cap * sizeof(int32_t) + 63) / 64 * 64);
+  }
+  struct { int32_t* p; int32_t* data() { return p; } } c32{c32_buf};
   convert_q32(cost, c32.data(), nr * ncp);
-  const int64_t nb = ncp / 16;
-  w.u.assign(nr, 0); w.v.assign(ncp, 0); w.spc.resize(ncp); w.path.assign(ncp, -1); w.col4row.assign(nr, -1);
-  w.row4col.assign(ncp, -1); w.remaining.resize(nc); w.pos.resize(ncp); w.live.resize(nb); w.SR.assign(nr, 0);
-  w.sr_list.reserve(nr);
-  w.freec.assign(nb, 0xffff);
+  AlignedBuf<int32_t> veff(ncp, QDEADV), spc(ncp), pos(ncp, -1), posfree(ncp, -1);
+  AlignedBuf<int16_t> path(ncp, -1);
+  std::vector<int32_t> u(nr, 0), v(ncp, 0), spcsave(ncp, 0), col4row(nr, -1), row4col(ncp, -1);
+  std::vector<int32_t> remaining(nc), remaining0(nc), pos0(ncp, -1), posfree0(ncp, -1);
+  std::vector<int32_t> sr_list, dead_list;
+  sr_list.reserve(nr); dead_list.reserve(nc);
+  for (int64_t it = 0; it < nc; ++it) {
+    remaining0[it] = (int32_t)(nc - it - 1);       // reversed start: a constant matrix solves to the identity (scipy #11602)
+    pos0[nc - it - 1] = posfree0[nc - it - 1] = (int32_t)it;
+    veff[it] = 0;
+  }
   for (int64_t curRow = 0; curRow < nr; ++curRow) {
     int32_t minVal = 0;
     int64_t i = curRow, num_remaining = nc, sink = -1;
-    for (int64_t it = 0; it < nc; ++it) {
-      w.remaining[it] = (int32_t)(nc - it - 1);
-      w.pos[nc - it - 1] = (int32_t)it;
-    }
-    for (int64_t b = 0; b < nb; ++b) {
-      int64_t left = nc - b * 16;
-      w.live[b] = left >= 16 ? 0xffff : (left > 0 ? (uint16_t)((1u << left) - 1) : 0);
-    }
-    for (int32_t r : w.sr_list) w.SR[r] = 0;
-    w.sr_list.clear();
-    std::fill(w.spc.begin(), w.spc.end(), QINF);
+    std::memcpy(remaining.data(), remaining0.data(), sizeof(int32_t) * nc);
+    std::memcpy(pos.data(), pos0.data(), sizeof(int32_t) * ncp);
+    std::memcpy(posfree.data(), posfree0.data(), sizeof(int32_t) * ncp);   // -1 where the column already has a row
+    std::fill(spc.begin(), spc.end(), QINF);
+    sr_list.clear();
+    dead_list.clear();
     while (sink == -1) {
-      w.SR[i] = 1;
-      w.sr_list.push_back((int32_t)i);
+      sr_list.push_back((int32_t)i);
       ++g_steps;
-      int32_t lowest = relax_row_q32(c32.data() + i * ncp, w.v.data(), w.spc.data(), w.path.data(), w.live.data(), ncp,
-                                     minVal - w.u[i], (int16_t)i);
+      int32_t lowest = relax_row_q32(c32.data() + i * ncp, veff.data(), spc.data(), path.data(), ncp, minVal - u[i], (int16_t)i);
       if (lowest == QINF) return 2;
       if (lowest >= QLIM || lowest <= -QLIM) return 3;
-      // tie rule, vectorised: smallest `remaining` position among the tied columns, and the largest one among tied
-      // columns that have no row yet (w.freec: bit set while row4col[j] == -1)
-      int64_t first_pos, last_free_pos;
-      {
-        const __m512i vlow = _mm512_set1_epi32(lowest);
-        __m512i pmin = _mm512_set1_epi32(std::numeric_limits<int32_t>::max()), pmax = _mm512_set1_epi32(-1);
-        for (int64_t b = 0; b < nb; ++b) {
-          __mmask16 m = _mm512_mask_cmpeq_epi32_mask(w.live[b], _mm512_loadu_si512(w.spc.data() + b * 16), vlow);
-          if (!m) continue;
-          __m512i pv = _mm512_loadu_si512(w.pos.data() + b * 16);
-          pmin = _mm512_mask_min_epi32(pmin, m, pmin, pv);
-          pmax = _mm512_mask_max_epi32(pmax, m & w.freec[b], pmax, pv);
-        }
-        first_pos = _mm512_reduce_min_epi32(pmin);
-        last_free_pos = _mm512_reduce_max_epi32(pmax);
+      // tie rule of the scalar scan: the first column (in `remaining` order) reaching the minimum is taken, and every later
+      // tied column that has no row yet replaces it -> smallest position among the ties vs. largest among the free ties.
+      const __m512i vlow = _mm512_set1_epi32(lowest);
+      __m512i pmin = _mm512_set1_epi32(std::numeric_limits<int32_t>::max()), pmax = _mm512_set1_epi32(-1);
+      for (int64_t j = 0; j < ncp; j += 16) {
+        __mmask16 m = _mm512_cmpeq_epi32_mask(_mm512_loadu_si512(spc.data() + j), vlow);
+        pmin = _mm512_mask_min_epi32(pmin, m, pmin, _mm512_loadu_si512(pos.data() + j));
+        pmax = _mm512_mask_max_epi32(pmax, m, pmax, _mm512_loadu_si512(posfree.data() + j));
       }
-      int64_t index = (last_free_pos > first_pos) ? last_free_pos : first_pos;
+      const int64_t first_pos = _mm512_reduce_min_epi32(pmin), last_free_pos = _mm512_reduce_max_epi32(pmax);
+      const int64_t index = (last_free_pos > first_pos) ? last_free_pos : first_pos;
       minVal = lowest;
-      int64_t j = w.remaining[index];
-      if (w.row4col[j] == -1) sink = j; else i = w.row4col[j];
-      w.live[j >> 4] &= (uint16_t)~(1u << (j & 15));
+      const int64_t j = remaining[index];
+      if (row4col[j] == -1) sink = j; else i = row4col[j];
+      spcsave[j] = spc[j];
+      spc[j] = QINF;
+      veff[j] = QDEADV;
+      dead_list.push_back((int32_t)j);
       --num_remaining;
-      int32_t moved = w.remaining[num_remaining];
-      w.remaining[index] = moved;
-      w.pos[moved] = (int32_t)index;
+      const int32_t moved = remaining[num_remaining];
+      remaining[index] = moved;
+      pos[moved] = (int32_t)index;
+      posfree[moved] = row4col[moved] == -1 ? (int32_t)index : -1;
     }
-    w.u[curRow] += minVal;
     bool over = false;
-    for (int32_t r : w.sr_list)
+    u[curRow] += minVal;
+    over |= (u[curRow] >= QLIM || u[curRow] <= -QLIM);
+    for (int32_t r : sr_list)
       if (r != curRow) {
-        w.u[r] += minVal - w.spc[w.col4row[r]];
-        over |= (w.u[r] >= QLIM || w.u[r] <= -QLIM);
+        u[r] += minVal - spcsave[col4row[r]];
+        over |= (u[r] >= QLIM || u[r] <= -QLIM);
       }
-    over |= (w.u[curRow] >= QLIM || w.u[curRow] <= -QLIM);
-    for (int64_t b = 0; b < nb; ++b) {
-      int64_t left = nc - b * 16;
-      uint32_t full = left >= 16 ? 0xffffu : (left > 0 ? ((1u << left) - 1) : 0u);
-      uint32_t dead = full & ~(uint32_t)w.live[b];
-      while (dead) {
-        int64_t j = b * 16 + __builtin_ctz(dead);
-        dead &= dead - 1;
-        w.v[j] -= minVal - w.spc[j];
-        over |= (w.v[j] >= QLIM || w.v[j] <= -QLIM);
-      }
+    for (int32_t j : dead_list) {
+      v[j] -= minVal - spcsave[j];
+      veff[j] = v[j];
+      over |= (v[j] >= QLIM || v[j] <= -QLIM);
     }
     if (over) return 3;
     int64_t j = sink;
     while (true) {
-      int64_t r = w.path[j];
-      w.row4col[j] = (int32_t)r;
-      w.freec[j >> 4] &= (uint16_t)~(1u << (j & 15));
-      int32_t t = w.col4row[r];
-      w.col4row[r] = (int32_t)j;
+      const int64_t r = path[j];
+      row4col[j] = (int32_t)r;
+      posfree0[j] = -1;
+      const int32_t t = col4row[r];
+      col4row[r] = (int32_t)j;
       j = t;
       if (r == curRow) break;
     }
   }
-  for (int64_t r = 0; r < nr; ++r) col4row_out[r] = w.col4row[r];
+  for (int64_t r = 0; r < nr; ++r) col4row_out[r] = col4row[r];
   return 0;
 }
 static const bool g_have_q = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
@@ -351,16 +368,27 @@ static bool prepare_q(const uint16_t* cost, int64_t ld, const int64_t* row_map, 
   const int64_t R = transpose ? nc : nr;
   out.assign((size_t)R * ncp, 0);
   bool ok = true;
+  unsigned bad = 0;
   for (int64_t i = 0; i < nr; ++i) {
     const uint16_t* src = cost + (row_map ? row_map[i] : i) * ld;
-    for (int64_t j = 0; j < nc; ++j) {
-      uint16_t h = src[j];
-      uint32_t e = (h >> 10) & 0x1f;
-      if (e == 31) { if (h & 0x3ff) h = 0; else ok = false; }
-      else if (e >= 18) ok = false;               // |x| >= 8
-      if (transpose) out[(size_t)j * ncp + i] = h; else out[(size_t)i * ncp + j] = h;
+    if (!transpose) {
+      uint16_t* dst = &out[(size_t)i * ncp];
+      for (int64_t j = 0; j < nc; ++j) {           // branch-free so it vectorises
+        uint16_t h = src[j], e = h & 0x7c00;
+        uint16_t isnan = (uint16_t)((e == 0x7c00) & ((h & 0x3ff) != 0));
+        bad |= (unsigned)((e >= 0x4800) & !isnan);   // |x| >= 8 or inf
+        dst[j] = isnan ? (uint16_t)0 : h;
+      }
+    } else {
+      for (int64_t j = 0; j < nc; ++j) {
+        uint16_t h = src[j], e = h & 0x7c00;
+        bool isnan = e == 0x7c00 && (h & 0x3ff);
+        bad |= (unsigned)(e >= 0x4800 && !isnan);
+        out[(size_t)j * ncp + i] = isnan ? (uint16_t)0 : h;
+      }
     }
   }
+  ok = bad == 0;
   return ok;
 }
 #endif
