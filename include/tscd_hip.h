@@ -43,7 +43,7 @@ int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* b
  * ds_read_b64_tr_b16 operand fetch and a deterministic split-K reduction; dw is fp32 in torch layout
  * [Cout][Cin][KH][KW].  The data gradient is tscd_conv2d_nhwc_f16 on dY with tscd_pack_conv_weight(mode=1).
  * tscd_bn_silu_bwd_f16: gradient of SiLU(BatchNorm_train(raw)); sums_out = [dbeta | dgamma]. */
-int tscd_conv_wgrad_splits(long M);
+int tscd_conv_wgrad_splits(long M, int Cout, int Cin, int ksize);
 long tscd_conv_wgrad_workspace_bytes(long M, int Cout, int Cin, int ksize);
 int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
                              int ldx, int lddy, void* workspace, long workspace_bytes, void* stream);

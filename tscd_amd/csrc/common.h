@@ -49,3 +49,6 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// SiLU gate of the BatchNorm+SiLU passes: v_exp_f32 + v_rcp_f32 (1 ulp each, far below the fp16 rounding of the result)
+// instead of the IEEE division sequence -- those passes are VALU-bound otherwise.
+__device__ __forceinline__ float sigmoid_fast_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

@@ -155,15 +155,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int S, int C
   }
 }
 
-extern "C" int tscd_conv_wgrad_splits(long M) {
+// Split-K over the pixel axis: enough splits that tiles x splits covers the 256 CUs about twice, at least 8 k-tiles
+// (256 pixels) per split so the fp32 slab traffic stays small next to the operand reads.
+extern "C" int tscd_conv_wgrad_splits(long M, int Cout, int Cin, int ksize) {
   long kt = (M + 31) / 32;
-  int s = (int)(kt / 96);   // >= ~96 k-tiles per split
+  long tiles = (long)cdiv(Cout, 128) * cdiv((long)ksize * ksize * Cin, 128);
+  long s = (512 + tiles - 1) / tiles;
+  if (s > kt / 8) s = kt / 8;
   if (s < 1) s = 1;
-  if (s > 32) s = 32;
-  return s;
+  if (s > 256) s = 256;
+  return (int)s;
 }
 extern "C" long tscd_conv_wgrad_workspace_bytes(long M, int Cout, int Cin, int ksize) {
-  return 4L * tscd_conv_wgrad_splits(M) * Cout * ksize * ksize * Cin + 256;
+  return 4L * tscd_conv_wgrad_splits(M, Cout, Cin, ksize) * Cout * ksize * ksize * Cin + 256;
 }
 
 extern "C" int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
@@ -179,7 +183,7 @@ extern "C" int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw
   long M = (long)B * H * W;
   TSCD_CHECK_ARG(M < (1L << 31), "conv_wgrad: M too large");
   p.M = (int)M; p.Ncols = ksize * ksize * Cin;
-  p.S = tscd_conv_wgrad_splits(M);
+  p.S = tscd_conv_wgrad_splits(M, Cout, Cin, ksize);
   TSCD_CHECK_ARG(workspace_bytes >= tscd_conv_wgrad_workspace_bytes(M, Cout, Cin, ksize), "conv_wgrad: workspace too small");
   int ktotal = (p.M + 31) / 32;
   p.ktiles_per_split = (ktotal + p.S - 1) / p.S;
@@ -195,35 +199,51 @@ extern "C" int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw
 }
 
 // ---------------------------------------------------------------------------------------------- BN + SiLU backward
-#define BNB_ROWS 128
-// partial [nblk][2][C]: sum dt, sum dt*xhat over the block's rows
-__global__ void bn_silu_bwd_stats_kernel(const f16* __restrict__ dy, const f16* __restrict__ raw, const float* __restrict__ ss,
-                                         const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C,
-                                         float* __restrict__ partial) {
-  const int cv = C >> 3;
+#define BNB_ROWS 32
+// SiLU'(t) with the fast gate (see sigmoid_fast_)
+__device__ __forceinline__ float silu_grad_(float t) {
+  float sg = sigmoid_fast_(t);
+  return sg * (1.f + t * (1.f - sg));
+}
+// partial [nblk][2][C]: sum dt, sum dt*xhat over the block's BNB_ROWS rows.  Block = (256/cv) row groups x cv chunk
+// threads; the row groups are combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void bn_silu_bwd_stats_kernel(const f16* __restrict__ dy, const f16* __restrict__ raw,
+                                                                const float* __restrict__ ss, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, long M, int C, int cv, int rg,
+                                                                float* __restrict__ partial) {
+  extern __shared__ float red[];   // [rg][2][C]
+  const int tid = threadIdx.x;
+  const int c8 = tid % cv, g = tid / cv;
   const long r0 = (long)blockIdx.x * BNB_ROWS;
-  for (int c8 = threadIdx.x; c8 < cv; c8 += blockDim.x) {
-    const int c = c8 << 3;
-    float s1[8], s2[8], sc[8], sh[8], mu[8], iv[8];
+  if (g < rg) {
+    for (int cc = c8; cc < (C >> 3); cc += cv) {
+      const int c = cc << 3;
+      float s1[8], s2[8], sc[8], sh[8], mu[8], iv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] = s2[e] = 0.f; sc[e] = ss[c + e]; sh[e] = ss[C + c + e]; mu[e] = mean[c + e]; iv[e] = invstd[c + e]; }
-    for (long r = r0; r < r0 + BNB_ROWS && r < M; ++r) {
-      f16x8 g = *(const f16x8*)(dy + r * C + c), x = *(const f16x8*)(raw + r * C + c);
+      for (int e = 0; e < 8; ++e) { s1[e] = s2[e] = 0.f; sc[e] = ss[c + e]; sh[e] = ss[C + c + e]; mu[e] = mean[c + e]; iv[e] = invstd[c + e]; }
+      for (long r = r0 + g; r < r0 + BNB_ROWS && r < M; r += rg) {
+        f16x8 gy = *(const f16x8*)(dy + r * C + c), x = *(const f16x8*)(raw + r * C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xr = (float)x[e];
+          float t = (float)(f16)(xr * sc[e] + sh[e]);
+          float dt = (float)gy[e] * silu_grad_(t);
+          s1[e] += dt;
+          s2[e] += dt * ((xr - mu[e]) * iv[e]);
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float xr = (float)x[e];
-        float t = (float)(f16)(xr * sc[e] + sh[e]);
-        float sg = sigmoidf_(t);
-        float dt = (float)g[e] * (sg * (1.f + t * (1.f - sg)));
-        s1[e] += dt;
-        s2[e] += dt * ((xr - mu[e]) * iv[e]);
+        red[(g * 2 + 0) * C + c + e] = s1[e];
+        red[(g * 2 + 1) * C + c + e] = s2[e];
       }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      partial[((long)blockIdx.x * 2 + 0) * C + c + e] = s1[e];
-      partial[((long)blockIdx.x * 2 + 1) * C + c + e] = s2[e];
-    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += blockDim.x) {
+    float a = 0.f;
+    for (int q = 0; q < rg; ++q) a += red[q * 2 * C + i];
+    partial[(long)blockIdx.x * 2 * C + i] = a;
   }
 }
 // sums [2][C] (fp32) from the partials, one wave per channel, fixed order, fp64 accumulation
@@ -254,8 +274,7 @@ __global__ void bn_silu_bwd_apply_kernel(const f16* __restrict__ dy, const f16* 
     for (int e = 0; e < 8; ++e) {
       float xr = (float)x[e];
       float t = (float)(f16)(xr * ss[c + e] + ss[C + c + e]);
-      float sg = sigmoidf_(t);
-      float dt = (float)g[e] * (sg * (1.f + t * (1.f - sg)));
+      float dt = (float)g[e] * silu_grad_(t);
       float xh = (xr - mean[c + e]) * invstd[c + e];
       o[e] = (f16)(gamma[c + e] * invstd[c + e] * (dt - sums[c + e] * invn - xh * sums[C + c + e] * invn));
     }
@@ -273,9 +292,12 @@ extern "C" int tscd_bn_silu_bwd_f16(const void* dy, const void* raw, const float
   TSCD_CHECK_ARG(workspace_bytes >= tscd_bn_silu_bwd_workspace_bytes(M, C), "bn_silu_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   int nblk = (int)((M + BNB_ROWS - 1) / BNB_ROWS);
-  int threads = (C / 8) < 64 ? 64 : ((C / 8) > 256 ? 256 : (C / 8 + 63) / 64 * 64);
-  hipLaunchKernelGGL(bn_silu_bwd_stats_kernel, dim3(nblk), dim3(threads), 0, st, (const f16*)dy, (const f16*)raw, scale_shift, mean,
-                     invstd, M, C, (float*)workspace);
+  int cv = C / 8;
+  if (cv > 256) cv = 256;
+  int rg = 256 / cv;
+  if (rg > BNB_ROWS) rg = BNB_ROWS;
+  hipLaunchKernelGGL(bn_silu_bwd_stats_kernel, dim3(nblk), dim3(256), (size_t)rg * 2 * C * sizeof(float), st, (const f16*)dy,
+                     (const f16*)raw, scale_shift, mean, invstd, M, C, cv, rg, (float*)workspace);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, nblk, C, sums_out);
   long total = M * (C / 8);
   int grid = (int)((total + 255) / 256);

@@ -139,25 +139,34 @@ extern "C" int tscd_bn_fold(const float* gamma, const float* beta, const float* 
 }
 
 // y = act(half(x*scale+shift)) (+ residual), 8 channels per lane.  act: 0 none, 1 SiLU, 2 ReLU.
-__global__ void bn_act_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy, const float* __restrict__ ss,
-                              const f16* __restrict__ res, int ldr, long M, int C, int act) {
-  const int cv = C >> 3;
-  const long total = M * cv;
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    long m = idx / cv;
-    int c = (int)(idx - m * cv) << 3;
-    f16x8 v = *(const f16x8*)(x + m * ldx + c);
-    f16x8 r;
-    if (res) r = *(const f16x8*)(res + m * ldr + c);
-    f16x8 o;
+// A thread keeps ONE 8-channel chunk for its whole life (block = rows_per_block x C/8 threads), so scale/shift sit in
+// registers and there is no index division in the loop; consecutive lanes still cover consecutive 16-B chunks of a row.
+template <int ACT, bool RES>
+__global__ __launch_bounds__(256) void bn_act_kernel(const f16* __restrict__ x, int ldx, f16* __restrict__ y, int ldy,
+                                                     const float* __restrict__ ss, const f16* __restrict__ res, int ldr, long M, int C,
+                                                     int cv, int rpb) {
+  const int tid = threadIdx.x;
+  if (tid >= cv * rpb) return;
+  const int c8 = tid % cv, r = tid / cv;
+  float sc[8], sh[8];
+  for (int cc = c8; cc < (C >> 3); cc += cv) {      // cv < C/8 only for C > 2048
+    const int c = cc << 3;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = (float)(f16)((float)v[e] * ss[c + e] + ss[C + c + e]);
-      f16 h = act == 1 ? (f16)(t * sigmoidf_(t)) : (act == 2 ? (f16)fmaxf(t, 0.f) : (f16)t);
-      if (res) h = (f16)((float)h + (float)r[e]);
-      o[e] = h;
+    for (int e = 0; e < 8; ++e) { sc[e] = ss[c + e]; sh[e] = ss[C + c + e]; }
+    for (long m = (long)blockIdx.x * rpb + r; m < M; m += (long)gridDim.x * rpb) {
+      f16x8 v = *(const f16x8*)(x + m * ldx + c);
+      f16x8 rr;
+      if (RES) rr = *(const f16x8*)(res + m * ldr + c);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (float)(f16)((float)v[e] * sc[e] + sh[e]);
+        f16 h = ACT == 1 ? (f16)(t * sigmoid_fast_(t)) : (ACT == 2 ? (f16)fmaxf(t, 0.f) : (f16)t);
+        if (RES) h = (f16)((float)h + (float)rr[e]);
+        o[e] = h;
+      }
+      *(f16x8*)(y + m * ldy + c) = o;
     }
-    *(f16x8*)(y + m * ldy + c) = o;
   }
 }
 
@@ -168,8 +177,23 @@ extern "C" int tscd_bn_act_nhwc_f16(const void* x, int ldx, void* y, int ldy, co
                  "bn_act: C / strides must be multiples of 8 (C=%d ldx=%d ldy=%d)", C, ldx, ldy);
   TSCD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)residual & 15) == 0,
                  "bn_act: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(bn_act_kernel, dim3(ew_grid(M * (C / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16*)x, ldx,
-                     (f16*)y, ldy, scale_shift, (const f16*)residual, ldr, M, C, act);
+  TSCD_CHECK_ARG(act >= 0 && act <= 2, "bn_act: bad act %d", act);
+  int cv = C / 8;
+  if (cv > 256) cv = 256;
+  const int rpb = 256 / cv;                       // rows per block pass
+  long nblk = (M + rpb - 1) / rpb;
+  if (nblk > 8192) nblk = 8192;
+  dim3 grid((unsigned)nblk), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define BNACT(A, R)                                                                                                             \
+  hipLaunchKernelGGL((bn_act_kernel<A, R>), grid, block, 0, st, (const f16*)x, ldx, (f16*)y, ldy, scale_shift, (const f16*)residual, \
+                     ldr, M, C, cv, rpb)
+  if (residual) {
+    if (act == 1) BNACT(1, true); else if (act == 2) BNACT(2, true); else BNACT(0, true);
+  } else {
+    if (act == 1) BNACT(1, false); else if (act == 2) BNACT(2, false); else BNACT(0, false);
+  }
+#undef BNACT
   TSCD_CHECK_LAUNCH("bn_act");
   return TSCD_OK;
 }
