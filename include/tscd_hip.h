@@ -31,6 +31,10 @@ const char* tscd_last_error(void);
  * 2 +bias,ReLU, 3 folded BN + SiLU (eval), 4 folded BN, 5 Hungarian cost 1 - v/2 with NaN->0
  * (tscd_matching.py:926-930). */
 int tscd_conv_tile_m(void);
+/* Main-loop selection of tscd_conv2d_nhwc_f16: -1 automatic (LDS-DMA ring when Cin % 32 == 0 and Cout > 32, register
+ * staging otherwise), 0 force register staging, 1 same as -1.  Both variants accumulate in the same order: outputs and
+ * BatchNorm partial sums are bit-identical (tests/test_gpu_conv.py). */
+void tscd_conv_set_variant(int variant);
 int tscd_conv_tile_n(int cout);
 int tscd_pack_conv_weight(const void* w, int src_is_f32, void* out, int Cout, int Cin, int CinPad, int KH, int KW,
                           int rows_pad, int Kpad, int mode, void* stream);

@@ -160,3 +160,42 @@ def test_conv_wgrad_and_dgrad(case):
     torch.cuda.synchronize()
     assert_close(dw, w.grad, rel=1e-3, abs_=1e-3)
     assert_close(dx.permute(0, 3, 1, 2), xr.grad, rel=2e-3, abs_=2e-3)
+
+
+DMA_CASES = [
+    # B, H, W, Cin, Cout, k, stride, epilogue-with-stats
+    (2, 36, 36, 256, 256, 3, 1),     # head tower level (multi-tile M and N, 72 k-tiles: the ring wraps 18 times)
+    (1, 19, 23, 64, 128, 3, 2),      # stride 2, odd extent, ragged M
+    (3, 9, 13, 128, 128, 1, 1),      # 1x1, 4 k-tiles
+    (2, 5, 7, 32, 64, 1, 1),         # single k-tile (prologue shorter than the ring), BN=64 tile
+    (2, 5, 7, 64, 72, 3, 1),         # Cout not a tile multiple
+    (1, 6, 6, 1024, 512, 1, 1),      # deep K
+    (1, 1, 500, 256, 256, 1, 1),     # linear layer
+    (4, 18, 18, 512, 512, 3, 1),     # 18x18 level
+]
+
+
+@pytest.mark.parametrize("case", DMA_CASES)
+def test_conv_lds_dma_variant_bit_identical_to_register_staging(case):
+    """The LDS-DMA main loop (global_load_lds ring, XOR-swizzled image) must reproduce the register-staged loop bit for bit
+    (same MFMA sequence per output), including the BatchNorm partial sums, and both must match the fp32 oracle."""
+    from tscd_amd import ops
+    from tscd_amd._lib import lib
+    B, H, W, Cin, Cout, k, s = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).half()
+    xg = x.to(dev()).permute(0, 2, 3, 1).contiguous()
+    wpk = ops.pack_conv_weight(w.to(dev()))
+    try:
+        lib.tscd_conv_set_variant(0)
+        y0, st0 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
+        lib.tscd_conv_set_variant(1)
+        y1, st1 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
+    finally:
+        lib.tscd_conv_set_variant(-1)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.equal(st0, st1)
+    ref = F.conv2d(x.float(), w.float(), None, s, (k - 1) // 2)
+    assert_close(y1.permute(0, 3, 1, 2), ref)

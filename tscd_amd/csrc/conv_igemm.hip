@@ -15,6 +15,7 @@
 // Epilogues: raw fp16 store (+ per-channel partial sum / sum-of-squares for train-mode BatchNorm, written
 // per M-tile so the reduction order is fixed => deterministic), bias, bias+ReLU, folded-BN(+SiLU) for eval.
 #include "common.h"
+#include <type_traits>
 
 struct ConvParams {
   const f16* x;
@@ -32,6 +33,102 @@ struct ConvParams {
 };
 
 enum { EPI_RAW = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BN_SILU = 3, EPI_BN = 4, EPI_COST = 5 };
+
+// ---- epilogue shared by both main-loop variants.  C layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// The finished fp16 tile is staged in LDS (row pitch BN+8 halves: the two half-waves of a ds_write land on disjoint bank
+// quarters, the 16-B read-back of a row is conflict-free) and leaves as 16-byte stores, 16 lanes per 256-B row segment,
+// instead of 64 two-byte stores per lane; the per-channel BatchNorm sums stay in the MFMA layout (in-lane over 16 rows).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], f16* smem, int m0, int n0, int mt, int tid,
+                                              int lane, int wm, int wn) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, CP = BN + 8;
+  f16* ctile = smem;                               // [BM][CP]
+  float* red = (float*)(smem + BM * CP);           // [WAVES_M][BN][2]
+  __syncthreads();                                 // every wave is done with the staging buffers of the main loop
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int cl = wn * WN + j * 32 + (lane & 31);
+    const int n = n0 + cl;
+    const bool nok = n < p.Cout;
+    float bias = 0.f, sc = 1.f, sh = 0.f;
+    if (nok) {
+      if (p.epilogue == EPI_BIAS || p.epilogue == EPI_BIAS_RELU) bias = p.bias[n];
+      if (p.epilogue == EPI_BN_SILU || p.epilogue == EPI_BN) { sc = p.scale[n]; sh = p.shift[n]; }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        float v = acc[i][j][e];
+        f16 o;
+        if (p.epilogue == EPI_RAW) {
+          o = (f16)v;
+          float vf = (float)o;  // statistics of the fp16-rounded conv output, as the reference's BN sees it
+          s1[j] += vf;
+          s2[j] += vf * vf;
+        } else if (p.epilogue == EPI_BIAS) {
+          o = (f16)(v + bias);
+        } else if (p.epilogue == EPI_BIAS_RELU) {
+          o = (f16)fmaxf(v + bias, 0.f);
+        } else if (p.epilogue == EPI_COST) {
+          // Hungarian cost of double_match_embds (tscd_matching.py:912-937): 1 - (cos_reg + cos_cls)/2, NaN -> 0
+          float c = 1.0f - 0.5f * (float)(f16)v;
+          o = (c != c) ? (f16)0.f : (f16)c;
+        } else {
+          // eval: conv (fp16) -> BN with running stats (fp16 out) -> SiLU (fp16 out)
+          float t = (float)(f16)((float)(f16)v * sc + sh);
+          o = (p.epilogue == EPI_BN_SILU) ? (f16)(t * sigmoidf_(t)) : (f16)t;
+        }
+        ctile[row * CP + cl] = o;
+      }
+    }
+  }
+  const bool stats = p.epilogue == EPI_RAW && p.bn_partial != nullptr;
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float a = s1[j] + __shfl_xor(s1[j], 32, 64);
+      float b = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (lane < 32) {
+        int col = wn * WN + j * 32 + lane;
+        red[(wm * BN + col) * 2 + 0] = a;
+        red[(wm * BN + col) * 2 + 1] = b;
+      }
+    }
+  }
+  __syncthreads();
+  const bool vec_ok = (p.Cout & 7) == 0 && (p.ldy & 7) == 0 && ((uintptr_t)p.y & 15) == 0;
+  if (vec_ok) {
+    constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
+#pragma unroll
+    for (int it = 0; it < BM * CPR / 256; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx / CPR, ch = idx % CPR;
+      const int m = m0 + row, n = n0 + ch * 8;
+      if (m < p.M && n < p.Cout) *(f16x8*)(p.y + (long)m * p.ldy + n) = *(const f16x8*)(ctile + row * CP + ch * 8);
+    }
+  } else {                                         // ragged Cout (prediction heads: 1 / 4 / NC channels, cost matrices)
+    for (int idx = tid; idx < BM * BN; idx += 256) {
+      const int row = idx / BN, cl = idx % BN;
+      const int m = m0 + row, n = n0 + cl;
+      if (m < p.M && n < p.Cout) p.y[(long)m * p.ldy + n] = ctile[row * CP + cl];
+    }
+  }
+  if (stats && tid < BN) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES_M; ++w) {
+      a += red[(w * BN + tid) * 2 + 0];
+      b += red[(w * BN + tid) * 2 + 1];
+    }
+    p.bn_partial[((long)mt * 2 + 0) * p.cstride + n0 + tid] = a;
+    p.bn_partial[((long)mt * 2 + 1) * p.cstride + n0 + tid] = b;
+  }
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
@@ -145,74 +242,184 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     buf ^= 1;
   }
 
-  // ---- epilogue.  C layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
-  float s1[TN], s2[TN];
+  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, smem, m0, n0, mt, tid, lane, wm, wn);
+}
+
+// ====================================================================================================================
+// Main-loop variant 2 (Cin % 32 == 0): LDS-DMA staging with a 4-deep ring.
+//   * every k-tile (128 x 32 A rows + BN x 32 B rows, 64 B per row) is fetched with global_load_lds_dwordx4: one
+//     wave-instruction lands 16 rows x 64 B contiguously in LDS, the per-lane SOURCE address does the im2col gather
+//     (out-of-image taps and rows >= M read a 16-byte zero block instead) -- no staging VGPRs, no ds_write pass;
+//   * the LDS image is lane-linear, so bank conflicts are removed by an XOR swizzle applied on both sides: the lane
+//     that fills 16-B slot s of row r fetches k-chunk s ^ ((r>>2)&3), and the fragment read of chunk c goes to slot
+//     c ^ ((r>>2)&3) (16 consecutive rows x one chunk then cover all 64 banks exactly once);
+//   * three k-tiles stay in flight across the (single) barrier of a k-step: counted s_waitcnt vmcnt(8) + raw s_barrier,
+//     so a workgroup alone on a CU still hides the ~1 us L2/MALL latency (the 18x18 and 36x36 levels launch only
+//     80-330 workgroups for 256 CUs).
+// With Cin % 32 == 0 a k-tile never straddles a filter tap: tap / channel offset are wave-uniform scalars and each lane
+// only tests one bit of its precomputed 9-bit tap-validity mask.
+// ====================================================================================================================
+__device__ __attribute__((aligned(16))) f16 g_zero_chunk[8];
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(N < 0, "unsupported vmcnt");
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(ConvParams p) {
+  constexpr int BM = 128, NS = 4, WAVES_M = 2, WAVES_N = 2;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_LD = 2, B_LD = BN / 64;                 // glds wave-instructions per wave and k-tile
+  constexpr int LD = A_LD + B_LD;
+  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-lane source state: slot s = lane&3 of row (lane>>2) in each 16-row piece; chunk = s ^ ((row>>2)&3) ----
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const f16* a_src[A_LD];
+  unsigned a_mask[A_LD];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WN + j * 32 + (lane & 31);
-    const bool nok = n < p.Cout;
-    float bias = 0.f, sc = 1.f, sh = 0.f;
-    if (nok) {
-      if (p.epilogue == EPI_BIAS || p.epilogue == EPI_BIAS_RELU) bias = p.bias[n];
-      if (p.epilogue == EPI_BN_SILU || p.epilogue == EPI_BN) { sc = p.scale[n]; sh = p.shift[n]; }
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int m = m0 + wm * WM + i * 32 + row;
-        float v = acc[i][j][e];
-        f16 o;
-        if (p.epilogue == EPI_RAW) {
-          o = (f16)v;
-          float vf = (float)o;  // statistics of the fp16-rounded conv output, as the reference's BN sees it
-          s1[j] += vf;
-          s2[j] += vf * vf;
-        } else if (p.epilogue == EPI_BIAS) {
-          o = (f16)(v + bias);
-        } else if (p.epilogue == EPI_BIAS_RELU) {
-          o = (f16)fmaxf(v + bias, 0.f);
-        } else if (p.epilogue == EPI_COST) {
-          // Hungarian cost of double_match_embds (tscd_matching.py:912-937): 1 - (cos_reg + cos_cls)/2, NaN -> 0
-          float c = 1.0f - 0.5f * (float)(f16)v;
-          o = (c != c) ? (f16)0.f : (f16)c;
-        } else {
-          // eval: conv (fp16) -> BN with running stats (fp16 out) -> SiLU (fp16 out)
-          float t = (float)(f16)((float)(f16)v * sc + sh);
-          o = (p.epilogue == EPI_BN_SILU) ? (f16)(t * sigmoidf_(t)) : (f16)t;
-        }
-        if (nok && m < p.M) p.y[(long)m * p.ldy + n] = o;
-      }
-    }
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = m0 + wave * 32 + i * 16 + (lane >> 2);
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / (p.Ho * p.Wo);
+    const int rem = mm - b * (p.Ho * p.Wo);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+    a_src[i] = p.x + ((long)(b * p.H + hi0) * p.W + wi0) * p.ldx + chunk * 8;
+    unsigned mask = 0;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw)
+        if (ok && (unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W) mask |= 1u << (kh * p.KW + kw);
+    a_mask[i] = mask;
   }
-  if (p.epilogue == EPI_RAW && p.bn_partial != nullptr) {
-    float* red = (float*)smem;  // [WAVES_M][BN][2]
-    __syncthreads();
+  const f16* b_src[B_LD];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float a = s1[j] + __shfl_xor(s1[j], 32, 64);
-      float b = s2[j] + __shfl_xor(s2[j], 32, 64);
-      if (lane < 32) {
-        int col = wn * WN + j * 32 + lane;
-        red[(wm * BN + col) * 2 + 0] = a;
-        red[(wm * BN + col) * 2 + 1] = b;
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      float a = 0.f, b = 0.f;
+  for (int j = 0; j < B_LD; ++j) b_src[j] = p.w + (long)(n0 + wave * (BN / 4) + j * 16 + (lane >> 2)) * p.Kpad + chunk * 8;
+
+  const int nk = p.Kpad >> 5;
+  int ld_tap = 0, ld_cin = 0, ld_kw = 0;     // wave-uniform position of the NEXT k-tile to issue
+  long ld_tapoff = 0;
+  auto issue = [&](int stage) {
+    char* sbase = smem + stage * STAGE;
 #pragma unroll
-      for (int w = 0; w < WAVES_M; ++w) {
-        a += red[(w * BN + tid) * 2 + 0];
-        b += red[(w * BN + tid) * 2 + 1];
-      }
-      p.bn_partial[((long)mt * 2 + 0) * p.cstride + n0 + tid] = a;
-      p.bn_partial[((long)mt * 2 + 1) * p.cstride + n0 + tid] = b;
+    for (int i = 0; i < A_LD; ++i) {
+      const f16* src = ((a_mask[i] >> ld_tap) & 1u) ? a_src[i] + ld_tapoff + ld_cin : g_zero_chunk;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sbase + (wave * 32 + i * 16) * 64), 16, 0, 0);
     }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[j],
+                                       (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wave * (BN / 4) + j * 16) * 64), 16,
+                                       0, 0);
+      b_src[j] += 32;
+    }
+    ld_cin += 32;
+    if (ld_cin == p.Cin) {
+      ld_cin = 0;
+      ++ld_tap;
+      if (++ld_kw == p.KW) { ld_kw = 0; ld_tapoff += (long)(p.W - p.KW + 1) * p.ldx; } else ld_tapoff += p.ldx;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read offsets (bytes inside a stage): row r, chunk c -> r*64 + ((c ^ ((r>>2)&3)) * 16)
+  const int frow = lane & 31, fsw = (frow >> 2) & 3, fk = lane >> 5;
+  int a_off[TM][2], b_off[TN][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_off[i][ks] = (wm * WM + i * 32 + frow) * 64 + (((ks * 2 + fk) ^ fsw) * 16);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_off[j][ks] = A_BYTES + (wn * WN + j * 32 + frow) * 64 + (((ks * 2 + fk) ^ fsw) * 16);
   }
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) issue(s);
+
+  // Software pipeline: the fragments of tile kt+1 are fetched into the second register set while the MFMAs of tile kt run,
+  // so the only exposed waits per k-step are the (2-tiles-early) vmcnt and the barrier.
+  f16x8 fa[2][2][TM], fb[2][2][TN];     // [register set][ks][tile]
+  auto wait_tile = [&](int t) {          // tile t landed (this wave's share); up to NS-2 younger tiles stay in flight
+    const int younger = nk - 1 - t;
+    if (younger >= NS - 2) wait_vmcnt<(NS - 2) * LD>();
+    else if (younger == 1) wait_vmcnt<LD>();
+    else wait_vmcnt<0>();
+  };
+  auto read_frags = [&](auto setc, int t) {
+    constexpr int S = decltype(setc)::value;
+    const char* sb = smem + (t % NS) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[S][ks][i] = *(const f16x8*)(sb + a_off[i][ks]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[S][ks][j] = *(const f16x8*)(sb + b_off[j][ks]);
+    }
+  };
+  auto mfmas = [&](auto setc) {
+    constexpr int S = decltype(setc)::value;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][i], fb[S][ks][j], acc[i][j], 0, 0, 0);
+  };
+  // one k-step that has a successor: fetch tile kt+1 into the other register set, then the MFMAs of tile kt (no control
+  // flow between the reads and the MFMAs, or hipcc falls back to lgkmcnt(0) at the join and the overlap is lost)
+  auto phase = [&](auto setc, int kt) {
+    constexpr int S = decltype(setc)::value;
+    __builtin_amdgcn_sched_barrier(0);                       // keep the previous step's MFMAs ahead of the wait
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): this wave's reads of tile kt are in registers ...
+    wait_tile(kt + 1);
+    __builtin_amdgcn_s_barrier();                            // ... everyone's are: tile kt's buffer may be refilled
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + NS < nk) issue((kt + NS) % NS);
+    read_frags(std::integral_constant<int, 1 - S>{}, kt + 1);
+    mfmas(setc);
+  };
+  wait_tile(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (NS - 1 < nk) issue(NS - 1);
+  read_frags(std::integral_constant<int, 0>{}, 0);
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 2) {
+    phase(std::integral_constant<int, 0>{}, kt);
+    phase(std::integral_constant<int, 1>{}, kt + 1);
+  }
+  if (nk - kt == 2) {
+    phase(std::integral_constant<int, 0>{}, kt);
+    mfmas(std::integral_constant<int, 1>{});
+  } else {
+    mfmas(std::integral_constant<int, 0>{});
+  }
+  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
 }
 
 // Tile choice: BN follows Cout (128 / 64 / 32); BM = 128.
@@ -220,6 +427,9 @@ static int pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
 extern "C" int tscd_conv_tile_n(int cout) { return pick_bn(cout); }
 extern "C" int tscd_conv_tile_m(void) { return 128; }
+
+static int g_conv_variant = -1;   // -1 auto, 0 force register staging, 1 force LDS-DMA where eligible (tests / A-B timing)
+extern "C" void tscd_conv_set_variant(int v) { g_conv_variant = v; }
 
 extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* bias, const float* scale,
                                     const float* shift, float* bn_partial, int B, int H, int W, int Cin, int Cout,
@@ -255,7 +465,12 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
   p.cstride = p.ntiles * BN;
   dim3 grid(p.mtiles * p.ntiles), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (BN == 128)
+  const bool dma_ok = Cin % 32 == 0 && BN >= 64 && g_conv_variant != 0;
+  if (dma_ok && BN == 128)
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<128>), grid, block, 0, s, p);
+  else if (dma_ok && BN == 64)
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<64>), grid, block, 0, s, p);
+  else if (BN == 128)
     hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2>), grid, block, 0, s, p);
   else if (BN == 64)
     hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2>), grid, block, 0, s, p);
