@@ -30,6 +30,7 @@ struct ConvParams {
   int K, Kpad, M;
   int epilogue;
   int mtiles, ntiles, cstride;
+  int debug;   // experiments only: bit0 = A gather reads the zero chunk, bit1 = B rows all read row 0
 };
 
 enum { EPI_RAW = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BN_SILU = 3, EPI_BN = 4, EPI_COST = 5 };
@@ -41,7 +42,7 @@ enum { EPI_RAW = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BN_SILU = 3, EPI_BN = 4
 template <int BM, int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], f16* smem, int m0, int n0, int mt, int tid,
                                               int lane, int wm, int wn) {
-  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, CP = BN + 8;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, CP = BN + 8, NT = 64 * WAVES_M * WAVES_N;
   f16* ctile = smem;                               // [BM][CP]
   float* red = (float*)(smem + BM * CP);           // [WAVES_M][BN][2]
   __syncthreads();                                 // every wave is done with the staging buffers of the main loop
@@ -105,14 +106,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
   if (vec_ok) {
     constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
 #pragma unroll
-    for (int it = 0; it < BM * CPR / 256; ++it) {
-      const int idx = tid + it * 256;
+    for (int it = 0; it < BM * CPR / NT; ++it) {
+      const int idx = tid + it * NT;
       const int row = idx / CPR, ch = idx % CPR;
       const int m = m0 + row, n = n0 + ch * 8;
       if (m < p.M && n < p.Cout) *(f16x8*)(p.y + (long)m * p.ldy + n) = *(const f16x8*)(ctile + row * CP + ch * 8);
     }
   } else {                                         // ragged Cout (prediction heads: 1 / 4 / NC channels, cost matrices)
-    for (int idx = tid; idx < BM * BN; idx += 256) {
+    for (int idx = tid; idx < BM * BN; idx += NT) {
       const int row = idx / BN, cl = idx % BN;
       const int m = m0 + row, n = n0 + cl;
       if (m < p.M && n < p.Cout) p.y[(long)m * p.ldy + n] = ctile[row * CP + cl];
@@ -271,13 +272,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(ConvParams p) {
-  constexpr int BM = 128, NS = 4, WAVES_M = 2, WAVES_N = 2;
+// Tiles: 128 x 256 with 8 waves (Cout > 128: the A gather is fetched once for 256 output channels -- the per-CU vector
+// memory path, not the MFMA, bounds the 128 x 128 tile at ~64 FLOP per loaded byte), 128 x 128 and 128 x 64 with 4 waves.
+template <int BN, int WAVES_N>
+__global__ __launch_bounds__(128 * WAVES_N, (BN == 256 ? 1 : 2)) void conv_igemm_glds_kernel(ConvParams p) {
+  constexpr int BM = 128, NS = 4, WAVES_M = 2, NW = WAVES_M * WAVES_N, NT = 64 * NW;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_LD = 2, B_LD = BN / 64;                 // glds wave-instructions per wave and k-tile
+  constexpr int A_LD = 8 / NW, B_LD = BN / 16 / NW;       // glds wave-instructions (16 rows each) per wave and k-tile
   constexpr int LD = A_LD + B_LD;
+  static_assert(A_LD >= 1 && B_LD >= 1, "tile / wave split");
   __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(ConvParams p) {
   unsigned a_mask[A_LD];
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
-    const int m = m0 + wave * 32 + i * 16 + (lane >> 2);
+    const int m = m0 + wave * (16 * A_LD) + i * 16 + (lane >> 2);
     const bool ok = m < p.M;
     const int mm = ok ? m : 0;
     const int b = mm / (p.Ho * p.Wo);
@@ -306,11 +310,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(ConvParams p) {
     for (int kh = 0; kh < p.KH; ++kh)
       for (int kw = 0; kw < p.KW; ++kw)
         if (ok && (unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W) mask |= 1u << (kh * p.KW + kw);
-    a_mask[i] = mask;
+    a_mask[i] = (p.debug & 1) ? 0u : mask;
   }
   const f16* b_src[B_LD];
 #pragma unroll
-  for (int j = 0; j < B_LD; ++j) b_src[j] = p.w + (long)(n0 + wave * (BN / 4) + j * 16 + (lane >> 2)) * p.Kpad + chunk * 8;
+  for (int j = 0; j < B_LD; ++j)
+    b_src[j] = p.w + ((p.debug & 2) ? 0L : (long)(n0 + wave * (16 * B_LD) + j * 16 + (lane >> 2)) * p.Kpad) + chunk * 8;
 
   const int nk = p.Kpad >> 5;
   int ld_tap = 0, ld_cin = 0, ld_kw = 0;     // wave-uniform position of the NEXT k-tile to issue
@@ -321,12 +326,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(ConvParams p) {
     for (int i = 0; i < A_LD; ++i) {
       const f16* src = ((a_mask[i] >> ld_tap) & 1u) ? a_src[i] + ld_tapoff + ld_cin : g_zero_chunk;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sbase + (wave * 32 + i * 16) * 64), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(sbase + (wave * (16 * A_LD) + i * 16) * 64), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[j],
-                                       (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wave * (BN / 4) + j * 16) * 64), 16,
+                                       (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wave * (16 * B_LD) + j * 16) * 64), 16,
                                        0, 0);
       b_src[j] += 32;
     }
@@ -422,12 +427,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(ConvParams p) {
   conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
 }
 
-// Tile choice: BN follows Cout (128 / 64 / 32); BM = 128.
+// Tile choice: BN follows Cout (128 / 64 / 32); BM = 128.  Packed weights and BatchNorm partials are padded to a multiple of
+// this BN.  (A 128 x 256 tile with 8 waves was measured: no faster on the 72x72 level -- the limit is bytes in flight per CU
+// against the ~2 us loaded MALL latency, not bytes per FLOP -- and slower on the small levels, which get half the workgroups.)
 static int pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
 extern "C" int tscd_conv_tile_n(int cout) { return pick_bn(cout); }
 extern "C" int tscd_conv_tile_m(void) { return 128; }
 
+static int g_conv_debug = 0;
+extern "C" void tscd_conv_set_debug(int v) { g_conv_debug = v; }
 static int g_conv_variant = -1;   // -1 auto, 0 force register staging, 1 force LDS-DMA where eligible (tests / A-B timing)
 extern "C" void tscd_conv_set_variant(int v) { g_conv_variant = v; }
 
@@ -459,17 +468,19 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
   TSCD_CHECK_ARG(M < (1L << 31), "conv2d: M too large");
   p.M = (int)M;
   p.epilogue = epilogue;
-  const int BM = 128, BN = pick_bn(Cout);
+  p.debug = g_conv_debug;
+  const int BM = 128, BNP = pick_bn(Cout);
+  const bool dma_ok = Cin % 32 == 0 && BNP >= 64 && g_conv_variant != 0;
+  const int BN = BNP;
   p.mtiles = cdiv(M, BM);
   p.ntiles = cdiv(Cout, BN);
-  p.cstride = p.ntiles * BN;
+  p.cstride = cdiv(Cout, BNP) * BNP;
   dim3 grid(p.mtiles * p.ntiles), block(256);
   hipStream_t s = (hipStream_t)stream;
-  const bool dma_ok = Cin % 32 == 0 && BN >= 64 && g_conv_variant != 0;
   if (dma_ok && BN == 128)
-    hipLaunchKernelGGL((conv_igemm_glds_kernel<128>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 2>), grid, block, 0, s, p);
   else if (dma_ok && BN == 64)
-    hipLaunchKernelGGL((conv_igemm_glds_kernel<64>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 2>), grid, block, 0, s, p);
   else if (BN == 128)
     hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2>), grid, block, 0, s, p);
   else if (BN == 64)

@@ -24,6 +24,29 @@ def get_activation(name="silu", inplace=True):
     raise AttributeError("Unsupported act type: {}".format(name))
 
 
+_DEFERRED_TICKS = None     # list of num_batches_tracked buffers while a defer_bn_ticks() scope is open
+
+
+class defer_bn_ticks:
+    """Batches the ``num_batches_tracked += 1`` of every BatchNorm that runs inside the scope into ONE fused add at exit
+    (134 one-element kernels per TSCD step otherwise).  Re-entrant: only the outermost scope flushes."""
+
+    def __enter__(self):
+        global _DEFERRED_TICKS
+        self.outer = _DEFERRED_TICKS
+        if self.outer is None:
+            _DEFERRED_TICKS = []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED_TICKS
+        if self.outer is None:
+            ticks, _DEFERRED_TICKS = _DEFERRED_TICKS, None
+            if ticks:
+                torch._foreach_add_(ticks, 1)
+        return False
+
+
 class BaseConv(nn.Module):
     """Conv2d(no bias, same pad) -> BatchNorm2d -> SiLU, one fused HIP pipeline."""
 
@@ -42,7 +65,10 @@ class BaseConv(nn.Module):
         bn = self.bn
         training = self.training and bn.training
         if training and bn.track_running_stats:
-            bn.num_batches_tracked += 1
+            if _DEFERRED_TICKS is not None:
+                _DEFERRED_TICKS.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked += 1
         y = TF.conv_bn_silu(x, self.conv.weight, bn.weight.float(), bn.bias.float(),
                             bn.running_mean if bn.running_mean.dtype == torch.float32 else bn.running_mean.float(),
                             bn.running_var if bn.running_var.dtype == torch.float32 else bn.running_var.float(),

@@ -1,6 +1,8 @@
 """TSCD model wrapper (interface of the reference's yolox/models/tscd.py:11-50)."""
 import torch.nn as nn
 
+from .network_blocks import defer_bn_ticks
+
 
 class TSCD(nn.Module):
     """backbone (YOLOPAFPN) + TSCDHead.  Training returns the reference's loss dict, eval (result, result_ori)."""
@@ -11,6 +13,10 @@ class TSCD(nn.Module):
         self.head = head
 
     def forward(self, x, targets=None, time_embedding=None, nms_thresh=0.5, lframe=0, gframe=32, resume=False):
+        with defer_bn_ticks():
+            return self._forward(x, targets, time_embedding, nms_thresh, lframe, gframe, resume)
+
+    def _forward(self, x, targets, time_embedding, nms_thresh, lframe, gframe, resume):
         fpn_outs = self.backbone(x)
         if self.training:
             assert targets is not None
