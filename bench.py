@@ -171,8 +171,8 @@ def cpu_baseline(args, state_dict):
 
 
 def roofline_dominant_kernel(args, device, step):
-    """Dominant kernel = conv_igemm_kernel<128,128,2,2> (every conv / GEMM with Cout > 64: ~85 % of the step's FLOPs),
-    MFMA-bound.  Every launch of it inside real train steps is bracketed by device events on the stream it runs on
+    """Dominant kernel = conv_igemm_glds_kernel<128,2> (every conv / GEMM with Cout > 64 and Cin % 32 == 0: ~85 % of the
+    step's FLOPs), MFMA-bound.  Every launch of it inside real train steps is bracketed by device events on the stream it runs on
     (torch's current stream); achieved = sum of algorithmic FLOPs (2*M*Cout*K per launch) / sum of
     durations, i.e. per-launch average FLOPs / average launch duration -- the same average rocprofv3 --stats reports
     for this kernel name.  `dominant_shape` repeats the measurement for the single heaviest shape (head tower 3x3)."""
@@ -184,7 +184,7 @@ def roofline_dominant_kernel(args, device, step):
         step()
     torch.cuda.synchronize()
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-    sel = [(f, e0.elapsed_time(e1) * 1e-3) for (bn, f, e0, e1) in prof if bn == 128]
+    sel = [(f, e0.elapsed_time(e1) * 1e-3) for (bn, cin, f, e0, e1) in prof if bn == 128 and cin % 32 == 0]
     flops, secs = sum(f for f, _ in sel), sum(t for _, t in sel)
     W = int(256 * args.width)
     B, h = args.frames, args.size // 8
@@ -204,7 +204,7 @@ def roofline_dominant_kernel(args, device, step):
     torch.cuda.synchronize()
     t = s.elapsed_time(e) / n * 1e-3
     f1 = 2.0 * B * h * h * W * 9 * W
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel<128,128,2,2>", "achieved": flops / secs / 1e12, "peak": peak,
+    return {"bound": "mfma", "kernel": "conv_igemm_glds_kernel<128,2>", "achieved": flops / secs / 1e12, "peak": peak,
             "unit": "TFLOP/s", "frac": flops / secs / 1e12 / peak, "traffic": None,
             "launches_per_step": len(sel) / nsteps, "avg_launch_us": secs / len(sel) * 1e6, "gflop_per_launch": flops / len(sel) / 1e9,
             "kernel_ms_per_step": secs / nsteps * 1e3,

@@ -35,6 +35,9 @@ int tscd_conv_tile_m(void);
  * staging otherwise), 0 force register staging, 1 same as -1.  Both variants accumulate in the same order: outputs and
  * BatchNorm partial sums are bit-identical (tests/test_gpu_conv.py). */
 void tscd_conv_set_variant(int variant);
+/* Measurement hook (scratch experiments, never set by the product path): bit0 makes the LDS-DMA loop's A gather read a
+ * zero block, bit1 makes every B row read row 0 -- isolates how much of a launch is memory stall.  Results are wrong. */
+void tscd_conv_set_debug(int bits);
 int tscd_conv_tile_n(int cout);
 int tscd_pack_conv_weight(const void* w, int src_is_f32, void* out, int Cout, int Cin, int CinPad, int KH, int KW,
                           int rows_pad, int Kpad, int mode, void* stream);

@@ -478,9 +478,11 @@ extern "C" int tscd_se_fuse_bwd_f16(const void* reg, int ldr, const void* edge, 
                                     void* stream) {
   TSCD_CHECK_ARG(reg && edge && w0 && w2 && dout && dreg && dedge && dpos && dw0 && dw2, "se_fuse_bwd: null pointer");
   if (n == 0) return TSCD_OK;
+  // few fat blocks: every thread ends with a 128-value wave reduction of its weight-gradient partials, so the element
+  // loop has to be long enough (>= 8 elements per thread) to amortise that tail
   long total = n * C;
-  int grid = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(se_fuse_bwd_kernel, dim3(grid > 512 ? 512 : grid), dim3(256), 0, (hipStream_t)stream, (const f16*)reg, ldr,
+  int grid = (int)((total + 2047) / 2048);
+  hipLaunchKernelGGL(se_fuse_bwd_kernel, dim3(grid > 256 ? 256 : (grid < 1 ? 1 : grid)), dim3(256), 0, (hipStream_t)stream, (const f16*)reg, ldr,
                      (const f16*)edge, lde, w0, w2, (const f16*)dout, n, C, (f16*)dreg, (f16*)dedge, dpos, dw0, dw2);
   TSCD_CHECK_LAUNCH("se_fuse_bwd");
   return TSCD_OK;

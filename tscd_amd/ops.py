@@ -137,7 +137,7 @@ def conv2d(x, wpk, cout, ksize, stride=1, epilogue=EPI_RAW, bias=None, scale_shi
          _ptr(partial), B, H, W, Cin, cout, ksize, stride, ldx, ldy, epilogue, _stream())
     if prof is not None:
         e1.record()
-        prof.append((lib.tscd_conv_tile_n(cout), 2.0 * B * Ho * Wo * cout * ksize * ksize * Cin, e0, e1))
+        prof.append((lib.tscd_conv_tile_n(cout), Cin, 2.0 * B * Ho * Wo * cout * ksize * ksize * Cin, e0, e1))
     return out, partial
 
 
