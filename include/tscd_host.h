@@ -1,0 +1,38 @@
+/* Host-side C-ABI of the TSCD hot path (libtscd_host.so, built from tscd_amd/csrc_host/lap.cpp with g++).
+ *
+ * The one step of the path the reference itself runs on the host: the Hungarian assignment of CAFM's frame-to-frame
+ * matching, double_match_embds (yolox/models/tscd_matching.py:908-937), which calls
+ * scipy.optimize.linear_sum_assignment on a cost matrix copied from the device.  scipy is a third-party dependency of the
+ * reference (not vendored); its solver is the shortest-augmenting-path algorithm of D. F. Crouse, "On implementing 2D
+ * rectangular assignment algorithms", IEEE TAES 52(4), 2016.  These entry points restate that algorithm with scipy's
+ * iteration order and tie rules, so the returned indices equal scipy's for every input (tests/test_lap_host.py).
+ *
+ * Plain pointers and sizes, no allocation visible to the caller, thread-safe (per-thread scratch).  Return codes:
+ * 0 ok, 1 invalid entries (NaN / -inf in the f64 form), 2 infeasible.
+ */
+#ifndef TSCD_HOST_H
+#define TSCD_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cost: row-major [nr][nc] float64.  row_ind / col_ind: min(nr, nc) entries, rows ascending (as scipy returns them). */
+int tscd_lap_solve_f64(const double* cost, int64_t nr, int64_t nc, int64_t* row_ind, int64_t* col_ind);
+
+/* cost: fp16 bit patterns as the device GEMM (EPI_COST epilogue of tscd_conv2d_nhwc_f16) wrote them, leading dimension
+ * ld (elements).  row_map (may be NULL): row r of the solved matrix is cost[row_map[r]] -- the reference solves on the
+ * previous frame's rows re-ordered by the previous assignment.  NaN entries count as 0 like the reference's
+ * torch.where(isnan).  fp16 costs are exact multiples of 2^-24, so the solver runs in exact int32 fixed point with
+ * AVX-512 inner loops when the host has them (tscd_lap_fixed_point_available) and |cost| < 8, otherwise in double. */
+int tscd_lap_solve_f16(const uint16_t* cost, int64_t ld, const int64_t* row_map, int64_t nr, int64_t nc, int64_t* row_ind,
+                       int64_t* col_ind);
+int tscd_lap_fixed_point_available(void);
+
+/* Diagnostics: relaxation passes executed by the fixed-point solver since the last reset (not thread-safe). */
+int64_t tscd_lap_debug_steps(int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
