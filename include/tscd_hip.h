@@ -129,6 +129,18 @@ int tscd_add_layernorm_f16(const void* a, const void* b, const float* gamma, con
 int tscd_cos_attn_bwd_f16(const void* q, const void* k, const void* v, const void* dO, int n, int nk, int C, int heads,
                           const int* tiles, int ntiles, void* workspace, long workspace_bytes, void* dq, void* dk, void* dv,
                           void* stream);
+int tscd_cos_attn_bwd_finish_f16(const void* k, const void* workspace, int nk, int C, int heads, void* dk, void* dv,
+                                 void* stream);
+/* The same attention on the matrix cores (attn_mfma.hip) for head dims 16..160 that are multiples of 16: one wave per
+ * (32-query tile, head), tiles = (row0, nrows <= 32, key0, key1).  lsum [n][heads] fp32 receives the softmax denominators
+ * the backward needs; the backward writes dq and leaves fp32 [dk^ | dv] accumulators in `workspace` (>= 8*nk*C bytes) for
+ * tscd_cos_attn_bwd_finish_f16. */
+int tscd_cos_attn_mfma_supported(int head_dim);
+int tscd_cos_attn_mfma_f16(const void* q, const void* k, const void* v, int C, int heads, const int* tiles, int ntiles,
+                           void* out, float* lsum, void* stream);
+int tscd_cos_attn_mfma_bwd_f16(const void* q, const void* k, const void* v, const void* dO, const void* out, const float* lsum,
+                               int n, int nk, int C, int heads, const int* tiles, int ntiles, void* workspace,
+                               long workspace_bytes, void* dq, void* stream);
 int tscd_se_fuse_bwd_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
                          const void* dout, long n, int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2,
                          void* stream);

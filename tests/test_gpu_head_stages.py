@@ -308,7 +308,8 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("C,heads,nq,nk", [(256, 8, 150, 150), (1024, 8, 77, 77), (64, 8, 40, 130), (320, 8, 33, 90)])
+@pytest.mark.parametrize("C,heads,nq,nk", [(256, 8, 150, 150), (1024, 8, 77, 77), (64, 8, 40, 130), (320, 8, 33, 90),
+                                           (128, 8, 45, 70), (384, 8, 40, 33), (1280, 8, 37, 50)])
 def test_cafm_attention_pieces_backward_match_oracle_autograd(C, heads, nq, nk):
     """cos_attn / se_fuse / add_layernorm / linear backward kernels vs. autograd of the oracle's fp32 expressions
     (oracle cos_mh_attention, se_module, referring_cross_attention: the reference's tscd_matching.py:140-181, 264-283, 535-636)."""

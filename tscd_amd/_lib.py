@@ -31,6 +31,9 @@ SIGNATURES = {
     "tscd_se_fuse_f16": [P, I, P, I, P, P, P, L, I, P, P],
     "tscd_add_layernorm_f16": [P, P, P, P, I, I, F, P, P],
     "tscd_cos_attn_bwd_f16": [P, P, P, P, I, I, I, I, P, I, P, L, P, P, P, P],
+    "tscd_cos_attn_bwd_finish_f16": [P, P, I, I, I, P, P, P],
+    "tscd_cos_attn_mfma_f16": [P, P, P, I, I, P, I, P, P, P],
+    "tscd_cos_attn_mfma_bwd_f16": [P, P, P, P, P, P, I, I, I, I, P, I, P, L, P, P],
     "tscd_se_fuse_bwd_f16": [P, I, P, I, P, P, P, L, I, P, P, P, P, P, P],
     "tscd_add_layernorm_bwd_f16": [P, P, P, P, I, I, F, P, P, P, P],
     "tscd_row_normalize_f16": [P, I, I, I, I, F, P, I, P],
@@ -44,7 +47,7 @@ PLAIN = {"tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace
          "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
          "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),
          "tscd_nms_workspace_bytes": ([I, I], L), "tscd_simota_workspace_bytes": ([I, I, I, I], L),
-         "tscd_conv_set_variant": ([I], None), "tscd_conv_set_debug": ([I], None), "tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
+         "tscd_conv_set_variant": ([I], None), "tscd_conv_set_debug": ([I], None), "tscd_cos_attn_mfma_supported": ([I], I), "tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
          "tscd_last_error": ([], C.c_char_p)}
 
 

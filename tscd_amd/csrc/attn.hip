@@ -420,6 +420,19 @@ extern "C" int tscd_cos_attn_bwd_f16(const void* q, const void* k, const void* v
   return TSCD_OK;
 }
 
+// dk / dv (fp16) from the fp32 accumulators a cos_attn backward kernel left in `workspace` ([dk^ | dv], nk*C floats each)
+extern "C" int tscd_cos_attn_bwd_finish_f16(const void* k, const void* workspace, int nk, int C, int heads, void* dk, void* dv,
+                                            void* stream) {
+  TSCD_CHECK_ARG(k && workspace && dk && dv && heads > 0 && C % heads == 0, "cos_attn_bwd_finish: bad args");
+  if (nk == 0) return TSCD_OK;
+  const float* dkn = (const float*)workspace;
+  long waves = (long)nk * heads;
+  hipLaunchKernelGGL(cos_attn_bwd_finish_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f16*)k, dkn, dkn + (long)nk * C, nk, C, heads, (f16*)dk, (f16*)dv);
+  TSCD_CHECK_LAUNCH("cos_attn_bwd_finish");
+  return TSCD_OK;
+}
+
 // se_fuse backward: d reg, d edge (fp16), d pos [C], d w0 [32][2], d w2 [2][32] (fp32 atomics; caller zeroes them).
 __global__ void se_fuse_bwd_kernel(const f16* __restrict__ reg, int ldr, const f16* __restrict__ edge, int lde,
                                    const float* __restrict__ w0, const float* __restrict__ w2, const f16* __restrict__ dout, long n,

@@ -1,0 +1,348 @@
+// Cosine multi-head attention of CAFM / TaskAligned on the matrix cores (reference: PositionMHAttention / MHAttention,
+// yolox/models/tscd_matching.py:31-60, 140-181): out = softmax_k(q^.k^) v per head, q^ = q/||q||, k^ = k/||k||, rows grouped
+// in segments (one frame's queries attend to that frame's keys).  Head dims that are multiples of 16 (TSCD-L: 32 in CAFM,
+// 128 in TaskAligned) run here; the others keep the scalar kernels of attn.hip.
+//
+// One wave = one (32-query tile, head) task; a workgroup is a single wave, so the only synchronisation is the wave's own
+// LDS wait.  Every product is arranged so that the QUERY index lives on the lanes (MFMA column = lane & 31):
+//   S^T  [key  x query] = K^   Q^^T    A = k^ rows (each lane normalises and feeds its own key row), B = q^ rows (registers)
+//   O^T  [d    x query] = V^T  P^T     A = V^T by ds_read_b64_tr_b16 from the LDS copy of the V tile, B = P^T straight from
+//                                      the S^T accumulator registers (no transpose: the key order of the reduction is
+//                                      permuted identically on both operands)
+// so softmax sums, the 1/l scaling and (backward) delta = dO.O and the q-normalisation gradient are all per-lane scalars.
+// cos <= 1 bounds the logits: exp(s - 1) needs no running maximum.
+// Backward (same tiling, given dO, O and the saved row sums l):
+//   dP^T = V dO^T,  dS^T = P^T o (dP^T - delta),  dQ^^T = K^^T dS^T (A by transposing reads of the k^ tile),
+//   dK^ = dS^T Q^ and dV = P^T dO with both operands read transposed from LDS tiles (dS / P written once per key tile as
+//   fp16 [query][key]); their results have the channel on the lanes, so the fp32 atomics that sum them over query tiles are
+//   two full 128-byte segments per instruction.  k's normalisation gradient is applied by cos_attn_bwd_finish (attn.hip).
+#include "common.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+struct AttnTile { int row0, nrows, key0, key1; };
+
+// ds_read_b64_tr_b16 pair: the 16-lane group reads 4 rows x 16 columns twice (rows r..r+3 and r+ROW2..r+ROW2+3) and each
+// lane receives its column's 8 values.  `p` points at (row r, column 0 of the group's 16-column block).
+template <int ROW2>
+__device__ __forceinline__ f16x8 tr_pair(const f16* p, int pitch, int lane) {
+  const int i = lane & 15, q = i >> 2, c = i & 3;
+  auto a0 = (__attribute__((address_space(3))) s16x4*)(p + q * pitch + 4 * c);
+  auto a1 = (__attribute__((address_space(3))) s16x4*)(p + (q + ROW2) * pitch + 4 * c);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(a0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(a1);
+  f16x4 lo4 = __builtin_bit_cast(f16x4, lo), hi4 = __builtin_bit_cast(f16x4, hi);   // whole-vector casts (see conv_wgrad.hip)
+  return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// LDS row pitch (halves) of a [32][D] tile: pitch/2 = 16 mod 64 dwords puts the 4 rows of a transposing read on disjoint
+// bank quarters
+__host__ __device__ constexpr int tile_pitch(int D) { return D <= 32 ? 32 : 160; }
+
+// row of x (raw fp16) -> this lane's MFMA fragments (8 channels per 16-wide k-step: d = 16 s + 8 (lane>>5) + j) and the
+// inverse norm of the whole head row (the two half-lanes of a row exchange their partial sums)
+template <int KS>
+__device__ __forceinline__ float load_row(const f16* __restrict__ row, bool ok, int half, f16x8 (&f)[KS]) {
+  float ss = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    f[s] = ok ? *(const f16x8*)(row + 16 * s + 8 * half) : z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += (float)f[s][j] * (float)f[s][j];
+  }
+  ss += __shfl_xor(ss, 32, 64);
+  return ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
+}
+template <int KS>
+__device__ __forceinline__ void scale_row(f16x8 (&f)[KS], float inv) {
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[s][j] = (f16)((float)f[s][j] * inv);
+}
+
+template <int KS>
+__global__ __launch_bounds__(64) void cos_attn_mfma_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                          const f16* __restrict__ v, int C, int heads,
+                                                          const AttnTile* __restrict__ tiles, f16* __restrict__ out,
+                                                          float* __restrict__ lsum) {
+  constexpr int D = 16 * KS, MT = (KS + 1) / 2, P = tile_pitch(MT * 32);
+  __shared__ __attribute__((aligned(16))) f16 vt[32 * P];
+  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5, blk = (lane >> 4) & 1;
+  const AttnTile t = tiles[blockIdx.x / heads];
+  const int h = blockIdx.x % heads;
+  const bool qok = col < t.nrows;
+  const long qrow = t.row0 + (qok ? col : 0);
+
+  f16x8 qf[KS];
+  scale_row<KS>(qf, load_row<KS>(q + qrow * C + h * D, qok, half, qf));
+  // zero the pad columns of the V tile once (head dims that are not a multiple of 32)
+  if (MT * 32 > D)
+    for (int i = lane; i < 32 * (MT * 32 - D); i += 64) vt[(i / (MT * 32 - D)) * P + D + i % (MT * 32 - D)] = (f16)0.f;
+
+  f32x16 oacc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[m][e] = 0.f;
+  float psum = 0.f;
+
+  for (int kb = t.key0; kb < t.key1; kb += 32) {
+    const bool kok = kb + col < t.key1;
+    const long krow = kb + (kok ? col : 0);
+    f16x8 kf[KS], vf[KS];
+    scale_row<KS>(kf, load_row<KS>(k + krow * C + h * D, kok, half, kf));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      vf[s] = kok ? *(const f16x8*)(v + krow * C + h * D + 16 * s + 8 * half) : z;
+    }
+    __syncthreads();   // single-wave workgroup: orders the previous tile's transposing reads before the overwrite
+#pragma unroll
+    for (int s = 0; s < KS; ++s) *(f16x8*)(vt + col * P + 16 * s + 8 * half) = vf[s];
+    f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[s], st, 0, 0, 0);
+    // P^T in the accumulator layout: register e <-> key (e&3) + 8 (e>>2) + 4 half
+    f16x8 pb[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int kl = (e & 3) + 8 * (e >> 2) + 4 * half;
+      float pv = (kb + kl < t.key1) ? __expf(st[e] - 1.0f) : 0.f;
+      psum += pv;
+      pb[e >> 3][e & 7] = (f16)pv;
+    }
+    __syncthreads();
+    // O^T[d][query] += V^T P^T: k-step s2 <-> keys 16 s2 + 4 half + {0..3, 8..11} on both operands
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 a = tr_pair<8>(vt + (16 * s2 + 4 * half) * P + m * 32 + 16 * blk, P, lane);
+        oacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[s2], oacc[m], 0, 0, 0);
+      }
+  }
+  psum += __shfl_xor(psum, 32, 64);
+  const float il = psum > 0.f ? 1.0f / psum : 0.f;
+  if (qok) {
+    if (half == 0) lsum[qrow * heads + h] = psum;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = m * 32 + 8 * g + 4 * half;
+        if (d0 < D) {
+          f16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (f16)(oacc[m][4 * g + j] * il);
+          *(f16x4*)(out + qrow * C + h * D + d0) = o;
+        }
+      }
+  }
+}
+
+// workspace: 2 * nk * C floats (dk^ and dv accumulators, zeroed here); dq written directly
+template <int KS>
+__global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                              const f16* __restrict__ v, const f16* __restrict__ dO,
+                                                              const f16* __restrict__ o, const float* __restrict__ lsum, int C,
+                                                              int heads, const AttnTile* __restrict__ tiles, f16* __restrict__ dq,
+                                                              float* __restrict__ dkn, float* __restrict__ dvacc) {
+  constexpr int D = 16 * KS, MT = (KS + 1) / 2, P = tile_pitch(MT * 32), TP = 32;
+  __shared__ __attribute__((aligned(16))) f16 qt[32 * P], gt[32 * P], kt[32 * P];
+  __shared__ __attribute__((aligned(16))) f16 ts[32 * TP], tp[32 * TP];    // dS and P, [query][key]
+  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5, blk = (lane >> 4) & 1;
+  const AttnTile t = tiles[blockIdx.x / heads];
+  const int h = blockIdx.x % heads;
+  const bool qok = col < t.nrows;
+  const long qrow = t.row0 + (qok ? col : 0);
+
+  f16x8 qf[KS], gf[KS];
+  const float qinv = load_row<KS>(q + qrow * C + h * D, qok, half, qf);
+  scale_row<KS>(qf, qinv);
+  float delta = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    gf[s] = qok ? *(const f16x8*)(dO + qrow * C + h * D + 16 * s + 8 * half) : z;
+    f16x8 of = qok ? *(const f16x8*)(o + qrow * C + h * D + 16 * s + 8 * half) : z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) delta += (float)gf[s][j] * (float)of[j];
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  const float l = qok ? lsum[qrow * heads + h] : 0.f;
+  const float il = l > 0.f ? 1.0f / l : 0.f;
+  // LDS copies of q^ and dO ([query][d], zero pad columns) for the transposed operands of dK^ / dV
+  for (int i = lane; i < 32 * P; i += 64) { qt[i] = (f16)0.f; gt[i] = (f16)0.f; kt[i] = (f16)0.f; }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    *(f16x8*)(qt + col * P + 16 * s + 8 * half) = qf[s];
+    *(f16x8*)(gt + col * P + 16 * s + 8 * half) = gf[s];
+  }
+
+  f32x16 dqacc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dqacc[m][e] = 0.f;
+
+  for (int kb = t.key0; kb < t.key1; kb += 32) {
+    const bool kok = kb + col < t.key1;
+    const long krow = kb + (kok ? col : 0);
+    f16x8 kf[KS], vf[KS];
+    scale_row<KS>(kf, load_row<KS>(k + krow * C + h * D, kok, half, kf));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      vf[s] = kok ? *(const f16x8*)(v + krow * C + h * D + 16 * s + 8 * half) : z;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) *(f16x8*)(kt + col * P + 16 * s + 8 * half) = kf[s];
+    f32x16 st, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[s], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s], gf[s], dp, 0, 0, 0);
+    }
+    f16x8 sb[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f16x4 s4, p4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = 4 * g + j;
+        const int kl = j + 8 * g + 4 * half;
+        float pn = (kb + kl < t.key1) ? __expf(st[e] - 1.0f) * il : 0.f;
+        float ds = pn * (dp[e] - delta);
+        s4[j] = (f16)ds;
+        p4[j] = (f16)pn;
+        sb[e >> 3][e & 7] = (f16)ds;
+      }
+      *(f16x4*)(ts + col * TP + 8 * g + 4 * half) = s4;     // [query = this lane's column][4 consecutive keys]
+      *(f16x4*)(tp + col * TP + 8 * g + 4 * half) = p4;
+    }
+    __syncthreads();
+    // dQ^^T[d][query] += K^^T dS^T (keys permuted like the forward's V^T P^T)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 a = tr_pair<8>(kt + (16 * s2 + 4 * half) * P + m * 32 + 16 * blk, P, lane);
+        dqacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, sb[s2], dqacc[m], 0, 0, 0);
+      }
+    // dK^[key][d] = sum_q dS[q][key] q^[q][d],  dV[key][d] = sum_q P[q][key] dO[q][d]: both operands transposed from LDS,
+    // k-step s2 <-> queries 16 s2 + 8 half + 0..7
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x16 akk, avv;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) akk[e] = avv[e] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int r0 = 16 * s2 + 8 * half;
+        f16x8 aS = tr_pair<4>(ts + r0 * TP + 16 * blk, TP, lane);
+        f16x8 aP = tr_pair<4>(tp + r0 * TP + 16 * blk, TP, lane);
+        f16x8 bQ = tr_pair<4>(qt + r0 * P + m * 32 + 16 * blk, P, lane);
+        f16x8 bG = tr_pair<4>(gt + r0 * P + m * 32 + 16 * blk, P, lane);
+        akk = __builtin_amdgcn_mfma_f32_32x32x16_f16(aS, bQ, akk, 0, 0, 0);
+        avv = __builtin_amdgcn_mfma_f32_32x32x16_f16(aP, bG, avv, 0, 0, 0);
+      }
+      const int d = m * 32 + col;
+      if (d < D) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int kl = (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (kb + kl < t.key1) {
+            const long off = (long)(kb + kl) * C + h * D + d;
+            atomicAdd(dkn + off, akk[e]);
+            atomicAdd(dvacc + off, avv[e]);
+          }
+        }
+      }
+    }
+  }
+  // q normalisation backward, per lane: dq = (dq^ - q^ (q^.dq^)) / ||q||; this lane's d set is m*32 + 8 g + 4 half + j
+  float dot = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f16x4 q4 = *(const f16x4*)(qt + col * P + m * 32 + 8 * g + 4 * half);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dot += dqacc[m][4 * g + j] * (float)q4[j];
+    }
+  dot += __shfl_xor(dot, 32, 64);
+  if (qok) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = m * 32 + 8 * g + 4 * half;
+        if (d0 < D) {
+          f16x4 q4 = *(const f16x4*)(qt + col * P + d0), r;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r[j] = (f16)((dqacc[m][4 * g + j] - (float)q4[j] * dot) * qinv);
+          *(f16x4*)(dq + qrow * C + h * D + d0) = r;
+        }
+      }
+  }
+}
+
+extern "C" int tscd_cos_attn_mfma_supported(int head_dim) { return head_dim >= 16 && head_dim <= 160 && head_dim % 16 == 0; }
+
+// tiles: (row0, nrows <= 32, key0, key1).  lsum [n][heads] fp32: softmax denominators (sum_k exp(s-1)), kept for backward.
+extern "C" int tscd_cos_attn_mfma_f16(const void* q, const void* k, const void* v, int C, int heads, const int* tiles, int ntiles,
+                                      void* out, float* lsum, void* stream) {
+  TSCD_CHECK_ARG(q && k && v && tiles && out && lsum && heads > 0 && C % heads == 0, "cos_attn_mfma: bad args");
+  const int D = C / heads;
+  TSCD_CHECK_ARG(tscd_cos_attn_mfma_supported(D) && C % 8 == 0, "cos_attn_mfma: head dim %d not supported", D);
+  if (ntiles == 0) return TSCD_OK;
+  dim3 grid(ntiles * heads), block(64);
+  hipStream_t st = (hipStream_t)stream;
+#define CAM(KSV)                                                                                                              \
+  case KSV:                                                                                                                    \
+    hipLaunchKernelGGL((cos_attn_mfma_kernel<KSV>), grid, block, 0, st, (const f16*)q, (const f16*)k, (const f16*)v, C, heads, \
+                       (const AttnTile*)tiles, (f16*)out, lsum);                                                               \
+    break
+  switch (D / 16) {
+    CAM(1); CAM(2); CAM(3); CAM(4); CAM(5); CAM(6); CAM(7); CAM(8); CAM(9); CAM(10);
+  }
+#undef CAM
+  TSCD_CHECK_LAUNCH("cos_attn_mfma");
+  return TSCD_OK;
+}
+
+// gradients w.r.t. the raw q (written), and fp32 accumulators of d k^ and d v in `workspace` (>= 8*nk*C bytes, zeroed
+// here) that tscd_cos_attn_bwd_finish_f16 turns into dk / dv.
+extern "C" int tscd_cos_attn_mfma_bwd_f16(const void* q, const void* k, const void* v, const void* dO, const void* out,
+                                          const float* lsum, int n, int nk, int C, int heads, const int* tiles, int ntiles,
+                                          void* workspace, long workspace_bytes, void* dq, void* stream) {
+  TSCD_CHECK_ARG(q && k && v && dO && out && lsum && tiles && workspace && dq && heads > 0 && C % heads == 0, "cos_attn_mfma_bwd: bad args");
+  const int D = C / heads;
+  TSCD_CHECK_ARG(tscd_cos_attn_mfma_supported(D) && C % 8 == 0, "cos_attn_mfma_bwd: head dim %d not supported", D);
+  TSCD_CHECK_ARG(workspace_bytes >= 8L * nk * C, "cos_attn_mfma_bwd: workspace too small");
+  (void)n;
+  hipStream_t st = (hipStream_t)stream;
+  if (nk > 0) (void)hipMemsetAsync(workspace, 0, 8L * nk * C, st);
+  if (ntiles == 0) return TSCD_OK;
+  float* dkn = (float*)workspace;
+  float* dva = dkn + (long)nk * C;
+  dim3 grid(ntiles * heads), block(64);
+#define CAB(KSV)                                                                                                               \
+  case KSV:                                                                                                                     \
+    hipLaunchKernelGGL((cos_attn_mfma_bwd_kernel<KSV>), grid, block, 0, st, (const f16*)q, (const f16*)k, (const f16*)v,         \
+                       (const f16*)dO, (const f16*)out, lsum, C, heads, (const AttnTile*)tiles, (f16*)dq, dkn, dva);             \
+    break
+  switch (D / 16) {
+    CAB(1); CAB(2); CAB(3); CAB(4); CAB(5); CAB(6); CAB(7); CAB(8); CAB(9); CAB(10);
+  }
+#undef CAB
+  TSCD_CHECK_LAUNCH("cos_attn_mfma_bwd");
+  return TSCD_OK;
+}

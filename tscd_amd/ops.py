@@ -438,13 +438,44 @@ def linear_wgrad(x, dy):
 # ----------------------------------------------------------------------------------------------------
 # CAFM / TaskAligned pieces
 # ----------------------------------------------------------------------------------------------------
-def attn_tiles(segments, device):
-    """segments: list of (row0, nrows, key0, key1).  16-row tiles."""
+def attn_tiles(segments, device, rows=16):
+    """segments: list of (row0, nrows, key0, key1) -> query tiles of `rows` rows (16: scalar kernels, 32: MFMA kernels)."""
     t = []
     for (r0, n, k0, k1) in segments:
-        for r in range(0, n, 16):
-            t.append((r0 + r, min(16, n - r), k0, k1))
+        for r in range(0, n, rows):
+            t.append((r0 + r, min(rows, n - r), k0, k1))
     return h2d(t, torch.int32, device).reshape(-1, 4)
+
+
+def cos_attn_uses_mfma(C, heads):
+    return C % heads == 0 and bool(lib.tscd_cos_attn_mfma_supported(C // heads))
+
+
+def cos_attn_mfma(q, k, v, heads, tiles32):
+    """-> (out [n,C] fp16, lsum [n,heads] fp32)."""
+    n, C = q.shape
+    for t in (q, k, v):
+        assert t.is_contiguous() and t.dtype == torch.float16 and t.shape[1] == C
+    out = torch.zeros((n, C), dtype=torch.float16, device=q.device)       # rows outside every tile stay zero
+    lsum = torch.zeros((n, heads), dtype=torch.float32, device=q.device)
+    call("tscd_cos_attn_mfma_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), C, heads, tiles32.data_ptr(), tiles32.shape[0],
+         out.data_ptr(), lsum.data_ptr(), _stream())
+    return out, lsum
+
+
+def cos_attn_mfma_bwd(q, k, v, d_out, out, lsum, heads, tiles32):
+    n, C = q.shape
+    nk = k.shape[0]
+    dev = q.device
+    for t in (q, k, v, d_out, out):
+        assert t.is_contiguous() and t.dtype == torch.float16 and t.shape[1] == C
+    ws = torch.empty((2 * nk * C,), dtype=torch.float32, device=dev)
+    dq = torch.zeros((n, C), dtype=torch.float16, device=dev)
+    dk, dv = (torch.empty((nk, C), dtype=torch.float16, device=dev) for _ in range(2))
+    call("tscd_cos_attn_mfma_bwd_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), d_out.data_ptr(), out.data_ptr(), lsum.data_ptr(),
+         n, nk, C, heads, tiles32.data_ptr(), tiles32.shape[0], ws.data_ptr(), ws.numel() * 4, dq.data_ptr(), _stream())
+    call("tscd_cos_attn_bwd_finish_f16", k.data_ptr(), ws.data_ptr(), nk, C, heads, dk.data_ptr(), dv.data_ptr(), _stream())
+    return dq, dk, dv
 
 
 def cos_attn(q, k, v, heads, tiles):

@@ -56,6 +56,8 @@ def linear(x, lin):
 
 
 class _CosAttention(torch.autograd.Function):
+    """Scalar-kernel path (head dims that are not a multiple of 16)."""
+
     @staticmethod
     def forward(ctx, q, k, v, heads, tiles):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
@@ -70,10 +72,34 @@ class _CosAttention(torch.autograd.Function):
         return dq, dk, dv, None, None
 
 
+class _CosAttentionMFMA(torch.autograd.Function):
+    """Matrix-core path (attn_mfma.hip): the forward also returns the softmax denominators the backward re-uses."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, tiles32):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out, lsum = ops.cos_attn_mfma(q, k, v, heads, tiles32)
+        ctx.save_for_backward(q, k, v, tiles32, out, lsum)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, tiles32, out, lsum = ctx.saved_tensors
+        dq, dk, dv = ops.cos_attn_mfma_bwd(q, k, v, g.to(torch.float16).contiguous(), out, lsum, ctx.heads, tiles32)
+        return dq, dk, dv, None, None
+
+
 def cos_attention(q, k, v, heads, segments):
     """softmax(q^ k^T) v per head, rows grouped in segments [(row0, nrows, key0, key1)]."""
+    grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
+    if ops.cos_attn_uses_mfma(q.shape[1], heads):
+        tiles = ops.attn_tiles(segments, q.device, rows=32)
+        if grad:
+            return _CosAttentionMFMA.apply(q, k, v, heads, tiles)
+        return ops.cos_attn_mfma(q.contiguous(), k.contiguous(), v.contiguous(), heads, tiles)[0]
     tiles = ops.attn_tiles(segments, q.device)
-    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+    if grad:
         return _CosAttention.apply(q, k, v, heads, tiles)
     return ops.cos_attn(q.contiguous(), k.contiguous(), v.contiguous(), heads, tiles)
 
