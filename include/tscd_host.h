@@ -29,6 +29,14 @@ int tscd_lap_solve_f16(const uint16_t* cost, int64_t ld, const int64_t* row_map,
                        int64_t* col_ind);
 int tscd_lap_fixed_point_available(void);
 
+/* The dependent chain of assignments of one clip in one call (AwarePositionRegMatcher.forward, tscd_matching.py:940-1080).
+ * kind[k]: 0 first frame of a clip (self match), 1 against carried-over state (rows as given), 2 against the previous frame
+ * (rows gathered by the previous solve's column order; nr[k] == nc[k-1]).  cost[k]: fp16 bits [nr[k]][nc[k]].  Outputs are
+ * concatenated over k: row_out / col_out hold min(nr,nc) scipy pairs each, perm_out nc[k] entries (the pairs' columns, then
+ * the unmatched columns ascending; the identity for kind 0).  Returns 0, or 16*k + status of the first failing solve. */
+int tscd_lap_chain_f16(int K, const uint16_t* const* cost, const int64_t* nr, const int64_t* nc, const int32_t* kind,
+                       int64_t* row_out, int64_t* col_out, int64_t* perm_out);
+
 /* Diagnostics: relaxation passes executed by the fixed-point solver since the last reset (not thread-safe). */
 int64_t tscd_lap_debug_steps(int reset);
 

@@ -94,3 +94,41 @@ def test_lap_on_device_cost_sample():
     assert np.array_equal(r, z["scipy_rows"]) and np.array_equal(c, z["scipy_cols"])
     r0, c0 = linear_sum_assignment(z["cost_f16_bits"].view(np.float16).astype(float))
     assert np.array_equal(c0, z["scipy_cols"])
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_lap_chain_matches_stepwise_scipy(seed):
+    """tscd_lap_chain_f16 (the clip's dependent assignments in one call) against the reference's frame loop written with
+    scipy (tscd_matching.py:940-1080): previous rows re-ordered by the previous assignment, unmatched current proposals
+    appended when the reference frame was smaller, matched reference rows only when it was larger."""
+    from tscd_amd._host import lap_chain_f16, KIND_SELF, KIND_STATE, KIND_PREV
+    rng = np.random.default_rng(500 + seed)
+    for trial in range(10):
+        K = int(rng.integers(2, 6))
+        ns = [int(rng.integers(20, 90)) for _ in range(K)]
+        first_kind = KIND_SELF if trial % 2 == 0 else KIND_STATE
+        n_state = int(rng.integers(20, 90))
+        mats, kinds = [], []
+        for k in range(K):
+            nr = ns[k] if (k == 0 and first_kind == KIND_SELF) else (n_state if k == 0 else ns[k - 1])
+            base = rng.standard_normal((1, 16))
+            a = base + 0.03 * rng.standard_normal((nr, 16)); b = base + 0.03 * rng.standard_normal((ns[k], 16))
+            a /= np.linalg.norm(a, axis=1, keepdims=True); b /= np.linalg.norm(b, axis=1, keepdims=True)
+            mats.append(np.ascontiguousarray((1 - a @ b.T).astype(np.float16)))
+            kinds.append(first_kind if k == 0 else KIND_PREV)
+        flat = np.concatenate([m.reshape(-1) for m in mats])
+        got = lap_chain_f16(flat.ctypes.data, [m.shape for m in mats], kinds)
+        prev_perm = None
+        for k, m in enumerate(mats):
+            ref = m.astype(float)
+            if kinds[k] == KIND_PREV:
+                ref = ref[prev_perm]
+            r, c = linear_sum_assignment(ref)
+            if kinds[k] == KIND_SELF:
+                perm = np.arange(m.shape[1])
+            else:
+                rest = np.setdiff1d(np.arange(m.shape[1]), c)
+                perm = np.concatenate([c, rest])
+            assert np.array_equal(got[k][0], r) and np.array_equal(got[k][1], c), (seed, trial, k)
+            assert np.array_equal(got[k][2], perm), (seed, trial, k)
+            prev_perm = perm

@@ -55,7 +55,8 @@ def test_host_library_exports_every_declared_symbol():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "tscd_host.h")).read()
     names = set(re.findall(r"\b(tscd_[a-z0-9_]+)\s*\(", hdr))
-    assert names == {"tscd_lap_solve_f64", "tscd_lap_solve_f16", "tscd_lap_fixed_point_available", "tscd_lap_debug_steps"}
+    assert names == {"tscd_lap_solve_f64", "tscd_lap_solve_f16", "tscd_lap_chain_f16", "tscd_lap_fixed_point_available",
+                     "tscd_lap_debug_steps"}
     lib = ctypes.CDLL(_host.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n

@@ -44,3 +44,42 @@ def lap_f16(cost_u16, row_map=None):
     if st:
         raise ValueError("assignment failed (status %d)" % st)
     return a, b
+
+
+_lib.tscd_lap_chain_f16.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.tscd_lap_chain_f16.restype = C.c_int
+KIND_SELF, KIND_STATE, KIND_PREV = 0, 1, 2
+
+
+def lap_chain_f16(base_ptr, shapes, kinds, before=None):
+    """The clip's dependent chain of assignments in ONE foreign call (no Python between the solves; ctypes drops the GIL, so a
+    caller on a worker thread leaves the main thread free to queue device work).
+
+    base_ptr: address of the fp16 cost matrices laid out back to back ([nr_k, nc_k] each, C order); shapes: [(nr_k, nc_k)];
+    kinds: KIND_* per matrix; before: optional callable run first on the calling thread (e.g. wait for the copy).
+    Returns [(row_ind, col_ind, perm)] per matrix -- perm: the order in which the reference keeps the frame's rows."""
+    if before is not None:
+        before()
+    K = len(shapes)
+    if K == 0:
+        return []
+    ptrs = (C.c_void_p * K)()
+    off = 0
+    for i, (r, c) in enumerate(shapes):
+        ptrs[i] = base_ptr + 2 * off
+        off += r * c
+    nr = np.array([s[0] for s in shapes], np.int64)
+    nc = np.array([s[1] for s in shapes], np.int64)
+    kd = np.array(kinds, np.int32)
+    npair = np.minimum(nr, nc)
+    rows, cols, perms = np.empty(int(npair.sum()), np.int64), np.empty(int(npair.sum()), np.int64), np.empty(int(nc.sum()), np.int64)
+    st = _lib.tscd_lap_chain_f16(K, C.cast(ptrs, C.c_void_p), nr.ctypes.data, nc.ctypes.data, kd.ctypes.data, rows.ctypes.data,
+                                 cols.ctypes.data, perms.ctypes.data)
+    if st:
+        raise ValueError("assignment chain failed at matrix %d (status %d)" % (st // 16, st % 16))
+    out, a, b = [], 0, 0
+    for i in range(K):
+        out.append((rows[a:a + npair[i]], cols[a:a + npair[i]], perms[b:b + nc[i]]))
+        a += int(npair[i])
+        b += int(nc[i])
+    return out

@@ -449,6 +449,48 @@ int tscd_lap_solve_f16(const uint16_t* cost, int64_t ld, const int64_t* row_map,
   }
   return solve(nr, nc, c.data(), row_ind, col_ind);
 }
+// The whole frame-to-frame matching chain of one clip in a single call (AwarePositionRegMatcher.forward,
+// tscd_matching.py:940-1080): frame k's reference rows are frame k-1's rows re-ordered by frame k-1's assignment, so solve k
+// needs the column order produced by solve k-1 and nothing from the device.  Running the chain here lets the caller keep its
+// own thread free (ctypes drops the GIL for the duration) to queue device work that does not depend on the assignments.
+//   kind[k]: 0 = first frame of a clip (cost(cur, cur), identity row order), 1 = matched against carried-over state (rows as
+//            given), 2 = matched against the previous frame (rows gathered by the previous frame's column order).
+//   cost[k]: fp16 bits [nr[k]][nc[k]] (ld = nc[k]);  for kind 2, nr[k] == nc[k-1].
+// Outputs, concatenated over k: row_out / col_out (min(nr,nc) entries each: what scipy returns), perm_out (nc[k] entries:
+// col_out followed by the unmatched columns in ascending order when nr[k] < nc[k]; the identity for kind 0) -- the order in
+// which the reference keeps frame k's rows.  Returns 0, or 16*k + status of the first failing solve.
+int tscd_lap_chain_f16(int K, const uint16_t* const* cost, const int64_t* nr, const int64_t* nc, const int32_t* kind,
+                       int64_t* row_out, int64_t* col_out, int64_t* perm_out) {
+  std::vector<int64_t> prev_perm;
+  int64_t o_pair = 0, o_perm = 0;
+  for (int k = 0; k < K; ++k) {
+    const int64_t R = nr[k], Cn = nc[k], np = R < Cn ? R : Cn;
+    const int64_t* row_map = nullptr;
+    if (kind[k] == 2) {
+      if ((int64_t)prev_perm.size() != R) return 16 * k + 4;
+      row_map = prev_perm.data();
+    }
+    int st = tscd_lap_solve_f16(cost[k], Cn, row_map, R, Cn, row_out + o_pair, col_out + o_pair);
+    if (st != 0) return 16 * k + st;
+    std::vector<int64_t> perm(Cn);
+    if (kind[k] == 0) {
+      std::iota(perm.begin(), perm.end(), 0);
+    } else {
+      std::vector<uint8_t> taken(Cn, 0);
+      for (int64_t i = 0; i < np; ++i) { perm[i] = col_out[o_pair + i]; taken[perm[i]] = 1; }
+      int64_t w = np;
+      for (int64_t j = 0; j < Cn; ++j)
+        if (!taken[j]) perm[w++] = j;
+    }
+    std::memcpy(perm_out + o_perm, perm.data(), sizeof(int64_t) * Cn);
+    prev_perm.swap(perm);
+    // when the reference frame had more rows than the current one (R > Cn) only the matched reference rows survive: the next
+    // frame's reference is the current frame's Cn rows in column order -- prev_perm holds exactly col_out (np == Cn)
+    o_pair += np;
+    o_perm += Cn;
+  }
+  return 0;
+}
 int64_t tscd_lap_debug_steps(int reset) {
 #if defined(__x86_64__)
   int64_t s = g_steps;

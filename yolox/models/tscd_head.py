@@ -157,7 +157,6 @@ class TSCDHead(nn.Module):
             raw_levels.append(torch.cat([reg_o, obj_o, cls_o], -1))   # [B,h,w,5+NC]: tiny, autograd-tracked
             cls_maps.append(vid_feat)
             reg_maps.append(vid_feat_reg)
-            edge_maps.append(self.edge_enhance_reg[k][0](vid_feat_reg))
         self.hw = [tuple(f.shape[1:3]) for f in feats]
 
         with torch.no_grad():
@@ -182,11 +181,14 @@ class TSCDHead(nn.Module):
         a_idx = torch.cat([sel_idx[b, :ppf[b]] for b in range(B)]).long()
         b_idx = torch.repeat_interleave(torch.arange(B, device=dev), ops.h2d(ppf, torch.long, dev), output_size=N)
 
-        maps = [m.contiguous() for m in (cls_maps + reg_maps + edge_maps)]
-        if grad and any(m.requires_grad for m in maps):
-            f_cls, f_reg, f_edge = _GatherRows.apply(geo, sel_idx, frame_off, N, W, 3, *maps)
-        else:
-            f_cls, f_reg, f_edge = ops.gather_rows([maps[0:3], maps[3:6], maps[6:9]], geo, sel_idx, frame_off, N, W)
+        def gather(feature_maps):
+            maps = [m.contiguous() for m in feature_maps]
+            nf = len(maps) // 3
+            if grad and any(m.requires_grad for m in maps):
+                return _GatherRows.apply(geo, sel_idx, frame_off, N, W, nf, *maps)
+            return ops.gather_rows([maps[3 * f:3 * f + 3] for f in range(nf)], geo, sel_idx, frame_off, N, W)
+
+        f_cls, f_reg = gather(cls_maps + reg_maps)
         if training:
             raw_all = torch.cat([r.reshape(B, -1, nch) for r in raw_levels], 1)              # [B,A,5+NC] logits with grad
         if grad:
@@ -194,17 +196,47 @@ class TSCDHead(nn.Module):
             cls_scores = torch.sigmoid(raw_all[b_idx, a_idx, 5 + cid])                       # == pred_rows[:,5], differentiable
         else:
             cls_scores = pred_rows[:, 5]
+
+        kw = dict(preds_per_frame=ppf, lframe=lframe, gframe=gframe, conf_sim_thresh=self.kwargs.get("conf_sim_thresh", 0.99))
+        features_cls, features_reg = self.agg_iou(f_cls, f_reg, cls_scores, None, sim_thresh=self.sim_thresh, ave=self.ave,
+                                                  use_mask=self.use_mask, **kw)
+        # The matcher's cost matrices go to the host now; everything queued between prepare() and finish() -- the Haar edge
+        # block, its gather, the first MCA and the class predictions, none of which depend on the assignments -- runs on
+        # the device while the host solves them.
+        prep = self.local_reg_matcher.prepare(features_reg, features_cls, ppf[:lframe], resume=resume)
+        edge_maps = [self.edge_enhance_reg[k][0](reg_maps[k]) for k in range(len(reg_maps))]
+        (f_edge,) = gather(edge_maps)
         if self.debug is not None:
             self._dbg(agg_idx=[sel_idx[b, :ppf[b]] for b in range(B)], pred_rows=pred_rows, f_cls=f_cls, f_reg=f_reg,
                       f_edge=f_edge, edge_maps=edge_maps, reg_maps=reg_maps)
-
-        kw = dict(preds_per_frame=ppf, lframe=lframe, gframe=gframe, conf_sim_thresh=self.kwargs.get("conf_sim_thresh", 0.99))
         features_cls_matched, _ = self.agg(f_cls, f_reg, cls_scores, None, sim_thresh=self.sim_thresh, ave=self.ave,
                                            use_mask=self.use_mask, need_reg=False, **kw)
-        features_cls, features_reg = self.agg_iou(f_cls, f_reg, cls_scores, None, sim_thresh=self.sim_thresh, ave=self.ave,
-                                                  use_mask=self.use_mask, **kw)
-        matched = self.local_reg_matcher(f_reg, features_reg, features_cls, f_edge, ppf[:lframe], time_embedding[:lframe],
-                                         resume=resume)
+        cls_preds = hip_linear(features_cls_matched, self.cls_pred)
+        if training:
+            # ---------------- losses (get_matcher_refined_losses, tscd_head.py:1008-1203), dense + masked: everything that
+            # does not involve the matcher's outputs is queued here, inside the assignment window ----------------
+            raw_f = raw_all.float()
+            fg = fg_mask.bool()
+            lab = labels.float()
+            mg = matched_gt.clamp(min=0).long()
+            gt_box = torch.gather(lab[..., 1:5], 1, mg.unsqueeze(-1).expand(-1, -1, 4))          # [B,A,4] cxcywh of matched gt
+            gt_cls = torch.gather(lab[..., 0], 1, mg).long().clamp(0, nc - 1)
+            num_fg = num_fg_b.sum().float().clamp(min=1)
+            num_gts = ngt_b.sum().float()
+            iou_l = self.iou_loss(outputs[..., :4].float().reshape(-1, 4), gt_box.reshape(-1, 4)).view(B, -1)
+            loss_iou = torch.where(fg, iou_l, torch.zeros_like(iou_l)).sum() / num_fg
+            loss_obj = self.bcewithlog_loss(raw_f[..., 4], fg.float()).sum() / num_fg
+            cls_t = F.one_hot(gt_cls, nc).float() * pred_iou.unsqueeze(-1)
+            loss_cls = (self.bcewithlog_loss(raw_f[..., 5:], cls_t) * fg.unsqueeze(-1)).sum() / num_fg
+            # refined heads: local-frame proposals that SimOTA marked foreground
+            lb, la = b_idx[:nl], a_idx[:nl]
+            rmask = fg[lb, la]
+            num_fg_local = num_fg_b[:lframe].sum().float()
+            r_cls_t = cls_t[lb, la]
+            loss_r_cls = (self.bcewithlog_loss(cls_preds.float(), r_cls_t) * rmask.unsqueeze(-1)).sum() / num_fg_local
+            base = pred_rows[:nl, :4].float()
+            tgt = self._encode_reg(gt_box[lb, la], base, rmask)
+        matched = self.local_reg_matcher.finish(prep, f_reg, f_edge, time_embedding[:lframe])
         matched = f_reg[:nl] if matched is None else matched[-1]
         self._dbg(agg_cls=features_cls_matched, agg_iou_cls=features_cls, agg_iou_obj=features_reg, cafm=matched,
                   hungarian=list(self.local_reg_matcher.last_hungarian))
@@ -212,7 +244,6 @@ class TSCDHead(nn.Module):
         obj_refined = self.task_aligned(matched4, features_reg, ppf[:lframe])
         if obj_refined is None:
             obj_refined = features_reg
-        cls_preds = hip_linear(features_cls_matched, self.cls_pred)
         m_obj = hip_linear(obj_refined, self.matcher_obj_pred)
         m_reg = hip_linear(matched4, self.matcher_reg_pred)
         self._dbg(cls_preds=cls_preds, matcher_obj_preds=m_obj, matcher_reg_preds=m_reg)
@@ -223,29 +254,8 @@ class TSCDHead(nn.Module):
             self._dbg(nms_keep=keep)
             return res, res_ori
 
-        # ---------------- losses (get_matcher_refined_losses, tscd_head.py:1008-1203), dense + masked ----------------
-        raw_f = raw_all.float()
-        fg = fg_mask.bool()
-        lab = labels.float()
-        mg = matched_gt.clamp(min=0).long()
-        gt_box = torch.gather(lab[..., 1:5], 1, mg.unsqueeze(-1).expand(-1, -1, 4))          # [B,A,4] cxcywh of matched gt
-        gt_cls = torch.gather(lab[..., 0], 1, mg).long().clamp(0, nc - 1)
-        num_fg = num_fg_b.sum().float().clamp(min=1)
-        num_gts = ngt_b.sum().float()
-        iou_l = self.iou_loss(outputs[..., :4].float().reshape(-1, 4), gt_box.reshape(-1, 4)).view(B, -1)
-        loss_iou = torch.where(fg, iou_l, torch.zeros_like(iou_l)).sum() / num_fg
-        loss_obj = self.bcewithlog_loss(raw_f[..., 4], fg.float()).sum() / num_fg
-        cls_t = F.one_hot(gt_cls, nc).float() * pred_iou.unsqueeze(-1)
-        loss_cls = (self.bcewithlog_loss(raw_f[..., 5:], cls_t) * fg.unsqueeze(-1)).sum() / num_fg
-        # refined heads: local-frame proposals that SimOTA marked foreground
-        lb, la = b_idx[:nl], a_idx[:nl]
-        rmask = fg[lb, la]
-        num_fg_local = num_fg_b[:lframe].sum().float()
+        # ---------------- refined-head losses (the rest was queued inside the assignment window) ----------------
         loss_m_obj = self.bcewithlog_loss(m_obj.float().view(-1), rmask.float()).sum() / num_fg_local
-        r_cls_t = cls_t[lb, la]
-        loss_r_cls = (self.bcewithlog_loss(cls_preds.float(), r_cls_t) * rmask.unsqueeze(-1)).sum() / num_fg_local
-        base = pred_rows[:nl, :4].float()
-        tgt = self._encode_reg(gt_box[lb, la], base, rmask)
         sl1 = self.smooth_l1_loss(torch.where(rmask.unsqueeze(-1), m_reg.float(), torch.zeros_like(tgt)), tgt)
         loss_m_iou = (sl1 * rmask.unsqueeze(-1)).sum() / num_fg_local
         loss_m_obj = torch.where(loss_m_obj > 15, loss_m_obj / loss_m_obj.detach() * 15, loss_m_obj)

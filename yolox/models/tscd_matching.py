@@ -17,8 +17,14 @@ import torch.nn.functional as F
 from torch import nn
 
 from tscd_amd import ops
-from tscd_amd._host import lap_f16
+from concurrent.futures import ThreadPoolExecutor
+
+from tscd_amd._host import KIND_PREV, KIND_SELF, KIND_STATE, lap_chain_f16, lap_f16
 from tscd_amd.autograd import hip_op
+
+
+# the clip's chain of host assignments runs on this worker while the main thread keeps queueing device work
+_ASSIGN_WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="tscd-lap")
 
 
 def _f32(t):
@@ -268,37 +274,56 @@ class AwarePositionRegMatcher(nn.Module):
 
     @staticmethod
     @torch.no_grad()
-    def _cost_matrices(pairs):
+    def _cost_matrices_async(pairs, pinned=None):
         """pairs: list of (ref_reg, cur_reg, ref_cls, cur_cls).  One MFMA GEMM each (1 - mean cosine, fp16 like the
-        reference's torch.mm under autocast/.half(), tscd_matching.py:919-930), all copied to the host with ONE sync."""
+        reference's torch.mm under autocast/.half(), tscd_matching.py:919-930); all of them are copied to ONE pinned host
+        buffer asynchronously.  Returns (shapes, pinned buffer, event) -- `_cost_matrices_wait` blocks on the event."""
         costs = [ops.match_cost(a.detach().contiguous(), b.detach().contiguous(), c.detach().contiguous(), d.detach().contiguous())
                  for (a, b, c, d) in pairs]
         if not costs:
-            return []
+            return [], None, None
         flat = torch.cat([c.reshape(-1) for c in costs])
-        host = flat.cpu().numpy().view(np.uint16)        # the only device->host transfer of the matcher
+        if pinned is None or pinned.numel() < flat.numel():
+            pinned = torch.empty((max(flat.numel(), 1 << 20),), dtype=torch.float16, pin_memory=True)
+        host = pinned[:flat.numel()]
+        host.copy_(flat, non_blocking=True)               # the only device->host transfer of the matcher
+        ev = torch.cuda.Event()
+        ev.record()
+        return [tuple(c.shape) for c in costs], pinned, ev
+
+    @staticmethod
+    def _cost_matrices_wait(shapes, pinned, ev):
+        if not shapes:
+            return []
+        ev.synchronize()
+        host = pinned.numpy().view(np.uint16)
         out, o = [], 0
-        for c in costs:
-            n = c.numel()
-            out.append(np.ascontiguousarray(host[o:o + n].reshape(c.shape)))
+        for shp in shapes:
+            n = shp[0] * shp[1]
+            out.append(host[o:o + n].reshape(shp).copy())
             o += n
         return out
 
+    @staticmethod
+    def _cost_matrices(pairs):
+        return AwarePositionRegMatcher._cost_matrices_wait(*AwarePositionRegMatcher._cost_matrices_async(pairs))
+
     def forward(self, features, features_reg, features_cls, features_edge, preds_per_frame, time_embedding, resume=False):
         """features / features_edge [N,W] (first sum(preds_per_frame) rows used), features_reg / features_cls [N_L,4W],
-        time_embedding [lframe,256].  Returns [1, N_L, W] like the reference (the head takes [-1]) or None.
+        time_embedding [lframe,256].  Returns [1, N_L, W] like the reference (the head takes [-1]) or None."""
+        return self.finish(self.prepare(features_reg, features_cls, preds_per_frame, resume), features, features_edge,
+                           time_embedding)
+
+    def prepare(self, features_reg, features_cls, preds_per_frame, resume=False):
+        """First half of forward: plans the frame-to-frame matching and launches every Hungarian cost matrix of the clip plus
+        their (asynchronous) copy to the host.  The caller may queue device work that does not depend on the matcher's
+        output before calling `finish`: it runs while the host solves the assignments.
 
         The Hungarian cost of frame i is a row permutation of cost(MCA features of frame i-1, frame i): the reference's
         ``last_frame_*_embeds`` are the previous frame's MCA rows re-ordered by the previous assignment.  So every cost
         matrix of the clip is computed up front (no dependence on the attention outputs), copied to the host once, and
         the assignments are solved by the host solver (tscd_amd/csrc_host/lap.cpp, bit-identical to the scipy call of the
         reference) on the permuted rows while the device runs the previous frame's attention."""
-        dev = features.device
-        layer = self.transformer_aware_cross_attention_layers[0]
-        t_emb = linear(time_embedding.to(torch.float16).contiguous(), self.absolute_position_embedding)
-        self.last_hungarian = []
-        idx = lambda a: ops.h2d(np.ascontiguousarray(a), torch.long, dev)
-
         # ---- plan: which (reference, current) pair each non-empty frame is matched against ----
         spans, start = [], 0
         for n in preds_per_frame:
@@ -324,10 +349,26 @@ class AwarePositionRegMatcher(nn.Module):
             else:
                 p0, p1 = spans[pi]
                 pairs.append((features_reg[p0:p1], cur_reg, features_cls[p0:p1], cur_cls))
-        costs = self._cost_matrices(pairs)
+        shapes, self._pinned, ev = self._cost_matrices_async(pairs, getattr(self, "_pinned", None))
+        kinds = [{"self": KIND_SELF, "state": KIND_STATE, "prev": KIND_PREV}[kind] for (_, kind, _) in plan]
+        chain = None
+        if shapes:
+            chain = _ASSIGN_WORKER.submit(lap_chain_f16, self._pinned.data_ptr(), shapes, kinds, ev.synchronize)
+        return dict(plan=plan, spans=spans, chain=chain, ppf=list(preds_per_frame), resume=resume,
+                    features_reg=features_reg, features_cls=features_cls)
 
-        outs, prev_perm = [], None
-        for (i, kind, pi), cost in zip(plan, costs):
+    def finish(self, prep, features, features_edge, time_embedding):
+        dev = features.device
+        layer = self.transformer_aware_cross_attention_layers[0]
+        plan, spans, preds_per_frame, resume = prep["plan"], prep["spans"], prep["ppf"], prep["resume"]
+        features_reg, features_cls = prep["features_reg"], prep["features_cls"]
+        t_emb = linear(time_embedding.to(torch.float16).contiguous(), self.absolute_position_embedding)
+        self.last_hungarian = []
+        idx = lambda a: ops.h2d(np.ascontiguousarray(a), torch.long, dev)
+        solved = prep["chain"].result() if prep["chain"] is not None else []
+
+        outs = []
+        for (i, kind, pi), (row, col_raw, perm) in zip(plan, solved):
             n = preds_per_frame[i]
             s0, s1 = spans[i]
             if i == 0 and resume is False:
@@ -337,21 +378,17 @@ class AwarePositionRegMatcher(nn.Module):
             t_i = t_emb[i:i + 1]
             if kind == "self":
                 self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = cur_reg, cur_cls, n
-                ret = lap_f16(cost)[1]
+                ret = col_raw
                 self.last_hungarian.append(np.asarray(ret))
                 out = layer(cur, cur, cur, t_i, t_i, cur_edge, cur_edge)
                 new_edge = cur_edge
-                perm = np.arange(n)
             else:
-                # rows of the reference frame in the order the reference holds them (previous assignment applied)
-                row, col = lap_f16(cost, prev_perm if kind == "prev" else None)
-                self.last_hungarian.append(np.asarray(col))
+                # `perm`: the assignment's columns, followed by the unmatched current proposals (ascending) when the
+                # reference frame had fewer rows -- the order in which the reference keeps this frame from now on
+                self.last_hungarian.append(np.asarray(col_raw))
+                col = perm
                 if self.last_frame_n < n:
-                    taken = np.zeros(n, dtype=bool)
-                    taken[col] = True
-                    nomatch = np.nonzero(~taken)[0]
-                    col = np.append(col, nomatch).astype(np.int64)
-                    nm = idx(nomatch)
+                    nm = idx(perm[len(col_raw):])
                     last_feat = torch.cat((self.last_outputs, cur[nm]), 0)
                     last_edge = torch.cat((self.last_frame_edge_embeds, cur_edge[nm]), 0)
                 elif self.last_frame_n > n:
@@ -364,9 +401,7 @@ class AwarePositionRegMatcher(nn.Module):
                 ret = col
                 out = layer(cur[c], last_feat, cur, t_i, self.last_frame_time_embedding, cur_edge, last_edge)
                 new_edge = cur_edge[c]
-                perm = np.asarray(col)
             self.last_outputs, self.last_frame_time_embedding, self.last_frame_edge_embeds = out, t_i, new_edge
-            prev_perm = perm
             outs.append(out[idx(np.argsort(ret))])
         if not plan and len(preds_per_frame) and preds_per_frame[0] == 0 and resume is False:
             self._clear_state()
