@@ -204,12 +204,22 @@ def roofline_dominant_kernel(args, device, step):
     torch.cuda.synchronize()
     t = s.elapsed_time(e) / n * 1e-3
     f1 = 2.0 * B * h * h * W * 9 * W
+    # HBM-side bytes per launch come from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself;
+    # the file records the commands, the correction applied and the raw counters)
+    traffic, traffic_dom = None, None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01f_pmc_traffic.json")
+    if os.path.exists(pmc):
+        with open(pmc) as fh:
+            j = json.load(fh)
+        traffic, traffic_dom = j["all_launches"]["bytes_per_launch"], j["dominant_shape"]["bytes_per_launch"]
     return {"bound": "mfma", "kernel": "conv_igemm_glds_kernel<128,2>", "achieved": flops / secs / 1e12, "peak": peak,
-            "unit": "TFLOP/s", "frac": flops / secs / 1e12 / peak, "traffic": None,
+            "unit": "TFLOP/s", "frac": flops / secs / 1e12 / peak, "traffic": traffic,
+            "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01f_pmc_traffic.json)",
             "launches_per_step": len(sel) / nsteps, "avg_launch_us": secs / len(sel) * 1e6, "gflop_per_launch": flops / len(sel) / 1e9,
             "kernel_ms_per_step": secs / nsteps * 1e3,
             "dominant_shape": {"shape": f"B{B} {h}x{h} {W}->{W} 3x3", "gflop_per_launch": f1 / 1e9, "launch_us": t * 1e6,
-                               "achieved": f1 / t / 1e12, "frac": f1 / t / 1e12 / peak}}
+                               "achieved": f1 / t / 1e12, "frac": f1 / t / 1e12 / peak, "traffic": traffic_dom,
+                               "algorithmic_bytes": 2.0 * (2 * B * h * h * W) + 2.0 * 9 * W * W}}
 
 
 def main():
