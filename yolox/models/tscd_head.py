@@ -14,6 +14,8 @@ masks instead of boolean-mask gathers, so no further syncs occur.
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -49,7 +51,17 @@ class _GatherRows(torch.autograd.Function):
         return (None,) * 6 + tuple(zeros)
 
 
+LEVEL_STREAMS = os.environ.get("TSCD_LEVEL_STREAMS", "1") != "0"
+
+
 class TSCDHead(nn.Module):
+    def _side_streams(self, dev, n):
+        st = getattr(self, "_streams", None)
+        if st is None or len(st) < n or st[0].device != dev:
+            st = [torch.cuda.Stream(device=dev) for _ in range(n)]
+            self._streams = st
+        return st
+
     def __init__(self, num_classes, width=1.0, strides=[8, 16, 32], in_channels=[256, 512, 1024], act="silu", depthwise=False,
                  heads=4, drop=0.0, use_score=True, defualt_p=30, sim_thresh=0.75, pre_nms=0.75, ave=True, defulat_pre=750,
                  test_conf=0.001, use_mask=False, gmode=True, lmode=True, both_mode=False, localBlocks=1, **kwargs):
@@ -143,8 +155,9 @@ class TSCDHead(nn.Module):
         grad = torch.is_grad_enabled() and training
         geo = ops.LevelGeometry([f.shape[1:3] for f in feats], self.strides)
 
-        raw_levels, cls_maps, reg_maps, edge_maps = [], [], [], []
-        for k, x in enumerate(feats):
+        raw_levels, cls_maps, reg_maps = [None] * len(feats), [None] * len(feats), [None] * len(feats)
+
+        def level(k, x):
             with torch.no_grad():                                    # frozen stem / base towers (ovis_tscd_large.py:141-149)
                 x = self.stems[k](x)
                 reg_feat = self.reg_convs[k][1](self.reg_convs[k][0](x))
@@ -154,9 +167,30 @@ class TSCDHead(nn.Module):
             reg_o = TF.conv_bias(reg_feat, self.reg_preds[k].weight, self.reg_preds[k].bias)
             obj_o = TF.conv_bias(reg_feat, self.obj_preds[k].weight, self.obj_preds[k].bias)
             cls_o = TF.conv_bias(cls_feat, self.cls_preds[k].weight, self.cls_preds[k].bias)
-            raw_levels.append(torch.cat([reg_o, obj_o, cls_o], -1))   # [B,h,w,5+NC]: tiny, autograd-tracked
-            cls_maps.append(vid_feat)
-            reg_maps.append(vid_feat_reg)
+            raw_levels[k] = torch.cat([reg_o, obj_o, cls_o], -1)      # [B,h,w,5+NC]: tiny, autograd-tracked
+            cls_maps[k], reg_maps[k] = vid_feat, vid_feat_reg
+
+        # The three pyramid levels are independent chains of 14 convs each; the 36x36 and 18x18 levels launch only 80-330
+        # workgroups per conv, so they run on side streams underneath the 72x72 level instead of after it.
+        if LEVEL_STREAMS and len(feats) > 1 and dev.type == "cuda":
+            main = torch.cuda.current_stream()
+            side = self._side_streams(dev, len(feats) - 1)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            joins = []
+            for k in range(1, len(feats)):
+                side[k - 1].wait_event(fork)
+                with torch.cuda.stream(side[k - 1]):
+                    level(k, feats[k])
+                    ev = torch.cuda.Event()
+                    ev.record(side[k - 1])
+                    joins.append(ev)
+            level(0, feats[0])
+            for ev in joins:
+                main.wait_event(ev)
+        else:
+            for k, x in enumerate(feats):
+                level(k, x)
         self.hw = [tuple(f.shape[1:3]) for f in feats]
 
         with torch.no_grad():

@@ -9,6 +9,8 @@ q/k/v GEMMs, the cosine attention kernel and the fused residual+LayerNorm; the a
 the reference's scipy call, solved by tscd_amd/csrc_host/lap.cpp (same algorithm and tie rules, SIMD inner loop) -- all
 cost matrices of a clip reach the host with ONE D2H.
 """
+import functools
+from concurrent.futures import ThreadPoolExecutor
 from typing import Optional
 
 import numpy as np
@@ -17,14 +19,18 @@ import torch.nn.functional as F
 from torch import nn
 
 from tscd_amd import ops
-from concurrent.futures import ThreadPoolExecutor
-
 from tscd_amd._host import KIND_PREV, KIND_SELF, KIND_STATE, lap_chain_f16, lap_f16
 from tscd_amd.autograd import hip_op
 
 
 # the clip's chain of host assignments runs on this worker while the main thread keeps queueing device work
 _ASSIGN_WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="tscd-lap")
+
+
+def _wait_copy(device_index, event):
+    """Runs on the worker: bind the thread to the rank's GPU (a fresh thread defaults to device 0) and wait for the copy."""
+    torch.cuda.set_device(device_index)
+    event.synchronize()
 
 
 def _f32(t):
@@ -353,7 +359,9 @@ class AwarePositionRegMatcher(nn.Module):
         kinds = [{"self": KIND_SELF, "state": KIND_STATE, "prev": KIND_PREV}[kind] for (_, kind, _) in plan]
         chain = None
         if shapes:
-            chain = _ASSIGN_WORKER.submit(lap_chain_f16, self._pinned.data_ptr(), shapes, kinds, ev.synchronize)
+            dev_index = features_reg.device.index if features_reg.device.index is not None else torch.cuda.current_device()
+            chain = _ASSIGN_WORKER.submit(lap_chain_f16, self._pinned.data_ptr(), shapes, kinds,
+                                          functools.partial(_wait_copy, dev_index, ev))
         return dict(plan=plan, spans=spans, chain=chain, ppf=list(preds_per_frame), resume=resume,
                     features_reg=features_reg, features_cls=features_cls)
 
