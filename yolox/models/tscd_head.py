@@ -54,14 +54,17 @@ class _GatherRows(torch.autograd.Function):
 LEVEL_STREAMS = os.environ.get("TSCD_LEVEL_STREAMS", "1") != "0"
 
 
-class TSCDHead(nn.Module):
-    def _side_streams(self, dev, n):
-        st = getattr(self, "_streams", None)
-        if st is None or len(st) < n or st[0].device != dev:
-            st = [torch.cuda.Stream(device=dev) for _ in range(n)]
-            self._streams = st
-        return st
+_SIDE_STREAMS = {}      # device -> [torch.cuda.Stream]; process-wide (module attributes must stay deep-copyable for ModelEMA)
 
+
+def _side_streams(dev, n):
+    st = _SIDE_STREAMS.get(dev)
+    if st is None or len(st) < n:
+        st = _SIDE_STREAMS[dev] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return st
+
+
+class TSCDHead(nn.Module):
     def __init__(self, num_classes, width=1.0, strides=[8, 16, 32], in_channels=[256, 512, 1024], act="silu", depthwise=False,
                  heads=4, drop=0.0, use_score=True, defualt_p=30, sim_thresh=0.75, pre_nms=0.75, ave=True, defulat_pre=750,
                  test_conf=0.001, use_mask=False, gmode=True, lmode=True, both_mode=False, localBlocks=1, **kwargs):
@@ -174,7 +177,7 @@ class TSCDHead(nn.Module):
         # workgroups per conv, so they run on side streams underneath the 72x72 level instead of after it.
         if LEVEL_STREAMS and len(feats) > 1 and dev.type == "cuda":
             main = torch.cuda.current_stream()
-            side = self._side_streams(dev, len(feats) - 1)
+            side = _side_streams(dev, len(feats) - 1)
             fork = torch.cuda.Event()
             fork.record(main)
             joins = []

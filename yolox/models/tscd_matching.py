@@ -27,6 +27,9 @@ from tscd_amd.autograd import hip_op
 _ASSIGN_WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="tscd-lap")
 
 
+_PINNED = {}            # device index -> pinned fp16 staging buffer of the cost matrices (grow-only)
+
+
 def _wait_copy(device_index, event):
     """Runs on the worker: bind the thread to the rank's GPU (a fresh thread defaults to device 0) and wait for the copy."""
     torch.cuda.set_device(device_index)
@@ -355,12 +358,13 @@ class AwarePositionRegMatcher(nn.Module):
             else:
                 p0, p1 = spans[pi]
                 pairs.append((features_reg[p0:p1], cur_reg, features_cls[p0:p1], cur_cls))
-        shapes, self._pinned, ev = self._cost_matrices_async(pairs, getattr(self, "_pinned", None))
+        dev_index = features_reg.device.index if features_reg.device.index is not None else torch.cuda.current_device()
+        shapes, pinned, ev = self._cost_matrices_async(pairs, _PINNED.get(dev_index))
+        _PINNED[dev_index] = pinned
         kinds = [{"self": KIND_SELF, "state": KIND_STATE, "prev": KIND_PREV}[kind] for (_, kind, _) in plan]
         chain = None
         if shapes:
-            dev_index = features_reg.device.index if features_reg.device.index is not None else torch.cuda.current_device()
-            chain = _ASSIGN_WORKER.submit(lap_chain_f16, self._pinned.data_ptr(), shapes, kinds,
+            chain = _ASSIGN_WORKER.submit(lap_chain_f16, pinned.data_ptr(), shapes, kinds,
                                           functools.partial(_wait_copy, dev_index, ev))
         return dict(plan=plan, spans=spans, chain=chain, ppf=list(preds_per_frame), resume=resume,
                     features_reg=features_reg, features_cls=features_cls)
