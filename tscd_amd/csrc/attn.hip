@@ -131,7 +131,7 @@ extern "C" int tscd_cos_attn_f16(const void* q, const void* k, const void* v, in
 }
 
 // out[n][c] = reg*g0 + edge*g1 + pos[c],  (g0,g1) = sigmoid(W2 relu(W0 [reg, edge])).  w0 [32][2], w2 [2][32] fp32.
-__global__ void se_fuse_kernel(const f16* __restrict__ reg, int ldr, const f16* __restrict__ edge, int lde,
+__global__ __launch_bounds__(256) void se_fuse_kernel(const f16* __restrict__ reg, int ldr, const f16* __restrict__ edge, int lde,
                                const float* __restrict__ w0, const float* __restrict__ w2, const float* __restrict__ pos, long n,
                                int C, f16* __restrict__ out) {
   __shared__ float sw0[64], sw2[64];
@@ -434,7 +434,7 @@ extern "C" int tscd_cos_attn_bwd_finish_f16(const void* k, const void* workspace
 }
 
 // se_fuse backward: d reg, d edge (fp16), d pos [C], d w0 [32][2], d w2 [2][32] (fp32 atomics; caller zeroes them).
-__global__ void se_fuse_bwd_kernel(const f16* __restrict__ reg, int ldr, const f16* __restrict__ edge, int lde,
+__global__ __launch_bounds__(256) void se_fuse_bwd_kernel(const f16* __restrict__ reg, int ldr, const f16* __restrict__ edge, int lde,
                                    const float* __restrict__ w0, const float* __restrict__ w2, const f16* __restrict__ dout, long n,
                                    int C, f16* __restrict__ dreg, f16* __restrict__ dedge, float* __restrict__ dpos,
                                    float* __restrict__ dw0, float* __restrict__ dw2) {
@@ -442,10 +442,10 @@ __global__ void se_fuse_bwd_kernel(const f16* __restrict__ reg, int ldr, const f
   if (threadIdx.x < 64) { sw0[threadIdx.x] = w0[threadIdx.x]; sw2[threadIdx.x] = w2[threadIdx.x]; }
   if (threadIdx.x < 128) acc[threadIdx.x] = 0.f;
   __syncthreads();
-  float g0w[32], g1w[32];   // per-thread partial sums of dw2[0][j], dw2[1][j]
-  float h0w[32], h1w[32];   // dw0[j][0], dw0[j][1]
+  // per-thread partial sums: v[j] = dw2[0][j], v[32+j] = dw2[1][j], v[64+2j] = dw0[j][0], v[64+2j+1] = dw0[j][1]
+  float v[128];
 #pragma unroll
-  for (int j = 0; j < 32; ++j) g0w[j] = g1w[j] = h0w[j] = h1w[j] = 0.f;
+  for (int j = 0; j < 128; ++j) v[j] = 0.f;
   long total = n * C;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     long row = idx / C;
@@ -466,22 +466,33 @@ __global__ void se_fuse_bwd_kernel(const f16* __restrict__ reg, int ldr, const f
       float dh = hid[j] > 0.f ? dz0 * sw2[j] + dz1 * sw2[32 + j] : 0.f;
       da += dh * sw0[2 * j];
       db += dh * sw0[2 * j + 1];
-      g0w[j] += dz0 * hid[j];
-      g1w[j] += dz1 * hid[j];
-      h0w[j] += dh * a;
-      h1w[j] += dh * b;
+      v[j] += dz0 * hid[j];
+      v[32 + j] += dz1 * hid[j];
+      v[64 + 2 * j] += dh * a;
+      v[64 + 2 * j + 1] += dh * b;
     }
     dreg[idx] = (f16)da;
     dedge[idx] = (f16)db;
     atomicAdd(dpos + c, go);
   }
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    float a = wave_sum(g0w[j]), b = wave_sum(g1w[j]), c = wave_sum(h0w[j]), d = wave_sum(h1w[j]);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&acc[j], a); atomicAdd(&acc[32 + j], b); atomicAdd(&acc[64 + 2 * j], c); atomicAdd(&acc[64 + 2 * j + 1], d);
-    }
+  // wave reduce-scatter: at each step a lane keeps one half of its values and receives the partner's share of that half,
+  // so the 128 column sums cost 126 shuffles instead of 128 x 6; afterwards lane l owns values base(l), base(l)+1
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+#define RS_STEP(HALF, BIT)                                              \
+  {                                                                     \
+    const bool up = (lane & BIT) != 0;                                  \
+    _Pragma("unroll") for (int i = 0; i < HALF; ++i) {                  \
+      float keep = up ? v[i + HALF] : v[i];                             \
+      float send = up ? v[i] : v[i + HALF];                             \
+      v[i] = keep + __shfl_xor(send, BIT, 64);                          \
+    }                                                                   \
+    base += up ? HALF : 0;                                              \
   }
+  RS_STEP(64, 32) RS_STEP(32, 16) RS_STEP(16, 8) RS_STEP(8, 4) RS_STEP(4, 2) RS_STEP(2, 1)
+#undef RS_STEP
+  atomicAdd(&acc[base], v[0]);
+  atomicAdd(&acc[base + 1], v[1]);
   __syncthreads();
   if (threadIdx.x < 64) atomicAdd(dw2 + threadIdx.x, acc[threadIdx.x]);
   else if (threadIdx.x < 128) atomicAdd(dw0 + threadIdx.x - 64, acc[threadIdx.x]);
@@ -491,11 +502,9 @@ extern "C" int tscd_se_fuse_bwd_f16(const void* reg, int ldr, const void* edge, 
                                     void* stream) {
   TSCD_CHECK_ARG(reg && edge && w0 && w2 && dout && dreg && dedge && dpos && dw0 && dw2, "se_fuse_bwd: null pointer");
   if (n == 0) return TSCD_OK;
-  // few fat blocks: every thread ends with a 128-value wave reduction of its weight-gradient partials, so the element
-  // loop has to be long enough (>= 8 elements per thread) to amortise that tail
   long total = n * C;
-  int grid = (int)((total + 2047) / 2048);
-  hipLaunchKernelGGL(se_fuse_bwd_kernel, dim3(grid > 256 ? 256 : (grid < 1 ? 1 : grid)), dim3(256), 0, (hipStream_t)stream, (const f16*)reg, ldr,
+  int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(se_fuse_bwd_kernel, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, (hipStream_t)stream, (const f16*)reg, ldr,
                      (const f16*)edge, lde, w0, w2, (const f16*)dout, n, C, (f16*)dreg, (f16*)dedge, dpos, dw0, dw2);
   TSCD_CHECK_LAUNCH("se_fuse_bwd");
   return TSCD_OK;
