@@ -51,3 +51,47 @@ def hip_op(hip_fn, torch_fn, *inputs):
     if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs):
         return _HipFwdTorchBwd.apply(hip_fn, torch_fn, *inputs)
     return hip_fn(*inputs)
+
+
+class _EagerBranch(torch.autograd.Function):
+    """Runs ``fn(*activations)`` (a scalar loss branch built from modules whose trainable tensors are ``params``) AND its
+    backward immediately, inside forward -- so the branch's gradient kernels are queued where the caller is, not where
+    autograd's reverse order would put them.  The outer backward only rescales the stored gradients by the upstream
+    scalar.  Used by TSCDHead to push the first MCA's backward into the window in which the host solves the matcher's
+    assignments and the device would otherwise idle.
+
+    The eager backward is seeded with ``seed`` (the loss scale the caller expects upstream, e.g. GradScaler's 65536) so
+    fp16 gradient kernels see the same magnitudes as in a normal scaled backward; the outer backward multiplies by
+    upstream/seed on the device (no sync).  Parameter gradients still reach their AccumulateGrad nodes through the outer
+    graph, so DistributedDataParallel hooks fire as usual."""
+
+    @staticmethod
+    def forward(ctx, fn, seed, n_act, *tensors):
+        acts, params = tensors[:n_act], tensors[n_act:]
+        det = [a.detach().requires_grad_(a.requires_grad and a.is_floating_point()) for a in acts]
+        with torch.enable_grad():
+            loss, extras = fn(*det)
+            wrt = [d for d in det if d.requires_grad] + [p for p in params if p.requires_grad]
+            grads = torch.autograd.grad(loss * seed, wrt, allow_unused=True) if wrt else ()
+        ctx.mask = [d.requires_grad for d in det] + [p.requires_grad for p in params]
+        ctx.grads = grads
+        ctx.seed = seed
+        ctx.mark_non_differentiable(*extras)
+        return (loss.detach(),) + tuple(extras)
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        scale = g.float() / ctx.seed
+        it = iter(ctx.grads)
+        out = []
+        for m in ctx.mask:
+            gr = next(it) if m else None
+            out.append(None if gr is None else (gr * scale.to(gr.dtype) if gr.dtype == torch.float32 else (gr.float() * scale).to(gr.dtype)))
+        ctx.grads = None
+        return (None, None, None) + tuple(out)
+
+
+def eager_branch(fn, activations, params, seed=65536.0):
+    """-> (loss, *extras).  ``fn(*activations) -> (scalar fp32 loss, tuple of detached extra outputs)``."""
+    params = [p for p in params]
+    return _EagerBranch.apply(fn, float(seed), len(activations), *activations, *params)

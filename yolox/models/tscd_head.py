@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from tscd_amd import functional as TF
 from tscd_amd import ops
+from tscd_amd.autograd import eager_branch
 
 from .losses import IOUloss
 from .network_blocks import BaseConv
@@ -52,6 +53,7 @@ class _GatherRows(torch.autograd.Function):
 
 
 LEVEL_STREAMS = os.environ.get("TSCD_LEVEL_STREAMS", "1") != "0"
+EAGER_CLASS_BRANCH = os.environ.get("TSCD_EAGER_CLASS_BRANCH", "1") != "0"
 
 
 _SIDE_STREAMS = {}      # device -> [torch.cuda.Stream]; process-wide (module attributes must stay deep-copyable for ModelEMA)
@@ -246,9 +248,14 @@ class TSCDHead(nn.Module):
         if self.debug is not None:
             self._dbg(agg_idx=[sel_idx[b, :ppf[b]] for b in range(B)], pred_rows=pred_rows, f_cls=f_cls, f_reg=f_reg,
                       f_edge=f_edge, edge_maps=edge_maps, reg_maps=reg_maps)
-        features_cls_matched, _ = self.agg(f_cls, f_reg, cls_scores, None, sim_thresh=self.sim_thresh, ave=self.ave,
-                                           use_mask=self.use_mask, need_reg=False, **kw)
-        cls_preds = hip_linear(features_cls_matched, self.cls_pred)
+        def class_branch(fc, fr, cs):
+            fcm, _ = self.agg(fc, fr, cs, None, sim_thresh=self.sim_thresh, ave=self.ave, use_mask=self.use_mask,
+                              need_reg=False, **kw)
+            return fcm, hip_linear(fcm, self.cls_pred)
+
+        eager = grad and EAGER_CLASS_BRANCH
+        if not eager:
+            features_cls_matched, cls_preds = class_branch(f_cls, f_reg, cls_scores)
         if training:
             # ---------------- losses (get_matcher_refined_losses, tscd_head.py:1008-1203), dense + masked: everything that
             # does not involve the matcher's outputs is queued here, inside the assignment window ----------------
@@ -270,7 +277,21 @@ class TSCDHead(nn.Module):
             rmask = fg[lb, la]
             num_fg_local = num_fg_b[:lframe].sum().float()
             r_cls_t = cls_t[lb, la]
-            loss_r_cls = (self.bcewithlog_loss(cls_preds.float(), r_cls_t) * rmask.unsqueeze(-1)).sum() / num_fg_local
+
+            def class_loss(cp):
+                return (self.bcewithlog_loss(cp.float(), r_cls_t) * rmask.unsqueeze(-1)).sum() / num_fg_local
+
+            if eager:
+                # first MCA -> cls_pred -> refined class loss, forward AND backward, queued inside the assignment window
+                # (nothing downstream of the matcher feeds this branch); the main backward only rescales its gradients
+                def branch(fc, fr, cs):
+                    fcm, cp = class_branch(fc, fr, cs)
+                    return class_loss(cp), (fcm.detach(), cp.detach())
+
+                loss_r_cls, features_cls_matched, cls_preds = eager_branch(
+                    branch, [f_cls, f_reg, cls_scores], list(self.agg.parameters()) + list(self.cls_pred.parameters()))
+            else:
+                loss_r_cls = class_loss(cls_preds)
             base = pred_rows[:nl, :4].float()
             tgt = self._encode_reg(gt_box[lb, la], base, rmask)
         matched = self.local_reg_matcher.finish(prep, f_reg, f_edge, time_embedding[:lframe])
