@@ -59,7 +59,10 @@ class YOLOPAFPN(nn.Module):
         return pan_out2, pan_out1, pan_out0
 
     def forward(self, input):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        plist = self.__dict__.get("_plist")
+        if plist is None:                       # flat parameter list, built once (Module.parameters() walks the module tree)
+            plist = self.__dict__["_plist"] = list(self.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in plist):
             raise NotImplementedError(
                 "backbone/neck backward is not built yet: every TSCD exp freezes it (ovis_tscd_large.py:116-117); "
                 "base-detector training is row N4 of SURVEY.md section 8f")
