@@ -229,8 +229,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        # rehearsal hook: TSCD_BENCH_REHEARSAL=1 runs every rank on GPU 0 over gloo (a one-GPU box cannot host two RCCL
+        # ranks) to exercise the DDP path; the driver's real multi-GPU launch leaves it unset
+        rehearsal = bool(os.environ.get("TSCD_BENCH_REHEARSAL"))
+        if rehearsal:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if rehearsal else "nccl")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
