@@ -386,3 +386,56 @@ def test_cafm_attention_pieces_backward_match_oracle_autograd(C, heads, nq, nk):
     for name, got, want in (("dx", xd.grad, xr.grad), ("dw", lin.weight.grad, wl.grad), ("db", lin.bias.grad, bl.grad)):
         c = _cos(got.cpu(), want)
         assert c > 0.9995, (name, c)
+
+
+@pytest.mark.parametrize("W,counts", [(256, [[60, 0, 95, 40, 40], [33, 70, 70, 0, 51]]), (64, [[25, 40, 18], [18, 18, 31]])])
+def test_cafm_ragged_counts_and_carried_state_match_oracle(W, counts):
+    """The matcher on ragged clips: growing / shrinking / equal proposal counts, an empty frame, and a second clip that
+    continues from the first one's state (resume=True: first frame matched against carried-over rows).  Assignments (the
+    host chain solver's output) must equal the oracle's scipy calls; attention outputs within fp16 tolerance."""
+    from yolox.models.tscd_matching import AwarePositionRegMatcher
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(W + len(counts[0]))
+    mod = AwarePositionRegMatcher(hidden_channel=W, feedforward_channel=W, num_head=8, decoder_layer_num=1)
+    with torch.no_grad():
+        for prm in mod.parameters():
+            if prm.dim() == 1:
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.1 + (1.0 if "norm.weight" in "" else 0.0))
+        for n, prm in mod.named_parameters():
+            if n.endswith("norm.weight"):
+                prm.fill_(1.0)
+    sd = {"m." + k: v.detach().clone().float() for k, v in mod.state_dict().items()}
+    mod = mod.to(dev).half().eval()
+    cfg = O.TSCDConfig()
+    state = O.MatcherState()
+    mod._clear_state()
+    # cost features: every frame shows the first n objects of one pool (shuffled, slightly perturbed), so any two frames are
+    # nested sets and each assignment is unambiguous (matched pairs cost ~0, everything else ~1)
+    pool_reg = torch.nn.functional.normalize(torch.randn(128, 4 * W, generator=g), dim=1)
+    pool_cls = torch.nn.functional.normalize(torch.randn(128, 4 * W, generator=g), dim=1)
+
+    def cost_feats(n):
+        order = torch.randperm(n, generator=g)
+        return ((pool_reg[order] + 0.01 * torch.randn(n, 4 * W, generator=g)).half(),
+                (pool_cls[order] + 0.01 * torch.randn(n, 4 * W, generator=g)).half())
+
+    for ci, ppf in enumerate(counts):
+        n_all = sum(ppf)
+        feats = torch.randn(n_all, W, generator=g).half()
+        edge = torch.randn(n_all, W, generator=g).half()
+        pairs = [cost_feats(n) for n in ppf]
+        reg = torch.cat([a for a, _ in pairs], 0)
+        cls = torch.cat([b for _, b in pairs], 0)
+        temb = torch.randn(len(ppf), 256, generator=g).half()
+        resume = ci > 0
+        with torch.no_grad():
+            out = mod(feats.to(dev), reg.to(dev), cls.to(dev), edge.to(dev), ppf, temb.to(dev), resume=resume)
+        torch.cuda.synchronize()
+        aux = {}
+        ref = O.aware_position_reg_matcher(sd, "m", feats.float(), reg.float(), cls.float(), edge.float(), ppf, temb.float(),
+                                           resume, state, cfg, aux)
+        hung = [np.asarray(h) for h in mod.last_hungarian]
+        assert len(hung) == len(aux["hungarian"])
+        for fi, (a, b) in enumerate(zip(hung, aux["hungarian"])):
+            assert np.array_equal(a, np.asarray(b)), (ci, fi)
+        close(out[-1], ref, 6e-2, 1.5e-2)

@@ -415,16 +415,17 @@ def mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale,
 
 
 def linear_dgrad(dy, weight):
-    """dX = dY @ W for y = x @ W^T (W [out, in]); the same MFMA GEMM with W^T as the 'weight'."""
+    """dX = dY @ W for y = x @ W^T (W [out, in]): the same MFMA GEMM on W packed in data-gradient order (one pack kernel,
+    no transpose copy); tiny prediction heads (out = 1 / 4 / NC) get their reduction axis padded to 8."""
     out_f, in_f = weight.shape
+    n = dy.shape[0]
     kp = (out_f + 7) // 8 * 8
-    if kp == out_f:
-        return linear(dy.contiguous(), weight.detach().t().contiguous())
-    d2 = dy.new_zeros((dy.shape[0], kp))          # tiny prediction heads (out = 1 / 4 / NC): pad the reduction axis to 8
-    d2[:, :out_f] = dy
-    wt = weight.new_zeros((in_f, kp))
-    wt[:, :out_f] = weight.detach().t()
-    return linear(d2, wt)
+    if kp != out_f or not dy.is_contiguous():
+        d2 = dy.new_zeros((n, kp))
+        d2[:, :out_f] = dy
+        dy = d2
+    wpk = pack_conv_weight(weight.detach().reshape(out_f, in_f, 1, 1), mode=1)
+    return linear(dy, None, out=torch.empty((n, in_f), dtype=torch.float16, device=dy.device), wpk=wpk)
 
 
 def linear_wgrad(x, dy):

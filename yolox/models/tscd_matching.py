@@ -58,7 +58,7 @@ class _Linear(torch.autograd.Function):
         g = g.to(torch.float16).contiguous()
         dx = ops.linear_dgrad(g, w) if ctx.needs_input_grad[0] else None
         dw = ops.linear_wgrad(x, g).to(w.dtype).reshape(w.shape) if ctx.needs_input_grad[1] else None
-        db = g.float().sum(0).to(w.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = torch.sum(g, 0, dtype=torch.float32).to(w.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 
