@@ -171,8 +171,9 @@ def cpu_baseline(args, state_dict):
 
 
 def roofline_dominant_kernel(args, device, step):
-    """Dominant kernel = conv_igemm_glds_kernel<128,2> (every conv / GEMM with Cout > 64 and Cin % 32 == 0: ~85 % of the
-    step's FLOPs), MFMA-bound.  Every launch of it inside real train steps is bracketed by device events on the stream it runs on
+    """Dominant kernel = the LDS-DMA implicit-GEMM conv (conv_igemm_glds_kernel<128,2>, and conv_igemm_v3_kernel for the
+    launches that qualify for 128x256 tiles): every conv / GEMM with Cout > 64 and Cin % 32 == 0, ~85 % of the step's FLOPs,
+    MFMA-bound.  Every launch of it inside real train steps is bracketed by device events on the stream it runs on
     (torch's current stream); achieved = sum of algorithmic FLOPs (2*M*Cout*K per launch) / sum of
     durations, i.e. per-launch average FLOPs / average launch duration -- the same average rocprofv3 --stats reports
     for this kernel name.  `dominant_shape` repeats the measurement for the single heaviest shape (head tower 3x3)."""
@@ -212,7 +213,7 @@ def roofline_dominant_kernel(args, device, step):
         with open(pmc) as fh:
             j = json.load(fh)
         traffic, traffic_dom = j["all_launches"]["bytes_per_launch"], j["dominant_shape"]["bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "conv_igemm_glds_kernel<128,2>", "achieved": flops / secs / 1e12, "peak": peak,
+    return {"bound": "mfma", "kernel": "LDS-DMA implicit GEMM: conv_igemm_glds_kernel<128,2> + conv_igemm_v3_kernel (128x256 tiles on the 72x72 level)", "achieved": flops / secs / 1e12, "peak": peak,
             "unit": "TFLOP/s", "frac": flops / secs / 1e12 / peak, "traffic": traffic,
             "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01f_pmc_traffic.json)",
             "launches_per_step": len(sel) / nsteps, "avg_launch_us": secs / len(sel) * 1e6, "gflop_per_launch": flops / len(sel) / 1e9,

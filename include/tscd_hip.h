@@ -31,9 +31,11 @@ const char* tscd_last_error(void);
  * 2 +bias,ReLU, 3 folded BN + SiLU (eval), 4 folded BN, 5 Hungarian cost 1 - v/2 with NaN->0
  * (tscd_matching.py:926-930). */
 int tscd_conv_tile_m(void);
-/* Main-loop selection of tscd_conv2d_nhwc_f16: -1 automatic (LDS-DMA ring when Cin % 32 == 0 and Cout > 32, register
- * staging otherwise), 0 force register staging, 1 same as -1.  Both variants accumulate in the same order: outputs and
- * BatchNorm partial sums are bit-identical (tests/test_gpu_conv.py). */
+/* Main-loop selection of tscd_conv2d_nhwc_f16: -1 automatic (LDS-DMA ring when Cin % 32 == 0 and Cout > 32 -- as 128 x 256
+ * tiles with BK = 64 when Cin % 64 == 0, Cout is a multiple of 256 and the launch still has >= 512 workgroups -- register
+ * staging otherwise), 0 force register staging, 1 LDS-DMA with 128-wide tiles only, 3 the 128 x 256 variant wherever its
+ * shape constraints hold.  All variants accumulate in the same order: outputs and BatchNorm partial sums are bit-identical
+ * (tests/test_gpu_conv.py). */
 void tscd_conv_set_variant(int variant);
 /* Measurement hook (scratch experiments, never set by the product path): bit0 makes the LDS-DMA loop's A gather read a
  * zero block, bit1 makes every B row read row 0 -- isolates how much of a launch is memory stall.  Results are wrong. */

@@ -172,6 +172,9 @@ DMA_CASES = [
     (1, 6, 6, 1024, 512, 1, 1),      # deep K
     (1, 1, 500, 256, 256, 1, 1),     # linear layer
     (4, 18, 18, 512, 512, 3, 1),     # 18x18 level
+    (2, 9, 11, 64, 256, 3, 1),       # one 64-channel chunk per tap, ragged M (128 x 256 variant: 9 k-tiles)
+    (1, 5, 5, 128, 384, 1, 1),       # Cout padded to 384: not a multiple of 256 -> stays on the 128-wide tiles
+    (2, 8, 8, 192, 256, 3, 2),       # stride 2, 3 chunks per tap
 ]
 
 
@@ -190,12 +193,14 @@ def test_conv_lds_dma_variant_bit_identical_to_register_staging(case):
     try:
         lib.tscd_conv_set_variant(0)
         y0, st0 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
-        lib.tscd_conv_set_variant(1)
+        lib.tscd_conv_set_variant(1)              # 128-wide LDS-DMA tiles only
         y1, st1 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
+        lib.tscd_conv_set_variant(3)              # the 128 x 256 / BK=64 variant wherever the shape allows it
+        y2, st2 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
     finally:
         lib.tscd_conv_set_variant(-1)
     torch.cuda.synchronize()
-    assert torch.equal(y0, y1)
-    assert torch.equal(st0, st1)
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)
+    assert torch.equal(st0, st1) and torch.equal(st0, st2)
     ref = F.conv2d(x.float(), w.float(), None, s, (k - 1) // 2)
     assert_close(y1.permute(0, 3, 1, 2), ref)

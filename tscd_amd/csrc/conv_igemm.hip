@@ -427,6 +427,179 @@ __global__ __launch_bounds__(128 * WAVES_N, (BN == 256 ? 1 : 2)) void conv_igemm
   conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
 }
 
+// ====================================================================================================================
+// Main-loop variant 3 (Cin % 64 == 0, Cout > 128): 128 x 256 tile, 8 waves, BK = 64.
+// Per-launch counters of variant 2 on the dominant shape (rocprofv3 SQ_*: waves 33 % issuing, 27 % parked on
+// s_waitcnt / s_barrier, 41 % waiting for the MFMA pipe; ~95 instructions per 8 MFMAs) say the 128^2 / BK=32 loop spends its
+// time on everything but the MFMAs.  This variant halves the per-MFMA overhead: one barrier and one set of waits per 16
+// MFMAs, 128-byte rows (one gather address per 64 channels, full cache lines per request), a ring of 3 x 48 KB stages whose
+// index is a compile-time constant in every phase (fragment reads and LDS-DMA destinations are immediates), and the A
+// gather fetched once for all 256 output channels.  K order is unchanged, so results stay bit-identical to variants 1 / 2.
+// ====================================================================================================================
+template <int N> __device__ __forceinline__ void wait_vmcnt6() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(ConvParams p) {
+  constexpr int BM = 128, BN = 256, NS = 3, WAVES_M = 2, WAVES_N = 4, TM = 2, TN = 2, WM = 64, WN = 64;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 16 KB + 32 KB
+  constexpr int A_LD = 2, B_LD = 4, LD = A_LD + B_LD;                                 // glds (8 rows x 128 B) per wave and k-tile
+  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // LDS image: row r (128 B = 8 slots of 16 B), slot s holds k-chunk s ^ ((r >> 1) & 7).  The lane that fills slot lane&7 of
+  // row (piece base + lane>>3) therefore fetches chunk (lane&7) ^ (4*(piece&1) + (lane>>4)).
+  const int ch0 = (lane & 7) ^ (lane >> 4), ch1 = (lane & 7) ^ (4 + (lane >> 4));
+  const f16* a_src[A_LD];
+  unsigned a_mask[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = m0 + wave * 16 + i * 8 + (lane >> 3);
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / (p.Ho * p.Wo);
+    const int rem = mm - b * (p.Ho * p.Wo);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+    a_src[i] = p.x + ((long)(b * p.H + hi0) * p.W + wi0) * p.ldx + (i ? ch1 : ch0) * 8;
+    unsigned mask = 0;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw)
+        if (ok && (unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W) mask |= 1u << (kh * p.KW + kw);
+    a_mask[i] = mask;
+  }
+  const f16* b_src[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j)
+    b_src[j] = p.w + (long)(n0 + wave * 32 + j * 8 + (lane >> 3)) * p.Kpad + ((j & 1) ? ch1 : ch0) * 8;
+
+  const int nk = p.Kpad >> 6;
+  int ld_tap = 0, ld_cin = 0, ld_kw = 0;
+  long ld_tapoff = 0;
+  auto issue = [&](auto stagec) __attribute__((always_inline)) {
+    constexpr int ST = decltype(stagec)::value;
+    char* sbase = smem + ST * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const f16* src = ((a_mask[i] >> ld_tap) & 1u) ? a_src[i] + ld_tapoff + ld_cin : g_zero_chunk;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sbase + (wave * 16 + i * 8) * 128), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[j],
+                                       (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wave * 32 + j * 8) * 128), 16, 0, 0);
+      b_src[j] += 64;
+    }
+    ld_cin += 64;
+    if (ld_cin == p.Cin) {
+      ld_cin = 0;
+      ++ld_tap;
+      if (++ld_kw == p.KW) { ld_kw = 0; ld_tapoff += (long)(p.W - p.KW + 1) * p.ldx; } else ld_tapoff += p.ldx;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read offsets inside a stage: row r, chunk c = 2 ks + (lane >> 5)  ->  r*128 + ((c ^ ((r>>1)&7)) * 16)
+  const int frow = lane & 31, fsw = (frow >> 1) & 7, fk = lane >> 5;
+  int a_off[TM], b_off[TN];           // chunk-0 offsets; the chunk term is XORed in per k-step
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_off[i] = (wm * WM + i * 32 + frow) * 128;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_off[j] = A_BYTES + (wn * WN + j * 32 + frow) * 128;
+  int cslot[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) cslot[ks] = ((2 * ks + fk) ^ fsw) * 16;
+
+  // Two half-tile fragment sets (k-steps {0,1} and {2,3}, 32 VGPRs each).  Per tile: read the second half under the first
+  // half's 8 MFMAs; then wait + ONE barrier (every wave now holds all of tile t in registers), refill tile t's stage, read
+  // the next tile's first half under the second half's 8 MFMAs.  Stage indices are compile-time constants.
+  f16x8 fa[2][2][TM], fb[2][2][TN];     // [half][ks within half][tile]
+  auto read_half = [&](auto halfc, auto stagec) __attribute__((always_inline)) {
+    constexpr int HF = decltype(halfc)::value, ST = decltype(stagec)::value;
+    const char* sb = smem + ST * STAGE;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[HF][k2][i] = *(const f16x8*)(sb + a_off[i] + cslot[2 * HF + k2]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[HF][k2][j] = *(const f16x8*)(sb + b_off[j] + cslot[2 * HF + k2]);
+    }
+  };
+  auto mfma_half = [&](auto halfc) __attribute__((always_inline)) {
+    constexpr int HF = decltype(halfc)::value;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[HF][k2][i], fb[HF][k2][j], acc[i][j], 0, 0, 0);
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>;
+  // tile kt lives in stage ST and has a successor
+  auto phase = [&](auto stagec, auto steadyc, int kt) __attribute__((always_inline)) {
+    constexpr int ST = decltype(stagec)::value;
+    constexpr bool STEADY = decltype(steadyc)::value;
+    read_half(C1{}, stagec);
+    mfma_half(C0{});
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): all of tile kt is in this wave's registers
+    if (STEADY || kt + 2 < nk) wait_vmcnt6<6>(); else wait_vmcnt6<0>();   // tile kt+1 landed; tile kt+2 may stay in flight
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (STEADY || kt + NS < nk) issue(stagec);               // tile kt+3 -> the stage tile kt just left
+    read_half(C0{}, std::integral_constant<int, (ST + 1) % NS>{});
+    mfma_half(C1{});
+  };
+  auto last = [&](auto stagec) __attribute__((always_inline)) {
+    read_half(C1{}, stagec);
+    mfma_half(C0{});
+    mfma_half(C1{});
+  };
+
+  issue(C0{});
+  if (nk > 1) issue(C1{});
+  if (nk > 1) wait_vmcnt6<6>(); else wait_vmcnt6<0>();      // tile 0 landed (tile 1 may still be in flight)
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (nk > 2) issue(C2{});
+  read_half(C0{}, C0{});
+  int kt = 0;
+  for (; kt + 2 + NS < nk; kt += 3) {
+    phase(C0{}, std::true_type{}, kt);
+    phase(C1{}, std::true_type{}, kt + 1);
+    phase(C2{}, std::true_type{}, kt + 2);
+  }
+  // tail (at most 2 + NS tiles left): same stage sequence, each step checked
+  bool done = false;
+#define V3_TAIL(STC)                                                         \
+  if (!done) {                                                               \
+    if (kt + 1 < nk) { phase(STC{}, std::false_type{}, kt); ++kt; }          \
+    else { last(STC{}); done = true; }                                       \
+  }
+  V3_TAIL(C0) V3_TAIL(C1) V3_TAIL(C2) V3_TAIL(C0) V3_TAIL(C1) V3_TAIL(C2)
+#undef V3_TAIL
+  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
+}
+
 // Tile choice: BN follows Cout (128 / 64 / 32); BM = 128.  Packed weights and BatchNorm partials are padded to a multiple of
 // this BN.  (A 128 x 256 tile with 8 waves was measured: no faster on the 72x72 level -- the limit is bytes in flight per CU
 // against the ~2 us loaded MALL latency, not bytes per FLOP -- and slower on the small levels, which get half the workgroups.)
@@ -437,7 +610,7 @@ extern "C" int tscd_conv_tile_m(void) { return 128; }
 
 static int g_conv_debug = 0;
 extern "C" void tscd_conv_set_debug(int v) { g_conv_debug = v; }
-static int g_conv_variant = -1;   // -1 auto, 0 force register staging, 1 force LDS-DMA where eligible (tests / A-B timing)
+static int g_conv_variant = -1;   // -1 auto, 0 register staging, 1 LDS-DMA 128-wide tiles only, 3 128x256 variant wherever its shape allows (tests / A-B timing)
 extern "C" void tscd_conv_set_variant(int v) { g_conv_variant = v; }
 
 extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* bias, const float* scale,
@@ -471,13 +644,21 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
   p.debug = g_conv_debug;
   const int BM = 128, BNP = pick_bn(Cout);
   const bool dma_ok = Cin % 32 == 0 && BNP >= 64 && g_conv_variant != 0;
-  const int BN = BNP;
+  const int cout_pad = cdiv(Cout, BNP) * BNP;
+  // the 128 x 256 / BK=64 variant pays off (+7 %) only when its half-as-many, twice-as-large workgroups still cover the
+  // chip at least twice (measured: 72x72 level x1.07, 36x36 x1.01, 18x18 x0.77); g_conv_variant == 3 forces it (tests)
+  const bool v3_shape = Cin % 64 == 0 && Cout > 128 && cout_pad % 256 == 0;
+  const bool v3_ok = dma_ok && v3_shape && g_conv_variant != 1 &&
+                     (g_conv_variant == 3 || (long)cdiv(M, 128) * cdiv(Cout, 256) >= 512);
+  const int BN = v3_ok ? 256 : BNP;
   p.mtiles = cdiv(M, BM);
   p.ntiles = cdiv(Cout, BN);
   p.cstride = cdiv(Cout, BNP) * BNP;
-  dim3 grid(p.mtiles * p.ntiles), block(256);
+  dim3 grid(p.mtiles * p.ntiles), block(v3_ok ? 512 : 256);
   hipStream_t s = (hipStream_t)stream;
-  if (dma_ok && BN == 128)
+  if (v3_ok)
+    hipLaunchKernelGGL(conv_igemm_v3_kernel, grid, block, 0, s, p);
+  else if (dma_ok && BN == 128)
     hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 2>), grid, block, 0, s, p);
   else if (dma_ok && BN == 64)
     hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 2>), grid, block, 0, s, p);
