@@ -87,7 +87,6 @@ class _EagerBranch(torch.autograd.Function):
         for m in ctx.mask:
             gr = next(it) if m else None
             out.append(None if gr is None else (gr * scale.to(gr.dtype) if gr.dtype == torch.float32 else (gr.float() * scale).to(gr.dtype)))
-        ctx.grads = None
         return (None, None, None) + tuple(out)
 
 
