@@ -164,7 +164,11 @@ def cpu_baseline(args, state_dict):
         out = O.tscd_forward(sd, cfg, imgs.float(), targets.float(), temb.float(), 0.5, nl, nf - nl, False, True, O.MatcherState(), None)
         out["total_loss"].backward()
         dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "clips/s", "cores": ncores, "kind": "port",
+    losses = None
+    if div == 1:      # whole clip, same weights and inputs as the GPU's first step: keep the losses as a full-size parity signal
+        losses = {k: float(v) for k, v in out.items() if k in ("total_loss", "iou_loss", "conf_loss", "cls_loss",
+                                                                "loss_matched_cls", "loss_matched_obj", "loss_matched_iou")}
+    return {"value": 1.0 / dt, "unit": "clips/s", "cores": ncores, "kind": "port", "losses_step0": losses,
             "sample": f"{nf} of {args.frames} frames ({nl} local + {nf - nl} global) @{args.size}^2, TSCD d{args.depth}/w{args.width}, "
                       f"fwd+bwd, {args.props} props/frame, measured {dt / div:.1f} s x{div} = {dt:.1f} s per clip; "
                       f"oracle/tscd_oracle.py, torch {torch.__version__} fp32, {ncores} threads"}
@@ -268,6 +272,13 @@ def main():
         torch.cuda.synchronize()
 
     verbose = bool(os.environ.get("TSCD_BENCH_VERBOSE"))
+    losses_step0 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # untimed: the loss terms of the very first step (initial weights) for the full-size parity line below
+        out0 = net(imgs, targets, temb, lframe=args.lframe, gframe=gframe, resume=False)
+        losses_step0 = {k: float(v) for k, v in out0.items() if k in ("total_loss", "iou_loss", "conf_loss", "cls_loss",
+                                                                       "loss_matched_cls", "loss_matched_obj", "loss_matched_iou")}
+        del out0
     for i in range(args.warmup):
         t1 = time.perf_counter()
         l = step()
@@ -298,6 +309,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args, sd0)
+                ref = line["cpu_baseline"].pop("losses_step0", None)
+                if ref and losses_step0:
+                    # same clip, same initial weights: product (fp16, HIP) vs CPU oracle (fp32), every loss term
+                    line["parity_full_size"] = {
+                        "what": "loss terms of step 0 at the benchmark size, HIP product vs CPU oracle on identical weights/inputs",
+                        "gpu": losses_step0, "oracle": ref,
+                        "max_rel_diff": max(abs(losses_step0[k] - ref[k]) / max(abs(ref[k]), 1e-6) for k in ref)}
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)

@@ -255,13 +255,29 @@ def linear(x, weight, bias=None, out=None, wpk=None):
 # ----------------------------------------------------------------------------------------------------
 # proposal stage
 # ----------------------------------------------------------------------------------------------------
+_H2D_CACHE = {}
+
+
 def h2d(data, dtype, device):
-    """Small host table -> device WITHOUT a stream-blocking pageable copy: stage through (cached) pinned memory and copy
-    asynchronously on the current stream.  Every index / tile / offset table of the proposal stage goes through here."""
+    """Small host table -> device WITHOUT a stream-blocking pageable copy: stage through pinned memory and copy
+    asynchronously on the current stream.  Every index / tile / offset table of the proposal stage goes through here.
+    Tables up to 4 KB are cached by content (the same tile / offset tables recur clip after clip); callers treat the
+    result as read-only."""
     t = torch.as_tensor(data, dtype=dtype)
     if device is None or torch.device(device).type != "cuda":
         return t
-    return t.pin_memory().to(device, non_blocking=True)
+    small = t.numel() * t.element_size() <= 4096
+    if small:
+        key = (dtype, str(device), tuple(t.shape), t.numpy().tobytes())
+        hit = _H2D_CACHE.get(key)
+        if hit is not None:
+            return hit
+    out = t.pin_memory().to(device, non_blocking=True)
+    if small:
+        if len(_H2D_CACHE) > 1024:
+            _H2D_CACHE.clear()
+        _H2D_CACHE[key] = out
+    return out
 
 
 def _i32(vals, device):
@@ -444,8 +460,24 @@ def linear_wgrad(x, dy):
 # ----------------------------------------------------------------------------------------------------
 # CAFM / TaskAligned pieces
 # ----------------------------------------------------------------------------------------------------
+_TILE_CACHE = {}
+
+
 def attn_tiles(segments, device, rows=16):
-    """segments: list of (row0, nrows, key0, key1) -> query tiles of `rows` rows (16: scalar kernels, 32: MFMA kernels)."""
+    """segments: list of (row0, nrows, key0, key1) -> query tiles of `rows` rows (16: scalar kernels, 32: MFMA kernels).
+    The (tiny) tile tables are cached per segment list: proposal counts repeat from clip to clip."""
+    key = (tuple(segments), str(device), rows)
+    hit = _TILE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    if len(_TILE_CACHE) > 512:
+        _TILE_CACHE.clear()
+    t = _attn_tiles(segments, device, rows)
+    _TILE_CACHE[key] = t
+    return t
+
+
+def _attn_tiles(segments, device, rows):
     t = []
     for (r0, n, k0, k1) in segments:
         for r in range(0, n, rows):

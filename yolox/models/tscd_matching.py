@@ -376,11 +376,37 @@ class AwarePositionRegMatcher(nn.Module):
         features_reg, features_cls = prep["features_reg"], prep["features_cls"]
         t_emb = linear(time_embedding.to(torch.float16).contiguous(), self.absolute_position_embedding)
         self.last_hungarian = []
-        idx = lambda a: ops.h2d(np.ascontiguousarray(a), torch.long, dev)
         solved = prep["chain"].result() if prep["chain"] is not None else []
 
-        outs = []
+        # every index table of the clip (column orders, unmatched / surviving rows, inverse permutations) goes to the device
+        # in ONE copy; the per-frame loop below only slices views of it
+        host_idx, slots = [], []
+        last_n = self.last_frame_n if not (len(preds_per_frame) and resume is False) else 0
         for (i, kind, pi), (row, col_raw, perm) in zip(plan, solved):
+            n = preds_per_frame[i]
+            ent = {}
+            if kind == "self":
+                ret = col_raw
+            else:
+                ret = perm
+                if last_n < n:
+                    ent["nm"] = perm[len(col_raw):]
+                elif last_n > n:
+                    ent["r"] = row
+                ent["c"] = perm
+            ent["inv"] = np.argsort(ret)
+            last_n = n
+            rec = {}
+            for k, a in ent.items():
+                a = np.ascontiguousarray(a, dtype=np.int64)
+                rec[k] = (sum(len(h) for h in host_idx), len(a))
+                host_idx.append(a)
+            slots.append(rec)
+        dev_idx = ops.h2d(np.concatenate(host_idx), torch.long, dev) if host_idx else None
+        view = lambda rec, k: dev_idx[rec[k][0]:rec[k][0] + rec[k][1]]
+
+        outs = []
+        for (i, kind, pi), (row, col_raw, perm), rec in zip(plan, solved, slots):
             n = preds_per_frame[i]
             s0, s1 = spans[i]
             if i == 0 and resume is False:
@@ -390,31 +416,28 @@ class AwarePositionRegMatcher(nn.Module):
             t_i = t_emb[i:i + 1]
             if kind == "self":
                 self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = cur_reg, cur_cls, n
-                ret = col_raw
-                self.last_hungarian.append(np.asarray(ret))
+                self.last_hungarian.append(np.asarray(col_raw))
                 out = layer(cur, cur, cur, t_i, t_i, cur_edge, cur_edge)
                 new_edge = cur_edge
             else:
                 # `perm`: the assignment's columns, followed by the unmatched current proposals (ascending) when the
                 # reference frame had fewer rows -- the order in which the reference keeps this frame from now on
                 self.last_hungarian.append(np.asarray(col_raw))
-                col = perm
-                if self.last_frame_n < n:
-                    nm = idx(perm[len(col_raw):])
+                if "nm" in rec:
+                    nm = view(rec, "nm")
                     last_feat = torch.cat((self.last_outputs, cur[nm]), 0)
                     last_edge = torch.cat((self.last_frame_edge_embeds, cur_edge[nm]), 0)
-                elif self.last_frame_n > n:
-                    r = idx(row)
+                elif "r" in rec:
+                    r = view(rec, "r")
                     last_feat, last_edge = self.last_outputs[r], self.last_frame_edge_embeds[r]
                 else:
                     last_feat, last_edge = self.last_outputs, self.last_frame_edge_embeds
-                c = idx(col)
+                c = view(rec, "c")
                 self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = cur_reg[c], cur_cls[c], n
-                ret = col
                 out = layer(cur[c], last_feat, cur, t_i, self.last_frame_time_embedding, cur_edge, last_edge)
                 new_edge = cur_edge[c]
             self.last_outputs, self.last_frame_time_embedding, self.last_frame_edge_embeds = out, t_i, new_edge
-            outs.append(out[idx(np.argsort(ret))])
+            outs.append(out[view(rec, "inv")])
         if not plan and len(preds_per_frame) and preds_per_frame[0] == 0 and resume is False:
             self._clear_state()
         if not outs:
