@@ -183,16 +183,11 @@ def roofline_dominant_kernel(args, device, step):
     for this kernel name.  `dominant_shape` repeats the measurement for the single heaviest shape (head tower 3x3)."""
     from tscd_amd import ops
     peak = 2500.0
-    import yolox.models.tscd_head as head_mod
     ops.CONV_PROFILE = []
     nsteps = 3
-    streams, head_mod.LEVEL_STREAMS = head_mod.LEVEL_STREAMS, False    # per-launch durations: no co-running pyramid levels
-    try:
-        for _ in range(nsteps):
-            step()
-        torch.cuda.synchronize()
-    finally:
-        head_mod.LEVEL_STREAMS = streams
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize()
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
     sel = [(f, e0.elapsed_time(e1) * 1e-3) for (bn, cin, f, e0, e1) in prof if bn == 128 and cin % 32 == 0]
     flops, secs = sum(f for f, _ in sel), sum(t for _, t in sel)
