@@ -212,14 +212,18 @@ def roofline_dominant_kernel(args, device, step):
     # HBM-side bytes per launch come from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself;
     # the file records the commands, the correction applied and the raw counters)
     traffic, traffic_dom = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01f_pmc_traffic.json")
-    if os.path.exists(pmc):
-        with open(pmc) as fh:
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    pmc_name = None
+    if pmcs:
+        pmc_name = os.path.basename(pmcs[-1])
+        with open(pmcs[-1]) as fh:
             j = json.load(fh)
-        traffic, traffic_dom = j["all_launches"]["bytes_per_launch"], j["dominant_shape"]["bytes_per_launch"]
+        traffic = j["all_launches"]["bytes_per_launch"]
+        traffic_dom = (j.get("dominant_shape") or {}).get("bytes_per_launch")
     return {"bound": "mfma", "kernel": "LDS-DMA implicit GEMM: conv_igemm_glds_kernel<128,2> + conv_igemm_v3_kernel (128x256 tiles on the 72x72 level)", "achieved": flops / secs / 1e12, "peak": peak,
             "unit": "TFLOP/s", "frac": flops / secs / 1e12 / peak, "traffic": traffic,
-            "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01f_pmc_traffic.json)",
+            "traffic_unit": f"bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{pmc_name})",
             "launches_per_step": len(sel) / nsteps, "avg_launch_us": secs / len(sel) * 1e6, "gflop_per_launch": flops / len(sel) / 1e9,
             "kernel_ms_per_step": secs / nsteps * 1e3,
             "dominant_shape": {"shape": f"B{B} {h}x{h} {W}->{W} 3x3", "gflop_per_launch": f1 / 1e9, "launch_us": t * 1e6,
