@@ -183,11 +183,18 @@ def roofline_dominant_kernel(args, device, step):
     for this kernel name.  `dominant_shape` repeats the measurement for the single heaviest shape (head tower 3x3)."""
     from tscd_amd import ops
     peak = 2500.0
+    import yolox.models.tscd_head as head_mod
     ops.CONV_PROFILE = []
     nsteps = 3
-    for _ in range(nsteps):
-        step()
-    torch.cuda.synchronize()
+    # per-launch durations: the three pyramid levels run on ONE stream during these instrumented steps, otherwise the event
+    # brackets of a launch include the time it spends queued behind / sharing the CUs with another level's kernels
+    streams, head_mod.LEVEL_STREAMS = head_mod.LEVEL_STREAMS, False
+    try:
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        head_mod.LEVEL_STREAMS = streams
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
     sel = [(f, e0.elapsed_time(e1) * 1e-3) for (bn, cin, f, e0, e1) in prof if bn == 128 and cin % 32 == 0]
     flops, secs = sum(f for f, _ in sel), sum(t for _, t in sel)
