@@ -241,14 +241,25 @@ static int64_t g_steps = 0;        // relaxation passes of the last solves (diag
 // and spc = QINF (their real spc is parked in spcsave), which removes them from the update, the minimum and the tie test
 // without predicate loads.  Branch-free on purpose: data-dependent branches here mispredict.
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
-static int32_t relax_row_q32(const int32_t* crow, const int32_t* veff, int32_t* spc, int16_t* path, int64_t ncp, int32_t base,
-                             int16_t id) {
+static inline void set_lane(int32_t* arr, int64_t j, int32_t val) {     // arr 64-byte aligned
+  int32_t* blk = arr + (j & ~(int64_t)15);
+  _mm512_store_si512(blk, _mm512_mask_mov_epi32(_mm512_load_si512(blk), (__mmask16)(1u << (j & 15)), _mm512_set1_epi32(val)));
+}
+template <typename CT>
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static inline __m512i load16(const CT* p) {
+  if constexpr (sizeof(CT) == 2) return _mm512_cvtepi16_epi32(_mm256_loadu_si256((const __m256i*)p));
+  else return _mm512_loadu_si512(p);
+}
+template <typename CT>
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static int32_t relax_row_q(const CT* crow, const int32_t* veff, int32_t* spc, int16_t* path, int64_t ncp, int32_t base, int16_t id) {
   const __m512i vbase = _mm512_set1_epi32(base);
   const __m512i vid = _mm512_set1_epi16(id);
   __m512i low0 = _mm512_set1_epi32(QINF), low1 = low0;
   for (int64_t j = 0; j < ncp; j += 32) {
-    __m512i r0 = _mm512_sub_epi32(_mm512_add_epi32(_mm512_loadu_si512(crow + j), vbase), _mm512_loadu_si512(veff + j));
-    __m512i r1 = _mm512_sub_epi32(_mm512_add_epi32(_mm512_loadu_si512(crow + j + 16), vbase), _mm512_loadu_si512(veff + j + 16));
+    __m512i r0 = _mm512_sub_epi32(_mm512_add_epi32(load16<CT>(crow + j), vbase), _mm512_loadu_si512(veff + j));
+    __m512i r1 = _mm512_sub_epi32(_mm512_add_epi32(load16<CT>(crow + j + 16), vbase), _mm512_loadu_si512(veff + j + 16));
     __m512i s0 = _mm512_loadu_si512(spc + j), s1 = _mm512_loadu_si512(spc + j + 16);
     __mmask16 m0 = _mm512_cmplt_epi32_mask(r0, s0), m1 = _mm512_cmplt_epi32_mask(r1, s1);
     s0 = _mm512_min_epi32(s0, r0);
@@ -261,25 +272,67 @@ static int32_t relax_row_q32(const int32_t* crow, const int32_t* veff, int32_t* 
   }
   return _mm512_reduce_min_epi32(_mm512_min_epi32(low0, low1));
 }
+// fp16 -> integers in units of 2^(E-25) (E = smallest biased exponent among the non-zero entries, at least 1): exact, since
+// every fp16 value with exponent field e >= E is a multiple of that unit.  Scaling all costs by one power of two changes no
+// comparison and no tie in the algorithm.
+template <typename CT>
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
-static void convert_q32(const uint16_t* src, int32_t* dst, int64_t n) {   // n % 16 == 0
-  const __m512 scale = _mm512_set1_ps(16777216.0f);
-  for (int64_t j = 0; j < n; j += 16)
-    _mm512_storeu_si512(dst + j, _mm512_cvtps_epi32(_mm512_mul_ps(_mm512_cvtph_ps(_mm256_loadu_si256((const __m256i*)(src + j))), scale)));
+static void convert_q(const uint16_t* src, CT* dst, int64_t n, int E) {   // n % 16 == 0
+  const __m512 scale = _mm512_set1_ps(std::ldexp(1.0f, 25 - E));
+  for (int64_t j = 0; j < n; j += 16) {
+    __m512i v = _mm512_cvtps_epi32(_mm512_mul_ps(_mm512_cvtph_ps(_mm256_loadu_si256((const __m256i*)(src + j))), scale));
+    if constexpr (sizeof(CT) == 2) _mm256_storeu_si256((__m256i*)(dst + j), _mm512_cvtepi32_epi16(v));
+    else _mm512_storeu_si512(dst + j, v);
+  }
 }
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static void exponent_span(const uint16_t* src, int64_t n, int& emin, int& emax) {   // n % 32 == 0
+  const __m512i m15 = _mm512_set1_epi16(0x7fff), one = _mm512_set1_epi16(1);
+  __m512i lo = _mm512_set1_epi16(31), hi = _mm512_setzero_si512();
+  for (int64_t j = 0; j < n; j += 32) {
+    __m512i h = _mm512_and_si512(_mm512_loadu_si512(src + j), m15);
+    __mmask32 nz = _mm512_test_epi16_mask(h, h);
+    __m512i e = _mm512_max_epu16(_mm512_srli_epi16(h, 10), one);       // subnormals share exponent 1's unit
+    lo = _mm512_mask_min_epu16(lo, nz, lo, e);
+    hi = _mm512_mask_max_epu16(hi, nz, hi, e);
+  }
+  alignas(64) uint16_t a[32], b[32];
+  _mm512_store_si512(a, lo);
+  _mm512_store_si512(b, hi);
+  unsigned l = 31, g = 0;
+  for (int k = 0; k < 32; ++k) { l = a[k] < l ? a[k] : l; g = b[k] > g ? b[k] : g; }
+  emin = (int)l; emax = (int)g;
+}
+
+template <typename CT>
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int E, int32_t* col4row_out);
+
 // cost: fp16 bits, [nr][ncp] with ncp % 32 == 0 (padding columns are never live), nr <= nc.  0 ok, 2 infeasible, 3 overflow.
+// The integer matrix is int16 (0.5 MB for 500x500: stays in the core's L2) when the entries' exponents span <= 4 binades --
+// CAFM's costs 1 - cos live in [0.5, 1.2] -- and int32 otherwise (e.g. the self-match, whose diagonal is ~0).
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
 static int solve_q(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int32_t* col4row_out) {
-  // 2^-24 units, converted once; the 1 MB buffer is kept per thread (fresh pages cost more than the solve's first rows)
-  static thread_local int32_t* c32_buf = nullptr;
-  static thread_local size_t c32_cap = 0;
-  if (c32_cap < (size_t)nr * ncp) {
-    std::free(c32_buf);
-    c32_cap = (size_t)nr * ncp;
-    c32_buf = (int32_t*)std::aligned_alloc(64, (c32_cap * sizeof(int32_t) + 63) / 64 * 64);
+  int emin, emax;
+  exponent_span(cost, nr * ncp, emin, emax);
+  if (emax < emin) { emin = emax = 1; }                      // all zeros
+  if (emax - emin <= 4) return solve_q_t<int16_t>(nr, nc, ncp, cost, emin, col4row_out);
+  return solve_q_t<int32_t>(nr, nc, ncp, cost, 1, col4row_out);   // unit 2^-24
+}
+
+template <typename CT>
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int E, int32_t* col4row_out) {
+  // converted once; the buffer is kept per thread (fresh pages cost more than the solve's first rows)
+  static thread_local CT* c_buf = nullptr;
+  static thread_local size_t c_cap = 0;
+  if (c_cap < (size_t)nr * ncp) {
+    std::free(c_buf);
+    c_cap = (size_t)nr * ncp;
+    c_buf = (CT*)std::aligned_alloc(64, (c_cap * sizeof(CT) + 63) / 64 * 64);
   }
-  struct { int32_t* p; int32_t* data() { return p; } } c32{c32_buf};
-  convert_q32(cost, c32.data(), nr * ncp);
+  struct { CT* p; CT* data() { return p; } } c32{c_buf};
+  convert_q<CT>(cost, c32.data(), nr * ncp, E);
   AlignedBuf<int32_t> veff(ncp, QDEADV), spc(ncp), pos(ncp, -1), posfree(ncp, -1);
   AlignedBuf<int16_t> path(ncp, -1);
   std::vector<int32_t> u(nr, 0), v(ncp, 0), spcsave(ncp, 0), col4row(nr, -1), row4col(ncp, -1);
@@ -303,32 +356,39 @@ static int solve_q(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, in
     while (sink == -1) {
       sr_list.push_back((int32_t)i);
       ++g_steps;
-      int32_t lowest = relax_row_q32(c32.data() + i * ncp, veff.data(), spc.data(), path.data(), ncp, minVal - u[i], (int16_t)i);
+      int32_t lowest = relax_row_q<CT>(c32.data() + i * ncp, veff.data(), spc.data(), path.data(), ncp, minVal - u[i], (int16_t)i);
       if (lowest == QINF) return 2;
       if (lowest >= QLIM || lowest <= -QLIM) return 3;
       // tie rule of the scalar scan: the first column (in `remaining` order) reaching the minimum is taken, and every later
       // tied column that has no row yet replaces it -> smallest position among the ties vs. largest among the free ties.
       const __m512i vlow = _mm512_set1_epi32(lowest);
       __m512i pmin = _mm512_set1_epi32(std::numeric_limits<int32_t>::max()), pmax = _mm512_set1_epi32(-1);
-      for (int64_t j = 0; j < ncp; j += 16) {
-        __mmask16 m = _mm512_cmpeq_epi32_mask(_mm512_loadu_si512(spc.data() + j), vlow);
-        pmin = _mm512_mask_min_epi32(pmin, m, pmin, _mm512_loadu_si512(pos.data() + j));
-        pmax = _mm512_mask_max_epi32(pmax, m, pmax, _mm512_loadu_si512(posfree.data() + j));
+      __m512i pmin1 = pmin, pmax1 = pmax;
+      for (int64_t j = 0; j < ncp; j += 32) {      // two independent accumulator chains
+        __mmask16 m0 = _mm512_cmpeq_epi32_mask(_mm512_load_si512(spc.data() + j), vlow);
+        __mmask16 m1 = _mm512_cmpeq_epi32_mask(_mm512_load_si512(spc.data() + j + 16), vlow);
+        pmin = _mm512_mask_min_epi32(pmin, m0, pmin, _mm512_load_si512(pos.data() + j));
+        pmin1 = _mm512_mask_min_epi32(pmin1, m1, pmin1, _mm512_load_si512(pos.data() + j + 16));
+        pmax = _mm512_mask_max_epi32(pmax, m0, pmax, _mm512_load_si512(posfree.data() + j));
+        pmax1 = _mm512_mask_max_epi32(pmax1, m1, pmax1, _mm512_load_si512(posfree.data() + j + 16));
       }
-      const int64_t first_pos = _mm512_reduce_min_epi32(pmin), last_free_pos = _mm512_reduce_max_epi32(pmax);
+      const int64_t first_pos = _mm512_reduce_min_epi32(_mm512_min_epi32(pmin, pmin1));
+      const int64_t last_free_pos = _mm512_reduce_max_epi32(_mm512_max_epi32(pmax, pmax1));
       const int64_t index = (last_free_pos > first_pos) ? last_free_pos : first_pos;
       minVal = lowest;
       const int64_t j = remaining[index];
       if (row4col[j] == -1) sink = j; else i = row4col[j];
       spcsave[j] = spc[j];
-      spc[j] = QINF;
-      veff[j] = QDEADV;
+      // single-lane updates of arrays the vector passes re-read right away: write the whole 64-byte block (a 4-byte store
+      // followed by an overlapping 64-byte load cannot be store-forwarded and stalls until the store retires)
+      set_lane(spc.data(), j, QINF);
+      set_lane(veff.data(), j, QDEADV);
       dead_list.push_back((int32_t)j);
       --num_remaining;
       const int32_t moved = remaining[num_remaining];
       remaining[index] = moved;
-      pos[moved] = (int32_t)index;
-      posfree[moved] = row4col[moved] == -1 ? (int32_t)index : -1;
+      set_lane(pos.data(), moved, (int32_t)index);
+      set_lane(posfree.data(), moved, row4col[moved] == -1 ? (int32_t)index : -1);
     }
     bool over = false;
     u[curRow] += minVal;
