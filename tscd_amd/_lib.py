@@ -76,5 +76,13 @@ def check(status, name):
         raise RuntimeError(f"{name} failed (status {status}): {lib.tscd_last_error().decode()}")
 
 
+_FN = {}
+
+
 def call(name, *args):
-    check(getattr(lib, name)(*args), name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(lib, name)
+    st = fn(*args)
+    if st != 0:
+        check(st, name)

@@ -161,6 +161,7 @@ extern "C" int tscd_conv_wgrad_splits(long M, int Cout, int Cin, int ksize) {
   long kt = (M + 31) / 32;
   long tiles = (long)cdiv(Cout, 128) * cdiv((long)ksize * ksize * Cin, 128);
   long s = (512 + tiles - 1) / tiles;
+  if (ksize == 1 && kt <= 24) return 1;      // proposal-stage linears (a few hundred rows): one pass, written straight into dw
   if (s > kt / 8) s = kt / 8;
   if (s < 1) s = 1;
   if (s > 256) s = 256;
@@ -189,8 +190,11 @@ extern "C" int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw
   p.ktiles_per_split = (ktotal + p.S - 1) / p.S;
   p.mtiles = cdiv(Cout, 128); p.ntiles = cdiv(p.Ncols, 128);
   hipStream_t st = (hipStream_t)stream;
+  const bool direct = p.S == 1 && ksize == 1;   // [Cout][Cin] slab == torch layout: no reduction pass
+  if (direct) p.part = dw;
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.mtiles * p.ntiles, p.S), dim3(256), 0, st, p);
   TSCD_CHECK_LAUNCH("conv_wgrad");
+  if (direct) return TSCD_OK;
   long total = (long)Cout * p.Ncols;
   int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, st, p.part, p.S, Cout, Cin, ksize, ksize, dw);

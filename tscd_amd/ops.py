@@ -235,7 +235,9 @@ LINEAR_WEIGHTS = _LinearCache()
 
 
 def linear(x, weight, bias=None, out=None, wpk=None):
-    """x [n, K] fp16 (row stride may exceed K) @ weight[out,K]^T (+ bias) -> [n, out] fp16 via the MFMA conv kernel."""
+    """x [n, K] fp16 (row stride may exceed K) @ weight[out,K]^T (+ bias) -> [n, out] fp16 via the MFMA conv kernel (called
+    directly as a 1 x n image: this wrapper sits on the launch-bound stretch of the step, so it skips conv2d's generic layout
+    checks)."""
     n, K = x.shape
     nout = weight.shape[0] if weight is not None else out.shape[1]
     wpk = LINEAR_WEIGHTS.get(weight) if wpk is None else wpk
@@ -243,12 +245,19 @@ def linear(x, weight, bias=None, out=None, wpk=None):
         out = torch.empty((n, nout), dtype=torch.float16, device=x.device)
     if n == 0:
         return out
-    x4 = x.unsqueeze(0).unsqueeze(0)
-    o4 = out.unsqueeze(0).unsqueeze(0)
+    if not (x.is_cuda and x.dtype == torch.float16 and x.stride(1) == 1 and out.stride(1) == 1 and K % 8 == 0
+            and wpk.shape[1] == (K + 31) // 32 * 32 and wpk.shape[0] >= nout) or CONV_PROFILE is not None:
+        x4, o4 = x.unsqueeze(0).unsqueeze(0), out.unsqueeze(0).unsqueeze(0)       # generic path (checks, profiling)
+        if bias is not None:
+            conv2d(x4, wpk, nout, 1, 1, EPI_BIAS, bias=bias.float(), out=o4)
+        else:
+            conv2d(x4, wpk, nout, 1, 1, EPI_RAW, out=o4)
+        return out
+    b32 = None
     if bias is not None:
-        conv2d(x4, wpk, nout, 1, 1, EPI_BIAS, bias=bias.float(), out=o4)
-    else:
-        conv2d(x4, wpk, nout, 1, 1, EPI_RAW, out=o4)
+        b32 = bias if bias.dtype == torch.float32 else bias.float()
+    call("tscd_conv2d_nhwc_f16", x.data_ptr(), wpk.data_ptr(), out.data_ptr(), 0 if b32 is None else b32.data_ptr(), 0, 0, 0,
+         1, 1, n, K, nout, 1, 1, x.stride(0), out.stride(0), EPI_RAW if b32 is None else EPI_BIAS, _stream())
     return out
 
 
