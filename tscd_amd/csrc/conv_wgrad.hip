@@ -310,3 +310,65 @@ extern "C" int tscd_bn_silu_bwd_f16(const void* dy, const void* raw, const float
   TSCD_CHECK_LAUNCH("bn_silu_bwd");
   return TSCD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- fused nn.Linear backward
+// dX = dY W, dW = dY^T X, db = column sums of dY in ONE host call (the matcher's ~23 linears per step sit on a launch-bound
+// stretch of the backward: their cost is the host's, not the device's).  Kernels: weight pack (data-gradient order) + the
+// MFMA GEMM for dX, the pixel-axis wgrad GEMM (+ slab reduction unless it writes dW directly), one column-sum kernel.
+extern "C" int tscd_pack_conv_weight(const void* w, int src_is_f32, void* out, int Cout, int Cin, int CinPad, int KH, int KW,
+                                     int rows_pad, int Kpad, int mode, void* stream);
+extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* bias, const float* scale, const float* shift,
+                                    float* bn_partial, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int ldx, int ldy,
+                                    int epilogue, void* stream);
+extern "C" int tscd_conv_tile_n(int cout);
+
+__global__ void col_sum_f16_kernel(const f16* __restrict__ g, int n, int ld, int C, float* __restrict__ out) {
+  // one wave per 64 columns; rows strided over the block's waves, combined through LDS in a fixed order
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+  float a = 0.f;
+  if (c < C)
+    for (int r = wave; r < n; r += 4) a += (float)g[(long)r * ld + c];
+  red[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && c < C) out[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+static long linear_bwd_pack_bytes(int in_f, int outp) {
+  const int bn = tscd_conv_tile_n(in_f);
+  const long rows_pad = (long)cdiv(in_f, bn) * bn, kpad = (long)cdiv(outp, 32) * 32;
+  return (rows_pad * kpad * 2 + 255) / 256 * 256;
+}
+// outp = out_f rounded up to 8 (dY arrives padded with zero columns)
+extern "C" long tscd_linear_bwd_workspace_bytes(int n, int in_f, int outp) {
+  return linear_bwd_pack_bytes(in_f, outp) + tscd_conv_wgrad_workspace_bytes(n, outp, in_f, 1);
+}
+// x [n][in_f] (row stride ldx), dY [n][outp] contiguous fp16 (outp % 8 == 0; columns >= out_f zero), w [out_f][in_f] fp32 or
+// fp16.  Outputs (each may be NULL): dx [n][in_f] fp16 contiguous, dw [outp][in_f] fp32, db [out_f] fp32.
+extern "C" int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, const void* w, int w_is_f32, int n, int in_f, int out_f,
+                                   int outp, void* dx, float* dw, float* db, void* workspace, long workspace_bytes, void* stream) {
+  TSCD_CHECK_ARG(x && dy && w && workspace && n > 0, "linear_bwd: bad args");
+  TSCD_CHECK_ARG(outp % 8 == 0 && outp >= out_f && in_f % 8 == 0, "linear_bwd: in_f / padded out_f must be multiples of 8");
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_linear_bwd_workspace_bytes(n, in_f, outp), "linear_bwd: workspace too small");
+  const long pack_bytes = linear_bwd_pack_bytes(in_f, outp);
+  int st;
+  if (dx) {
+    const int bn = tscd_conv_tile_n(in_f);
+    const int rows_pad = cdiv(in_f, bn) * bn, kpad = cdiv(outp, 32) * 32;
+    // data-gradient packing of a 1x1 "conv": rows = in_f, k = out channel (CinPad carries the padded out count)
+    if ((st = tscd_pack_conv_weight(w, w_is_f32, workspace, out_f, in_f, outp, 1, 1, rows_pad, kpad, 1, stream)) != TSCD_OK) return st;
+    if ((st = tscd_conv2d_nhwc_f16(dy, workspace, dx, nullptr, nullptr, nullptr, nullptr, 1, 1, n, outp, in_f, 1, 1, outp, in_f, 0,
+                                   stream)) != TSCD_OK)
+      return st;
+  }
+  if (dw) {
+    char* ws2 = (char*)workspace + pack_bytes;
+    if ((st = tscd_conv_wgrad_nhwc_f16(x, dy, dw, 1, 1, n, in_f, outp, 1, ldx, outp, ws2, workspace_bytes - pack_bytes, stream)) != TSCD_OK)
+      return st;
+  }
+  if (db) {
+    hipLaunchKernelGGL(col_sum_f16_kernel, dim3(cdiv(out_f, 64)), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, n, outp, out_f, db);
+    TSCD_CHECK_LAUNCH("linear_bwd col_sum");
+  }
+  return TSCD_OK;
+}

@@ -453,6 +453,32 @@ def linear_dgrad(dy, weight):
     return linear(dy, None, out=torch.empty((n, in_f), dtype=torch.float16, device=dy.device), wpk=wpk)
 
 
+def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False):
+    """Backward of y = x W^T (+ b) in ONE foreign call -> (dx fp16 [n,in] | None, dw fp32 [out,in] | None, db fp32 [out] | None).
+    x [n,in] fp16 (unit column stride), dy [n,out] fp16."""
+    n, in_f = x.shape
+    out_f = weight.shape[0]
+    outp = (out_f + 7) // 8 * 8
+    if outp != out_f or not dy.is_contiguous():
+        d2 = dy.new_zeros((n, outp))
+        d2[:, :out_f] = dy
+        dy = d2
+    dev = x.device
+    dx = torch.empty((n, in_f), dtype=torch.float16, device=dev) if need_dx else None
+    dw = torch.empty((outp, in_f), dtype=torch.float32, device=dev) if need_dw else None
+    db = torch.empty((out_f,), dtype=torch.float32, device=dev) if need_db else None
+    if n == 0:
+        return (dx, None if dw is None else dw.zero_()[:out_f], None if db is None else db.zero_())
+    ws_bytes = lib.tscd_linear_bwd_workspace_bytes(n, in_f, outp)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    call("tscd_linear_bwd_f16", x.data_ptr(), x.stride(0), dy.data_ptr(), w.data_ptr(), int(w.dtype == torch.float32), n, in_f, out_f,
+         outp, _ptr(dx), _ptr(dw), _ptr(db), ws.data_ptr(), ws_bytes, _stream())
+    return dx, (None if dw is None else dw[:out_f]), db
+
+
 def linear_wgrad(x, dy):
     """dW [out, in] fp32 = dY^T @ X  (the pixel-axis GEMM of conv_wgrad.hip with 1x1 taps)."""
     n, cin = x.shape

@@ -55,10 +55,14 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        g = g.to(torch.float16).contiguous()
-        dx = ops.linear_dgrad(g, w) if ctx.needs_input_grad[0] else None
-        dw = ops.linear_wgrad(x, g).to(w.dtype).reshape(w.shape) if ctx.needs_input_grad[1] else None
-        db = torch.sum(g, 0, dtype=torch.float32).to(w.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        if g.dtype != torch.float16:
+            g = g.to(torch.float16)
+        need = ctx.needs_input_grad
+        dx, dw, db = ops.linear_bwd(x, g, w, need[0], need[1], ctx.has_bias and need[2])
+        if dw is not None and dw.dtype != w.dtype:
+            dw = dw.to(w.dtype)
+        if db is not None and db.dtype != w.dtype:
+            db = db.to(w.dtype)
         return dx, dw, db
 
 
