@@ -82,11 +82,20 @@ class _EagerBranch(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *unused):
         scale = g.float() / ctx.seed
+        live = [gr for gr in ctx.grads if gr is not None]
+        # two fused multi-tensor launches (fp32 parameter gradients, fp16 activation gradients) instead of one per tensor
+        f32 = [gr for gr in live if gr.dtype == torch.float32]
+        f16 = [gr for gr in live if gr.dtype != torch.float32]
+        scaled = {}
+        if f32:
+            scaled.update(zip(map(id, f32), torch._foreach_mul(f32, scale)))
+        if f16:
+            scaled.update(zip(map(id, f16), torch._foreach_mul(f16, scale.to(f16[0].dtype))))
         it = iter(ctx.grads)
         out = []
         for m in ctx.mask:
             gr = next(it) if m else None
-            out.append(None if gr is None else (gr * scale.to(gr.dtype) if gr.dtype == torch.float32 else (gr.float() * scale).to(gr.dtype)))
+            out.append(None if gr is None else scaled[id(gr)])
         return (None, None, None) + tuple(out)
 
 

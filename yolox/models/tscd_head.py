@@ -162,11 +162,14 @@ class TSCDHead(nn.Module):
 
         raw_levels, cls_maps, reg_maps = [None] * len(feats), [None] * len(feats), [None] * len(feats)
 
-        def level(k, x):
+        def frozen(k, x):
             with torch.no_grad():                                    # frozen stem / base towers (ovis_tscd_large.py:141-149)
                 x = self.stems[k](x)
                 reg_feat = self.reg_convs[k][1](self.reg_convs[k][0](x))
                 cls_feat = self.cls_convs[k][1](self.cls_convs[k][0](x))
+            return x, reg_feat, cls_feat
+
+        def trainable(k, x, reg_feat, cls_feat):
             vid_feat = self.cls_convs2[k][1](self.cls_convs2[k][0](x))
             vid_feat_reg = self.reg_convs2[k][1](self.reg_convs2[k][0](x))
             reg_o = TF.conv_bias(reg_feat, self.reg_preds[k].weight, self.reg_preds[k].bias)
@@ -176,26 +179,34 @@ class TSCDHead(nn.Module):
             cls_maps[k], reg_maps[k] = vid_feat, vid_feat_reg
 
         # The three pyramid levels are independent chains of 14 convs each; the 36x36 and 18x18 levels launch only 80-330
-        # workgroups per conv, so they run on side streams underneath the 72x72 level instead of after it.
+        # workgroups per conv, so they run on side streams underneath the 72x72 level instead of after it.  Under
+        # DistributedDataParallel only their no-grad half does: the reducer syncs its all-reduce with the ONE stream that is
+        # current when a bucket's last gradient arrives, so gradient-producing kernels must all live on one stream.
         if LEVEL_STREAMS and len(feats) > 1 and dev.type == "cuda":
+            import torch.distributed as dist
+            one_grad_stream = grad and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
             main = torch.cuda.current_stream()
             side = _side_streams(dev, len(feats) - 1)
             fork = torch.cuda.Event()
             fork.record(main)
-            joins = []
+            joins, held = [], {}
             for k in range(1, len(feats)):
                 side[k - 1].wait_event(fork)
                 with torch.cuda.stream(side[k - 1]):
-                    level(k, feats[k])
+                    held[k] = frozen(k, feats[k])
+                    if not one_grad_stream:
+                        trainable(k, *held[k])
                     ev = torch.cuda.Event()
                     ev.record(side[k - 1])
                     joins.append(ev)
-            level(0, feats[0])
-            for ev in joins:
+            trainable(0, *frozen(0, feats[0]))
+            for k, ev in zip(range(1, len(feats)), joins):
                 main.wait_event(ev)
+                if one_grad_stream:
+                    trainable(k, *held[k])
         else:
             for k, x in enumerate(feats):
-                level(k, x)
+                trainable(k, *frozen(k, x))
         self.hw = [tuple(f.shape[1:3]) for f in feats]
 
         with torch.no_grad():
