@@ -379,6 +379,7 @@ class AwarePositionRegMatcher(nn.Module):
         plan, spans, preds_per_frame, resume = prep["plan"], prep["spans"], prep["ppf"], prep["resume"]
         features_reg, features_cls = prep["features_reg"], prep["features_cls"]
         t_emb = linear(time_embedding.to(torch.float16).contiguous(), self.absolute_position_embedding)
+        t_rows = t_emb.unbind(0)            # one stack in backward instead of a zero-filled slice gradient per use
         self.last_hungarian = []
         solved = prep["chain"].result() if prep["chain"] is not None else []
 
@@ -408,6 +409,13 @@ class AwarePositionRegMatcher(nn.Module):
             slots.append(rec)
         dev_idx = ops.h2d(np.concatenate(host_idx), torch.long, dev) if host_idx else None
         view = lambda rec, k: dev_idx[rec[k][0]:rec[k][0] + rec[k][1]]
+        # row gathers by index_select: its backward is one index_add into zeros (the indices are distinct rows), where
+        # advanced indexing would sort the indices first (8 small launches per gather on a launch-bound stretch)
+        rows = lambda t, i: t.index_select(0, i)
+        # per-frame views by ONE split (its backward is one cat) instead of a zero-filled [N, W] slice gradient per use
+        n_loc = sum(preds_per_frame)
+        f_loc = features[:n_loc].split(list(preds_per_frame))
+        e_loc = features_edge[:n_loc].split(list(preds_per_frame))
 
         outs = []
         for (i, kind, pi), (row, col_raw, perm), rec in zip(plan, solved, slots):
@@ -415,9 +423,9 @@ class AwarePositionRegMatcher(nn.Module):
             s0, s1 = spans[i]
             if i == 0 and resume is False:
                 self._clear_state()
-            cur, cur_edge = features[s0:s1], features_edge[s0:s1]
+            cur, cur_edge = f_loc[i], e_loc[i]
             cur_reg, cur_cls = features_reg[s0:s1], features_cls[s0:s1]
-            t_i = t_emb[i:i + 1]
+            t_i = t_rows[i].unsqueeze(0)
             if kind == "self":
                 self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = cur_reg, cur_cls, n
                 self.last_hungarian.append(np.asarray(col_raw))
@@ -429,19 +437,19 @@ class AwarePositionRegMatcher(nn.Module):
                 self.last_hungarian.append(np.asarray(col_raw))
                 if "nm" in rec:
                     nm = view(rec, "nm")
-                    last_feat = torch.cat((self.last_outputs, cur[nm]), 0)
-                    last_edge = torch.cat((self.last_frame_edge_embeds, cur_edge[nm]), 0)
+                    last_feat = torch.cat((self.last_outputs, rows(cur, nm)), 0)
+                    last_edge = torch.cat((self.last_frame_edge_embeds, rows(cur_edge, nm)), 0)
                 elif "r" in rec:
                     r = view(rec, "r")
-                    last_feat, last_edge = self.last_outputs[r], self.last_frame_edge_embeds[r]
+                    last_feat, last_edge = rows(self.last_outputs, r), rows(self.last_frame_edge_embeds, r)
                 else:
                     last_feat, last_edge = self.last_outputs, self.last_frame_edge_embeds
                 c = view(rec, "c")
-                self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = cur_reg[c], cur_cls[c], n
-                out = layer(cur[c], last_feat, cur, t_i, self.last_frame_time_embedding, cur_edge, last_edge)
-                new_edge = cur_edge[c]
+                self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = rows(cur_reg, c), rows(cur_cls, c), n
+                out = layer(rows(cur, c), last_feat, cur, t_i, self.last_frame_time_embedding, cur_edge, last_edge)
+                new_edge = rows(cur_edge, c)
             self.last_outputs, self.last_frame_time_embedding, self.last_frame_edge_embeds = out, t_i, new_edge
-            outs.append(out[view(rec, "inv")])
+            outs.append(rows(out, view(rec, "inv")))
         if not plan and len(preds_per_frame) and preds_per_frame[0] == 0 and resume is False:
             self._clear_state()
         if not outs:
