@@ -133,7 +133,7 @@ int tscd_add_layernorm_f16(const void* a, const void* b, const float* gamma, con
                            void* out, void* stream);
 /* Backward of the three kernels above (autograd under tscd_trainer.py:171-176).  cos_attn_bwd: gradients w.r.t. the raw
  * q/k (normalisation backward included) and v; q/dO/dq [n,C], k/v/dk/dv [nk,C]; workspace >= 8*nk*C bytes.  se_fuse_bwd / add_layernorm_bwd: parameter
- * gradients are fp32 atomics into buffers the caller zeroes (dpos[C], dw0[32*2], dw2[2*32]; dgamma[C], dbeta[C]). */
+ * gradients are fp32 atomic accumulators (dpos[C], dw0[32*2], dw2[2*32]; dgamma[C], dbeta[C]) that the entry points clear. */
 int tscd_cos_attn_bwd_f16(const void* q, const void* k, const void* v, const void* dO, int n, int nk, int C, int heads,
                           const int* tiles, int ntiles, void* workspace, long workspace_bytes, void* dq, void* dk, void* dv,
                           void* stream);

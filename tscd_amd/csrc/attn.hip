@@ -502,6 +502,15 @@ extern "C" int tscd_se_fuse_bwd_f16(const void* reg, int ldr, const void* edge, 
                                     void* stream) {
   TSCD_CHECK_ARG(reg && edge && w0 && w2 && dout && dreg && dedge && dpos && dw0 && dw2, "se_fuse_bwd: null pointer");
   if (n == 0) return TSCD_OK;
+  // dpos [C] | dw0 [64] | dw2 [64] are atomic accumulators: cleared here (callers pass them as one C+128 float block or apart)
+  hipStream_t sst = (hipStream_t)stream;
+  if (dw0 == dpos + C && dw2 == dw0 + 64) {
+    (void)hipMemsetAsync(dpos, 0, sizeof(float) * (C + 128), sst);
+  } else {
+    (void)hipMemsetAsync(dpos, 0, sizeof(float) * C, sst);
+    (void)hipMemsetAsync(dw0, 0, sizeof(float) * 64, sst);
+    (void)hipMemsetAsync(dw2, 0, sizeof(float) * 64, sst);
+  }
   long total = n * C;
   int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(se_fuse_bwd_kernel, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, (hipStream_t)stream, (const f16*)reg, ldr,
@@ -544,6 +553,12 @@ __global__ void add_layernorm_bwd_kernel(const f16* __restrict__ a, const f16* _
 extern "C" int tscd_add_layernorm_bwd_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
                                           void* dx, float* dgamma, float* dbeta, void* stream) {
   TSCD_CHECK_ARG(a && gamma && dy && dx && dgamma && dbeta && C > 0, "add_layernorm_bwd: bad args");
+  if (dbeta == dgamma + C) {                                                   // atomic accumulators
+    (void)hipMemsetAsync(dgamma, 0, sizeof(float) * 2 * C, (hipStream_t)stream);
+  } else {
+    (void)hipMemsetAsync(dgamma, 0, sizeof(float) * C, (hipStream_t)stream);
+    (void)hipMemsetAsync(dbeta, 0, sizeof(float) * C, (hipStream_t)stream);
+  }
   if (n == 0) return TSCD_OK;
   hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const f16*)a,
                      (const f16*)b, gamma, (const f16*)dy, n, C, eps, (f16*)dx, dgamma, dbeta);

@@ -524,26 +524,27 @@ def cos_attn_uses_mfma(C, heads):
     return C % heads == 0 and bool(lib.tscd_cos_attn_mfma_supported(C // heads))
 
 
-def cos_attn_mfma(q, k, v, heads, tiles32):
-    """-> (out [n,C] fp16, lsum [n,heads] fp32)."""
+def cos_attn_mfma(q, k, v, heads, tiles32, full=False):
+    """-> (out [n,C] fp16, lsum [n,heads] fp32).  ``full``: the tiles cover every query row (no zero fill needed)."""
     n, C = q.shape
     for t in (q, k, v):
         assert t.is_contiguous() and t.dtype == torch.float16 and t.shape[1] == C
-    out = torch.zeros((n, C), dtype=torch.float16, device=q.device)       # rows outside every tile stay zero
-    lsum = torch.zeros((n, heads), dtype=torch.float32, device=q.device)
+    alloc = torch.empty if full else torch.zeros                          # rows outside every tile stay zero
+    out = alloc((n, C), dtype=torch.float16, device=q.device)
+    lsum = alloc((n, heads), dtype=torch.float32, device=q.device)
     call("tscd_cos_attn_mfma_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), C, heads, tiles32.data_ptr(), tiles32.shape[0],
          out.data_ptr(), lsum.data_ptr(), _stream())
     return out, lsum
 
 
-def cos_attn_mfma_bwd(q, k, v, d_out, out, lsum, heads, tiles32):
+def cos_attn_mfma_bwd(q, k, v, d_out, out, lsum, heads, tiles32, full=False):
     n, C = q.shape
     nk = k.shape[0]
     dev = q.device
     for t in (q, k, v, d_out, out):
         assert t.is_contiguous() and t.dtype == torch.float16 and t.shape[1] == C
     ws = torch.empty((2 * nk * C,), dtype=torch.float32, device=dev)
-    dq = torch.zeros((n, C), dtype=torch.float16, device=dev)
+    dq = (torch.empty if full else torch.zeros)((n, C), dtype=torch.float16, device=dev)
     dk, dv = (torch.empty((nk, C), dtype=torch.float16, device=dev) for _ in range(2))
     call("tscd_cos_attn_mfma_bwd_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), d_out.data_ptr(), out.data_ptr(), lsum.data_ptr(),
          n, nk, C, heads, tiles32.data_ptr(), tiles32.shape[0], ws.data_ptr(), ws.numel() * 4, dq.data_ptr(), _stream())
@@ -601,7 +602,7 @@ def se_fuse_bwd(reg, edge, w0, w2, d_out):
     assert reg.stride(1) == 1 and edge.stride(1) == 1 and d_out.is_contiguous() and d_out.dtype == torch.float16
     d_reg = torch.empty((n, C), dtype=torch.float16, device=dev)
     d_edge = torch.empty((n, C), dtype=torch.float16, device=dev)
-    acc = torch.zeros((C + 128,), dtype=torch.float32, device=dev)
+    acc = torch.empty((C + 128,), dtype=torch.float32, device=dev)      # zeroed by the entry point
     call("tscd_se_fuse_bwd_f16", reg.data_ptr(), reg.stride(0), edge.data_ptr(), edge.stride(0), w0.data_ptr(), w2.data_ptr(),
          d_out.data_ptr(), n, C, d_reg.data_ptr(), d_edge.data_ptr(), acc.data_ptr(), acc[C:].data_ptr(), acc[C + 64:].data_ptr(),
          _stream())
@@ -614,7 +615,7 @@ def add_layernorm_bwd(a, b, gamma, d_out, eps=1e-5):
     dev = a.device
     assert a.is_contiguous() and (b is None or b.is_contiguous()) and d_out.is_contiguous() and d_out.dtype == torch.float16
     dx = torch.empty((n, C), dtype=torch.float16, device=dev)
-    acc = torch.zeros((2, C), dtype=torch.float32, device=dev)
+    acc = torch.empty((2, C), dtype=torch.float32, device=dev)          # zeroed by the entry point
     call("tscd_add_layernorm_bwd_f16", a.data_ptr(), _ptr(b), gamma.data_ptr(), d_out.data_ptr(), n, C, eps, dx.data_ptr(),
          acc[0].data_ptr(), acc[1].data_ptr(), _stream())
     return dx, acc[0], acc[1]

@@ -95,18 +95,18 @@ class _CosAttentionMFMA(torch.autograd.Function):
     """Matrix-core path (attn_mfma.hip): the forward also returns the softmax denominators the backward re-uses."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, tiles32):
+    def forward(ctx, q, k, v, heads, tiles32, full):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        out, lsum = ops.cos_attn_mfma(q, k, v, heads, tiles32)
+        out, lsum = ops.cos_attn_mfma(q, k, v, heads, tiles32, full)
         ctx.save_for_backward(q, k, v, tiles32, out, lsum)
-        ctx.heads = heads
+        ctx.heads, ctx.full = heads, full
         return out
 
     @staticmethod
     def backward(ctx, g):
         q, k, v, tiles32, out, lsum = ctx.saved_tensors
-        dq, dk, dv = ops.cos_attn_mfma_bwd(q, k, v, g.to(torch.float16).contiguous(), out, lsum, ctx.heads, tiles32)
-        return dq, dk, dv, None, None
+        dq, dk, dv = ops.cos_attn_mfma_bwd(q, k, v, g.to(torch.float16).contiguous(), out, lsum, ctx.heads, tiles32, ctx.full)
+        return dq, dk, dv, None, None, None
 
 
 def cos_attention(q, k, v, heads, segments):
@@ -114,9 +114,10 @@ def cos_attention(q, k, v, heads, segments):
     grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
     if ops.cos_attn_uses_mfma(q.shape[1], heads):
         tiles = ops.attn_tiles(segments, q.device, rows=32)
+        full = sum(seg[1] for seg in segments) == q.shape[0]      # every query row is in some tile: outputs need no zero fill
         if grad:
-            return _CosAttentionMFMA.apply(q, k, v, heads, tiles)
-        return ops.cos_attn_mfma(q.contiguous(), k.contiguous(), v.contiguous(), heads, tiles)[0]
+            return _CosAttentionMFMA.apply(q, k, v, heads, tiles, full)
+        return ops.cos_attn_mfma(q.contiguous(), k.contiguous(), v.contiguous(), heads, tiles, full)[0]
     tiles = ops.attn_tiles(segments, q.device)
     if grad:
         return _CosAttention.apply(q, k, v, heads, tiles)
@@ -379,7 +380,9 @@ class AwarePositionRegMatcher(nn.Module):
         plan, spans, preds_per_frame, resume = prep["plan"], prep["spans"], prep["ppf"], prep["resume"]
         features_reg, features_cls = prep["features_reg"], prep["features_cls"]
         t_emb = linear(time_embedding.to(torch.float16).contiguous(), self.absolute_position_embedding)
-        t_rows = t_emb.unbind(0)            # one stack in backward instead of a zero-filled slice gradient per use
+        # fp32 rows (the SE gate takes fp32 position vectors: one cast here instead of one per use and per gradient); unbind:
+        # one stack in backward instead of a zero-filled slice gradient per use
+        t_rows = t_emb.float().unbind(0)
         self.last_hungarian = []
         solved = prep["chain"].result() if prep["chain"] is not None else []
 
