@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)       # >= 50 timed iterations
+    ap.add_argument("--warmup", type=int, default=10)     # 10 warm-up iterations
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--lframe", type=int, default=4)
     ap.add_argument("--size", type=int, default=576)
