@@ -90,6 +90,11 @@ int tscd_maxpool_nhwc_f16(const void* src, int lds_, void* dst, int ldd, int B, 
 int tscd_haar_hf_nhwc_f16(const void* x, int ldx, void* hf, int B, int H, int W, int C, void* stream);
 int tscd_haar_idwt_mul_nhwc_f16(const void* hf, const void* content, int ldc, void* out, int ldo, int B, int H, int W,
                                 int C, void* stream);
+/* Backward of the two Haar steps (DWT_Function.backward / IDWT_Function.backward, surrounding_extraction.py:30-41,60-76):
+ * d haar_hf = tscd_haar_idwt_mul_nhwc_f16 with content == NULL (the synthesis with LL = 0 is the adjoint of the analysis);
+ * out = content * idwt(hf)  =>  dcontent = d * idwt(hf), dhf = dwt_hf(d * content) in one pass. */
+int tscd_haar_idwt_mul_bwd_nhwc_f16(const void* d, const void* hf, const void* content, int ldc, void* dcontent, void* dhf,
+                                    int B, int H, int W, int C, void* stream);
 
 /* ---- proposal stage: decode_outputs (tscd_head.py:755-770), postprocess_widx (tscd_head.py:1546-1693),
  * find_feature_score (tscd_head.py:976-1006).  hw3/w3/stride3 are (host) int[3]; maps is a (host) array of 9 device

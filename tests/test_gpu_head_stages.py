@@ -235,7 +235,8 @@ def test_wavelet_block_vs_reference_golden(golden):
 
 
 def test_trainable_tower_backward_matches_oracle_autograd():
-    """conv -> train-mode BN -> SiLU (x2) + wavelet block: HIP forward, composed backward vs the oracle's autograd."""
+    """conv -> train-mode BN -> SiLU (x2) + wavelet block: HIP forward and HIP backward (conv wgrad/dgrad, BN+SiLU, both Haar steps)
+    vs the oracle's autograd."""
     from yolox.models.network_blocks import BaseConv
     from yolox.models.surrounding_extraction import WaveletsHFBlock
     g = torch.Generator().manual_seed(0)

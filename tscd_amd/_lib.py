@@ -21,6 +21,7 @@ SIGNATURES = {
     "tscd_maxpool_nhwc_f16": [P, I, P, I, I, I, I, I, I, P],
     "tscd_haar_hf_nhwc_f16": [P, I, P, I, I, I, I, P],
     "tscd_haar_idwt_mul_nhwc_f16": [P, P, I, P, I, I, I, I, I, P],
+    "tscd_haar_idwt_mul_bwd_nhwc_f16": [P, P, P, I, P, P, I, I, I, I, P],
     "tscd_decode_score": [P, P, P, P, P, P, I, I, P, P, P, P],
     "tscd_select_proposals": [P, I, I, F, I, I, I, P, P, P],
     "tscd_gather_rows": [P, P, P, I, P, I, I, I, I, P, P, P, I, P],

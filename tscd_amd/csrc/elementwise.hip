@@ -359,22 +359,80 @@ __global__ void haar_idwt_mul_kernel(const f16* __restrict__ hf, const f16* __re
     for (int q = 0; q < 4; ++q) {
       int dy = q >> 1, dx = q & 1;
       long pp = p00 + (long)dy * W + dx;
-      f16x8 cc = *(const f16x8*)(content + pp * ldc + c);
+      f16x8 cc;
+      if (content) cc = *(const f16x8*)(content + pp * ldc + c);
       f16x8 o;
       float s_lh = dy ? -0.5f : 0.5f, s_hl = dx ? -0.5f : 0.5f, s_hh = (dx ^ dy) ? -0.5f : 0.5f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         f16 rec = (f16)(s_lh * (float)lh[e] + s_hl * (float)hl[e] + s_hh * (float)hh[e]);
-        o[e] = (f16)((float)cc[e] * (float)rec);
+        o[e] = content ? (f16)((float)cc[e] * (float)rec) : rec;
       }
       *(f16x8*)(out + pp * ldo + c) = o;
     }
   }
 }
+// backward of out = content * idwt(hf): dcontent = d * idwt(hf), dhf = dwt_hf(d * content) (IDWT_Function.backward,
+// surrounding_extraction.py:60-76); one pass over the 2x2 blocks
+__global__ void haar_idwt_mul_bwd_kernel(const f16* __restrict__ d, const f16* __restrict__ hf, const f16* __restrict__ content, int ldc,
+                                         f16* __restrict__ dcontent, f16* __restrict__ dhf, int B, int H, int W, int C) {
+  const int cv = C >> 3, Ho = H >> 1, Wo = W >> 1;
+  const long total = (long)B * Ho * Wo * cv;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int c = (int)(idx % cv) << 3;
+    long pix = idx / cv;
+    int wo = pix % Wo;
+    long t = pix / Wo;
+    int ho = t % Ho, b = t / Ho;
+    const f16* h = hf + pix * (3L * C) + c;
+    f16x8 lh = *(const f16x8*)h, hl = *(const f16x8*)(h + C), hh = *(const f16x8*)(h + 2 * C);
+    float glh[8], ghl[8], ghh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) glh[e] = ghl[e] = ghh[e] = 0.f;
+    long p00 = ((long)b * H + 2 * ho) * W + 2 * wo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int dy = q >> 1, dx = q & 1;
+      long pp = p00 + (long)dy * W + dx;
+      f16x8 cc = *(const f16x8*)(content + pp * ldc + c), dd = *(const f16x8*)(d + pp * (long)C + c), o;
+      float s_lh = dy ? -0.5f : 0.5f, s_hl = dx ? -0.5f : 0.5f, s_hh = (dx ^ dy) ? -0.5f : 0.5f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        f16 rec = (f16)(s_lh * (float)lh[e] + s_hl * (float)hl[e] + s_hh * (float)hh[e]);
+        o[e] = (f16)((float)dd[e] * (float)rec);
+        float g = (float)dd[e] * (float)cc[e];
+        glh[e] += s_lh * g;
+        ghl[e] += s_hl * g;
+        ghh[e] += s_hh * g;
+      }
+      *(f16x8*)(dcontent + pp * (long)C + c) = o;
+    }
+    f16x8 o1, o2, o3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o1[e] = (f16)glh[e]; o2[e] = (f16)ghl[e]; o3[e] = (f16)ghh[e]; }
+    f16* oh = dhf + pix * (3L * C) + c;
+    *(f16x8*)(oh) = o1;
+    *(f16x8*)(oh + C) = o2;
+    *(f16x8*)(oh + 2 * C) = o3;
+  }
+}
+// d, dcontent: contiguous [B,H,W,C]; hf, dhf: contiguous [B,H/2,W/2,3C]; content: pixel stride ldc
+extern "C" int tscd_haar_idwt_mul_bwd_nhwc_f16(const void* d, const void* hf, const void* content, int ldc, void* dcontent, void* dhf,
+                                               int B, int H, int W, int C, void* stream) {
+  TSCD_CHECK_ARG(d && hf && content && dcontent && dhf && C % 8 == 0 && ldc % 8 == 0 && H % 2 == 0 && W % 2 == 0,
+                 "haar_idwt_mul_bwd: bad args");
+  hipLaunchKernelGGL(haar_idwt_mul_bwd_kernel, dim3(ew_grid((long)B * (H / 2) * (W / 2) * (C / 8))), dim3(EW_BLOCK), 0,
+                     (hipStream_t)stream, (const f16*)d, (const f16*)hf, (const f16*)content, ldc, (f16*)dcontent, (f16*)dhf, B, H, W,
+                     C);
+  TSCD_CHECK_LAUNCH("haar_idwt_mul_bwd");
+  return TSCD_OK;
+}
+
 extern "C" int tscd_haar_idwt_mul_nhwc_f16(const void* hf, const void* content, int ldc, void* out, int ldo, int B, int H, int W,
                                            int C, void* stream) {
-  TSCD_CHECK_ARG(hf && content && out && C % 8 == 0 && ldc % 8 == 0 && ldo % 8 == 0 && H % 2 == 0 && W % 2 == 0,
-                 "haar_idwt_mul: bad args");
+  // content may be NULL: plain inverse transform with LL = 0 -- which is also the adjoint of haar_hf (DWT_Function.backward,
+  // surrounding_extraction.py:30-41), i.e. its backward
+  TSCD_CHECK_ARG(hf && out && C % 8 == 0 && ldc % 8 == 0 && ldo % 8 == 0 && H % 2 == 0 && W % 2 == 0, "haar_idwt_mul: bad args");
   hipLaunchKernelGGL(haar_idwt_mul_kernel, dim3(ew_grid((long)B * (H / 2) * (W / 2) * (C / 8))), dim3(EW_BLOCK), 0,
                      (hipStream_t)stream, (const f16*)hf, (const f16*)content, ldc, (f16*)out, ldo, B, H, W, C);
   TSCD_CHECK_LAUNCH("haar_idwt_mul");

@@ -123,38 +123,21 @@ class _HaarHF(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d):
-        # adjoint of the analysis step (DWT_Function.backward, surrounding_extraction.py:30-41)
-        B, h, w, C3 = d.shape
-        C = C3 // 3
-        lh, hl, hh = d[..., :C].float(), d[..., C:2 * C].float(), d[..., 2 * C:].float()
-        dx = d.new_empty(B, 2 * h, 2 * w, C)
-        dx[:, 0::2, 0::2] = (0.5 * (lh + hl + hh)).half()
-        dx[:, 0::2, 1::2] = (0.5 * (lh - hl - hh)).half()
-        dx[:, 1::2, 0::2] = (0.5 * (-lh + hl - hh)).half()
-        dx[:, 1::2, 1::2] = (0.5 * (-lh - hl + hh)).half()
-        return dx
+        # adjoint of the analysis step = synthesis with LL = 0 (DWT_Function.backward, surrounding_extraction.py:30-41)
+        return ops.haar_idwt(d.to(torch.float16).contiguous())
 
 
 class _HaarIdwtMul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hf, content):
+        hf = hf.contiguous()
         ctx.save_for_backward(hf, content)
-        return ops.haar_idwt_mul(hf.contiguous(), content)
+        return ops.haar_idwt_mul(hf, content)
 
     @staticmethod
     def backward(ctx, d):
         hf, content = ctx.saved_tensors
-        B, H, W, C = content.shape
-        lh, hl, hh = hf[..., :C].float(), hf[..., C:2 * C].float(), hf[..., 2 * C:].float()
-        rec = content.new_empty(B, H, W, C)
-        rec[:, 0::2, 0::2] = (0.5 * (lh + hl + hh)).half()
-        rec[:, 0::2, 1::2] = (0.5 * (lh - hl - hh)).half()
-        rec[:, 1::2, 0::2] = (0.5 * (-lh + hl - hh)).half()
-        rec[:, 1::2, 1::2] = (0.5 * (-lh - hl + hh)).half()
-        dcontent = d * rec
-        g = (d.float() * content.float())
-        a, b, c, e = g[:, 0::2, 0::2], g[:, 0::2, 1::2], g[:, 1::2, 0::2], g[:, 1::2, 1::2]
-        dhf = torch.cat((0.5 * (a + b - c - e), 0.5 * (a - b + c - e), 0.5 * (a - b - c + e)), -1).half()
+        dhf, dcontent = ops.haar_idwt_mul_bwd(d.to(torch.float16).contiguous(), hf, content)
         return dhf, dcontent
 
 

@@ -215,6 +215,27 @@ def haar_idwt_mul(hf, content, out=None):
     return out
 
 
+def haar_idwt(hf):
+    """Inverse Haar transform with LL = 0: [B,h,w,3C] -> [B,2h,2w,C]; also the backward (adjoint) of haar_hf."""
+    assert hf.is_contiguous() and hf.dtype == torch.float16
+    B, h, w, C3 = hf.shape
+    C = C3 // 3
+    out = empty_nhwc(B, 2 * h, 2 * w, C, hf.device)
+    call("tscd_haar_idwt_mul_nhwc_f16", hf.data_ptr(), 0, C, out.data_ptr(), C, B, 2 * h, 2 * w, C, _stream())
+    return out
+
+
+def haar_idwt_mul_bwd(d, hf, content):
+    """-> (dhf [B,h,w,3C], dcontent [B,H,W,C]) for out = content * idwt(hf)."""
+    B, H, W, C = content.shape
+    assert d.is_contiguous() and hf.is_contiguous() and d.dtype == torch.float16 and tuple(d.shape) == (B, H, W, C)
+    dcontent = empty_nhwc(B, H, W, C, d.device)
+    dhf = torch.empty_like(hf)
+    call("tscd_haar_idwt_mul_bwd_nhwc_f16", d.data_ptr(), hf.data_ptr(), content.data_ptr(), nhwc_ld(content), dcontent.data_ptr(),
+         dhf.data_ptr(), B, H, W, C, _stream())
+    return dhf, dcontent
+
+
 # ----------------------------------------------------------------------------------------------------
 # GEMM (nn.Linear) on the conv kernel
 # ----------------------------------------------------------------------------------------------------
