@@ -58,11 +58,11 @@ int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw, int B, in
                              int ldx, int lddy, void* workspace, long workspace_bytes, void* stream);
 long tscd_bn_silu_bwd_workspace_bytes(long M, int C);
 /* Backward of an nn.Linear (y = x W^T + b) in one host call: dx = dY W (MFMA GEMM on W packed in data-gradient order),
- * dw = dY^T x (pixel-axis wgrad GEMM), db = column sums.  dY [n][outp] is contiguous fp16 with outp = out_f rounded up to 8
+ * dw = dY^T x (pixel-axis wgrad GEMM), db = column sums.  dY [n][outp] is fp16 with row stride lddy and outp = out_f rounded up to 8
  * (extra columns zero); dx [n][in_f] fp16, dw [outp][in_f] fp32, db [out_f] fp32; any output may be NULL. */
 long tscd_linear_bwd_workspace_bytes(int n, int in_f, int outp);
-int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, const void* w, int w_is_f32, int n, int in_f, int out_f, int outp,
-                        void* dx, float* dw, float* db, void* workspace, long workspace_bytes, void* stream);
+int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, int lddy, const void* w, int w_is_f32, int n, int in_f, int out_f,
+                        int outp, void* dx, float* dw, float* db, void* workspace, long workspace_bytes, void* stream);
 int tscd_bn_silu_bwd_f16(const void* dy, const void* raw, const float* scale_shift, const float* mean,
                          const float* invstd, const float* gamma, long M, int C, void* draw, float* sums_out,
                          void* workspace, long workspace_bytes, void* stream);

@@ -343,12 +343,14 @@ static long linear_bwd_pack_bytes(int in_f, int outp) {
 extern "C" long tscd_linear_bwd_workspace_bytes(int n, int in_f, int outp) {
   return linear_bwd_pack_bytes(in_f, outp) + tscd_conv_wgrad_workspace_bytes(n, outp, in_f, 1);
 }
-// x [n][in_f] (row stride ldx), dY [n][outp] contiguous fp16 (outp % 8 == 0; columns >= out_f zero), w [out_f][in_f] fp32 or
-// fp16.  Outputs (each may be NULL): dx [n][in_f] fp16 contiguous, dw [outp][in_f] fp32, db [out_f] fp32.
-extern "C" int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, const void* w, int w_is_f32, int n, int in_f, int out_f,
-                                   int outp, void* dx, float* dw, float* db, void* workspace, long workspace_bytes, void* stream) {
+// x [n][in_f] (row stride ldx), dY [n][outp] fp16 with row stride lddy (outp % 8 == 0; columns >= out_f zero), w [out_f][in_f]
+// fp32 or fp16.  Outputs (each may be NULL): dx [n][in_f] fp16 contiguous, dw [outp][in_f] fp32, db [out_f] fp32.
+extern "C" int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, int lddy, const void* w, int w_is_f32, int n, int in_f,
+                                   int out_f, int outp, void* dx, float* dw, float* db, void* workspace, long workspace_bytes,
+                                   void* stream) {
   TSCD_CHECK_ARG(x && dy && w && workspace && n > 0, "linear_bwd: bad args");
-  TSCD_CHECK_ARG(outp % 8 == 0 && outp >= out_f && in_f % 8 == 0, "linear_bwd: in_f / padded out_f must be multiples of 8");
+  TSCD_CHECK_ARG(outp % 8 == 0 && outp >= out_f && in_f % 8 == 0 && lddy % 8 == 0 && lddy >= outp,
+                 "linear_bwd: in_f / padded out_f / lddy must be multiples of 8");
   TSCD_CHECK_ARG(workspace_bytes >= tscd_linear_bwd_workspace_bytes(n, in_f, outp), "linear_bwd: workspace too small");
   const long pack_bytes = linear_bwd_pack_bytes(in_f, outp);
   int st;
@@ -357,17 +359,17 @@ extern "C" int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, const
     const int rows_pad = cdiv(in_f, bn) * bn, kpad = cdiv(outp, 32) * 32;
     // data-gradient packing of a 1x1 "conv": rows = in_f, k = out channel (CinPad carries the padded out count)
     if ((st = tscd_pack_conv_weight(w, w_is_f32, workspace, out_f, in_f, outp, 1, 1, rows_pad, kpad, 1, stream)) != TSCD_OK) return st;
-    if ((st = tscd_conv2d_nhwc_f16(dy, workspace, dx, nullptr, nullptr, nullptr, nullptr, 1, 1, n, outp, in_f, 1, 1, outp, in_f, 0,
+    if ((st = tscd_conv2d_nhwc_f16(dy, workspace, dx, nullptr, nullptr, nullptr, nullptr, 1, 1, n, outp, in_f, 1, 1, lddy, in_f, 0,
                                    stream)) != TSCD_OK)
       return st;
   }
   if (dw) {
     char* ws2 = (char*)workspace + pack_bytes;
-    if ((st = tscd_conv_wgrad_nhwc_f16(x, dy, dw, 1, 1, n, in_f, outp, 1, ldx, outp, ws2, workspace_bytes - pack_bytes, stream)) != TSCD_OK)
+    if ((st = tscd_conv_wgrad_nhwc_f16(x, dy, dw, 1, 1, n, in_f, outp, 1, ldx, lddy, ws2, workspace_bytes - pack_bytes, stream)) != TSCD_OK)
       return st;
   }
   if (db) {
-    hipLaunchKernelGGL(col_sum_f16_kernel, dim3(cdiv(out_f, 64)), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, n, outp, out_f, db);
+    hipLaunchKernelGGL(col_sum_f16_kernel, dim3(cdiv(out_f, 64)), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, n, lddy, out_f, db);
     TSCD_CHECK_LAUNCH("linear_bwd col_sum");
   }
   return TSCD_OK;

@@ -480,7 +480,7 @@ def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False):
     n, in_f = x.shape
     out_f = weight.shape[0]
     outp = (out_f + 7) // 8 * 8
-    if outp != out_f or not dy.is_contiguous():
+    if outp != out_f or dy.stride(1) != 1 or dy.stride(0) % 8 != 0 or dy.data_ptr() % 16 != 0:
         d2 = dy.new_zeros((n, outp))
         d2[:, :out_f] = dy
         dy = d2
@@ -495,8 +495,8 @@ def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False):
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
-    call("tscd_linear_bwd_f16", x.data_ptr(), x.stride(0), dy.data_ptr(), w.data_ptr(), int(w.dtype == torch.float32), n, in_f, out_f,
-         outp, _ptr(dx), _ptr(dw), _ptr(db), ws.data_ptr(), ws_bytes, _stream())
+    call("tscd_linear_bwd_f16", x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), w.data_ptr(), int(w.dtype == torch.float32), n,
+         in_f, out_f, outp, _ptr(dx), _ptr(dw), _ptr(db), ws.data_ptr(), ws_bytes, _stream())
     return dx, (None if dw is None else dw[:out_f]), db
 
 
