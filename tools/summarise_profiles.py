@@ -3,7 +3,8 @@ import csv, glob, json, collections, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01h"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # repo root (this file lives in tools/)
 fin = os.path.join(root, "gpurun_out", "final")
-stats = glob.glob(os.path.join(fin, "stats", "*", "*kernel_stats.csv"))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # gpurun merges runs into the same directory
+stats = newest(os.path.join(fin, "stats", "*", "*kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(root, "profiles", f"{tag}_bench_kernel_stats.csv"), "w") as out:
     out.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline   "
@@ -21,8 +22,8 @@ def load(path):
             key = (nm.split("(")[0], int(r["Grid_Size"]))
             dom[key][0] += 1; dom[key][1] += v
     return agg, dom
-fa, fd = load(glob.glob(os.path.join(fin, "pmc_fetch", "*", "*counter_collection.csv"))[0])
-wa, wd = load(glob.glob(os.path.join(fin, "pmc_write", "*", "*counter_collection.csv"))[0])
+fa, fd = load(newest(os.path.join(fin, "pmc_fetch", "*", "*counter_collection.csv")))
+wa, wd = load(newest(os.path.join(fin, "pmc_write", "*", "*counter_collection.csv")))
 n = fa["all"][0]; f = fa["all"][1] / n; w = wa["all"][1] / wa["all"][0]
 # dominant shape: B16 72x72 256->256 3x3 -> 648 workgroups x 512 threads of the 128x256 variant
 dk = [k for k in fd if "v3" in k[0] and k[1] == 648 * 512]

@@ -41,6 +41,7 @@ SIGNATURES = {
     "tscd_batched_nms": [P, I, P, I, P, P, P, I, F, F, I, I, P, L, P, P, P, P, P],
     "tscd_conv_wgrad_nhwc_f16": [P, P, P, I, I, I, I, I, I, I, I, P, L, P],
     "tscd_bn_silu_bwd_f16": [P, P, P, P, P, P, L, I, P, P, P, L, P],
+    "tscd_bias_relu_bwd_f16": [P, I, P, I, P, I, L, I, P, P],
     "tscd_linear_bwd_f16": [P, I, P, I, P, I, I, I, I, I, P, P, P, P, L, P],
     "tscd_simota_assign": [P, P, I, I, I, I, I, P, P, P, I, I, P, L, P, P, P, P, P, P],
 }

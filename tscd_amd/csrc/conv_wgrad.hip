@@ -322,16 +322,69 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
                                     int epilogue, void* stream);
 extern "C" int tscd_conv_tile_n(int cout);
 
-__global__ void col_sum_f16_kernel(const f16* __restrict__ g, int n, int ld, int C, float* __restrict__ out) {
-  // one wave per 64 columns; rows strided over the block's waves, combined through LDS in a fixed order
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
-  float a = 0.f;
-  if (c < C)
-    for (int r = wave; r < n; r += 4) a += (float)g[(long)r * ld + c];
-  red[wave][lane] = a;
+// db[c] += sum over rows of g[r][c] (optionally masked by y[r][c] > 0, in which case the masked gradient is also written):
+// the bias gradient of a Linear / biased conv and, with the mask, the backward of the fused ReLU.  A thread keeps one
+// 8-channel chunk, strides the block's rows, the row groups are combined through LDS, one fp32 atomic per column and block.
+__global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const f16* __restrict__ g, int ldg, const f16* __restrict__ y, int ldy,
+                                                            f16* __restrict__ gm, int ldm, long M, int C, int cv, int rpb,
+                                                            long rows_per_block, float* __restrict__ db) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x, c8 = tid % cv, rg = tid / cv;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const long r0 = blockIdx.x * rows_per_block, r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  if (rg < rpb) {
+    for (int cc = c8; cc < (C >> 3); cc += cv) {        // cv < C/8 only for C > 2048
+      const int c = cc << 3;
+      for (long r = r0 + rg; r < r1; r += rpb) {
+        f16x8 v = *(const f16x8*)(g + r * ldg + c);
+        if (y) {
+          f16x8 yy = *(const f16x8*)(y + r * ldy + c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (float)yy[e] > 0.f ? v[e] : (f16)0.f;
+          *(f16x8*)(gm + r * ldm + c) = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+      }
+      if (cv < (C >> 3)) {                               // wide case: flush per chunk
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomicAdd(db + c + e, acc[e]); acc[e] = 0.f; }
+      }
+    }
+  }
+  if (cv < (C >> 3)) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = (rg < rpb) ? acc[e] : 0.f;
   __syncthreads();
-  if (wave == 0 && c < C) out[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  if (tid < cv) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = 0.f;
+      for (int q = 0; q < rpb; ++q) a += red[(q * cv + tid) * 8 + e];
+      atomicAdd(db + tid * 8 + e, a);
+    }
+  }
+}
+// g [M][C] (row stride ldg), optional y (row stride ldy) and masked-gradient output gm (row stride ldm); db [C] fp32 is cleared
+// here.  C % 8 == 0.
+extern "C" int tscd_bias_relu_bwd_f16(const void* g, int ldg, const void* y, int ldy, void* gm, int ldm, long M, int C, float* db,
+                                      void* stream) {
+  TSCD_CHECK_ARG(g && db && C % 8 == 0 && ldg % 8 == 0 && (!y || (gm && ldy % 8 == 0 && ldm % 8 == 0)), "bias_relu_bwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(db, 0, sizeof(float) * C, st);
+  if (M == 0) return TSCD_OK;
+  int cv = C / 8;
+  if (cv > 256) cv = 256;
+  const int rpb = 256 / cv;
+  long rows_per_block = (long)rpb * 16;
+  long nblk = (M + rows_per_block - 1) / rows_per_block;
+  if (nblk > 2048) { nblk = 2048; rows_per_block = (M + nblk - 1) / nblk; }
+  hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const f16*)g, ldg, (const f16*)y, ldy, (f16*)gm, ldm,
+                     M, C, cv, rpb, rows_per_block, db);
+  TSCD_CHECK_LAUNCH("bias_relu_bwd");
+  return TSCD_OK;
 }
 
 static long linear_bwd_pack_bytes(int in_f, int outp) {
@@ -344,7 +397,7 @@ extern "C" long tscd_linear_bwd_workspace_bytes(int n, int in_f, int outp) {
   return linear_bwd_pack_bytes(in_f, outp) + tscd_conv_wgrad_workspace_bytes(n, outp, in_f, 1);
 }
 // x [n][in_f] (row stride ldx), dY [n][outp] fp16 with row stride lddy (outp % 8 == 0; columns >= out_f zero), w [out_f][in_f]
-// fp32 or fp16.  Outputs (each may be NULL): dx [n][in_f] fp16 contiguous, dw [outp][in_f] fp32, db [out_f] fp32.
+// fp32 or fp16.  Outputs (each may be NULL): dx [n][in_f] fp16 contiguous, dw [outp][in_f] fp32, db [outp] fp32.
 extern "C" int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, int lddy, const void* w, int w_is_f32, int n, int in_f,
                                    int out_f, int outp, void* dx, float* dw, float* db, void* workspace, long workspace_bytes,
                                    void* stream) {
@@ -368,9 +421,6 @@ extern "C" int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, int l
     if ((st = tscd_conv_wgrad_nhwc_f16(x, dy, dw, 1, 1, n, in_f, outp, 1, ldx, lddy, ws2, workspace_bytes - pack_bytes, stream)) != TSCD_OK)
       return st;
   }
-  if (db) {
-    hipLaunchKernelGGL(col_sum_f16_kernel, dim3(cdiv(out_f, 64)), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, n, lddy, out_f, db);
-    TSCD_CHECK_LAUNCH("linear_bwd col_sum");
-  }
+  if (db && (st = tscd_bias_relu_bwd_f16(dy, lddy, nullptr, 0, nullptr, 0, n, outp, db, stream)) != TSCD_OK) return st;   // db: outp floats
   return TSCD_OK;
 }

@@ -100,10 +100,19 @@ class _ConvBias(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
-        if ctx.relu:
-            dy = dy * (y > 0)
+        dy = dy.to(torch.float16)
+        C = dy.shape[-1]
+        db = None
+        if C % 8 == 0 and (ctx.relu or ctx.needs_input_grad[2]):
+            # ReLU mask and bias gradient in one pass over dy (one kernel instead of compare, multiply, cast and reduce)
+            dy, db = ops.bias_relu_bwd(dy.contiguous(), y if ctx.relu else None)
+        else:
+            if ctx.relu:
+                dy = dy * (y > 0)
+            db = dy.float().sum((0, 1, 2)) if ctx.needs_input_grad[2] else None
         dx, dw = _conv_backward(dy.contiguous(), x, weight, 1, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        db = dy.float().sum((0, 1, 2)) if ctx.needs_input_grad[2] else None
+        if db is not None:
+            db = db.to(weight.dtype) if ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 
 

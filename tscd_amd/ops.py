@@ -487,7 +487,7 @@ def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False):
     dev = x.device
     dx = torch.empty((n, in_f), dtype=torch.float16, device=dev) if need_dx else None
     dw = torch.empty((outp, in_f), dtype=torch.float32, device=dev) if need_dw else None
-    db = torch.empty((out_f,), dtype=torch.float32, device=dev) if need_db else None
+    db = torch.empty((outp,), dtype=torch.float32, device=dev) if need_db else None
     if n == 0:
         return (dx, None if dw is None else dw.zero_()[:out_f], None if db is None else db.zero_())
     ws_bytes = lib.tscd_linear_bwd_workspace_bytes(n, in_f, outp)
@@ -497,7 +497,24 @@ def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False):
         w = w.contiguous()
     call("tscd_linear_bwd_f16", x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), w.data_ptr(), int(w.dtype == torch.float32), n,
          in_f, out_f, outp, _ptr(dx), _ptr(dw), _ptr(db), ws.data_ptr(), ws_bytes, _stream())
-    return dx, (None if dw is None else dw[:out_f]), db
+    return dx, (None if dw is None else dw[:out_f]), (None if db is None else db[:out_f])
+
+
+def bias_relu_bwd(dy, y=None):
+    """Bias gradient of a biased conv / Linear, through the mask of its fused ReLU when ``y`` (the activation output) is given:
+    -> (masked dy fp16 (dy itself without a mask), db fp32 [C]).  dy / y: [..., C] fp16 with unit channel stride, NHWC(-slice)."""
+    C = dy.shape[-1]
+    M = dy.numel() // C
+    assert dy.dtype == torch.float16 and C % 8 == 0
+    ldg = nhwc_ld(dy) if dy.dim() == 4 else dy.stride(0)
+    db = torch.empty((C,), dtype=torch.float32, device=dy.device)
+    if y is None:
+        call("tscd_bias_relu_bwd_f16", dy.data_ptr(), ldg, 0, 0, 0, 0, M, C, db.data_ptr(), _stream())
+        return dy, db
+    gm = torch.empty(dy.shape, dtype=torch.float16, device=dy.device)
+    ldy = nhwc_ld(y) if y.dim() == 4 else y.stride(0)
+    call("tscd_bias_relu_bwd_f16", dy.data_ptr(), ldg, y.data_ptr(), ldy, gm.data_ptr(), C, M, C, db.data_ptr(), _stream())
+    return gm, db
 
 
 def linear_wgrad(x, dy):
