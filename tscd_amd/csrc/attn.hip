@@ -520,34 +520,69 @@ extern "C" int tscd_se_fuse_bwd_f16(const void* reg, int ldr, const void* edge, 
 }
 
 // add_layernorm backward: y = LN(a (+ b)) * gamma + beta.  dx (= da = db) fp16; dgamma / dbeta fp32 atomics (zeroed by caller).
-__global__ void add_layernorm_bwd_kernel(const f16* __restrict__ a, const f16* __restrict__ b, const float* __restrict__ gamma,
-                                         const f16* __restrict__ dy, int n, int C, float eps, f16* __restrict__ dx,
-                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (row >= n) return;
-  float s = 0.f, s2 = 0.f;
-  for (int c = lane; c < C; c += 64) {
-    float x = (float)a[(long)row * C + c];
-    if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
-    s += x; s2 += x * x;
+// One wave per row, rows strided over the grid; every lane keeps the d gamma / d beta partial sums of its columns
+// (c = lane + 64 k, k < 16) in registers for all its rows, the block's four waves are combined through LDS, and each block adds
+// ONE fp32 atomic per column (a per-element atomic was 4M atomics for TaskAligned's 2000 x 1024).
+#define LN_BWD_NC 16
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const f16* __restrict__ a, const f16* __restrict__ b,
+                                                                const float* __restrict__ gamma, const f16* __restrict__ dy, int n, int C,
+                                                                float eps, f16* __restrict__ dx, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = gridDim.x * 4;
+  float ag[LN_BWD_NC], ab[LN_BWD_NC];
+#pragma unroll
+  for (int k = 0; k < LN_BWD_NC; ++k) ag[k] = ab[k] = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < n; row += nwaves) {
+    float s = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      float x = (float)a[(long)row * C + c];
+      if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
+      s += x; s2 += x * x;
+    }
+    s = wave_sum(s); s2 = wave_sum(s2);
+    float mean = s / C, var = fmaxf(s2 / C - mean * mean, 0.f), inv = 1.0f / sqrtf(var + eps);
+    float m1 = 0.f, m2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      float x = (float)a[(long)row * C + c];
+      if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
+      float xh = (x - mean) * inv, g = (float)dy[(long)row * C + c] * gamma[c];
+      m1 += g; m2 += g * xh;
+    }
+    m1 = wave_sum(m1) / C; m2 = wave_sum(m2) / C;
+#pragma unroll
+    for (int k = 0; k < LN_BWD_NC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < C) {
+        float x = (float)a[(long)row * C + c];
+        if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
+        float xh = (x - mean) * inv, d = (float)dy[(long)row * C + c];
+        dx[(long)row * C + c] = (f16)(inv * (d * gamma[c] - m1 - xh * m2));
+        ag[k] += d * xh;
+        ab[k] += d;
+      }
+    }
+    for (int c = lane + 64 * LN_BWD_NC; c < C; c += 64) {        // C > 1024: the tail falls back to per-element atomics
+      float x = (float)a[(long)row * C + c];
+      if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
+      float xh = (x - mean) * inv, d = (float)dy[(long)row * C + c];
+      dx[(long)row * C + c] = (f16)(inv * (d * gamma[c] - m1 - xh * m2));
+      atomicAdd(dgamma + c, d * xh);
+      atomicAdd(dbeta + c, d);
+    }
   }
-  s = wave_sum(s); s2 = wave_sum(s2);
-  float mean = s / C, var = fmaxf(s2 / C - mean * mean, 0.f), inv = 1.0f / sqrtf(var + eps);
-  float m1 = 0.f, m2 = 0.f;
-  for (int c = lane; c < C; c += 64) {
-    float x = (float)a[(long)row * C + c];
-    if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
-    float xh = (x - mean) * inv, g = (float)dy[(long)row * C + c] * gamma[c];
-    m1 += g; m2 += g * xh;
-  }
-  m1 = wave_sum(m1) / C; m2 = wave_sum(m2) / C;
-  for (int c = lane; c < C; c += 64) {
-    float x = (float)a[(long)row * C + c];
-    if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
-    float xh = (x - mean) * inv, d = (float)dy[(long)row * C + c];
-    dx[(long)row * C + c] = (f16)(inv * (d * gamma[c] - m1 - xh * m2));
-    atomicAdd(dgamma + c, d * xh);
-    atomicAdd(dbeta + c, d);
+#pragma unroll
+  for (int k = 0; k < LN_BWD_NC; ++k) {
+    const int c = lane + 64 * k;
+    if (64 * k >= C) break;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+      red[wave][lane] = pass ? ab[k] : ag[k];
+      __syncthreads();
+      if (wave == 0 && c < C) atomicAdd((pass ? dbeta : dgamma) + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    }
   }
 }
 extern "C" int tscd_add_layernorm_bwd_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
@@ -560,7 +595,9 @@ extern "C" int tscd_add_layernorm_bwd_f16(const void* a, const void* b, const fl
     (void)hipMemsetAsync(dbeta, 0, sizeof(float) * C, (hipStream_t)stream);
   }
   if (n == 0) return TSCD_OK;
-  hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const f16*)a,
+  int grid = (n + 3) / 4;
+  if (grid > 256) grid = 256;                      // >= 1 row per wave; at most one block per CU
+  hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)a,
                      (const f16*)b, gamma, (const f16*)dy, n, C, eps, (f16*)dx, dgamma, dbeta);
   TSCD_CHECK_LAUNCH("add_layernorm_bwd");
   return TSCD_OK;
