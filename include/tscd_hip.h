@@ -56,6 +56,10 @@ int tscd_conv_wgrad_splits(long M, int Cout, int Cin, int ksize);
 long tscd_conv_wgrad_workspace_bytes(long M, int Cout, int Cin, int ksize);
 int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
                              int ldx, int lddy, void* workspace, long workspace_bytes, void* stream);
+/* Which main loop tscd_conv_wgrad_nhwc_f16 runs: 1 (default) the LDS-DMA ring (global_load_lds, swizzled lane-linear
+ * tiles), 0 the register-staged loop kept as the cross-check; same tiles, splits and accumulation order, so dw is
+ * bit-identical (tests/test_gpu_conv.py).  Returns the previous setting. */
+int tscd_conv_wgrad_set_variant(int variant);
 long tscd_bn_silu_bwd_workspace_bytes(long M, int C);
 /* Backward of an nn.Linear (y = x W^T + b) in one host call: dx = dY W (MFMA GEMM on W packed in data-gradient order),
  * dw = dY^T x (pixel-axis wgrad GEMM), db = column sums.  dY [n][outp] is fp16 with row stride lddy and outp = out_f rounded up to 8

@@ -162,6 +162,32 @@ def test_conv_wgrad_and_dgrad(case):
     assert_close(dx.permute(0, 3, 1, 2), xr.grad, rel=2e-3, abs_=2e-3)
 
 
+WGRAD_CASES = [(2, 36, 36, 256, 256, 3), (1, 9, 9, 768, 768, 1), (2, 9, 7, 128, 96, 3), (1, 1, 300, 96, 200, 1), (3, 5, 5, 8, 256, 3),
+               (16, 18, 18, 32, 256, 1), (1, 1, 2000, 1024, 32, 1), (2, 3, 2, 64, 64, 3), (1, 40, 40, 128, 128, 3), (5, 4, 4, 32, 8, 1)]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad_lds_dma_matches_register_loop(case):
+    """The LDS-DMA weight-gradient loop (swizzled lane-linear tiles, incremental halo test, counted vmcnt ring) against
+    the register-staged loop on the same operands: same tiles, splits and k order, so dw must be bit-identical -- images
+    smaller than a k-tile, ragged pixel counts, Cin of 8 (a tile spans 16 taps/chunks), splits with a short tail."""
+    from tscd_amd import ops
+    from tscd_amd._lib import lib
+    B, H, W, Ci, Co, k = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Ci, generator=g).half().to(dev())
+    dy = torch.randn(B, H, W, Co, generator=g).half().to(dev())
+    prev = lib.tscd_conv_wgrad_set_variant(0)
+    try:
+        ref = ops.conv_wgrad(x, dy, Ci, Co, k).clone()
+        lib.tscd_conv_wgrad_set_variant(1)
+        out = ops.conv_wgrad(x, dy, Ci, Co, k).clone()
+    finally:
+        lib.tscd_conv_wgrad_set_variant(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+
+
 DMA_CASES = [
     # B, H, W, Cin, Cout, k, stride, epilogue-with-stats
     (2, 36, 36, 256, 256, 3, 1),     # head tower level (multi-tile M and N, 72 k-tiles: the ring wraps 18 times)

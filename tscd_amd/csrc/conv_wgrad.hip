@@ -16,6 +16,7 @@
 //   pass 1: dt = dy * silu'(t), per-channel partial sums of dt and dt*xhat (fixed-order reduction via bn_bwd_reduce);
 //   pass 2: draw = gamma*invstd * (dt - mean(dt) - xhat*mean(dt*xhat)).
 #include "common.h"
+#include <type_traits>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -25,7 +26,7 @@ struct WgradParams {
   float* part;   // [S][Cout][Ncols]
   int B, H, W, Cin, Cout, KH, KW, pad;
   int ldx, lddy;
-  int M, Ncols, S, ktiles_per_split, mtiles, ntiles;
+  int M, Ncols, S, ktiles_per_split, mtiles, ntiles, debug;
 };
 
 __device__ __forceinline__ f16x8 tr_frag(const f16* tile_row0_col0, int ldst, int lane) {
@@ -138,29 +139,242 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     }
 }
 
-// dW[cout][cin][kh][kw] (fp32, torch layout) = sum_s part[s][cout][(kh*KW+kw)*Cin + cin]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int S, int Cout, int Cin, int KH, int KW, float* __restrict__ dw) {
-  const long total = (long)Cout * Cin * KH * KW;
-  const int Ncols = KH * KW * Cin;
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    int kw = idx % KW;
-    long t = idx / KW;
-    int kh = t % KH;
-    t /= KH;
-    int ci = t % Cin, co = t / Cin;
-    long src = (long)co * Ncols + (kh * KW + kw) * Cin + ci;
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the weight-gradient GEMM (the one that runs; the register-staged kernel above stays as the
+// bit-identical cross-check, tscd_conv_wgrad_set_variant(0)).  Same tiles and the same k order per split, but
+//   * both operands are fetched with global_load_lds_dwordx4 into a 4-deep ring (one wave-instruction = 4 pixel rows x
+//     256 B): no staging registers, no ds_write pass, no per-tile integer divisions -- a lane's source pointers advance by
+//     32 pixels per k-tile and its (ho, wo) image position is carried incrementally for the halo test;
+//   * the LDS image is lane-linear (256-B rows, no padding), so the 16-B chunk c of row r lives in slot c ^ ((r&3) << 2):
+//     the four rows of a transposing read then sit in the four 16-bank quarters;
+//   * fragments of tile kt+1 are read into a second register set while the MFMAs of tile kt issue; one raw s_barrier and
+//     one counted vmcnt per k-step (two younger tiles stay in flight).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) f16 g_wg_zero_chunk[8];
+
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(N < 0, "unsupported vmcnt");
+}
+
+// Transposing fragment fetch as inline asm: hipcc 7.2 orders the ds_read_tr16_b64 builtin behind EVERY pending LDS-DMA
+// (s_waitcnt vmcnt(0) before the first read of each k-step -- the builtin carries no memory operand for its alias check),
+// which drains the ring the loop keeps in flight.  The asm form is invisible to that pass; the loop below waits for its own
+// reads with an explicit lgkmcnt(0) before the MFMAs that consume them.
+template <int OFF> __device__ __forceinline__ f16x8 tr_frag_asm(unsigned addr) {
+  s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 4 * 256));
+  f16x4 lo4 = __builtin_bit_cast(f16x4, lo), hi4 = __builtin_bit_cast(f16x4, hi);
+  return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(WgradParams p) {
+  constexpr int BM = 128, BN = 128, BK = 32, NS = 4, LD = 4;
+  constexpr int T_BYTES = BK * 256, STAGE = 2 * T_BYTES;
+  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware order: the workgroups of one split (same pixel range) share an L2
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tiles = p.mtiles * p.ntiles;
+  const int s = lid / tiles, tile = lid - s * tiles;
+  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+  const int c0 = mt * BM, n0 = nt * BN;
+  const int ktotal = (p.M + BK - 1) / BK;
+  const int kt0 = s * p.ktiles_per_split;
+  int kt1 = kt0 + p.ktiles_per_split;
+  if (kt1 > ktotal) kt1 = ktotal;
+  const int nk = kt1 - kt0;
+
+  // ---- per-lane source state: a wave-instruction covers rows base..base+3; lane -> row lane>>4, slot lane&15 ----
+  const int rsub = lane >> 4;                         // == row & 3 (bases are multiples of 4)
+  const int chunk = (lane & 15) ^ (rsub << 2);
+  const int ych = c0 + chunk * 8;
+  const bool y_ok = ych < p.Cout;
+  const int ncol = n0 + chunk * 8;
+  const bool n_ok = ncol < p.Ncols;
+  const int tap = n_ok ? ncol / p.Cin : 0, cin = n_ok ? ncol - tap * p.Cin : 0;
+  const int dh = tap / p.KW - p.pad, dw = tap % p.KW - p.pad;
+  const int step_q = BK / p.W, step_r = BK % p.W;
+  const f16* y_src[2];
+  const f16* x_src[2];
+  int m_row[2], ho[2], wo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = kt0 * BK + wave * 8 + i * 4 + rsub;
+    m_row[i] = m;
+    const int rem = m % (p.H * p.W);
+    ho[i] = rem / p.W;
+    wo[i] = rem - ho[i] * p.W;
+    y_src[i] = p.dy + (long)m * p.lddy + ych;
+    x_src[i] = p.x + ((long)m + dh * p.W + dw) * p.ldx + cin;
+  }
+  auto issue = [&](int stage) {
+    char* sbase = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool mok = m_row[i] < p.M;
+      const f16* ys = (mok && y_ok && !(p.debug & 1)) ? y_src[i] : g_wg_zero_chunk;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ys,
+                                       (__attribute__((address_space(3))) void*)(sbase + (wave * 8 + i * 4) * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = m_row[i] < p.M && n_ok && (p.KH == 1 || ((unsigned)(ho[i] + dh) < (unsigned)p.H && (unsigned)(wo[i] + dw) < (unsigned)p.W));
+      const f16* xs = (ok && !(p.debug & 2)) ? x_src[i] : g_wg_zero_chunk;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xs,
+                                       (__attribute__((address_space(3))) void*)(sbase + T_BYTES + (wave * 8 + i * 4) * 256), 16, 0, 0);
+      m_row[i] += BK;
+      y_src[i] += (long)BK * p.lddy;
+      x_src[i] += (long)BK * p.ldx;
+      wo[i] += step_r;
+      ho[i] += step_q;
+      if (wo[i] >= p.W) { wo[i] -= p.W; ++ho[i]; }
+      ho[i] = ho[i] >= p.H ? ho[i] - p.H : ho[i];      // next image (the launcher guarantees 32 / W + 1 <= H for 3x3)
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment byte offsets inside an operand tile: 16-lane group g -> channel block 16*(g&1), pixel block 8*(g>>1);
+  // lane 4q+p of the group supplies row q, halves 4p..4p+3 of the block (see tr_frag)
+  const int g = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = (wm * 64 + i * 32 + 16 * (g & 1)) / 8 + (fp >> 1);
+    const int cb = (wn * 64 + i * 32 + 16 * (g & 1)) / 8 + (fp >> 1);
+    a_off[i] = (8 * (g >> 1) + fq) * 256 + ((ca ^ (fq << 2)) * 16) + (fp & 1) * 8;
+    b_off[i] = T_BYTES + (8 * (g >> 1) + fq) * 256 + ((cb ^ (fq << 2)) * 16) + (fp & 1) * 8;
+  }
+
+  if (nk > 0) {
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+      if (st < nk) issue(st);
+    f16x8 fa[2][2][2], fb[2][2][2];     // [register set][ks][tile]
+    auto wait_tile = [&](int t) __attribute__((always_inline)) {
+      const int younger = nk - 1 - t;
+      if (younger >= NS - 2) wg_wait_vmcnt<(NS - 2) * LD>();
+      else if (younger == 1) wg_wait_vmcnt<LD>();
+      else wg_wait_vmcnt<0>();
+    };
+    auto read_frags = [&](auto setc, int t) __attribute__((always_inline)) {
+      constexpr int S = decltype(setc)::value;
+      const unsigned sb = smem_base + (t % NS) * STAGE;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[S][0][i] = tr_frag_asm<0>(sb + a_off[i]);
+        fa[S][1][i] = tr_frag_asm<16 * 256>(sb + a_off[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        fb[S][0][j] = tr_frag_asm<0>(sb + b_off[j]);
+        fb[S][1][j] = tr_frag_asm<16 * 256>(sb + b_off[j]);
+      }
+    };
+    auto drain_reads = [&]() __attribute__((always_inline)) {   // the asm reads are not tracked by the compiler's waitcnt pass
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfmas = [&](auto setc) __attribute__((always_inline)) {
+      constexpr int S = decltype(setc)::value;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][i], fb[S][ks][j], acc[i][j], 0, 0, 0);
+    };
+    auto phase = [&](auto setc, int kt) __attribute__((always_inline)) {
+      constexpr int S = decltype(setc)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): this wave's fragments of tile kt are in registers
+      wait_tile(kt + 1);
+      __builtin_amdgcn_s_barrier();                            // everyone's are: tile kt's buffer may be refilled
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + NS < nk) issue((kt + NS) % NS);
+      read_frags(std::integral_constant<int, 1 - S>{}, kt + 1);
+      mfmas(setc);
+    };
+    wait_tile(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (NS - 1 < nk) issue(NS - 1);
+    read_frags(std::integral_constant<int, 0>{}, 0);
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+      phase(std::integral_constant<int, 0>{}, kt);
+      phase(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if (nk - kt == 2) {
+      phase(std::integral_constant<int, 0>{}, kt);
+      drain_reads();
+      mfmas(std::integral_constant<int, 1>{});
+    } else {
+      drain_reads();
+      mfmas(std::integral_constant<int, 0>{});
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = c0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < p.Cout && col < p.Ncols) p.part[((long)s * p.Cout + row) * p.Ncols + col] = acc[i][j][e];
+      }
+    }
+}
+
+// dW[cout][cin][kh][kw] (fp32, torch layout) = sum_s part[s][cout][(kh*KW+kw)*Cin + cin].  Threads walk the slabs in SLAB
+// order (a wave reads 256 contiguous bytes of every slab; the S-times smaller dw stream takes the scattered side), four
+// wave-groups share the splits of 64 outputs and combine through LDS in a fixed order (deterministic, no atomics).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int S, int Cout, int Cin, int KH, int KW, float* __restrict__ dw) {
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int taps = KH * KW, Ncols = taps * Cin;
+  const long total = (long)Cout * Ncols;
+  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+    const long src = base + o;
     float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part[(long)s * Cout * Ncols + src];
-    dw[idx] = a;
+    if (src < total) {
+#pragma unroll 4
+      for (int s = g; s < S; s += 4) a += part[(long)s * total + src];
+    }
+    red[g][o] = a;
+    __syncthreads();
+    if (g == 0 && src < total) {
+      a = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+      const int co = (int)(src / Ncols), col = (int)(src - (long)co * Ncols);
+      const int tap = col / Cin, ci = col - tap * Cin;
+      dw[((long)co * Cin + ci) * taps + tap] = a;
+    }
+    __syncthreads();
   }
 }
 
-// Split-K over the pixel axis: enough splits that tiles x splits covers the 256 CUs about twice, at least 8 k-tiles
+// Split-K over the pixel axis: as many splits as keep tiles x splits within the 512 resident workgroups, at least 8 k-tiles
 // (256 pixels) per split so the fp32 slab traffic stays small next to the operand reads.
 extern "C" int tscd_conv_wgrad_splits(long M, int Cout, int Cin, int ksize) {
   long kt = (M + 31) / 32;
   long tiles = (long)cdiv(Cout, 128) * cdiv((long)ksize * ksize * Cin, 128);
-  long s = (512 + tiles - 1) / tiles;
+  long s = 512 / tiles;                      // two workgroups per CU, never a second round (540 blocks take ~1.5x the time of 504)
   if (ksize == 1 && kt <= 24) return 1;      // proposal-stage linears (a few hundred rows): one pass, written straight into dw
   if (s > kt / 8) s = kt / 8;
   if (s < 1) s = 1;
@@ -170,6 +384,9 @@ extern "C" int tscd_conv_wgrad_splits(long M, int Cout, int Cin, int ksize) {
 extern "C" long tscd_conv_wgrad_workspace_bytes(long M, int Cout, int Cin, int ksize) {
   return 4L * tscd_conv_wgrad_splits(M, Cout, Cin, ksize) * Cout * ksize * ksize * Cin + 256;
 }
+
+static int g_wgrad_variant = 1;      // 1: LDS-DMA kernel, 0: register-staged cross-check
+extern "C" int tscd_conv_wgrad_set_variant(int v) { int o = g_wgrad_variant; g_wgrad_variant = v; return o; }
 
 extern "C" int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
                                         int ldx, int lddy, void* workspace, long workspace_bytes, void* stream) {
@@ -192,12 +409,18 @@ extern "C" int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw
   hipStream_t st = (hipStream_t)stream;
   const bool direct = p.S == 1 && ksize == 1;   // [Cout][Cin] slab == torch layout: no reduction pass
   if (direct) p.part = dw;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.mtiles * p.ntiles, p.S), dim3(256), 0, st, p);
+  p.debug = g_wgrad_variant >> 4;
+  // the LDS-DMA loop carries (ho, wo) incrementally with a single wrap per k-tile: images at least 32 / W + 1 rows high
+  const bool dma_ok = ksize == 1 || 32 / W + 1 <= H;
+  if ((g_wgrad_variant & 15) == 0 || !dma_ok)
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.mtiles * p.ntiles, p.S), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(conv_wgrad_glds_kernel, dim3(p.mtiles * p.ntiles * p.S), dim3(256), 0, st, p);
   TSCD_CHECK_LAUNCH("conv_wgrad");
   if (direct) return TSCD_OK;
   long total = (long)Cout * p.Ncols;
-  int grid = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, st, p.part, p.S, Cout, Cin, ksize, ksize, dw);
+  long grid = (total + 63) / 64;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(grid > 8192 ? 8192 : grid)), dim3(256), 0, st, p.part, p.S, Cout, Cin, ksize, ksize, dw);
   TSCD_CHECK_LAUNCH("wgrad_reduce");
   return TSCD_OK;
 }
