@@ -27,7 +27,7 @@ const char* tscd_last_error(void);
  * (yolox/models/tscd_head.py:213-239), WaveletsHFBlock.filter1/2 (yolox/models/surrounding_extraction.py:223-232)
  * and, with ksize=1/H=1, every nn.Linear of the proposal stage (post_trans.py:565-576,1139-1143;
  * tscd_matching.py:24-26,151-153,704; tscd_head.py:123,130-133).
- * epilogue: 0 raw (+ per-M-tile BN partial sums into bn_partial[mtiles][2][cstride] when non-NULL), 1 +bias,
+ * epilogue: 0 raw (+ per-M-tile BN partial sums into bn_partial[2][cstride][mtiles] when non-NULL), 1 +bias,
  * 2 +bias,ReLU, 3 folded BN + SiLU (eval), 4 folded BN, 5 Hungarian cost 1 - v/2 with NaN->0
  * (tscd_matching.py:926-930). */
 int tscd_conv_tile_m(void);

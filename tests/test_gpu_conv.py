@@ -162,6 +162,36 @@ def test_conv_wgrad_and_dgrad(case):
     assert_close(dx.permute(0, 3, 1, 2), xr.grad, rel=2e-3, abs_=2e-3)
 
 
+@pytest.mark.parametrize("case", [(2, 37, 41, 64, 30, False), (3, 20, 20, 32, 4, False), (1, 50, 30, 64, 1, False), (9, 72, 72, 256, 256, True),
+                                  (2, 11, 13, 32, 40, True)])
+def test_conv_bias_backward_matches_autograd(case):
+    """Biased 1x1 conv (prediction convs: 30 / 4 / 1 output channels, padded to 8 for the kernels) and the fused-ReLU form:
+    bias, weight and data gradients vs PyTorch autograd in fp32 on the same fp16 operands.  (9,72,72,256) makes the bias /
+    mask kernel loop grid-strided (46656 rows > 1024 blocks x 32 rows)."""
+    from tscd_amd import functional as TF
+    B, H, W, Ci, Co, relu = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(B, H, W, Ci, generator=g).half()
+    wt = (torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5).half()
+    bias = torch.randn(Co, generator=g).half()
+    gy = torch.randn(B, H, W, Co, generator=g).half()
+    xr, wr, br = x.float().requires_grad_(True), wt.float().requires_grad_(True), bias.float().requires_grad_(True)
+    xg, wg, bg = x.to(dev()).requires_grad_(True), wt.to(dev()).requires_grad_(True), bias.to(dev()).requires_grad_(True)
+    out = TF.conv_bias(xg, wg, bg, relu=relu)
+    (out.float() * gy.to(dev()).float()).sum().backward()
+    torch.cuda.synchronize()
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), wr, br).permute(0, 2, 3, 1)
+    if relu:      # the product's own activation pattern (a pre-activation within fp16 rounding of 0 may land on either side)
+        ref = ref * (out.detach().float().cpu() > 0)
+    (ref * gy.float()).sum().backward()
+    assert_close(out, ref.detach(), rel=3e-3, abs_=3e-3)
+    scale = max(1.0, float(br.grad.abs().max()))
+    assert_close(bg.grad.float() / scale, br.grad / scale, rel=2e-3, abs_=2e-3)
+    wscale = max(1.0, float(wr.grad.abs().max()))
+    assert_close(wg.grad.float() / wscale, wr.grad / wscale, rel=2e-3, abs_=2e-3)
+    assert_close(xg.grad, xr.grad, rel=3e-3, abs_=3e-3)
+
+
 WGRAD_CASES = [(2, 36, 36, 256, 256, 3), (1, 9, 9, 768, 768, 1), (2, 9, 7, 128, 96, 3), (1, 1, 300, 96, 200, 1), (3, 5, 5, 8, 256, 3),
                (16, 18, 18, 32, 256, 1), (1, 1, 2000, 1024, 32, 1), (2, 3, 2, 64, 64, 3), (1, 40, 40, 128, 128, 3), (5, 4, 4, 32, 8, 1)]
 

@@ -126,8 +126,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
       a += red[(w * BN + tid) * 2 + 0];
       b += red[(w * BN + tid) * 2 + 1];
     }
-    p.bn_partial[((long)mt * 2 + 0) * p.cstride + n0 + tid] = a;
-    p.bn_partial[((long)mt * 2 + 1) * p.cstride + n0 + tid] = b;
+    // channel-major [2][cstride][mtiles]: bn_finalize's wave-per-channel reduction then reads contiguous floats
+    p.bn_partial[(long)(n0 + tid) * p.mtiles + mt] = a;
+    p.bn_partial[((long)p.cstride + n0 + tid) * p.mtiles + mt] = b;
   }
 }
 

@@ -550,26 +550,38 @@ extern "C" int tscd_conv_tile_n(int cout);
 // 8-channel chunk, strides the block's rows, the row groups are combined through LDS, one fp32 atomic per column and block.
 __global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const f16* __restrict__ g, int ldg, const f16* __restrict__ y, int ldy,
                                                             f16* __restrict__ gm, int ldm, long M, int C, int cv, int rpb,
-                                                            long rows_per_block, float* __restrict__ db) {
+                                                            float* __restrict__ db) {
+  // thread = (8-channel chunk c8, row group rg); a block walks chunks of 4*rpb rows grid-strided, the 4 rows of a thread are
+  // loaded before any is used (4 x 2 x 16 B in flight per thread); one atomic per column and block at the end
   __shared__ float red[256 * 8];
   const int tid = threadIdx.x, c8 = tid % cv, rg = tid / cv;
+  const long chunk = 4L * rpb;
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  const long r0 = blockIdx.x * rows_per_block, r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
   if (rg < rpb) {
     for (int cc = c8; cc < (C >> 3); cc += cv) {        // cv < C/8 only for C > 2048
       const int c = cc << 3;
-      for (long r = r0 + rg; r < r1; r += rpb) {
-        f16x8 v = *(const f16x8*)(g + r * ldg + c);
-        if (y) {
-          f16x8 yy = *(const f16x8*)(y + r * ldy + c);
+      for (long base = blockIdx.x * chunk; base < M; base += gridDim.x * chunk) {
+        f16x8 v[4], yy[4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (float)yy[e] > 0.f ? v[e] : (f16)0.f;
-          *(f16x8*)(gm + r * ldm + c) = v;
+        for (int u = 0; u < 4; ++u) {
+          const long r = base + rg + (long)u * rpb;
+          v[u] = r < M ? *(const f16x8*)(g + r * ldg + c) : zero8;
+          if (y) yy[u] = r < M ? *(const f16x8*)(y + r * ldy + c) : zero8;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        for (int u = 0; u < 4; ++u) {
+          const long r = base + rg + (long)u * rpb;
+          if (y) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[u][e] = (float)yy[u][e] > 0.f ? v[u][e] : (f16)0.f;
+            if (r < M) *(f16x8*)(gm + r * ldm + c) = v[u];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += (float)v[u][e];
+        }
       }
       if (cv < (C >> 3)) {                               // wide case: flush per chunk
 #pragma unroll
@@ -601,11 +613,10 @@ extern "C" int tscd_bias_relu_bwd_f16(const void* g, int ldg, const void* y, int
   int cv = C / 8;
   if (cv > 256) cv = 256;
   const int rpb = 256 / cv;
-  long rows_per_block = (long)rpb * 16;
-  long nblk = (M + rows_per_block - 1) / rows_per_block;
-  if (nblk > 2048) { nblk = 2048; rows_per_block = (M + nblk - 1) / nblk; }
+  long nblk = (M + 4L * rpb - 1) / (4L * rpb);
+  if (nblk > 1024) nblk = 1024;        // bounds the same-address atomics on db (one per column and block)
   hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const f16*)g, ldg, (const f16*)y, ldy, (f16*)gm, ldm,
-                     M, C, cv, rpb, rows_per_block, db);
+                     M, C, cv, rpb, db);
   TSCD_CHECK_LAUNCH("bias_relu_bwd");
   return TSCD_OK;
 }

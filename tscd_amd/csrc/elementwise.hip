@@ -68,7 +68,8 @@ extern "C" int tscd_pack_conv_weight(const void* w, int src_is_f32, void* out, i
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Train-mode BatchNorm: reduce the conv kernel's per-M-tile partials in a fixed order (one wave per channel,
+// Train-mode BatchNorm: reduce the conv kernel's per-M-tile partials ([2][cstride][mtiles], channel-major: a wave reads
+// contiguous floats) in a fixed order (one wave per channel,
 // fp64 accumulation), emit scale/shift for the apply pass, the saved mean/invstd for backward, and update the
 // running statistics exactly like torch (momentum, unbiased variance) -- reference: network_blocks.py:52-58 with
 // eps=1e-3, momentum=0.03 (exps/TSCD_OVIS/ovis_tscd_large.py:109-113).
@@ -81,9 +82,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int mtiles
   int lane = threadIdx.x & 63;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
+  // issued ahead of the reduction so their latency overlaps the partial loads (the kernel is one dependent chain otherwise)
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float rm0 = running_mean ? running_mean[c] : 0.f, rv0 = running_mean ? running_var[c] : 0.f;
   for (int t = lane; t < mtiles; t += 64) {
-    s1 += (double)partial[((long)t * 2 + 0) * cstride + c];
-    s2 += (double)partial[((long)t * 2 + 1) * cstride + c];
+    s1 += (double)partial[(long)c * mtiles + t];
+    s2 += (double)partial[((long)cstride + c) * mtiles + t];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -95,15 +99,14 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int mtiles
     double var = s2 / count - mean * mean;
     if (var < 0) var = 0;
     float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     scale_shift[c] = g * invstd;
     scale_shift[C + c] = b - (float)mean * g * invstd;
     if (save_mean) save_mean[c] = (float)mean;
     if (save_invstd) save_invstd[c] = invstd;
     if (running_mean) {
       double unbiased = count > 1 ? var * count / (count - 1.0) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+      running_mean[c] = (1.f - momentum) * rm0 + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * rv0 + momentum * (float)unbiased;
     }
   }
 }

@@ -20,22 +20,38 @@ def _nchw(t):
     return t.permute(0, 3, 1, 2)
 
 
-def _conv_backward(dy, x, weight, stride, need_dx, need_dw):
+def _pad8(dy):
+    """dY with its channels zero-padded to a multiple of 8 (rows stay 16-byte aligned); dy itself when already aligned."""
+    c = dy.shape[-1]
+    if c % 8 == 0:
+        return dy.contiguous()
+    dyp = dy.new_zeros(dy.shape[:-1] + ((c + 7) // 8 * 8,))
+    dyp[..., :c] = dy
+    return dyp
+
+
+def _conv_backward(dy, x, weight, stride, need_dx, need_dw, dy_padded=None):
     """Stride-1 'same' conv gradients on the HIP kernels: dgrad = the forward MFMA kernel with dgrad-packed weights,
     wgrad = conv_wgrad.hip (pixel-axis GEMM, transposing LDS reads, deterministic split-K)."""
     assert stride == 1, "only stride-1 convs are trainable on the TSCD path"
     cout, cin, k, _ = weight.shape
     dy = dy.to(torch.float16)
-    dx = ops.conv_dgrad(dy, weight) if need_dx else None
+    # prediction convs (Cout = 25 / 4 / 1): dY's channels zero-padded so rows stay 16-byte aligned
+    dyp = dy_padded
+    if dyp is None and cout % 8 and (need_dx or need_dw):
+        dyp = _pad8(dy)
+    dx = None
+    if need_dx:
+        if cout % 8:      # zero weight rows for the padded channels; packed per call (not a cached parameter)
+            wp = weight.new_zeros((dyp.shape[-1], cin, k, k))
+            wp[:cout] = weight
+            dx, _ = ops.conv2d(dyp, ops.pack_conv_weight(wp, None, 1), cin, k, 1, ops.EPI_RAW)
+        else:
+            dx = ops.conv_dgrad(dy, weight)
     dw = None
     if need_dw:
-        if cout % 8:   # prediction convs (Cout = 25 / 4 / 1): zero-pad dY's channels so rows stay 16-byte aligned
-            cp = (cout + 7) // 8 * 8
-            dyp = dy.new_zeros(dy.shape[:-1] + (cp,))
-            dyp[..., :cout] = dy
-            dw = ops.conv_wgrad(x, dyp, cin, cp, k)[:cout].to(weight.dtype)
-        else:
-            dw = ops.conv_wgrad(x, dy.contiguous(), cin, cout, k).to(weight.dtype)
+        dyp = dy.contiguous() if dyp is None else dyp
+        dw = ops.conv_wgrad(x, dyp, cin, dyp.shape[-1], k)[:cout].to(weight.dtype)
     return dx, dw
 
 
@@ -102,15 +118,18 @@ class _ConvBias(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         dy = dy.to(torch.float16)
         C = dy.shape[-1]
-        db = None
+        db = dyp = None
         if C % 8 == 0 and (ctx.relu or ctx.needs_input_grad[2]):
             # ReLU mask and bias gradient in one pass over dy (one kernel instead of compare, multiply, cast and reduce)
             dy, db = ops.bias_relu_bwd(dy.contiguous(), y if ctx.relu else None)
         else:
             if ctx.relu:
                 dy = dy * (y > 0)
-            db = dy.float().sum((0, 1, 2)) if ctx.needs_input_grad[2] else None
-        dx, dw = _conv_backward(dy.contiguous(), x, weight, 1, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+            if ctx.needs_input_grad[2]:
+                # prediction convs (C = 25 / 4 / 1): column sums on the zero-padded copy the weight gradient needs anyway
+                dyp = _pad8(dy)
+                db = ops.bias_relu_bwd(dyp)[1][:C]
+        dx, dw = _conv_backward(dy.contiguous(), x, weight, 1, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dy_padded=dyp)
         if db is not None:
             db = db.to(weight.dtype) if ctx.needs_input_grad[2] else None
         return dx, dw, db, None

@@ -130,7 +130,7 @@ def conv2d(x, wpk, cout, ksize, stride=1, epilogue=EPI_RAW, bias=None, scale_shi
     partial = None
     if want_stats:
         mt = (B * Ho * Wo + lib.tscd_conv_tile_m() - 1) // lib.tscd_conv_tile_m()
-        partial = torch.empty((mt, 2, wpk.shape[0]), dtype=torch.float32, device=x.device)
+        partial = torch.empty((2, wpk.shape[0], mt), dtype=torch.float32, device=x.device)
     scale = shift = None
     if scale_shift is not None:
         scale, shift = scale_shift[0], scale_shift[1]
@@ -152,7 +152,7 @@ def bn_finalize(partial, count, gamma, beta, running_mean, running_var, eps=BN_E
     ss = torch.empty((2, C), dtype=torch.float32, device=partial.device)
     mean = torch.empty(C, dtype=torch.float32, device=partial.device)
     invstd = torch.empty(C, dtype=torch.float32, device=partial.device)
-    call("tscd_bn_finalize", partial.data_ptr(), partial.shape[0], partial.shape[2], C, int(count), gamma.data_ptr(),
+    call("tscd_bn_finalize", partial.data_ptr(), partial.shape[2], partial.shape[1], C, int(count), gamma.data_ptr(),
          beta.data_ptr(), eps, momentum, _ptr(running_mean), _ptr(running_var), ss.data_ptr(), mean.data_ptr(),
          invstd.data_ptr(), _stream())
     return ss, mean, invstd
