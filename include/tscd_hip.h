@@ -66,7 +66,9 @@ long tscd_bn_silu_bwd_workspace_bytes(long M, int C);
  * (extra columns zero); dx [n][in_f] fp16, dw [outp][in_f] fp32, db [outp] fp32; any output may be NULL.
  * tscd_bias_relu_bwd_f16: db[c] = sum_r g[r][c], optionally through the mask of a fused ReLU (y > 0), in which case the masked
  * gradient gm is written as well -- the bias gradient of a Linear / biased conv in one pass. */
-int tscd_bias_relu_bwd_f16(const void* g, int ldg, const void* y, int ldy, void* gm, int ldm, long M, int C, float* db, void* stream);
+long tscd_bias_relu_bwd_workspace_bytes(long M, int C);
+int tscd_bias_relu_bwd_f16(const void* g, int ldg, const void* y, int ldy, void* gm, int ldm, long M, int C, float* db,
+                           void* workspace, long workspace_bytes, void* stream);
 long tscd_linear_bwd_workspace_bytes(int n, int in_f, int outp);
 int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, int lddy, const void* w, int w_is_f32, int n, int in_f, int out_f,
                         int outp, void* dx, float* dw, float* db, void* workspace, long workspace_bytes, void* stream);

@@ -473,18 +473,24 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_stats_kernel(const f16* __res
     partial[(long)blockIdx.x * 2 * C + i] = a;
   }
 }
-// sums [2][C] (fp32) from the partials, one wave per channel, fixed order, fp64 accumulation
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums) {
-  int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int t = lane; t < nblk; t += 64) {
-    a += (double)partial[((long)t * 2 + 0) * C + c];
-    b += (double)partial[((long)t * 2 + 1) * C + c];
+// out[c] = sum_t partial[t][c] over nrows x ncols fp32 partials, fixed order, fp64 accumulation: 64 columns per block (a wave
+// reads 256 contiguous bytes per row), the 16 waves take rows t = g mod 16 and combine through LDS.
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ partial, int nrows, int ncols, float* __restrict__ out) {
+  __shared__ double red[16][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + o;
+  double a = 0.0;
+  if (c < ncols) {
+#pragma unroll 8
+    for (int t = g; t < nrows; t += 16) a += (double)partial[(long)t * ncols + c];
   }
+  red[g][o] = a;
+  __syncthreads();
+  if (g == 0 && c < ncols) {
+    double r = 0.0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-  if (lane == 0) { sums[c] = (float)a; sums[C + c] = (float)b; }
+    for (int q = 0; q < 16; ++q) r += red[q][o];
+    out[c] = (float)r;
+  }
 }
 __global__ void bn_silu_bwd_apply_kernel(const f16* __restrict__ dy, const f16* __restrict__ raw, const float* __restrict__ ss,
                                          const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -525,7 +531,7 @@ extern "C" int tscd_bn_silu_bwd_f16(const void* dy, const void* raw, const float
   if (rg > BNB_ROWS) rg = BNB_ROWS;
   hipLaunchKernelGGL(bn_silu_bwd_stats_kernel, dim3(nblk), dim3(256), (size_t)rg * 2 * C * sizeof(float), st, (const f16*)dy,
                      (const f16*)raw, scale_shift, mean, invstd, M, C, cv, rg, (float*)workspace);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, nblk, C, sums_out);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, st, (const float*)workspace, nblk, 2 * C, sums_out);
   long total = M * (C / 8);
   int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, st, (const f16*)dy, (const f16*)raw,
@@ -550,19 +556,21 @@ extern "C" int tscd_conv_tile_n(int cout);
 // 8-channel chunk, strides the block's rows, the row groups are combined through LDS, one fp32 atomic per column and block.
 __global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const f16* __restrict__ g, int ldg, const f16* __restrict__ y, int ldy,
                                                             f16* __restrict__ gm, int ldm, long M, int C, int cv, int rpb,
-                                                            float* __restrict__ db) {
+                                                            float* __restrict__ partial) {
   // thread = (8-channel chunk c8, row group rg); a block walks chunks of 4*rpb rows grid-strided, the 4 rows of a thread are
-  // loaded before any is used (4 x 2 x 16 B in flight per thread); one atomic per column and block at the end
+  // loaded before any is used (4 x 2 x 16 B in flight per thread); the block's column sums go to partial[block][C] (no
+  // atomics: a few hundred blocks adding into the same eight cache lines serialise in L2 -- measured 0.2 us per block)
   __shared__ float red[256 * 8];
   const int tid = threadIdx.x, c8 = tid % cv, rg = tid / cv;
   const long chunk = 4L * rpb;
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  float acc[8];
+  for (int c0 = 0; c0 < (C >> 3); c0 += cv) {           // one pass unless C > 2048
+    const int cc = c0 + c8, c = cc << 3;
+    const bool live = rg < rpb && cc < (C >> 3);
+    float acc[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  if (rg < rpb) {
-    for (int cc = c8; cc < (C >> 3); cc += cv) {        // cv < C/8 only for C > 2048
-      const int c = cc << 3;
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (live) {
       for (long base = blockIdx.x * chunk; base < M; base += gridDim.x * chunk) {
         f16x8 v[4], yy[4];
 #pragma unroll
@@ -583,40 +591,49 @@ __global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const f16* __restric
           for (int e = 0; e < 8; ++e) acc[e] += (float)v[u][e];
         }
       }
-      if (cv < (C >> 3)) {                               // wide case: flush per chunk
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { atomicAdd(db + c + e, acc[e]); acc[e] = 0.f; }
-      }
     }
-  }
-  if (cv < (C >> 3)) return;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = (rg < rpb) ? acc[e] : 0.f;
-  __syncthreads();
-  if (tid < cv) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float a = 0.f;
-      for (int q = 0; q < rpb; ++q) a += red[(q * cv + tid) * 8 + e];
-      atomicAdd(db + tid * 8 + e, a);
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = live ? acc[e] : 0.f;
+    __syncthreads();
+    // red is [rpb][cv*8]: fold the row groups pairwise (all threads), then one coalesced store of the block's sums
+    const int ncol = cv * 8;
+    for (int n = rpb; n > 1;) {
+      const int h = (n + 1) >> 1;
+      for (int idx = tid; idx < (n - h) * ncol; idx += 256) red[idx] += red[idx + h * ncol];
+      __syncthreads();
+      n = h;
     }
+    for (int j = tid; j < ncol; j += 256)
+      if (c0 * 8 + j < C) partial[(long)blockIdx.x * C + c0 * 8 + j] = red[j];
+    __syncthreads();
   }
 }
-// g [M][C] (row stride ldg), optional y (row stride ldy) and masked-gradient output gm (row stride ldm); db [C] fp32 is cleared
-// here.  C % 8 == 0.
-extern "C" int tscd_bias_relu_bwd_f16(const void* g, int ldg, const void* y, int ldy, void* gm, int ldm, long M, int C, float* db,
-                                      void* stream) {
-  TSCD_CHECK_ARG(g && db && C % 8 == 0 && ldg % 8 == 0 && (!y || (gm && ldy % 8 == 0 && ldm % 8 == 0)), "bias_relu_bwd: bad args");
-  hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(db, 0, sizeof(float) * C, st);
-  if (M == 0) return TSCD_OK;
+static int bias_relu_bwd_blocks(long M, int C) {
   int cv = C / 8;
   if (cv > 256) cv = 256;
   const int rpb = 256 / cv;
   long nblk = (M + 4L * rpb - 1) / (4L * rpb);
-  if (nblk > 1024) nblk = 1024;        // bounds the same-address atomics on db (one per column and block)
+  return (int)(nblk > 512 ? 512 : (nblk < 1 ? 1 : nblk));
+}
+extern "C" long tscd_bias_relu_bwd_workspace_bytes(long M, int C) { return 4L * bias_relu_bwd_blocks(M, C) * C + 256; }
+// g [M][C] (row stride ldg), optional y (row stride ldy) and masked-gradient output gm (row stride ldm); db [C] fp32.
+// C % 8 == 0.  workspace: per-block column sums, reduced in a fixed order (deterministic).
+extern "C" int tscd_bias_relu_bwd_f16(const void* g, int ldg, const void* y, int ldy, void* gm, int ldm, long M, int C, float* db,
+                                      void* workspace, long workspace_bytes, void* stream) {
+  TSCD_CHECK_ARG(g && db && workspace && C % 8 == 0 && ldg % 8 == 0 && (!y || (gm && ldy % 8 == 0 && ldm % 8 == 0)), "bias_relu_bwd: bad args");
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_bias_relu_bwd_workspace_bytes(M, C), "bias_relu_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    (void)hipMemsetAsync(db, 0, sizeof(float) * C, st);
+    return TSCD_OK;
+  }
+  int cv = C / 8;
+  if (cv > 256) cv = 256;
+  const int rpb = 256 / cv;
+  const int nblk = bias_relu_bwd_blocks(M, C);
   hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const f16*)g, ldg, (const f16*)y, ldy, (f16*)gm, ldm,
-                     M, C, cv, rpb, db);
+                     M, C, cv, rpb, (float*)workspace);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, st, (const float*)workspace, nblk, C, db);
   TSCD_CHECK_LAUNCH("bias_relu_bwd");
   return TSCD_OK;
 }
@@ -628,7 +645,7 @@ static long linear_bwd_pack_bytes(int in_f, int outp) {
 }
 // outp = out_f rounded up to 8 (dY arrives padded with zero columns)
 extern "C" long tscd_linear_bwd_workspace_bytes(int n, int in_f, int outp) {
-  return linear_bwd_pack_bytes(in_f, outp) + tscd_conv_wgrad_workspace_bytes(n, outp, in_f, 1);
+  return linear_bwd_pack_bytes(in_f, outp) + tscd_conv_wgrad_workspace_bytes(n, outp, in_f, 1) + tscd_bias_relu_bwd_workspace_bytes(n, outp);
 }
 // x [n][in_f] (row stride ldx), dY [n][outp] fp16 with row stride lddy (outp % 8 == 0; columns >= out_f zero), w [out_f][in_f]
 // fp32 or fp16.  Outputs (each may be NULL): dx [n][in_f] fp16 contiguous, dw [outp][in_f] fp32, db [outp] fp32.
@@ -655,6 +672,10 @@ extern "C" int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, int l
     if ((st = tscd_conv_wgrad_nhwc_f16(x, dy, dw, 1, 1, n, in_f, outp, 1, ldx, lddy, ws2, workspace_bytes - pack_bytes, stream)) != TSCD_OK)
       return st;
   }
-  if (db && (st = tscd_bias_relu_bwd_f16(dy, lddy, nullptr, 0, nullptr, 0, n, outp, db, stream)) != TSCD_OK) return st;   // db: outp floats
+  if (db) {                                                                                             // db: outp floats
+    const long off = pack_bytes + tscd_conv_wgrad_workspace_bytes(n, outp, in_f, 1);
+    if ((st = tscd_bias_relu_bwd_f16(dy, lddy, nullptr, 0, nullptr, 0, n, outp, db, (char*)workspace + off, workspace_bytes - off, stream)) != TSCD_OK)
+      return st;
+  }
   return TSCD_OK;
 }

@@ -85,6 +85,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int mtiles
   // issued ahead of the reduction so their latency overlaps the partial loads (the kernel is one dependent chain otherwise)
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   const float rm0 = running_mean ? running_mean[c] : 0.f, rv0 = running_mean ? running_var[c] : 0.f;
+#pragma unroll 8
   for (int t = lane; t < mtiles; t += 64) {
     s1 += (double)partial[(long)c * mtiles + t];
     s2 += (double)partial[((long)cstride + c) * mtiles + t];

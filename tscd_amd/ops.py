@@ -508,12 +508,15 @@ def bias_relu_bwd(dy, y=None):
     assert dy.dtype == torch.float16 and C % 8 == 0
     ldg = nhwc_ld(dy) if dy.dim() == 4 else dy.stride(0)
     db = torch.empty((C,), dtype=torch.float32, device=dy.device)
+    ws_bytes = lib.tscd_bias_relu_bwd_workspace_bytes(M, C)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
     if y is None:
-        call("tscd_bias_relu_bwd_f16", dy.data_ptr(), ldg, 0, 0, 0, 0, M, C, db.data_ptr(), _stream())
+        call("tscd_bias_relu_bwd_f16", dy.data_ptr(), ldg, 0, 0, 0, 0, M, C, db.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
         return dy, db
     gm = torch.empty(dy.shape, dtype=torch.float16, device=dy.device)
     ldy = nhwc_ld(y) if y.dim() == 4 else y.stride(0)
-    call("tscd_bias_relu_bwd_f16", dy.data_ptr(), ldg, y.data_ptr(), ldy, gm.data_ptr(), C, M, C, db.data_ptr(), _stream())
+    call("tscd_bias_relu_bwd_f16", dy.data_ptr(), ldg, y.data_ptr(), ldy, gm.data_ptr(), C, M, C, db.data_ptr(), ws.data_ptr(), ws_bytes,
+         _stream())
     return gm, db
 
 
