@@ -273,7 +273,7 @@ def test_trainable_tower_backward_matches_oracle_autograd():
 
 
 @pytest.mark.parametrize("W,ppf,L,mode", [(64, [40, 25, 90], 2, "hip"), (64, [40, 25, 90], 2, "torch"), (256, [70, 33, 150], 2, "hip"),
-                                          (128, [64, 64, 1], 3, "hip")])
+                                          (128, [64, 64, 1], 3, "hip"), (128, [200, 180, 150, 170], 3, "hip")])
 def test_mca_backward_matches_oracle_autograd(W, ppf, L, mode):
     """HIP backward kernel (mca_bwd.hip + GEMM grads) and the PyTorch-expression path vs the oracle's fp32 autograd."""
     from yolox.models.post_trans import MCA_tscd_g2l_reg
