@@ -91,7 +91,10 @@ def make_optimizer(model, lr=0.002 / 64 * 16, momentum=0.9, weight_decay=5e-4, s
         elif hasattr(v, "weight") and isinstance(v.weight, torch.nn.Parameter):
             (pg3 if ("head.stem" in k or "head.reg_convs" in k or "head.cls_convs" in k) else pg1).append(v.weight)
     tr = lambda ps: [p for p in ps if p.requires_grad]
-    opt = torch.optim.SGD(tr(pg0), lr=lr, momentum=momentum, nesterov=True)
+    # fused=True: one multi-tensor launch per group AND the GradScaler inf check stays on the device (found_inf is handed to the
+    # fused step), so the host does not drain the GPU once per step; same SGD update rule (TSCD_FUSED_SGD=0: foreach path)
+    fused = bool(tr(pg0)) and tr(pg0)[0].is_cuda and os.environ.get("TSCD_FUSED_SGD", "1") != "0"
+    opt = torch.optim.SGD(tr(pg0), lr=lr, momentum=momentum, nesterov=True, fused=fused)
     opt.add_param_group({"params": tr(pg1), "weight_decay": weight_decay})
     opt.add_param_group({"params": tr(pg2)})
     if tr(pg3):
@@ -189,12 +192,15 @@ def roofline_dominant_kernel(args, device, step):
     # per-launch durations: the three pyramid levels run on ONE stream during these instrumented steps, otherwise the event
     # brackets of a launch include the time it spends queued behind / sharing the CUs with another level's kernels
     streams, head_mod.LEVEL_STREAMS = head_mod.LEVEL_STREAMS, False
+    import yolox.models.tscd as tscd_mod
+    prefetch, tscd_mod.PREFETCH_BACKBONE = tscd_mod.PREFETCH_BACKBONE, False     # same reason: one stream while timing launches
     try:
         for _ in range(nsteps):
             step()
         torch.cuda.synchronize()
     finally:
         head_mod.LEVEL_STREAMS = streams
+        tscd_mod.PREFETCH_BACKBONE = prefetch
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
     sel = [(f, e0.elapsed_time(e1) * 1e-3) for (bn, cin, f, e0, e1) in prof if bn == 128 and cin % 32 == 0]
     flops, secs = sum(f for f, _ in sel), sum(t for _, t in sel)
@@ -268,12 +274,15 @@ def main():
     gframe = args.frames - args.lframe
 
     def step():
-        out = net(imgs, targets, temb, lframe=args.lframe, gframe=gframe, resume=False)
+        # next_x: the following clip (here the same synthetic tensor); its frozen backbone pass runs inside this step's
+        # assignment window (yolox/models/tscd.py) and is consumed by the next call -- one backbone pass per step either way
+        out = net(imgs, targets, temb, lframe=args.lframe, gframe=gframe, resume=False, next_x=imgs)
         loss = out["total_loss"]
         opt.zero_grad(set_to_none=True)
         scaler.scale(loss).backward()
         scaler.step(opt)
         scaler.update()
+        model.join_prefetch()          # the EMA reads the backbone's running statistics: behind the prefetched pass that updates them
         ema.update()
         return loss
 

@@ -106,7 +106,10 @@ class Exp(BaseExp):
         if "optimizer" not in self.__dict__:
             lr = self.warmup_lr if self.warmup_epochs > 0 else self.basic_lr_per_img * batch_size
             pg0, pg1, pg2, pg3 = self._param_groups(split_head=hasattr(self, "stem_lr_ratio"))
-            opt = torch.optim.SGD(pg0, lr=lr, momentum=self.momentum, nesterov=True)
+            # fused multi-tensor SGD on the GPU: same update rule; with amp the GradScaler's inf check then stays on the
+            # device instead of draining the GPU once per step (tscd_trainer.py:171-176 semantics unchanged)
+            fused = bool(pg0) and pg0[0].is_cuda
+            opt = torch.optim.SGD(pg0, lr=lr, momentum=self.momentum, nesterov=True, fused=fused)
             opt.add_param_group({"params": pg1, "weight_decay": self.weight_decay})
             opt.add_param_group({"params": pg2})
             if pg3:

@@ -37,7 +37,18 @@ int tscd_lap_fixed_point_available(void);
 int tscd_lap_chain_f16(int K, const uint16_t* const* cost, const int64_t* nr, const int64_t* nc, const int32_t* kind,
                        int64_t* row_out, int64_t* col_out, int64_t* perm_out);
 
-/* Diagnostics: relaxation passes executed by the fixed-point solver since the last reset (not thread-safe). */
+/* The chain's matrices depend on each other only through the ORDER of their rows, so they are solved side by side (identity
+ * order, a small persistent thread pool) and the in-order answer is recovered by relabelling wherever the optimum is certified
+ * unique from the exact integer duals (no alternating cycle of tight entries, no free move to an unassigned column); a matrix
+ * that fails the certificate is solved again strictly in order, so the result is always the reference's.
+ * The side-by-side pass is adaptive: after a chain where fewer than half the matrices were certified (tie-heavy costs, e.g. a
+ * randomly initialised network) it pauses and is probed again every 64th chain.  tscd_lap_chain_set_parallel(0) forces the
+ * strictly sequential chain, (2) the side-by-side pass on every chain, (1) the adaptive default (returns the previous setting);
+ * tscd_lap_chain_spec_hits counts matrices answered from the side-by-side solve. */
+int tscd_lap_chain_set_parallel(int on);
+int64_t tscd_lap_chain_spec_hits(int reset);
+
+/* Diagnostics: relaxation passes executed by the fixed-point solver since the last reset. */
 int64_t tscd_lap_debug_steps(int reset);
 
 #ifdef __cplusplus

@@ -114,3 +114,49 @@ def test_train_losses_and_grads(golden, model):
         cos = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item()
         assert cos > 0.85, (k, cos)   # assignment sets differ by fp16 noise; exact-input backward checks live in test_gpu_head_stages.py
     assert all(torch.isfinite(p.grad).all() for p in named.values() if p.grad is not None)
+
+
+def test_backbone_prefetch_in_assignment_window_is_exact(golden, model):
+    """forward(..., next_x=clip) runs the next clip's frozen backbone pass inside the assignment window (side stream) and the
+    next call consumes it: the pyramid must be bit-identical to an in-place pass, the BatchNorm running statistics must
+    advance exactly once per clip, and a call with a different tensor must ignore the stash."""
+    cfg, sd, vec, meta = golden
+    import copy
+    import yolox.models.tscd as tscd_mod
+    imgs = torch.from_numpy(vec["evalA_imgs"]).float().cuda().half()
+    imgs2 = (imgs.flip(0) * 0.9).contiguous()
+    labels = torch.from_numpy(vec["train_labels"]).cuda().half()
+    temb = torch.from_numpy(vec["time_embedding"]).cuda().half()
+    kw = dict(lframe=int(meta["lframe"]), gframe=int(meta["gframe"]), resume=False)
+
+    def fresh():
+        m = copy.deepcopy(model).train()
+        for p in m.backbone.parameters():
+            p.requires_grad = False
+        return m
+
+    a, b, c = fresh(), fresh(), fresh()
+    # a: clip 1 with the prefetch of clip 2, then clip 2;  b: the same two clips back to back without it
+    out_a1 = a(imgs, labels, temb, next_x=imgs2, **kw)
+    assert id(a) in tscd_mod._PREFETCHED
+    stash = [t.clone() for t in tscd_mod._PREFETCHED[id(a)][1]]
+    out_a2 = a(imgs2, labels, temb, **kw)
+    assert id(a) not in tscd_mod._PREFETCHED
+    out_b1 = b(imgs, labels, temb, **kw)
+    c(imgs, labels, temb, **kw)
+    with torch.no_grad():
+        direct = c.backbone(imgs2)                           # what an in-place pass of clip 2 produces at this point
+    out_b2 = b(imgs2, labels, temb, **kw)
+    torch.cuda.synchronize()
+    for s_, d_ in zip(stash, direct):
+        assert torch.equal(s_, d_)
+    for k in ("total_loss", "iou_loss", "conf_loss", "cls_loss"):
+        assert float(out_a1[k]) == float(out_b1[k]), k
+        assert float(out_a2[k]) == float(out_b2[k]), k
+    sa, sb = a.backbone.state_dict(), b.backbone.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k                  # running statistics / num_batches_tracked advanced identically
+    # a stash for another tensor is dropped, not used
+    a(imgs, labels, temb, next_x=imgs2, **kw)
+    out_c = a(imgs, labels, temb, **kw)
+    assert id(a) not in tscd_mod._PREFETCHED and torch.isfinite(out_c["total_loss"])

@@ -132,3 +132,70 @@ def test_lap_chain_matches_stepwise_scipy(seed):
             assert np.array_equal(got[k][0], r) and np.array_equal(got[k][1], c), (seed, trial, k)
             assert np.array_equal(got[k][2], perm), (seed, trial, k)
             prev_perm = perm
+
+
+def _chain_reference(mats, kinds, KIND_SELF, KIND_PREV):
+    out, prev_perm = [], None
+    for k, m in enumerate(mats):
+        ref = m.astype(float)
+        if kinds[k] == KIND_PREV:
+            ref = ref[prev_perm]
+        r, c = linear_sum_assignment(ref)
+        perm = np.arange(m.shape[1]) if kinds[k] == KIND_SELF else np.concatenate([c, np.setdiff1d(np.arange(m.shape[1]), c)])
+        out.append((r, c, perm))
+        prev_perm = perm
+    return out
+
+
+@pytest.mark.parametrize("mode", ["ties", "real", "mixed"])
+def test_lap_chain_side_by_side_solves_match_in_order_scipy(mode):
+    """The chain solves its matrices side by side in identity row order and relabels the answer where the optimum is certified
+    unique (exact integer duals), falling back to the in-order solve otherwise.  Whatever the certificate says, the result must be
+    the reference's in-order scipy answer: tie-heavy costs (a handful of distinct fp16 values: most optima are NOT unique and the
+    tie rules decide), real-valued costs (unique: answered from the side-by-side solve) and mixtures, square and rectangular in
+    both directions -- and the strictly sequential chain must agree."""
+    from tscd_amd import _host
+    from tscd_amd._host import lap_chain_f16, KIND_SELF, KIND_STATE, KIND_PREV
+    rng = np.random.default_rng({"ties": 1, "real": 2, "mixed": 3}[mode])
+    hits = 0
+    for trial in range(60):
+        K = int(rng.integers(2, 6))
+        ns = [int(rng.integers(3, 40)) for _ in range(K)]
+        first_kind = KIND_SELF if trial % 2 == 0 else KIND_STATE
+        n_state = int(rng.integers(3, 40))
+        mats, kinds = [], []
+        for k in range(K):
+            nr = ns[k] if (k == 0 and first_kind == KIND_SELF) else (n_state if k == 0 else ns[k - 1])
+            tie = mode == "ties" or (mode == "mixed" and rng.random() < 0.5)
+            if tie:
+                levels = int(rng.integers(2, 6))
+                m = rng.integers(0, levels, (nr, ns[k])).astype(np.float16) / 8
+                if rng.random() < 0.3:      # a nearly-unique matrix with one tied pair of rows
+                    m = rng.random((nr, ns[k])).astype(np.float16)
+                    if nr > 1:
+                        m[1] = m[0]
+            else:
+                m = (0.5 + 0.5 * rng.random((nr, ns[k]))).astype(np.float16)
+            mats.append(np.ascontiguousarray(m))
+            kinds.append(first_kind if k == 0 else KIND_PREV)
+        flat = np.concatenate([m.reshape(-1) for m in mats])
+        ref = _chain_reference(mats, kinds, KIND_SELF, KIND_PREV)
+        for parallel in (2, 0):                    # 2: side-by-side pass on every chain (1 = adaptive default)
+            prev = _host._lib.tscd_lap_chain_set_parallel(parallel)
+            _host._lib.tscd_lap_chain_spec_hits(1)
+            try:
+                got = lap_chain_f16(flat.ctypes.data, [m.shape for m in mats], kinds)
+            finally:
+                _host._lib.tscd_lap_chain_set_parallel(prev)
+            if parallel:
+                hits += _host._lib.tscd_lap_chain_spec_hits(1)
+            else:
+                assert _host._lib.tscd_lap_chain_spec_hits(1) == 0
+            for k in range(K):
+                for a, b in zip(got[k], ref[k]):
+                    assert np.array_equal(a, b), (mode, trial, k, parallel, mats[k].shape)
+    if _host._lib.tscd_lap_fixed_point_available():
+        if mode == "real":
+            assert hits > 100          # unique optima are answered from the side-by-side solves
+        if mode == "ties":
+            assert hits < 60           # tie-heavy optima are (almost) never certified unique

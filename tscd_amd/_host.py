@@ -48,6 +48,12 @@ def lap_f16(cost_u16, row_map=None):
 
 _lib.tscd_lap_chain_f16.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.tscd_lap_chain_f16.restype = C.c_int
+_lib.tscd_lap_chain_set_parallel.argtypes = [C.c_int]
+_lib.tscd_lap_chain_set_parallel.restype = C.c_int
+_lib.tscd_lap_chain_spec_hits.argtypes = [C.c_int]
+_lib.tscd_lap_chain_spec_hits.restype = C.c_int64
+if os.environ.get("TSCD_LAP_PARALLEL", "1") == "0":       # diagnostics / A-B runs: strictly in-order chain
+    _lib.tscd_lap_chain_set_parallel(0)
 KIND_SELF, KIND_STATE, KIND_PREV = 0, 1, 2
 
 

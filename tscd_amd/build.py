@@ -22,7 +22,7 @@ def build_host(force=False, verbose=True):
     if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) > os.path.getmtime(HOST_SRC):
         return HOST_LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", HOST_SRC, "-o", HOST_LIB]
+    cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-pthread", HOST_SRC, "-o", HOST_LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

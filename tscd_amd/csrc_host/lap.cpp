@@ -18,6 +18,13 @@
 #include <vector>
 #include <algorithm>
 #include <numeric>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <unistd.h>
 
 namespace {
 
@@ -235,7 +242,7 @@ struct AlignedBuf {
   T* end() { return p + n; }
 };
 constexpr int32_t QLIM = 1 << 27, QINF = 1 << 30, QDEADV = -(QINF + (QINF >> 1));
-static int64_t g_steps = 0;        // relaxation passes of the last solves (diagnostics)
+static std::atomic<int64_t> g_steps{0};        // relaxation passes of the last solves (diagnostics; solves may run on pool threads)
 
 // One relaxation pass from row i, mask-free: columns already in SC carry veff = QDEADV (so their candidate exceeds QINF)
 // and spc = QINF (their real spc is parked in spcsave), which removes them from the update, the minimum and the tie test
@@ -304,25 +311,77 @@ static void exponent_span(const uint16_t* src, int64_t n, int& emin, int& emax) 
   emin = (int)l; emax = (int)g;
 }
 
+// Uniqueness certificate (exact, integer duals).  At termination (u, v) is dual feasible, every assigned pair is tight
+// (c - u - v == 0) and unassigned columns keep v == 0 <= every other v.  With nc - nr dummy rows (cost 0, dual 0: tight exactly
+// on the columns with v == 0) the optimal solutions are the perfect matchings of the tight graph, so the real rows' columns
+// are the same in every optimal solution iff, in the column digraph  j -> j'  (the row assigned to j has another tight entry
+// in j'),  (a) no cycle runs through assigned columns and (b) no assigned column with v == 0 reaches an unassigned column.
+// A unique optimum does not depend on the order in which rows / columns are presented: the speculative identity-order solve of
+// tscd_lap_chain_f16 is then the reference's answer up to relabelling.
+template <typename CT>
+static bool unique_optimum(int64_t nr, int64_t nc, int64_t ncp, const CT* c, const int32_t* u, const int32_t* v, const int32_t* col4row,
+                           const int32_t* row4col) {
+  std::vector<int32_t> start(nc + 1, 0), adj;
+  adj.reserve(4 * nr);
+  for (int64_t j = 0; j < nc; ++j) {
+    const int32_t i = row4col[j];
+    if (i >= 0) {
+      const CT* crow = c + (int64_t)i * ncp;
+      const int32_t ui = u[i];
+      for (int64_t t = 0; t < nc; ++t)
+        if (t != j && (int32_t)crow[t] - ui - v[t] == 0) adj.push_back((int32_t)t);
+    }
+    start[j + 1] = (int32_t)adj.size();
+  }
+  // iterative DFS over assigned columns: colour 0 new / 1 on stack / 2 done; reach[j]: an unassigned column is reachable from j
+  std::vector<uint8_t> colour(nc, 0), reach(nc, 0);
+  std::vector<int32_t> stack, edge;
+  for (int64_t root = 0; root < nc; ++root) {
+    if (row4col[root] < 0 || colour[root]) continue;
+    stack.assign(1, (int32_t)root);
+    edge.assign(1, start[root]);
+    colour[root] = 1;
+    while (!stack.empty()) {
+      const int32_t j = stack.back();
+      if (edge.back() < start[j + 1]) {
+        const int32_t t = adj[edge.back()++];
+        if (row4col[t] < 0) { reach[j] = 1; continue; }
+        if (colour[t] == 1) return false;                    // (a) alternating cycle of tight entries
+        if (colour[t] == 0) { colour[t] = 1; stack.push_back(t); edge.push_back(start[t]); }
+        else reach[j] |= reach[t];
+      } else {
+        colour[j] = 2;
+        stack.pop_back(); edge.pop_back();
+        if (!stack.empty()) reach[stack.back()] |= reach[j];
+      }
+    }
+  }
+  if (nr < nc)
+    for (int64_t j = 0; j < nc; ++j)
+      if (row4col[j] >= 0 && v[j] == 0 && reach[j]) return false;   // (b) a row may move to an unassigned column for free
+  return true;
+}
+
 template <typename CT>
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
-static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int E, int32_t* col4row_out);
+static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int E, int32_t* col4row_out, int* unique_out);
 
 // cost: fp16 bits, [nr][ncp] with ncp % 32 == 0 (padding columns are never live), nr <= nc.  0 ok, 2 infeasible, 3 overflow.
 // The integer matrix is int16 (0.5 MB for 500x500: stays in the core's L2) when the entries' exponents span <= 4 binades --
 // CAFM's costs 1 - cos live in [0.5, 1.2] -- and int32 otherwise (e.g. the self-match, whose diagonal is ~0).
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
-static int solve_q(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int32_t* col4row_out) {
+static int solve_q(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int32_t* col4row_out, int* unique_out = nullptr) {
   int emin, emax;
   exponent_span(cost, nr * ncp, emin, emax);
   if (emax < emin) { emin = emax = 1; }                      // all zeros
-  if (emax - emin <= 4) return solve_q_t<int16_t>(nr, nc, ncp, cost, emin, col4row_out);
-  return solve_q_t<int32_t>(nr, nc, ncp, cost, 1, col4row_out);   // unit 2^-24
+  if (emax - emin <= 4) return solve_q_t<int16_t>(nr, nc, ncp, cost, emin, col4row_out, unique_out);
+  return solve_q_t<int32_t>(nr, nc, ncp, cost, 1, col4row_out, unique_out);   // unit 2^-24
 }
 
 template <typename CT>
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
-static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int E, int32_t* col4row_out) {
+static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int E, int32_t* col4row_out, int* unique_out) {
+  int64_t steps = 0;
   // converted once; the buffer is kept per thread (fresh pages cost more than the solve's first rows)
   static thread_local CT* c_buf = nullptr;
   static thread_local size_t c_cap = 0;
@@ -355,7 +414,7 @@ static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, 
     dead_list.clear();
     while (sink == -1) {
       sr_list.push_back((int32_t)i);
-      ++g_steps;
+      ++steps;
       int32_t lowest = relax_row_q<CT>(c32.data() + i * ncp, veff.data(), spc.data(), path.data(), ncp, minVal - u[i], (int16_t)i);
       if (lowest == QINF) return 2;
       if (lowest >= QLIM || lowest <= -QLIM) return 3;
@@ -416,6 +475,8 @@ static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, 
     }
   }
   for (int64_t r = 0; r < nr; ++r) col4row_out[r] = col4row[r];
+  g_steps.fetch_add(steps, std::memory_order_relaxed);
+  if (unique_out) *unique_out = unique_optimum<CT>(nr, nc, ncp, c32.data(), u.data(), v.data(), col4row.data(), row4col.data()) ? 1 : 0;
   return 0;
 }
 static const bool g_have_q = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
@@ -461,6 +522,83 @@ inline double half_to_double(uint16_t h) {
   else val = std::ldexp((double)(man | 0x400), (int)exp - 25);
   return sign ? -val : val;
 }
+
+// Persistent worker threads for the chain's independent solves (their thread_local conversion buffers stay warm; threads are
+// never joined -- the pool is leaked at exit on purpose -- and are re-created in a forked child).
+class Pool {
+ public:
+  static Pool& get() {
+    static std::mutex gm;
+    static Pool* inst = nullptr;
+    std::lock_guard<std::mutex> lk(gm);
+    if (!inst || inst->pid_ != getpid()) inst = new Pool();
+    return *inst;
+  }
+  // runs jobs[0..n) on the workers (the caller takes part) and returns when all are done
+  void run(std::vector<std::function<void()>>& jobs) {
+    if (jobs.empty()) return;
+    std::unique_lock<std::mutex> lk(m_);
+    pending_ += (int)jobs.size();
+    for (auto& j : jobs) q_.push_back(&j);
+    cv_.notify_all();
+    while (true) {
+      if (!q_.empty()) {
+        std::function<void()>* j = q_.front();
+        q_.pop_front();
+        lk.unlock();
+        (*j)();
+        lk.lock();
+        if (--pending_ == 0) done_.notify_all();
+      } else if (pending_ > 0) {
+        done_.wait(lk);
+      } else {
+        break;
+      }
+    }
+  }
+
+ private:
+  Pool() : pid_(getpid()) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = hw > 4 ? 3 : (hw > 1 ? (int)hw - 1 : 0);     // + the calling thread: 4 solves side by side
+    for (int i = 0; i < n; ++i) std::thread([this] { loop(); }).detach();
+  }
+  void loop() {
+    std::unique_lock<std::mutex> lk(m_);
+    while (true) {
+      cv_.wait(lk, [this] { return !q_.empty(); });
+      std::function<void()>* j = q_.front();
+      q_.pop_front();
+      lk.unlock();
+      (*j)();
+      lk.lock();
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  pid_t pid_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  std::deque<std::function<void()>*> q_;
+  int pending_ = 0;
+};
+
+#if defined(__x86_64__)
+// Identity-order solve of one chain matrix on the fixed-point path.  c4r: assignment in the solver's orientation (rows =
+// the shorter side).  Returns false when the fixed-point path does not apply (the caller then solves in order).
+struct Spec { bool ok = false, transpose = false; int unique = 0; int status = 0; std::vector<int32_t> c4r; };
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static void speculate(const uint16_t* cost, int64_t nr, int64_t nc, Spec& sp) {
+  sp.ok = false;
+  if (!g_have_q || nr >= 32000 || nc >= 32000 || nr == 0 || nc == 0) return;
+  sp.transpose = nc < nr;
+  const int64_t R = sp.transpose ? nc : nr, Cc = sp.transpose ? nr : nc, ncp = (Cc + 31) / 32 * 32;
+  std::vector<uint16_t> q;
+  if (!prepare_q(cost, nc, nullptr, nr, nc, sp.transpose, ncp, q)) return;
+  sp.c4r.assign(R, -1);
+  sp.status = solve_q(R, Cc, ncp, q.data(), sp.c4r.data(), &sp.unique);
+  sp.ok = sp.status == 0;
+}
+#endif
 
 }  // namespace
 
@@ -519,10 +657,40 @@ int tscd_lap_solve_f16(const uint16_t* cost, int64_t ld, const int64_t* row_map,
 // Outputs, concatenated over k: row_out / col_out (min(nr,nc) entries each: what scipy returns), perm_out (nc[k] entries:
 // col_out followed by the unmatched columns in ascending order when nr[k] < nc[k]; the identity for kind 0) -- the order in
 // which the reference keeps frame k's rows.  Returns 0, or 16*k + status of the first failing solve.
+static std::atomic<int> g_chain_parallel{1};
+static std::atomic<int64_t> g_chain_spec_hits{0};
+// 1 (default): chain matrices are solved side by side and relabelled where the optimum is certified unique, adaptively (see
+// below); 2: always; 0: strictly in order.  Returns the previous setting.  tscd_lap_chain_spec_hits: matrices answered from the side-by-side solve so far.
+int tscd_lap_chain_set_parallel(int on) { return g_chain_parallel.exchange(on); }
+int64_t tscd_lap_chain_spec_hits(int reset) { int64_t h = g_chain_spec_hits; if (reset) g_chain_spec_hits = 0; return h; }
 int tscd_lap_chain_f16(int K, const uint16_t* const* cost, const int64_t* nr, const int64_t* nc, const int32_t* kind,
                        int64_t* row_out, int64_t* col_out, int64_t* perm_out) {
   std::vector<int64_t> prev_perm;
   int64_t o_pair = 0, o_perm = 0;
+#if defined(__x86_64__)
+  // Solve k needs solve k-1's column order only to ORDER its rows.  All matrices are therefore solved side by side in
+  // identity order first; where the optimum is certified unique (unique_optimum: it almost always is for real-valued
+  // features) the in-order answer is that assignment relabelled, otherwise the matrix is solved again in order below.
+  // Adaptive: the side-by-side solves pay off only when most optima are certified unique (trained features).  Tie-heavy costs
+  // (e.g. a randomly initialised network: near-duplicate proposals) fail the certificate and would be solved twice, so after a
+  // chain with fewer hits than misses speculation pauses and is only probed again every 64th chain.  g_chain_parallel == 2
+  // forces it (tests).
+  static std::atomic<int> cooldown{0};
+  bool speculate_now = g_chain_parallel == 2 || (g_chain_parallel == 1 && cooldown.load() <= 0);
+  if (g_chain_parallel == 1 && !speculate_now) --cooldown;
+  std::vector<Spec> spec(K);
+  int tried = 0;
+  if (speculate_now && K > 1) {
+    std::vector<std::function<void()>> jobs;
+    for (int k = 0; k < K; ++k)
+      if (kind[k] == 2 && nr[k] > 0 && nc[k] > 0) jobs.emplace_back([&, k] { speculate(cost[k], nr[k], nc[k], spec[k]); });
+    tried = (int)jobs.size();
+    Pool::get().run(jobs);
+    int hits = 0;
+    for (int k = 0; k < K; ++k) hits += spec[k].ok && spec[k].unique;
+    if (g_chain_parallel == 1) cooldown = (2 * hits < tried) ? 64 : 0;
+  }
+#endif
   for (int k = 0; k < K; ++k) {
     const int64_t R = nr[k], Cn = nc[k], np = R < Cn ? R : Cn;
     const int64_t* row_map = nullptr;
@@ -530,7 +698,27 @@ int tscd_lap_chain_f16(int K, const uint16_t* const* cost, const int64_t* nr, co
       if ((int64_t)prev_perm.size() != R) return 16 * k + 4;
       row_map = prev_perm.data();
     }
-    int st = tscd_lap_solve_f16(cost[k], Cn, row_map, R, Cn, row_out + o_pair, col_out + o_pair);
+    int st = 0;
+    bool done = false;
+#if defined(__x86_64__)
+    if (kind[k] == 2 && spec[k].ok && spec[k].unique) {
+      // relabel: presented row i is cost row row_map[i]
+      int64_t* ro = row_out + o_pair; int64_t* co = col_out + o_pair;
+      if (!spec[k].transpose) {            // every presented row is assigned
+        for (int64_t i = 0; i < R; ++i) { ro[i] = i; co[i] = spec[k].c4r[row_map[i]]; }
+      } else {                             // c4r[column] = cost row; only Cn of the R presented rows are assigned
+        std::vector<int64_t> inv(R);
+        for (int64_t i = 0; i < R; ++i) inv[row_map[i]] = i;
+        std::vector<std::pair<int64_t, int64_t>> pr(Cn);
+        for (int64_t c = 0; c < Cn; ++c) pr[c] = {inv[spec[k].c4r[c]], c};
+        std::sort(pr.begin(), pr.end());
+        for (int64_t c = 0; c < Cn; ++c) { ro[c] = pr[c].first; co[c] = pr[c].second; }
+      }
+      ++g_chain_spec_hits;
+      done = true;
+    }
+#endif
+    if (!done) st = tscd_lap_solve_f16(cost[k], Cn, row_map, R, Cn, row_out + o_pair, col_out + o_pair);
     if (st != 0) return 16 * k + st;
     std::vector<int64_t> perm(Cn);
     if (kind[k] == 0) {

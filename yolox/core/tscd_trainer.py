@@ -89,18 +89,36 @@ class Trainer:
     def progress_in_iter(self):
         return self.epoch * self.max_iter + self.iter
 
-    def train_one_iter(self):
-        t0 = time.time()
+    def _next_batch(self):
         inps, targets, time_embedding = self.prefetcher.next()
         inps, targets, time_embedding = inps.half(), targets.half(), time_embedding.half()      # tscd_trainer.py:159-161
         targets.requires_grad = False
         inps, targets = self.exp.preprocess(inps, targets, self.input_size)
-        outputs = self.model(inps, targets, time_embedding, lframe=self.exp.lframe, gframe=self.exp.gframe, resume=False)
+        return inps, targets, time_embedding
+
+    def _join_prefetch(self):
+        m = self.model.module if is_parallel(self.model) else self.model
+        if hasattr(m, "join_prefetch"):
+            m.join_prefetch()
+
+    def train_one_iter(self):
+        t0 = time.time()
+        # one clip of look-ahead: the model runs the NEXT clip's frozen backbone pass inside this step's assignment window
+        # (yolox/models/tscd.py).  Never across the end of an epoch or a multiscale resize (the next clip's size is not decided yet).
+        batch, self._ahead = getattr(self, "_ahead", None), None
+        inps, targets, time_embedding = batch if batch is not None else self._next_batch()
+        resize_next = (self.progress_in_iter + 1) % 10 == 0 and getattr(self.exp, "multiscale_range", 0) > 0
+        if self.iter + 1 < self.max_iter and not resize_next:
+            self._ahead = self._next_batch()
+        next_x = self._ahead[0] if self._ahead is not None else None
+        outputs = self.model(inps, targets, time_embedding, lframe=self.exp.lframe, gframe=self.exp.gframe, resume=False,
+                             next_x=next_x)
         loss = outputs["total_loss"]
         self.optimizer.zero_grad()
         self.scaler.scale(loss).backward()
         self.scaler.step(self.optimizer)
         self.scaler.update()
+        self._join_prefetch()          # EMA (and anything after the step) sees the backbone's buffers behind the prefetched pass
         if self.use_model_ema:
             self.ema_model.update(self.model)
         lr = self.lr_scheduler.update_lr(self.progress_in_iter + 1)

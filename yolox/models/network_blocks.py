@@ -43,7 +43,16 @@ class defer_bn_ticks:
         if self.outer is None:
             ticks, _DEFERRED_TICKS = _DEFERRED_TICKS, None
             if ticks:
-                torch._foreach_add_(ticks, 1)
+                # a module may run more than once inside the scope (tscd.py runs the next clip's backbone pass in the
+                # assignment window): one entry per buffer and pass count, a fused add must not see a tensor twice
+                count = {}
+                for t in ticks:
+                    count[id(t)] = (t, count[id(t)][1] + 1) if id(t) in count else (t, 1)
+                by_n = {}
+                for t, n in count.values():
+                    by_n.setdefault(n, []).append(t)
+                for n, ts in by_n.items():
+                    torch._foreach_add_(ts, n)
         return False
 
 

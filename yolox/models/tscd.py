@@ -1,7 +1,30 @@
 """TSCD model wrapper (interface of the reference's yolox/models/tscd.py:11-50)."""
+import os
+
+import torch
 import torch.nn as nn
 
 from .network_blocks import defer_bn_ticks
+
+# Cross-step overlap (training, frozen backbone): while the host solves the clip's assignments the device has ~3 ms with
+# nothing to do, and the launch-bound stretch after it leaves more holes.  `forward(..., next_x=<next clip>)` runs the NEXT
+# clip's frozen backbone pass inside that window on a low-priority side stream; the next call (same tensor object) picks the
+# pyramid up instead of recomputing it.  Frozen weights do not change at the optimizer step, so the features are exactly
+# those of an in-place pass.  TSCD_PREFETCH_BACKBONE=0 disables it.
+PREFETCH_BACKBONE = os.environ.get("TSCD_PREFETCH_BACKBONE", "1") != "0"
+_PREFETCHED = {}        # id(model) -> (clip tensor, pyramid, ready event); module-level: the model must stay deep-copyable
+_PREFETCH_STREAM = {}   # device -> low-priority stream
+
+
+def _prefetch_stream(dev):
+    st = _PREFETCH_STREAM.get(dev)
+    if st is None:
+        try:
+            st = torch.cuda.Stream(device=dev, priority=1)      # below the default stream where the runtime has such a level
+        except Exception:
+            st = torch.cuda.Stream(device=dev)
+        _PREFETCH_STREAM[dev] = st
+    return st
 
 
 class TSCD(nn.Module):
@@ -12,16 +35,47 @@ class TSCD(nn.Module):
         self.backbone = backbone
         self.head = head
 
-    def forward(self, x, targets=None, time_embedding=None, nms_thresh=0.5, lframe=0, gframe=32, resume=False):
+    def forward(self, x, targets=None, time_embedding=None, nms_thresh=0.5, lframe=0, gframe=32, resume=False, next_x=None):
         with defer_bn_ticks():
-            return self._forward(x, targets, time_embedding, nms_thresh, lframe, gframe, resume)
+            return self._forward(x, targets, time_embedding, nms_thresh, lframe, gframe, resume, next_x)
 
-    def _forward(self, x, targets, time_embedding, nms_thresh, lframe, gframe, resume):
-        fpn_outs = self.backbone(x)
+    def _pyramid(self, x):
+        hit = _PREFETCHED.pop(id(self), None)
+        if hit is not None and hit[0] is x:
+            torch.cuda.current_stream().wait_event(hit[2])
+            for t in hit[1]:
+                t.record_stream(torch.cuda.current_stream())
+            return hit[1]
+        return self.backbone(x)
+
+    def join_prefetch(self):
+        """Orders the current stream behind a pending prefetched backbone pass (it updates the BatchNorm running statistics):
+        call before anything else reads or writes the backbone's buffers -- EMA update, checkpointing, evaluation."""
+        hit = _PREFETCHED.get(id(self))
+        if hit is not None:
+            torch.cuda.current_stream().wait_event(hit[2])
+
+    def _prefetch(self, next_x):
+        side = _prefetch_stream(next_x.device)
+        side.wait_stream(torch.cuda.current_stream())            # next_x and every buffer the pass recycles are settled
+        with torch.cuda.stream(side), torch.no_grad():
+            outs = self.backbone(next_x)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        _PREFETCHED[id(self)] = (next_x, outs, ev)
+
+    def _forward(self, x, targets, time_embedding, nms_thresh, lframe, gframe, resume, next_x=None):
+        fpn_outs = self._pyramid(x)
         if self.training:
             assert targets is not None
-            (loss, iou_loss, conf_loss, cls_loss, l1_loss, num_fg, loss_matched_cls, loss_matched_obj,
-             loss_matched_iou) = self.head(fpn_outs, targets, x, time_embedding, lframe=lframe, gframe=gframe, resume=resume)
+            frozen = not any(p.requires_grad for p in self.backbone.parameters())
+            if PREFETCH_BACKBONE and next_x is not None and next_x.is_cuda and frozen:
+                self.head.window_hook = lambda: self._prefetch(next_x)
+            try:
+                (loss, iou_loss, conf_loss, cls_loss, l1_loss, num_fg, loss_matched_cls, loss_matched_obj,
+                 loss_matched_iou) = self.head(fpn_outs, targets, x, time_embedding, lframe=lframe, gframe=gframe, resume=resume)
+            finally:
+                self.head.window_hook = None
             return {"total_loss": loss, "iou_loss": iou_loss, "l1_loss": l1_loss, "conf_loss": conf_loss, "cls_loss": cls_loss,
                     "num_fg": num_fg, "loss_matched_cls": loss_matched_cls, "loss_matched_obj": loss_matched_obj,
                     "loss_matched_iou": loss_matched_iou}

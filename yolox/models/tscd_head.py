@@ -305,6 +305,9 @@ class TSCDHead(nn.Module):
                 loss_r_cls = class_loss(cls_preds)
             base = pred_rows[:nl, :4].float()
             tgt = self._encode_reg(gt_box[lb, la], base, rmask)
+        hook = getattr(self, "window_hook", None)
+        if hook is not None:          # queued behind the window's own work: the next clip's frozen backbone pass (tscd.py)
+            hook()
         matched = self.local_reg_matcher.finish(prep, f_reg, f_edge, time_embedding[:lframe])
         matched = f_reg[:nl] if matched is None else matched[-1]
         self._dbg(agg_cls=features_cls_matched, agg_iou_cls=features_cls, agg_iou_obj=features_reg, cafm=matched,
