@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void mca_stats_kernel(McaParams p) {
 
 // -------------------------------------------------------------------------------------------------- pass B
 template <int DP, bool NEED_REG>
-__global__ __launch_bounds__(256) void mca_aggregate_kernel(McaParams p) {
+__global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p) {
   constexpr int KS = DP / 16, NT = DP / 32;
   constexpr int PST = 33;   // fp32 tile row stride
   constexpr int HST = 40;   // fp16 tile row stride (80 B: conflict-free b128 rows)

@@ -119,7 +119,7 @@ __global__ void mca_bwd_tiles_kernel(const McaTile* __restrict__ tiles, int ntil
 
 // ------------------------------------------------------------------------------------------------ core
 template <int DP, bool NEED_REG, int PASS>
-__global__ __launch_bounds__(256) void mca_bwd_core_kernel(McaBwdParams p) {
+__global__ __launch_bounds__(256, PASS == 1 ? 2 : 1) void mca_bwd_core_kernel(McaBwdParams p) {
   constexpr int KS = DP / 16, NT = DP / 32;
   constexpr int PST = 33, HST = 40;
   __shared__ float X[3][MCA_HEADS][32][PST];          // cross-head exchange (round 1: P, Rc, Rr; round 2: -, dAc, dAr)
