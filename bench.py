@@ -103,7 +103,7 @@ def make_optimizer(model, lr=0.002 / 64 * 16, momentum=0.9, weight_decay=5e-4, s
 
 
 class FusedEMA:
-    """ModelEMA.update (yolox/utils/ema.py:48-60) over every floating state tensor, as two multi-tensor launches."""
+    """ModelEMA.update (yolox/utils/ema.py:48-60) over every floating state tensor, as one launch."""
 
     def __init__(self, model, decay=0.9998):
         self.src = [v for v in model.state_dict().values() if v.dtype.is_floating_point]
@@ -115,8 +115,12 @@ class FusedEMA:
     def update(self):
         self.updates += 1
         d = self.decay(self.updates)
-        torch._foreach_mul_(self.ema, d)
-        torch._foreach_add_(self.ema, self.src, alpha=1.0 - d)
+        if self.ema and self.ema[0].is_cuda and all(v.dtype == torch.float32 for v in self.ema):
+            from tscd_amd import ops
+            ops.ema_update(self.ema, self.src, d)          # one launch (elementwise.hip: tscd_ema_update_f32)
+        else:
+            torch._foreach_mul_(self.ema, d)
+            torch._foreach_add_(self.ema, self.src, alpha=1.0 - d)
 
 
 def synth_clip(B, S, device, seed=0):
@@ -324,7 +328,7 @@ def main():
             "config": {"workload": f"TSCD d{args.depth}/w{args.width} train step (fwd+bwd+SGD+EMA), {args.frames}-frame {args.size}^2 clip per GPU, "
                                    f"lframe {args.lframe}+gframe {gframe}, {args.props} proposals/frame, {NUM_CLASSES} classes, random init",
                        "clips_per_step": world, "parallelism": f"dp{world}"},
-            "loss": float(loss), "roofline": roof,
+            "loss": float(loss.detach()), "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -102,6 +102,10 @@ int tscd_haar_idwt_mul_nhwc_f16(const void* hf, const void* content, int ldc, vo
 /* Backward of the two Haar steps (DWT_Function.backward / IDWT_Function.backward, surrounding_extraction.py:30-41,60-76):
  * d haar_hf = tscd_haar_idwt_mul_nhwc_f16 with content == NULL (the synthesis with LL = 0 is the adjoint of the analysis);
  * out = content * idwt(hf)  =>  dcontent = d * idwt(hf), dhf = dwt_hf(d * content) in one pass. */
+/* ModelEMA.update (yolox/utils/ema.py:48-60) over all fp32 state tensors in one launch: v = fma(1-d, model_v, d*v).  table: device
+ * array of nchunks records {float* dst; const float* src; long n} with n <= tscd_ema_chunk_elems() (one workgroup per record). */
+int tscd_ema_chunk_elems(void);
+int tscd_ema_update_f32(const void* table, long nchunks, float d, float one_minus_d, void* stream);
 int tscd_haar_idwt_mul_bwd_nhwc_f16(const void* d, const void* hf, const void* content, int ldc, void* dcontent, void* dhf,
                                     int B, int H, int W, int C, void* stream);
 

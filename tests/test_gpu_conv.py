@@ -260,3 +260,33 @@ def test_conv_lds_dma_variant_bit_identical_to_register_staging(case):
     assert torch.equal(st0, st1) and torch.equal(st0, st2)
     ref = F.conv2d(x.float(), w.float(), None, s, (k - 1) // 2)
     assert_close(y1.permute(0, 3, 1, 2), ref)
+
+
+def test_ema_update_matches_foreach_formulation():
+    """One-launch EMA (tscd_ema_update_f32) against the reference formulation v *= d; v += (1-d) * src on the same tensors:
+    odd sizes, a tensor spanning several chunks, an unaligned view -- bit-identical, src untouched, table cache reused and rebuilt."""
+    from tscd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    sizes = [1, 7, 64, 1000, 16384, 16385, 70001, 3]
+    base = torch.randn(sum(sizes) + 1, generator=g).to(dev())
+    dst = [torch.randn(n, generator=g).to(dev()) for n in sizes]
+    src = [torch.randn(n, generator=g).to(dev()) for n in sizes]
+    dst[1] = base[1:8]                      # 4-byte aligned only
+    src0 = [t.clone() for t in src]
+    for d in (0.37, 0.9998):
+        ref = [t.clone() for t in dst]
+        torch._foreach_mul_(ref, d)
+        torch._foreach_add_(ref, src, alpha=1.0 - d)
+        ops.ema_update(dst, src, d)
+        torch.cuda.synchronize()
+        for a, b in zip(dst, ref):
+            assert torch.equal(a, b)
+    for a, b in zip(src, src0):
+        assert torch.equal(a, b)
+    src[2] = src[2].clone()                 # a moved tensor: the cached table must be rebuilt, not reused
+    ref = [t.clone() for t in dst]
+    torch._foreach_mul_(ref, 0.5)
+    torch._foreach_add_(ref, src, alpha=0.5)
+    ops.ema_update(dst, src, 0.5)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(dst, ref))

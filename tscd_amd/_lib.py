@@ -22,6 +22,7 @@ SIGNATURES = {
     "tscd_haar_hf_nhwc_f16": [P, I, P, I, I, I, I, P],
     "tscd_haar_idwt_mul_nhwc_f16": [P, P, I, P, I, I, I, I, I, P],
     "tscd_haar_idwt_mul_bwd_nhwc_f16": [P, P, P, I, P, P, I, I, I, I, P],
+    "tscd_ema_update_f32": [P, L, F, F, P],
     "tscd_decode_score": [P, P, P, P, P, P, I, I, P, P, P, P],
     "tscd_select_proposals": [P, I, I, F, I, I, I, P, P, P],
     "tscd_gather_rows": [P, P, P, I, P, I, I, I, I, P, P, P, I, P],
@@ -45,7 +46,7 @@ SIGNATURES = {
     "tscd_linear_bwd_f16": [P, I, P, I, P, I, I, I, I, I, P, P, P, P, L, P],
     "tscd_simota_assign": [P, P, I, I, I, I, I, P, P, P, I, I, P, L, P, P, P, P, P, P],
 }
-PLAIN = {"tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
+PLAIN = {"tscd_ema_chunk_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
          "tscd_bn_silu_bwd_workspace_bytes": ([L, I], L), "tscd_linear_bwd_workspace_bytes": ([I, I, I], L),
          "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
          "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),

@@ -442,3 +442,41 @@ extern "C" int tscd_haar_idwt_mul_nhwc_f16(const void* hf, const void* content, 
   TSCD_CHECK_LAUNCH("haar_idwt_mul");
   return TSCD_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------
+// ModelEMA.update (reference: yolox/utils/ema.py:48-60): v = d * v + (1 - d) * model_v over every floating state tensor.
+// One launch for all of them: the host passes a chunk table {dst, src, count} (<= EMA_CHUNK elements per chunk, one workgroup
+// each); each element is read and written once (the two multi-tensor passes of the torch formulation move 5 words per element,
+// this moves 3).  Same arithmetic as `_foreach_mul_(v, d); _foreach_add_(v, src, alpha=1-d)`: fma(1-d, src, fl(d*v)).
+// ------------------------------------------------------------------------------------------------------
+#define EMA_CHUNK 16384
+struct EmaChunk { float* dst; const float* src; long n; };
+__global__ __launch_bounds__(256) void ema_update_kernel(const EmaChunk* __restrict__ table, float d, float omd) {
+  const EmaChunk c = table[blockIdx.x];
+  if ((((uintptr_t)c.dst | (uintptr_t)c.src) & 15) == 0) {
+    const long n4 = c.n >> 2;
+    float4* dv = (float4*)c.dst;
+    const float4* sv = (const float4*)c.src;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+      float4 a = dv[i];
+      const float4 b = sv[i];
+      a.x = __builtin_fmaf(omd, b.x, d * a.x); a.y = __builtin_fmaf(omd, b.y, d * a.y);
+      a.z = __builtin_fmaf(omd, b.z, d * a.z); a.w = __builtin_fmaf(omd, b.w, d * a.w);
+      dv[i] = a;
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) c.dst[i] = __builtin_fmaf(omd, c.src[i], d * c.dst[i]);
+  } else {
+    for (long i = threadIdx.x; i < c.n; i += 256) c.dst[i] = __builtin_fmaf(omd, c.src[i], d * c.dst[i]);
+  }
+}
+extern "C" int tscd_ema_chunk_elems(void) { return EMA_CHUNK; }
+// table: device array of nchunks {float* dst, const float* src, long n} records (24 bytes each)
+extern "C" int tscd_ema_update_f32(const void* table, long nchunks, float d, float one_minus_d, void* stream) {
+  TSCD_CHECK_ARG(table || nchunks == 0, "ema_update: null table");
+  if (nchunks == 0) return TSCD_OK;
+  TSCD_CHECK_ARG(nchunks < (1L << 31), "ema_update: too many chunks");
+  hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const EmaChunk*)table, d, one_minus_d);
+  TSCD_CHECK_LAUNCH("ema_update");
+  return TSCD_OK;
+}

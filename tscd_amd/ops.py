@@ -757,3 +757,37 @@ def bn_silu_bwd(dy, raw, scale_shift, mean, invstd, gamma):
     call("tscd_bn_silu_bwd_f16", dy.data_ptr(), raw.data_ptr(), scale_shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
          gamma.data_ptr(), M, C, draw.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
     return draw, sums[1], sums[0]
+
+
+# ----------------------------------------------------------------------------------------------------
+# ModelEMA.update over every fp32 state tensor in one launch (elementwise.hip: tscd_ema_update_f32)
+# ----------------------------------------------------------------------------------------------------
+_EMA_TABLES = {}
+
+
+def ema_update(dst, src, decay):
+    """dst[i] = decay * dst[i] + (1 - decay) * src[i] for lists of same-shaped contiguous fp32 CUDA tensors, one launch.
+    The chunk table (device pointers) is cached per list identity and validated against ~33 sampled addresses: parameters and
+    buffers are updated in place, so their addresses only change when the model is moved or cast (the table is rebuilt then)."""
+    if not dst:
+        return
+    dev = dst[0].device
+    key = (id(dst[0]), id(dst[-1]), len(dst), dev)
+    probe = list(range(0, len(dst), max(1, len(dst) // 32))) + [len(dst) - 1]        # ~33 sampled addresses per call
+    sig = tuple(dst[i].data_ptr() for i in probe) + tuple(src[i].data_ptr() for i in probe)
+    hit = _EMA_TABLES.get(key)
+    if hit is None or hit[0] != sig:
+        import numpy as np
+        ch = lib.tscd_ema_chunk_elems()
+        rec = []
+        for a, b in zip(dst, src):
+            assert a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() \
+                and b.is_contiguous() and a.numel() == b.numel(), "ema_update: contiguous fp32 CUDA tensors of equal size"
+            pa, pb, n = a.data_ptr(), b.data_ptr(), a.numel()
+            for o in range(0, n, ch):
+                rec.append((pa + 4 * o, pb + 4 * o, min(ch, n - o)))
+        table = torch.from_numpy(np.array(rec, dtype=np.int64).reshape(-1, 3)).to(dev)
+        if len(_EMA_TABLES) > 16:
+            _EMA_TABLES.clear()
+        hit = _EMA_TABLES[key] = (sig, table, len(rec))
+    call("tscd_ema_update_f32", hit[1].data_ptr(), hit[2], float(decay), float(1.0 - decay), _stream())

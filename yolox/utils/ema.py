@@ -30,5 +30,10 @@ class ModelEMA:
             if v.dtype.is_floating_point:
                 dst.append(v)
                 src.append(msd[k].detach().to(v.dtype))
-        torch._foreach_mul_(dst, d)
-        torch._foreach_add_(dst, src, alpha=1.0 - d)
+        if dst and all(a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous()
+                       and b.is_contiguous() for a, b in zip(dst, src)):
+            from tscd_amd import ops          # one launch, every element read and written once (elementwise.hip)
+            ops.ema_update(dst, src, d)
+        else:                                 # CPU models (tests), half-precision copies
+            torch._foreach_mul_(dst, d)
+            torch._foreach_add_(dst, src, alpha=1.0 - d)
