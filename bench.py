@@ -34,6 +34,12 @@ def parse():
     ap.add_argument("--depth", type=float, default=1.0)
     ap.add_argument("--width", type=float, default=1.0)
     ap.add_argument("--props", type=str, default="500", choices=["500", "50"], help="proposal regime (SURVEY 8d)")
+    # Learning rate of the synthetic run.  The reference ramps from warmup_lr = 0 (quadratic, one epoch: tscd_base.py / LRScheduler
+    # "yoloxwarmcos"); a randomly initialised head on synthetic targets driven at the post-warm-up rate (5e-4) diverges within ~40
+    # steps (refined-box loss -> inf -> NaN weights), after which proposals and assignments degenerate and a "step" is no longer
+    # the workload.  1e-6 = the ramp a few iterations in: every kernel of the step runs, the weights stay finite, the loss terms
+    # stay those of the parity line.  bench.py fails if the final loss is not finite.
+    ap.add_argument("--lr", type=float, default=1e-6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-only-baseline", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -267,8 +273,11 @@ def main():
 
     model = build_model(args.depth, args.width, args.props).to(device).train()
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if rank == 0 else None
-    opt = make_optimizer(model)
-    scaler = torch.amp.GradScaler("cuda")
+    opt = make_optimizer(model, lr=args.lr)
+    # init_scale 2^10: the loss of the random-init head is ~2e3, so the default 2^16 overflows fp16 activation gradients and the
+    # scaler would spend its first ~8 steps skipping (found_inf) while it backs off; start where it settles so that every timed
+    # step applies its update
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
     ema = FusedEMA(model)
     net = model
     if world > 1:
@@ -319,6 +328,9 @@ def main():
         t = torch.tensor([dt], device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
+    final_loss = float(loss.detach())
+    if not math.isfinite(final_loss):
+        raise SystemExit(f"bench: the loss after the timed steps is {final_loss}: the run left the workload (see --lr)")
     roof = roofline_dominant_kernel(args, device, step)   # every rank takes part (DDP steps are collective)
     if rank == 0:
         line = {
@@ -328,7 +340,7 @@ def main():
             "config": {"workload": f"TSCD d{args.depth}/w{args.width} train step (fwd+bwd+SGD+EMA), {args.frames}-frame {args.size}^2 clip per GPU, "
                                    f"lframe {args.lframe}+gframe {gframe}, {args.props} proposals/frame, {NUM_CLASSES} classes, random init",
                        "clips_per_step": world, "parallelism": f"dp{world}"},
-            "loss": float(loss.detach()), "roofline": roof,
+            "loss": final_loss, "lr": args.lr, "grad_scale": float(scaler.get_scale()), "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
