@@ -20,6 +20,7 @@
 // transposed copies prepared once (q^T, dO^T, dsoft^T: [tile][4*DP][32], 16-byte aligned rows).  dq accumulates in
 // registers; dk / dv / dscore are summed over query tiles with fp32 atomics (two 128-byte segments per wave instruction).
 #include "mca_common.h"
+#include <type_traits>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -361,6 +362,259 @@ __global__ __launch_bounds__(256, PASS == 1 ? 2 : 1) void mca_bwd_core_kernel(Mc
   }
 }
 
+// ------------------------------------------------------------------------------------------------ pass 2, paired tiles
+// Pass 2 is bound by its float atomics: every (query tile, key block) pair adds a 32 x WP block into each of dk^c, dk^r, dv^c
+// (dv^r) -- ~0.6 G atomics per call at 16 x 500 proposals.  Two consecutive query tiles of the SAME frame see the same key
+// blocks, so one workgroup walks the key blocks once for both: dk / dv / dscore contributions of the two tiles are summed in
+// registers and flushed once (half the atomics), dq stays per tile in registers.  The q-side fragments are fetched per visit
+// (L2-resident) instead of being held, which pays for the second tile's dq accumulators.  Tiles whose neighbour belongs to
+// another frame (or the odd last tile) take the same loop with a group of one.
+template <int DP, bool NEED_REG>
+__global__ __launch_bounds__(256) void mca_bwd_pair_kernel(McaBwdParams p, int ntiles) {
+  constexpr int KS = DP / 16, NT = DP / 32;
+  constexpr int PST = 33, HST = 40;
+  __shared__ float X[3][MCA_HEADS][32][PST];
+  __shared__ float A32[2][32][PST];
+  __shared__ __attribute__((aligned(16))) f16 A16[2][32][HST];
+  __shared__ __attribute__((aligned(16))) f16 T16[3][MCA_HEADS][32][HST];
+  __shared__ float invl[2][MCA_HEADS][2][32];
+  __shared__ float dlt[2][MCA_HEADS][2][32];
+  __shared__ float dinv[2][2][32];
+  __shared__ float gdt[2][2][32];
+
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int s = blockIdx.y;
+  const int tile0 = 2 * blockIdx.x;
+  const McaTile ta = p.tiles[tile0];
+  const bool has_b = tile0 + 1 < ntiles;
+  const McaTile tb = has_b ? p.tiles[tile0 + 1] : ta;
+  const bool paired = has_b && tb.loc_start == ta.loc_start && tb.loc_end == ta.loc_end;
+  {
+    const int hh = tid >> 6, rem = tid & 63, br = rem >> 5, row = rem & 31;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const McaTile t = sub ? tb : ta;
+      const bool ok = (sub == 0 || has_b) && row < t.nrows;
+      const float l = ok ? p.stats[((long)hh * 2 + br) * p.N_L + t.row0 + row] : 0.f;
+      invl[sub][hh][br][row] = l > 0.f ? 1.0f / l : 0.f;
+      float dsum = 0.f;
+      if (ok)
+        for (int ss = 0; ss < p.S; ++ss) dsum += p.delta_part[(((long)ss * MCA_HEADS + hh) * 2 + br) * p.N_L + t.row0 + row];
+      dlt[sub][hh][br][row] = dsum;
+      if (tid < 64) {
+        const float dn = ok ? p.stats[(long)MCA_HEADS * 2 * p.N_L + (long)br * p.N_L + t.row0 + row] : 0.f;
+        dinv[sub][br][row] = dn > 0.f ? 1.0f / dn : 0.f;
+        gdt[sub][br][row] = ok ? p.gdot[(long)br * p.N_L + t.row0 + row] : 0.f;
+      }
+    }
+  }
+  f32x16 dqc[2][NT], dqr[2][NT];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dqc[sub][n][e] = dqr[sub][n][e] = 0.f;
+  __syncthreads();
+
+  const int col = lane & 31, half = lane >> 5, g = lane >> 4;
+  // groups: {a, b} when paired, else {a} then {b}
+  const int ngroups = paired ? 1 : (has_b ? 2 : 1);
+  for (int grp = 0; grp < ngroups; ++grp) {
+    const int first = paired ? 0 : grp;
+    const McaTile tg = first ? tb : ta;
+    const int n_local = ((tg.loc_end + 31) >> 5) - (tg.loc_start >> 5);
+    const int n_glob = ((p.N + 31) >> 5) - (p.N_L >> 5);
+    const int nblk = n_local + n_glob;
+    for (int j = s; j < nblk; j += p.S) {
+      int key0, lo, hi;
+      block_range(tg, p.N_L, p.N, j, key0, lo, hi, n_local);
+      const int key = key0 + col;
+      const bool valid = key >= lo && key < hi;
+      const float kscore = valid ? (float)p.score[key] : 0.f;
+      f32x16 akc[NT], akr[NT], avc[NT], avr[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) akc[n][e] = akr[n][e] = avc[n][e] = avr[n][e] = 0.f;
+      float dsco = 0.f;
+      auto visit = [&](auto subc) __attribute__((always_inline)) {
+        {
+          constexpr int sub = decltype(subc)::value;   // compile-time: dq[sub] must stay in registers
+          const McaTile t = sub ? tb : ta;
+          const int tile = tile0 + sub;
+          int qrow = t.row0 + (lane & 31);
+          if (qrow >= t.row0 + t.nrows) qrow = t.row0;
+          // scores and similarity products first (their accumulators die at the first exchange), the gradient products after
+          // it: 64 fewer live registers than one fused loop
+          f32x16 sc, sr, rc, rr;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sc[e] = sr[e] = rc[e] = rr[e] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const long oq = (long)qrow * p.WP + h * DP + ks * 16 + half * 8;
+            const long o = (long)key * p.WP + h * DP + ks * 16 + half * 8;
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.qn_c + oq), *(const f16x8*)(p.kn_c + o), sc, 0, 0, 0);
+            sr = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.qn_r + oq), *(const f16x8*)(p.kn_r + o), sr, 0, 0, 0);
+            rc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.vn_c + oq), *(const f16x8*)(p.vn_c + o), rc, 0, 0, 0);
+            if (NEED_REG) rr = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.vn_r + oq), *(const f16x8*)(p.vn_r + o), rr, 0, 0, 0);
+          }
+          float pc[16], pr[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            pc[e] = valid ? __expf(p.scale * kscore * sc[e] - p.scale) * invl[sub][h][0][row] : 0.f;
+            pr[e] = valid ? __expf(p.scale * sr[e] - p.scale) * invl[sub][h][1][row] : 0.f;
+            X[0][h][row][col] = 0.5f * (pc[e] + pr[e]);
+            X[1][h][row][col] = valid ? rc[e] : -2.f;
+            X[2][h][row][col] = (valid && NEED_REG) ? rr[e] : -2.f;
+          }
+          __syncthreads();
+          f32x16 gvc, gvr, gac, gar;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) gvc[e] = gvr[e] = gac[e] = gar[e] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const long oq = (long)qrow * p.WP + h * DP + ks * 16 + half * 8;
+            const long o = (long)key * p.WP + h * DP + ks * 16 + half * 8;
+            const f16x8 vrc = *(const f16x8*)(p.vraw_c + o);
+            gvc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.gO_c + oq), vrc, gvc, 0, 0, 0);
+            gac = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.gS_c + oq), vrc, gac, 0, 0, 0);
+            if (NEED_REG) {
+              const f16x8 vrr = *(const f16x8*)(p.vraw_r + o);
+              gvr = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.gO_r + oq), vrr, gvr, 0, 0, 0);
+              gar = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.gS_r + oq), vrr, gar, 0, 0, 0);
+            }
+          }
+          {
+            const int row = tid >> 3, c0 = (tid & 7) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              int cc = c0 + c;
+              float mp = 0.25f * (X[0][0][row][cc] + X[0][1][row][cc] + X[0][2][row][cc] + X[0][3][row][cc]);
+              float mc = 0.25f * (X[1][0][row][cc] + X[1][1][row][cc] + X[1][2][row][cc] + X[1][3][row][cc]);
+              float mr = 0.25f * (X[2][0][row][cc] + X[2][1][row][cc] + X[2][2][row][cc] + X[2][3][row][cc]);
+              float ex = __expf(mp);
+              float ac = mc > p.sim_thresh ? ex * dinv[sub][0][row] : 0.f;
+              float ar = (NEED_REG && mr > p.conf_thresh) ? ex * dinv[sub][1][row] : 0.f;
+              A32[0][row][cc] = ac; A32[1][row][cc] = ar;
+              A16[0][row][cc] = (f16)ac; A16[1][row][cc] = (f16)ar;
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            X[1][h][row][col] = gac[e];
+            X[2][h][row][col] = NEED_REG ? gar[e] : 0.f;
+          }
+          __syncthreads();
+          {
+            const int row = tid >> 3, c0 = (tid & 7) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              int cc = c0 + c;
+              float dac = X[1][0][row][cc] + X[1][1][row][cc] + X[1][2][row][cc] + X[1][3][row][cc];
+              float dar = X[2][0][row][cc] + X[2][1][row][cc] + X[2][2][row][cc] + X[2][3][row][cc];
+              X[0][0][row][cc] = A32[0][row][cc] * (dac - gdt[sub][0][row]) + A32[1][row][cc] * (dar - gdt[sub][1][row]);   // dM
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            float hdp = 0.5f * (gvc[e] + gvr[e] + 0.25f * X[0][0][row][col]);
+            float dsc = pc[e] * (hdp - dlt[sub][h][0][row]);
+            float dsr = pr[e] * (hdp - dlt[sub][h][1][row]);
+            dsco += dsc * p.scale * sc[e];
+            T16[0][h][row][col] = (f16)(dsc * p.scale * kscore);
+            T16[1][h][row][col] = (f16)(dsr * p.scale);
+            T16[2][h][row][col] = (f16)(0.5f * (pc[e] + pr[e]));
+          }
+          __syncthreads();
+          // ---- products that reduce over keys: dq^ += T K^ ----
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int ko = ks * 16 + half * 8;
+            f16x8 atc = *(const f16x8*)(&T16[0][h][col][ko]);
+            f16x8 atr = *(const f16x8*)(&T16[1][h][col][ko]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              long o = (long)(h * DP + n * 32 + col) * p.Npad + key0 + ko;
+              dqc[sub][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(atc, *(const f16x8*)(p.kt_c + o), dqc[sub][n], 0, 0, 0);
+              dqr[sub][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(atr, *(const f16x8*)(p.kt_r + o), dqr[sub][n], 0, 0, 0);
+            }
+          }
+          // ---- products that reduce over query rows: dk^ += T^T q^,  dv += P^T dO + A^T dsoft ----
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const int kb = ks * 16 + 8 * (g >> 1), mb = 16 * (g & 1);
+              long ob = ((long)tile * p.WP + h * DP + n * 32 + col) * 32 + ks * 16 + half * 8;
+              f16x8 tcT = tr_frag16(&T16[0][h][kb][mb], HST, lane);
+              f16x8 trT = tr_frag16(&T16[1][h][kb][mb], HST, lane);
+              f16x8 pT = tr_frag16(&T16[2][h][kb][mb], HST, lane);
+              f16x8 acT = tr_frag16(&A16[0][kb][mb], HST, lane);
+              akc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tcT, *(const f16x8*)(p.qT_c + ob), akc[n], 0, 0, 0);
+              akr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(trT, *(const f16x8*)(p.qT_r + ob), akr[n], 0, 0, 0);
+              avc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pT, *(const f16x8*)(p.gOT_c + ob), avc[n], 0, 0, 0);
+              avc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(acT, *(const f16x8*)(p.gST_c + ob), avc[n], 0, 0, 0);
+              if (NEED_REG) {
+                f16x8 arT = tr_frag16(&A16[1][kb][mb], HST, lane);
+                avr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pT, *(const f16x8*)(p.gOT_r + ob), avr[n], 0, 0, 0);
+                avr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(arT, *(const f16x8*)(p.gST_r + ob), avr[n], 0, 0, 0);
+              }
+            }
+          }
+          __syncthreads();
+        }
+      };
+      if (paired) {
+        visit(std::integral_constant<int, 0>{});
+        visit(std::integral_constant<int, 1>{});
+      } else if (first == 0) {
+        visit(std::integral_constant<int, 0>{});
+      } else {
+        visit(std::integral_constant<int, 1>{});
+      }
+      // ---- one flush per key block for the whole group ----
+      dsco += __shfl_xor(dsco, 32, 64);
+      if (half == 0 && valid) atomicAdd(p.dscore + key, dsco);
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int krow = key0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (krow >= lo && krow < hi) {
+            long o = (long)krow * p.WP + h * DP + n * 32 + col;
+            atomicAdd(p.dkn_c + o, akc[n][e]);
+            atomicAdd(p.dkn_r + o, akr[n][e]);
+            atomicAdd(p.dv_c + o, avc[n][e]);
+            if (NEED_REG) atomicAdd(p.dv_r + o, avr[n][e]);
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    if (sub == 0 || has_b) {
+      const McaTile t = sub ? tb : ta;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (row < t.nrows) {
+            long o = (long)(t.row0 + row) * p.WP + h * DP + n * 32 + col;
+            atomicAdd(p.dqn_c + o, dqc[sub][n][e]);
+            atomicAdd(p.dqn_r + o, dqr[sub][n][e]);
+          }
+        }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ normalisation backward
 // One wave per (row, branch): x^ = x/||x||  =>  dx = (dx^ - x^ (x^.dx^)) / ||x||  per head, for q and k; v passes through
 // (+ the gradient of the "x_ori" rows, i.e. d xcat[:, W:2W], for local rows).  Outputs fp16 dq [N_L,W], dkv [N,2W].
@@ -418,6 +672,10 @@ __global__ void mca_bwd_finish_kernel(const f16* __restrict__ q_c, const f16* __
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI
+static int g_mca_bwd_pair = 1;
+// 1 (default): pass 2 walks the key blocks once for two query tiles of a frame (half the dk / dv atomics); 0: one tile per
+// workgroup (the cross-check).  Returns the previous setting.
+extern "C" int tscd_mca_backward_set_paired(int on) { int o = g_mca_bwd_pair; g_mca_bwd_pair = on; return o; }
 extern "C" long tscd_mca_backward_workspace_bytes(int N, int N_L, int W, int S, int ntiles) {
   int d = W / MCA_HEADS, DP = (d + 31) / 32 * 32, WP = MCA_HEADS * DP;
   long Npad = (N + 31) / 32 * 32 + 32;
@@ -498,14 +756,17 @@ extern "C" int tscd_mca_backward(const void* q_c, const void* kv_c, const void* 
   p.N = N; p.N_L = N_L; p.Npad = Npad; p.WP = WP; p.S = S;
   p.scale = scale; p.sim_thresh = sim_thresh; p.conf_thresh = conf_thresh;
   dim3 grid(ntiles, S), block(256);
+  dim3 pgrid((ntiles + 1) / 2, S);      // pass 2: two same-frame query tiles per workgroup (mca_bwd_pair_kernel)
 #define MCAB(DPV)                                                                            \
   do {                                                                                       \
     if (need_reg) {                                                                          \
       hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, true, 1>), grid, block, 0, st, p);        \
-      hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, true, 2>), grid, block, 0, st, p);        \
+      if (g_mca_bwd_pair) hipLaunchKernelGGL((mca_bwd_pair_kernel<DPV, true>), pgrid, block, 0, st, p, ntiles); \
+      else hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, true, 2>), grid, block, 0, st, p);   \
     } else {                                                                                 \
       hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, false, 1>), grid, block, 0, st, p);       \
-      hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, false, 2>), grid, block, 0, st, p);       \
+      if (g_mca_bwd_pair) hipLaunchKernelGGL((mca_bwd_pair_kernel<DPV, false>), pgrid, block, 0, st, p, ntiles); \
+      else hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, false, 2>), grid, block, 0, st, p);  \
     }                                                                                        \
   } while (0)
   if (DP == 32) MCAB(32);
