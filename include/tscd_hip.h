@@ -81,6 +81,13 @@ int tscd_bn_silu_bwd_f16(const void* dy, const void* raw, const float* scale_shi
 int tscd_bn_finalize(const float* partial, int mtiles, int cstride, int C, long count, const float* gamma,
                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                      float* scale_shift, float* save_mean, float* save_invstd, void* stream);
+/* BaseConv in training mode (network_blocks.py:36-61 with BatchNorm in train mode) as one host call: the three launches above
+ * (conv with partial sums, finalize, apply + activation + residual).  small: [4][C] floats = scale | shift | save_mean | save_invstd;
+ * partial: [2][cstride][mtiles] floats; raw may alias out. */
+int tscd_conv_bn_act_train_f16(const void* x, const void* wpk, void* raw, int ldraw, float* partial, int cstride, int B, int H, int W,
+                               int Cin, int Cout, int ksize, int stride, int ldx, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, float* small, void* out, int ldo,
+                               const void* residual, int ldr, int act, void* stream);
 int tscd_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                  float* scale_shift, void* stream);
 int tscd_bn_act_nhwc_f16(const void* x, int ldx, void* y, int ldy, const float* scale_shift, const void* residual,

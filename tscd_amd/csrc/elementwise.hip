@@ -480,3 +480,33 @@ extern "C" int tscd_ema_update_f32(const void* table, long nchunks, float d, flo
   TSCD_CHECK_LAUNCH("ema_update");
   return TSCD_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------
+// BaseConv in training mode as ONE host call: conv (raw output + per-tile BN partial sums) -> batch statistics
+// (scale/shift, saved mean / invstd, running statistics) -> apply + activation (+ residual).  Three launches, the same three
+// kernels as the separate entry points -- what it saves is the host side: one foreign call and one set of argument
+// marshalling per BaseConv instead of three (134 BaseConvs per TSCD-L step).
+// small: [4][C] floats = scale | shift | save_mean | save_invstd.  raw may equal out (in-place apply) when nothing keeps raw.
+// ------------------------------------------------------------------------------------------------------
+extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* bias, const float* scale, const float* shift,
+                                    float* bn_partial, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int ldx, int ldy,
+                                    int epilogue, void* stream);
+extern "C" int tscd_conv_tile_m(void);
+extern "C" int tscd_conv_bn_act_train_f16(const void* x, const void* wpk, void* raw, int ldraw, float* partial, int cstride, int B, int H,
+                                          int W, int Cin, int Cout, int ksize, int stride, int ldx, const float* gamma, const float* beta,
+                                          float eps, float momentum, float* running_mean, float* running_var, float* small, void* out,
+                                          int ldo, const void* residual, int ldr, int act, void* stream) {
+  TSCD_CHECK_ARG(x && wpk && raw && partial && small && out && gamma && beta, "conv_bn_act_train: null pointer");
+  const int pad = (ksize - 1) / 2;
+  const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+  const long M = (long)B * Ho * Wo;
+  int st = tscd_conv2d_nhwc_f16(x, wpk, raw, nullptr, nullptr, nullptr, partial, B, H, W, Cin, Cout, ksize, stride, ldx, ldraw, 0, stream);
+  if (st != TSCD_OK) return st;
+  const int tm = tscd_conv_tile_m();
+  const int mtiles = (int)((M + tm - 1) / tm);
+  st = tscd_bn_finalize(partial, mtiles, cstride, Cout, M, gamma, beta, eps, momentum, running_mean, running_var, small, small + 2 * (long)Cout,
+                        small + 3 * (long)Cout, stream);
+  if (st != TSCD_OK) return st;
+  return tscd_bn_act_nhwc_f16(raw, ldraw, out, ldo, small, residual, ldr, M, Cout, act, stream);
+}

@@ -62,10 +62,8 @@ class _ConvBnSiluTrain(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum):
         wpk = ops.WEIGHTS.get(weight)
         cout, k = weight.shape[0], weight.shape[-1]
-        raw, part = ops.conv2d(x, wpk, cout, k, stride, ops.EPI_RAW, want_stats=True)
-        B, Ho, Wo, _ = raw.shape
-        ss, mean, invstd = ops.bn_finalize(part, B * Ho * Wo, gamma, beta, running_mean, running_var, eps, momentum)
-        out = ops.bn_act(raw, ss, ops.ACT_SILU, out=ops.empty_nhwc(B, Ho, Wo, cout, x.device))
+        out, raw, ss, mean, invstd = ops.conv_bn_act_train(x, wpk, cout, k, stride, gamma, beta, running_mean, running_var, eps,
+                                                           momentum, ops.ACT_SILU, keep_raw=True)
         ctx.save_for_backward(x, weight, gamma, raw, ss, mean, invstd)
         ctx.stride = stride
         return out
@@ -89,10 +87,8 @@ def conv_bn_silu(x, weight, gamma, beta, running_mean, running_var, stride, trai
     cin_pad = x.shape[-1] if x.shape[-1] != weight.shape[1] else None   # Focus: 12 -> 16 channels
     wpk = ops.WEIGHTS.get(weight, cin_pad)
     if training:
-        y, part = ops.conv2d(x, wpk, cout, k, stride, ops.EPI_RAW, out=out, want_stats=True)
-        B, Ho, Wo, _ = y.shape
-        ss, _, _ = ops.bn_finalize(part, B * Ho * Wo, gamma, beta, running_mean, running_var, eps, momentum)
-        return ops.bn_act(y, ss, ops.ACT_SILU, residual=residual)
+        return ops.conv_bn_act_train(x, wpk, cout, k, stride, gamma, beta, running_mean, running_var, eps, momentum, ops.ACT_SILU,
+                                     residual=residual, out=out)[0]
     ss = ops.bn_fold(gamma, beta, running_mean, running_var, eps)
     if residual is None:
         y, _ = ops.conv2d(x, wpk, cout, k, stride, ops.EPI_BN_SILU, scale_shift=ss, out=out)

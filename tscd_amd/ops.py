@@ -158,6 +158,32 @@ def bn_finalize(partial, count, gamma, beta, running_mean, running_var, eps=BN_E
     return ss, mean, invstd
 
 
+def conv_bn_act_train(x, wpk, cout, ksize, stride, gamma, beta, running_mean, running_var, eps=BN_EPS, momentum=BN_MOMENTUM,
+                      act=ACT_SILU, residual=None, out=None, keep_raw=False):
+    """BaseConv in training mode in one host call (conv + batch statistics + apply): -> (out, raw, scale_shift [2,C], mean, invstd).
+    keep_raw: raw conv output in its own buffer (the backward needs it); otherwise the apply pass runs in place on ``out``."""
+    if CONV_PROFILE is not None:            # roofline instrumentation brackets the conv launch alone: separate calls
+        raw, part = conv2d(x, wpk, cout, ksize, stride, EPI_RAW, out=None if keep_raw else out, want_stats=True)
+        B, Ho, Wo, _ = raw.shape
+        ss, mean, invstd = bn_finalize(part, B * Ho * Wo, gamma, beta, running_mean, running_var, eps, momentum)
+        o = bn_act(raw, ss, act, residual=residual, out=(out if out is not None else empty_nhwc(B, Ho, Wo, cout, x.device)) if keep_raw else None)
+        return o, raw, ss, mean, invstd
+    B, H, W, Cin = x.shape
+    Ho, Wo = conv_out_hw(H, W, ksize, stride)
+    dev = x.device
+    if out is None:
+        out = empty_nhwc(B, Ho, Wo, cout, dev)
+    raw = empty_nhwc(B, Ho, Wo, cout, dev) if keep_raw else out
+    mt = (B * Ho * Wo + lib.tscd_conv_tile_m() - 1) // lib.tscd_conv_tile_m()
+    partial = torch.empty((2, wpk.shape[0], mt), dtype=torch.float32, device=dev)
+    small = torch.empty((4, cout), dtype=torch.float32, device=dev)
+    call("tscd_conv_bn_act_train_f16", x.data_ptr(), wpk.data_ptr(), raw.data_ptr(), nhwc_ld(raw), partial.data_ptr(), wpk.shape[0],
+         B, H, W, Cin, cout, ksize, stride, nhwc_ld(x), gamma.data_ptr(), beta.data_ptr(), eps, momentum, _ptr(running_mean),
+         _ptr(running_var), small.data_ptr(), out.data_ptr(), nhwc_ld(out), _ptr(residual),
+         nhwc_ld(residual) if residual is not None else 0, act, _stream())
+    return out, raw, small[:2], small[2], small[3]
+
+
 def bn_fold(gamma, beta, running_mean, running_var, eps=BN_EPS):
     C = gamma.shape[0]
     ss = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
