@@ -156,6 +156,14 @@ def test_backbone_prefetch_in_assignment_window_is_exact(golden, model):
     sa, sb = a.backbone.state_dict(), b.backbone.state_dict()
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k                  # running statistics / num_batches_tracked advanced identically
+    # a next clip of another size (multiscale training): the stash is keyed on the tensor, not on the shape
+    big = torch.nn.functional.interpolate(imgs.float(), size=(imgs.shape[-2] + 64, imgs.shape[-1] + 64), mode="bilinear").half().contiguous()
+    a(imgs, labels, temb, next_x=big, **kw)
+    out_a3 = a(big, labels, temb, **kw)
+    b(imgs, labels, temb, **kw)
+    out_b3 = b(big, labels, temb, **kw)
+    for k in ("total_loss", "iou_loss", "conf_loss", "cls_loss"):
+        assert float(out_a3[k]) == float(out_b3[k]), k
     # a stash for another tensor is dropped, not used
     a(imgs, labels, temb, next_x=imgs2, **kw)
     out_c = a(imgs, labels, temb, **kw)
