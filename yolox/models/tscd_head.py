@@ -184,7 +184,8 @@ class TSCDHead(nn.Module):
         # current when a bucket's last gradient arrives, so gradient-producing kernels must all live on one stream.
         if LEVEL_STREAMS and len(feats) > 1 and dev.type == "cuda":
             import torch.distributed as dist
-            one_grad_stream = grad and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            one_grad_stream = grad and ((dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+                                        or os.environ.get("TSCD_ONE_GRAD_STREAM") == "1")      # env: single-GPU rehearsal of the DDP schedule
             main = torch.cuda.current_stream()
             side = _side_streams(dev, len(feats) - 1)
             fork = torch.cuda.Event()
