@@ -793,12 +793,12 @@ _EMA_TABLES = {}
 
 def ema_update(dst, src, decay):
     """dst[i] = decay * dst[i] + (1 - decay) * src[i] for lists of same-shaped contiguous fp32 CUDA tensors, one launch.
-    The chunk table (device pointers) is cached per list identity and validated against ~33 sampled addresses: parameters and
+    The chunk table (device pointers) is cached per (first, last address, count) and validated against ~33 sampled addresses: parameters and
     buffers are updated in place, so their addresses only change when the model is moved or cast (the table is rebuilt then)."""
     if not dst:
         return
     dev = dst[0].device
-    key = (id(dst[0]), id(dst[-1]), len(dst), dev)
+    key = (dst[0].data_ptr(), dst[-1].data_ptr(), len(dst), dev)      # addresses, not object ids: state_dict() hands out fresh tensor objects
     probe = list(range(0, len(dst), max(1, len(dst) // 32))) + [len(dst) - 1]        # ~33 sampled addresses per call
     sig = tuple(dst[i].data_ptr() for i in probe) + tuple(src[i].data_ptr() for i in probe)
     hit = _EMA_TABLES.get(key)

@@ -24,12 +24,18 @@ class ModelEMA:
     def update(self, model):
         self.updates += 1
         d = self.decay(self.updates)
-        msd = (model.module if is_parallel(model) else model).state_dict()
-        dst, src = [], []
-        for k, v in self.ema.state_dict().items():
-            if v.dtype.is_floating_point:
-                dst.append(v)
-                src.append(msd[k].detach().to(v.dtype))
+        inner = model.module if is_parallel(model) else model
+        # the (ema tensor, model tensor) pairs are collected once: parameters and buffers are updated in place, so the lists stay
+        # valid until the model is moved or cast (first parameter's address / dtype change) -- walking two state_dicts of ~900
+        # entries costs more host time per step than the update itself
+        p0 = next(inner.parameters())
+        key = (id(inner), p0.data_ptr(), p0.dtype, next(self.ema.parameters()).data_ptr())
+        if getattr(self, "_pairs_key", None) != key:
+            msd = inner.state_dict()
+            self._pairs = [(v, msd[k].detach()) for k, v in self.ema.state_dict().items() if v.dtype.is_floating_point]
+            self._pairs_key = key
+        dst = [a for a, _ in self._pairs]
+        src = [b if b.dtype == a.dtype else b.to(a.dtype) for a, b in self._pairs]
         if dst and all(a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous()
                        and b.is_contiguous() for a, b in zip(dst, src)):
             from tscd_amd import ops          # one launch, every element read and written once (elementwise.hip)
