@@ -47,7 +47,7 @@ def main(exp, args):
         for trainer.iter in range(args.max_iters):
             out = trainer.train_one_iter()
             if trainer.rank == 0:
-                print(f"iter {trainer.iter}: " + ", ".join(f"{k} {float(v):.3f}" for k, v in out.items()), flush=True)
+                print(f"iter {trainer.iter}: " + ", ".join(f"{k} {float(v.detach() if torch.is_tensor(v) else v):.3f}" for k, v in out.items()), flush=True)
         return
     trainer.train()
 

@@ -124,8 +124,16 @@ class Trainer:
         lr = self.lr_scheduler.update_lr(self.progress_in_iter + 1)
         for g in self.optimizer.param_groups:
             g["lr"] = lr
-        self.history.append({"iter_time": time.time() - t0, "lr": lr, **{k: float(v) for k, v in outputs.items()}})
+        # loss terms stay device tensors (a float() here would drain the GPU every iteration and undo the look-ahead above);
+        # history_floats() converts on demand (print / eval intervals)
+        self.history.append({"iter_time": time.time() - t0, "lr": lr,
+                             **{k: (v.detach() if torch.is_tensor(v) else v) for k, v in outputs.items()}})
         return outputs
+
+    def history_floats(self, last=None):
+        """The recorded iterations (or the last ``last`` of them) with every loss term as a Python float (synchronises)."""
+        rows = self.history if last is None else self.history[-last:]
+        return [{k: (float(v) if torch.is_tensor(v) else v) for k, v in r.items()} for r in rows]
 
     # ------------------------------------------------------------------ eval / checkpoints
     def evaluate(self):
