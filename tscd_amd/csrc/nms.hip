@@ -260,7 +260,7 @@ extern "C" int tscd_batched_nms(const void* det, int ndet, const int* frame_off,
   c.count = (int*)take(4L * L);
   int* order = (int*)take(4L * L * capM);
   unsigned char* keep = (unsigned char*)take((long)L * capM);
-  hipMemsetAsync(keep, 0, (long)L * capM, st);
+  (void)hipMemsetAsync(keep, 0, (long)L * capM, st);
   hipLaunchKernelGGL(nms_expand_kernel, dim3(L), dim3(256), 0, st, (const f16*)det, ndet, frame_off, (const f16*)cls_logit,
                      (const f16*)obj_logit, (const f16*)reg_delta, NC, conf_thresh, capM, mode, logf(736.0f / 32.0f), c);
   TSCD_CHECK_LAUNCH("nms_expand");

@@ -251,7 +251,7 @@ extern "C" int tscd_simota_assign(const void* outputs, const float* labels, int 
   int* matches = (int*)take(4L * B * G * topk);
   int* nmatch = (int*)take(4L * B * G);
   p.ngt = ngt;
-  hipMemsetAsync(num_fg, 0, 4L * B, st);
+  (void)hipMemsetAsync(num_fg, 0, 4L * B, st);
   hipLaunchKernelGGL(simota_count_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, labels, B, Lmax, ngt);
   hipLaunchKernelGGL(simota_cost_kernel, dim3(cdiv(A, 256), B), dim3(256), 0, st, p);
   hipLaunchKernelGGL(simota_match_kernel, dim3(G, B), dim3(1024), 0, st, p, topk, matches, nmatch);
