@@ -244,6 +244,13 @@ def simota_assign(outputs, labels, xs, ys, strides_a, cfg):
 
     outputs [B,A,5+NC]: decoded cxcywh boxes, raw obj / cls logits.  labels [B,L,5] (cls,cx,cy,w,h).
     Returns per-image lists (fg_idx, cls_target, reg_target, obj_target, fg_mask), num_fg, num_gts.
+
+    Dtype-faithful: every op below is the reference's op on the dtype it sees there.  With fp32 tensors this is the
+    fp32 evaluation; with fp16 ``outputs`` / ``labels`` / grids (what training feeds it: tscd_trainer.py:159-164 casts
+    images AND targets to fp16, the head runs under autocast) the in-box tests, the IoU chain, ``-log(iou + 1e-8)`` and
+    the top-10 IoU sum are evaluated op by op in fp16 while the class cost stays fp32 (autocast-off region
+    tscd_head.py:1390-1397).  Pinned by tests/golden/simota_fp16.npz (the reference's own get_fg_idx on fp16 tensors,
+    oracle/make_golden_simota.py).
     """
     B, A, _ = outputs.shape
     nc = cfg.num_classes
@@ -270,8 +277,10 @@ def simota_assign(outputs, labels, xs, ys, strides_a, cfg):
         ious = bboxes_iou_cxcywh(gt, boxes)
         gt_onehot = F.one_hot(gt_cls.to(torch.int64), nc).float().unsqueeze(1).repeat(1, n_in, 1)
         iou_loss = -torch.log(ious + 1e-8)
+        # tscd_head.py:1391-1394: only the class logits are .float()'ed; the objectness sigmoid runs in the dtype of
+        # ``outputs`` (fp16 under autocast -- one rounding the product's emu16 mode reproduces), the product is fp32
         p = (cls_p.float().unsqueeze(0).repeat(G, 1, 1).sigmoid_()
-             * obj_p.float().unsqueeze(0).repeat(G, 1, 1).sigmoid_())
+             * obj_p.unsqueeze(0).repeat(G, 1, 1).sigmoid_())
         cls_loss = F.binary_cross_entropy(p.sqrt_(), gt_onehot, reduction="none").sum(-1)
         cost = cls_loss + 3.0 * iou_loss + 100000.0 * (~in_bc)
         n_fg_img, matched_cls, pred_ious, matched_inds, fg_mask = dynamic_k_matching(

@@ -1,9 +1,11 @@
 """GPU end-to-end parity of the product (yolox mirror + HIP kernels) against the reference's golden vectors.
 
 The product computes in fp16 (as the reference does under autocast / .half()), the goldens are the reference's fp32
-run, so float outputs are compared with fp16 tolerances stated per check.  Integer outputs are compared on the
-intersection that is insensitive to fp16 score noise (proposal sets: >= 90 % overlap; Hungarian: bit-exact
-whenever the proposal sets of both frames are identical).
+run, so float outputs are compared with fp16 tolerances stated per check.  Proposal selection is checked twice: (1) the
+product's own selection against the reference's (counts +-3, >= 90 % of the anchors: fp16 noise in the backbone moves
+borderline scores across the 1e-3 threshold), and (2) with the selection FORCED to the reference's anchor sets (the
+test substitutes ops.select_proposals), so that every downstream tensor -- MCA, CAFM, TaskAligned, the prediction
+heads, the Hungarian columns -- is compared row by row on every run, not only when the sets happen to coincide.
 """
 import numpy as np
 import pytest
@@ -47,26 +49,63 @@ def test_eval_clipA_then_clipB_resume(golden, model):
         res, ori, dbg = run_eval(model, vec, meta, name, resume)
         # proposal selection: same counts, >= 90 % of the reference's anchors (fp16 score noise moves borderline ones)
         assert all(abs(a - b) <= 3 for a, b in zip(dbg["preds_per_frame"], vec[name + "n_agg"].tolist()))
-        same_sets = []
         for i in range(B):
             ours, ref = set(dbg["agg_idx"][i].cpu().tolist()), set(vec[f"{name}agg_idx{i}"].tolist())
             assert len(ours & ref) >= 0.9 * len(ref), (i, len(ours & ref), len(ref))
-            same_sets.append(ours == ref)
         # wavelet edge maps (a6) and reg towers: fp16 tolerance 2e-2 max / 4e-3 mean (relative to max / mean |ref|)
         for k in range(3):
             e = dbg["edge_maps"][k].permute(0, 3, 1, 2)
             mx, mn = rel_err(e, vec[f"{name}edge{k}"])
             assert mx < 0.2 and mn < 0.15, ("edge", k, mx, mn)   # fp16 noise of backbone+towers upstream; the tight check is
             # tests/test_gpu_head_stages.py::test_wavelet_block_vs_reference_golden
-        if all(same_sets):
-            # identical proposals -> proposal-stage tensors are comparable row by row
-            for key, tol in (("agg_cls", 3e-2), ("agg_iou_cls", 3e-2), ("agg_iou_obj", 3e-2), ("cafm", 8e-2),
-                             ("cls_preds", 5e-2), ("matcher_obj_preds", 5e-2), ("matcher_reg_preds", 5e-2)):
-                mx, mn = rel_err(dbg[key], vec[name + key])
-                assert mx < tol * 3 and mn < tol, (key, mx, mn)
         for i in range(L):
             ref = vec[f"{name}result{i}"]
             assert res[i] is not None and abs(res[i].shape[0] - ref.shape[0]) <= 0.1 * ref.shape[0] + 5, (res[i].shape, ref.shape)
+
+
+def test_eval_with_reference_proposal_sets_matches_stage_by_stage(golden, model, monkeypatch):
+    """Same two clips (the second with resume=True: CAFM state carried over), proposal selection substituted by the
+    reference's own anchor sets: the proposal-stage tensors are then comparable row by row with the goldens (fp16 vs the
+    reference's fp32: tolerances relative to max|ref| / mean|ref|), and the Hungarian columns with the reference's."""
+    from tscd_amd import ops
+    cfg, sd, vec, meta = golden
+    L, B = int(meta["lframe"]), int(meta["B"])
+    model.head.local_reg_matcher._clear_state()
+    for name, resume in (("evalA_", False), ("evalB_", True)):
+        ref_idx = [torch.from_numpy(vec[f"{name}agg_idx{i}"]).int() for i in range(B)]
+
+        def forced(score, conf_thresh, min_keep, max_keep, _ref=ref_idx):
+            cap = max(max(len(r) for r in _ref), 1)
+            idx = torch.zeros((len(_ref), cap), dtype=torch.int32)
+            for b, r in enumerate(_ref):
+                idx[b, :len(r)] = r
+            return idx.to(score.device), torch.tensor([len(r) for r in _ref], dtype=torch.int32, device=score.device)
+
+        monkeypatch.setattr(ops, "select_proposals", forced)
+        res, ori, dbg = run_eval(model, vec, meta, name, resume)
+        assert dbg["preds_per_frame"] == vec[name + "n_agg"].tolist()
+        for key, tol in (("agg_cls", 3e-2), ("agg_iou_cls", 3e-2), ("agg_iou_obj", 3e-2), ("cafm", 8e-2),
+                         ("cls_preds", 5e-2), ("matcher_obj_preds", 5e-2), ("matcher_reg_preds", 5e-2)):
+            mx, mn = rel_err(dbg[key], vec[name + key])
+            assert mx < tol * 3 and mn < tol, (name, key, mx, mn)
+        # Hungarian columns vs the reference's scipy call on its fp32 features.  The features agree to ~1e-2, the fp16 cost
+        # to 3e-3 per entry, so a frame may legitimately differ in near-tied pairs; what must hold is (a) a valid
+        # assignment of the same size and (b) most columns identical -- exactness on IDENTICAL costs is asserted in
+        # tests/test_gpu_proposal_stages.py::test_device_hungarian_cost_and_assignment_chain.
+        n_h = int(vec[name + "n_hung"])
+        assert len(dbg["hungarian"]) == n_h
+        same = tot = 0
+        for i in range(n_h):
+            a, b = np.asarray(dbg["hungarian"][i]), vec[f"{name}hung_col{i}"]
+            assert len(a) == len(b) and len(set(a.tolist())) == len(a), (name, i)
+            same += int((a == b).sum())
+            tot += len(a)
+        print(name, "hungarian columns identical to the reference's:", same, "of", tot)
+        assert same >= 0.9 * tot, (name, same, tot)
+        # detections: with identical proposals the NMS survivor count is within fp16 score noise of the reference's
+        for i in range(L):
+            ref = vec[f"{name}result{i}"]
+            assert res[i] is not None and abs(res[i].shape[0] - ref.shape[0]) <= 0.05 * ref.shape[0] + 3, (res[i].shape, ref.shape)
 
 
 def test_eval_half_model(golden, model):

@@ -119,20 +119,38 @@ def test_cafm_and_task_aligned_match_oracle(ctx):
     with torch.no_grad():
         out = h.local_reg_matcher(f_reg, a_obj, a_cls, f_edge, ppf[:L], temb[:L].cuda(), resume=False)[-1]
         hung = list(h.local_reg_matcher.last_hungarian)
+        hung_rows = list(h.local_reg_matcher.last_hungarian_rows)
     torch.cuda.synchronize()
-    # INT: Hungarian column assignment per local frame.  The product forms the cost in fp16 like the reference does
-    # under autocast/.half() (tscd_matching.py:919-930 runs torch.mm on fp16 tensors), so near-ties can resolve
-    # differently from the fp32 oracle: require >= 90 % identical columns AND a total cost within 1e-3 (relative) of
-    # the optimum under the oracle's fp32 cost.
+    # INT: Hungarian column assignment per local frame.  Exactness on identical inputs (the solver on the device-produced
+    # fp16 cost == scipy on that cost, whole chain) is tests/test_gpu_proposal_stages.py::
+    # test_device_hungarian_cost_and_assignment_chain.  Here the product's fp16 cost (the reference's own dtype under
+    # autocast/.half(): tscd_matching.py:919-930 runs torch.mm on fp16 tensors) meets the ORACLE's fp32 cost, so the
+    # criterion is optimality under the oracle's cost: every cost entry is within eps = 3e-3 of the fp32 one, hence an
+    # assignment that is optimal for the fp16 matrix costs at most 2*n*eps more than the fp32 optimum.
+    from scipy.optimize import linear_sum_assignment
     assert len(hung) == len(aux["hungarian"])
-    start, prev = 0, None
-    regs, clss = aux["agg_iou_obj"], aux["agg_iou_cls"]
+    regs, clss = aux["agg_iou_obj"].half().float(), aux["agg_iou_cls"].half().float()
     nz = lambda t: t / (t.norm(dim=1)[:, None] + 1e-6)
+    spans, s0 = [], 0
+    for n in ppf[:L]:
+        spans.append((s0, s0 + n)); s0 += n
+    order, identical = None, 0
     for fi, (a, b) in enumerate(zip(hung, aux["hungarian"])):
         a, b = np.asarray(a), np.asarray(b)
         assert len(a) == len(b)
-        assert (a == b).mean() >= 0.9, (fi, (a == b).mean())
         assert len(set(a.tolist())) == len(a)           # a valid assignment: no column used twice
+        (c0, c1) = spans[fi]
+        (p0, p1) = spans[max(fi - 1, 0)]
+        C = (1 - ((nz(clss[p0:p1]) @ nz(clss[c0:c1]).t() + nz(regs[p0:p1]) @ nz(regs[c0:c1]).t()) / 2)).double().numpy()
+        if fi > 0:
+            C = C[order]
+        r_opt, c_opt = linear_sum_assignment(C)
+        ours = C[np.asarray(hung_rows[fi]), a].sum()
+        assert ours <= C[r_opt, c_opt].sum() + 2 * len(a) * 3e-3, (fi, ours, C[r_opt, c_opt].sum())
+        identical += int(np.array_equal(a, b))
+        rest = np.setdiff1d(np.arange(C.shape[1]), a)
+        order = np.arange(C.shape[1]) if fi == 0 else (np.concatenate((a, rest)) if C.shape[0] < C.shape[1] else a)
+    print("frames whose assignment equals the fp32 oracle's:", identical, "of", len(hung))
     close(out, aux["cafm"], 6e-2, 1.5e-2)     # LayerNorm'd output, rms 1: reference's own fp16 noise is 5.4e-2 max
     with torch.no_grad():
         matched4 = torch.nn.functional.linear(aux["cafm"], m.head.fc_reg_matcher.weight.cpu(), m.head.fc_reg_matcher.bias.cpu())

@@ -20,7 +20,6 @@ from torch import nn
 
 from tscd_amd import ops
 from tscd_amd._host import KIND_PREV, KIND_SELF, KIND_STATE, lap_chain_f16, lap_f16
-from tscd_amd.autograd import hip_op
 
 
 # the clip's chain of host assignments runs on this worker while the main thread keeps queueing device work
@@ -276,7 +275,8 @@ class AwarePositionRegMatcher(nn.Module):
         self.edge_feature_embedding = nn.Linear(int(hidden_channel / 4), hidden_channel)
         self.decoder_norm = nn.LayerNorm(hidden_channel)
         self._clear_state()
-        self.last_hungarian = []     # test hook: scipy's column assignment per processed frame
+        self.last_hungarian = []     # test hook: the assignment's column indices per processed frame
+        self.last_hungarian_rows = []   # ... and its row indices
 
     def _clear_state(self):
         self.last_outputs = None              # reference name; here the previous frame's output rows [n,C]
@@ -383,7 +383,7 @@ class AwarePositionRegMatcher(nn.Module):
         # fp32 rows (the SE gate takes fp32 position vectors: one cast here instead of one per use and per gradient); unbind:
         # one stack in backward instead of a zero-filled slice gradient per use
         t_rows = t_emb.float().unbind(0)
-        self.last_hungarian = []
+        self.last_hungarian, self.last_hungarian_rows = [], []
         solved = prep["chain"].result() if prep["chain"] is not None else []
 
         # every index table of the clip (column orders, unmatched / surviving rows, inverse permutations) goes to the device
@@ -432,12 +432,14 @@ class AwarePositionRegMatcher(nn.Module):
             if kind == "self":
                 self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = cur_reg, cur_cls, n
                 self.last_hungarian.append(np.asarray(col_raw))
+                self.last_hungarian_rows.append(np.asarray(row))
                 out = layer(cur, cur, cur, t_i, t_i, cur_edge, cur_edge)
                 new_edge = cur_edge
             else:
                 # `perm`: the assignment's columns, followed by the unmatched current proposals (ascending) when the
                 # reference frame had fewer rows -- the order in which the reference keeps this frame from now on
                 self.last_hungarian.append(np.asarray(col_raw))
+                self.last_hungarian_rows.append(np.asarray(row))
                 if "nm" in rec:
                     nm = view(rec, "nm")
                     last_feat = torch.cat((self.last_outputs, rows(cur, nm)), 0)
