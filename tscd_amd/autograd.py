@@ -1,56 +1,5 @@
-"""HIP-forward / recompute-backward bridge.
-
-Every proposal-stage op runs its forward in a hand-written HIP kernel.  Until the matching backward kernel exists
-(pending rows in DESIGN.md), gradients are obtained by re-evaluating a device-side PyTorch expression of the SAME
-math inside ``backward`` and differentiating that.  The PyTorch expression is never used for a forward result.
-"""
+"""Autograd plumbing of the hot path: the eager loss branch."""
 import torch
-
-
-class _HipFwdTorchBwd(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, hip_fn, torch_fn, *inputs):
-        ctx.set_materialize_grads(False)   # unused outputs (e.g. agg_iou's detached cls branch) get no gradient
-        ctx.torch_fn = torch_fn
-        ctx.is_tensor = [isinstance(t, torch.Tensor) for t in inputs]
-        ctx.save_for_backward(*[t for t in inputs if isinstance(t, torch.Tensor)])
-        ctx.others = [t for t in inputs if not isinstance(t, torch.Tensor)]
-        out = hip_fn(*inputs)
-        ctx.single = not isinstance(out, tuple)
-        return out
-
-    @staticmethod
-    def backward(ctx, *grads):
-        saved = list(ctx.saved_tensors)
-        others = list(ctx.others)
-        ins, leaf = [], []
-        for i, is_t in enumerate(ctx.is_tensor):
-            if is_t:
-                t = saved.pop(0)
-                need = ctx.needs_input_grad[2 + i] and t.is_floating_point()
-                t = t.detach().requires_grad_(need)
-                if need:
-                    leaf.append((i, t))
-                ins.append(t)
-            else:
-                ins.append(others.pop(0))
-        with torch.enable_grad():
-            outs = ctx.torch_fn(*ins)
-            outs = (outs,) if ctx.single else outs
-            pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o is not None and o.requires_grad]
-            gin = torch.autograd.grad([o for o, _ in pairs], [t for _, t in leaf], [g.to(o.dtype) for o, g in pairs],
-                                      allow_unused=True) if pairs and leaf else [None] * len(leaf)
-        result = [None, None] + [None] * len(ctx.is_tensor)
-        for (i, _), g in zip(leaf, gin):
-            result[2 + i] = g
-        return tuple(result)
-
-
-def hip_op(hip_fn, torch_fn, *inputs):
-    """Run ``hip_fn(*inputs)``; if autograd needs it, differentiate ``torch_fn(*inputs)`` in backward."""
-    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs):
-        return _HipFwdTorchBwd.apply(hip_fn, torch_fn, *inputs)
-    return hip_fn(*inputs)
 
 
 class _EagerBranch(torch.autograd.Function):
@@ -60,28 +9,33 @@ class _EagerBranch(torch.autograd.Function):
     scalar.  Used by TSCDHead to push the first MCA's backward into the window in which the host solves the matcher's
     assignments and the device would otherwise idle.
 
-    The eager backward is seeded with ``seed`` (the loss scale the caller expects upstream, e.g. GradScaler's 65536) so
-    fp16 gradient kernels see the same magnitudes as in a normal scaled backward; the outer backward multiplies by
-    upstream/seed on the device (no sync).  Parameter gradients still reach their AccumulateGrad nodes through the outer
-    graph, so DistributedDataParallel hooks fire as usual."""
+    The eager backward is seeded with ``seed``, a 0-dim fp32 DEVICE tensor holding the loss scale the caller expects upstream
+    (GradScaler's current scale), so the fp16 gradient kernels see the same magnitudes as in a normal scaled backward and the
+    scaler's back-off / growth reaches this branch too; the outer backward multiplies by upstream/seed on the device (no
+    sync).  If the branch overflows at the current scale the stored gradients are inf, the outer backward hands inf to the
+    scaler, the step is skipped and the scale halves -- and the next forward is seeded with the halved scale.  Parameter
+    gradients still reach their AccumulateGrad nodes through the outer graph, so DistributedDataParallel hooks fire as usual."""
 
     @staticmethod
-    def forward(ctx, fn, seed, n_act, *tensors):
+    def forward(ctx, fn, seed, track, n_act, *tensors):
         acts, params = tensors[:n_act], tensors[n_act:]
         det = [a.detach().requires_grad_(a.requires_grad and a.is_floating_point()) for a in acts]
         with torch.enable_grad():
             loss, extras = fn(*det)
             wrt = [d for d in det if d.requires_grad] + [p for p in params if p.requires_grad]
-            grads = torch.autograd.grad(loss * seed, wrt, allow_unused=True) if wrt else ()
+            seed_now = seed.detach().clone()                      # the caller may update `seed` in place before backward
+            grads = torch.autograd.grad(loss * seed_now, wrt, allow_unused=True) if wrt else ()
         ctx.mask = [d.requires_grad for d in det] + [p.requires_grad for p in params]
         ctx.grads = grads
-        ctx.seed = seed
+        ctx.seed, ctx.track = seed_now, seed if track else None
         ctx.mark_non_differentiable(*extras)
         return (loss.detach(),) + tuple(extras)
 
     @staticmethod
     def backward(ctx, g, *unused):
         scale = g.float() / ctx.seed
+        if ctx.track is not None:
+            ctx.track.copy_(g.float().abs().clamp(min=1.0))       # follow the upstream loss scale (one step behind)
         live = [gr for gr in ctx.grads if gr is not None]
         # two fused multi-tensor launches (fp32 parameter gradients, fp16 activation gradients) instead of one per tensor
         f32 = [gr for gr in live if gr.dtype == torch.float32]
@@ -96,10 +50,11 @@ class _EagerBranch(torch.autograd.Function):
         for m in ctx.mask:
             gr = next(it) if m else None
             out.append(None if gr is None else scaled[id(gr)])
-        return (None, None, None) + tuple(out)
+        return (None, None, None, None) + tuple(out)
 
 
-def eager_branch(fn, activations, params, seed=65536.0):
-    """-> (loss, *extras).  ``fn(*activations) -> (scalar fp32 loss, tuple of detached extra outputs)``."""
+def eager_branch(fn, activations, params, seed, track=False):
+    """-> (loss, *extras).  ``fn(*activations) -> (scalar fp32 loss, tuple of detached extra outputs)``.  ``seed``: 0-dim fp32
+    device tensor (see _EagerBranch); ``track``: update it in place with the upstream gradient seen in backward."""
     params = [p for p in params]
-    return _EagerBranch.apply(fn, float(seed), len(activations), *activations, *params)
+    return _EagerBranch.apply(fn, seed, bool(track), len(activations), *activations, *params)

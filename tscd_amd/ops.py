@@ -793,14 +793,16 @@ _EMA_TABLES = {}
 
 def ema_update(dst, src, decay):
     """dst[i] = decay * dst[i] + (1 - decay) * src[i] for lists of same-shaped contiguous fp32 CUDA tensors, one launch.
-    The chunk table (device pointers) is cached per (first, last address, count) and validated against ~33 sampled addresses: parameters and
-    buffers are updated in place, so their addresses only change when the model is moved or cast (the table is rebuilt then)."""
+    The chunk table (device pointers) is cached and validated against EVERY address on each call (parameters and buffers are
+    updated in place, so the addresses only change when a tensor is replaced, moved or cast -- the table is rebuilt then;
+    ~0.1 ms of host time for ~1300 addresses).  The kernel writes through raw pointers, which autograd's version counters do
+    not see: the destinations' versions are bumped afterwards so that caches keyed on them (the packed conv / linear weights
+    of WeightCache) notice the update."""
     if not dst:
         return
     dev = dst[0].device
-    key = (dst[0].data_ptr(), dst[-1].data_ptr(), len(dst), dev)      # addresses, not object ids: state_dict() hands out fresh tensor objects
-    probe = list(range(0, len(dst), max(1, len(dst) // 32))) + [len(dst) - 1]        # ~33 sampled addresses per call
-    sig = tuple(dst[i].data_ptr() for i in probe) + tuple(src[i].data_ptr() for i in probe)
+    sig = tuple(t.data_ptr() for t in dst) + tuple(t.data_ptr() for t in src)
+    key = (len(dst), dev)
     hit = _EMA_TABLES.get(key)
     if hit is None or hit[0] != sig:
         import numpy as np
@@ -817,3 +819,4 @@ def ema_update(dst, src, decay):
             _EMA_TABLES.clear()
         hit = _EMA_TABLES[key] = (sig, table, len(rec))
     call("tscd_ema_update_f32", hit[1].data_ptr(), hit[2], float(decay), float(1.0 - decay), _stream())
+    torch.autograd.graph.increment_version(dst)

@@ -111,6 +111,12 @@ class Trainer:
         if self.iter + 1 < self.max_iter and not resize_next:
             self._ahead = self._next_batch()
         next_x = self._ahead[0] if self._ahead is not None else None
+        # the head's eager class branch backpropagates inside forward: hand it this step's loss scale (device tensor, no sync)
+        m = self.model.module if is_parallel(self.model) else self.model
+        if hasattr(getattr(m, "head", None), "loss_scale"):
+            if not hasattr(self, "_one"):
+                self._one = torch.ones((), dtype=torch.float32, device=inps.device)
+            m.head.loss_scale = self.scaler.scale(self._one)
         outputs = self.model(inps, targets, time_embedding, lframe=self.exp.lframe, gframe=self.exp.gframe, resume=False,
                              next_x=next_x)
         loss = outputs["total_loss"]

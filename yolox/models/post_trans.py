@@ -7,10 +7,8 @@ materialised, the four projections and the output linears are MFMA GEMMs writing
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from tscd_amd import ops
-from tscd_amd.autograd import hip_op
 
 
 class Attention_mca_g2l(nn.Module):
@@ -29,59 +27,6 @@ class Attention_mca_g2l(nn.Module):
         self.linear = nn.Linear(2 * dim, 2 * dim)
         if self.reconf:
             self.linear_reg = nn.Linear(2 * dim, 2 * dim)
-
-
-def _mca_torch(x_cls, x_reg, score, wq_c, wkv_c, wq_r, wkv_r, w_lin, b_lin, w_linr, b_linr, w_out, b_out, w_obj, b_obj,
-               ppf, lframe, heads, scale, sim_thresh, conf_thresh, need_reg):
-    """Device-side PyTorch expression of the same math, differentiated in backward only (never a forward result).
-    All local frames are evaluated as one padded batch [L, heads, n_max, n_max + N_G] (invalid keys masked to -inf,
-    padded query rows dropped at the end) so the op count does not grow with lframe."""
-    N, C = x_cls.shape
-    dev = x_cls.device
-    L, h = lframe, heads
-    nl = sum(ppf[:L])
-    nmax = max(ppf[:L])
-    ng = N - nl
-    K = nmax + ng
-    # row index tables: queries [L, nmax], keys [L, K]; padded slots point at row 0 and are masked
-    qrow = torch.zeros((L, nmax), dtype=torch.long)
-    qok = torch.zeros((L, nmax), dtype=torch.bool)
-    start = 0
-    for i in range(L):
-        qrow[i, :ppf[i]] = torch.arange(start, start + ppf[i])
-        qok[i, :ppf[i]] = True
-        start += ppf[i]
-    krow = ops.h2d(torch.cat((qrow, torch.arange(nl, N).unsqueeze(0).expand(L, -1)), 1), torch.long, dev)
-    kok = ops.h2d(torch.cat((qok, torch.ones((L, ng), dtype=torch.bool)), 1), torch.bool, dev)
-    qrow, qok = ops.h2d(qrow, torch.long, dev), ops.h2d(qok, torch.bool, dev)
-    hd = lambda t: t.view(L, t.shape[1], h, C // h).permute(0, 2, 1, 3)          # [L,h,n,d]
-    nrm = lambda t: t / torch.norm(t.float(), dim=-1, keepdim=True).to(t.dtype)
-    flat = lambda t: t.permute(0, 2, 1, 3).reshape(L, t.shape[2], C)              # [L,n,C]
-    kv_c, kv_r = F.linear(x_cls, wkv_c), F.linear(x_reg, wkv_r)
-    q_c, q_r = hd(F.linear(x_cls[:nl], wq_c)[qrow]), hd(F.linear(x_reg[:nl], wq_r)[qrow])
-    k_c, v_c = hd(kv_c[krow][..., :C]), hd(kv_c[krow][..., C:])
-    k_r, v_r = hd(kv_r[krow][..., :C]), hd(kv_r[krow][..., C:])
-    neg = torch.where(kok, 0.0, float("-inf")).view(L, 1, 1, K)
-    sc = score[krow].float().view(L, 1, 1, K)
-    a_c = (nrm(q_c) @ nrm(k_c).transpose(-2, -1)).float() * scale * sc + neg
-    a_r = (nrm(q_r) @ nrm(k_r).transpose(-2, -1)).float() * scale + neg
-    attn = (a_r.softmax(-1) + a_c.softmax(-1)) / 2
-    attn16 = attn.to(v_c.dtype)
-    sim2 = torch.softmax(attn.sum(1) / h + neg[:, 0], dim=-1)                      # [L,n,K]
-    def branch(v, w_l, b_l, thresh, w_o, b_o):
-        x = torch.cat([flat(attn16 @ v), flat(v[:, :, :nmax])], -1)
-        x = F.linear(x, w_l, b_l)
-        with torch.no_grad():
-            vn = nrm(v)
-            raw = (vn[:, :, :nmax] @ vn.transpose(-2, -1)).float().sum(1) / h
-            m = ((raw > thresh) & kok.view(L, 1, K)).float()
-        ave = m * sim2 / torch.sum(m * sim2, dim=-1, keepdim=True).clamp(min=1e-30)
-        out = torch.cat([ave.to(v.dtype) @ flat(v), x], -1)                       # [L,nmax,3C]
-        return F.linear(out[qok], w_o, b_o)                                        # valid rows, frame-major
-    trans_cls = branch(v_c, w_lin, b_lin, sim_thresh, w_out, b_out)
-    if not need_reg:
-        return trans_cls
-    return trans_cls, branch(v_r, w_linr, b_linr, conf_thresh, w_obj, b_obj)
 
 
 class _MCAFunction(torch.autograd.Function):
@@ -171,42 +116,10 @@ class MCA_tscd_g2l_reg(nn.Module):
         x_cls = x_cls[0] if x_cls.dim() == 3 else x_cls
         x_reg = x_reg[0] if x_reg.dim() == 3 else x_reg
         m = self.mca
-        half = lambda t: None if t is None else t.to(torch.float16)
         params = [m.q_cls_local.weight, m.kv_cls.weight, m.q_reg_local.weight, m.kv_reg.weight, m.linear.weight, m.linear.bias,
                   m.linear_reg.weight if need_reg else None, m.linear_reg.bias if need_reg else None,
                   self.linear.weight, self.linear.bias, self.linear_obj.weight if need_reg else None,
                   self.linear_obj.bias if need_reg else None]
-        N, W = x_cls.shape
-        nl = sum(ppf[:lframe])
-        args = (ppf, lframe, m.num_heads, float(m.scale), float(sim_thresh), float(conf_thresh), need_reg)
-
-        if kwargs.get("backward", "hip") == "hip" or not torch.is_grad_enabled():
-            cfg = (ppf, lframe, float(m.scale), float(sim_thresh), float(conf_thresh), need_reg)
-            out = _MCAFunction.apply(cfg, x_cls.to(torch.float16), x_reg.to(torch.float16), cls_score, *params)
-            return out if need_reg else (out, None)
-
-        # ---- reference path for gradient checks: HIP forward, backward by differentiating the PyTorch expression ----
-        def hip_fn(xc, xr, sc, *ws):
-            (wq_c, wkv_c, wq_r, wkv_r, w_lin, b_lin, w_linr, b_linr, w_out, b_out, w_obj, b_obj) = ws
-            xc, xr, sc = xc.contiguous(), xr.contiguous(), sc.to(torch.float16).contiguous()
-            q_c = ops.linear(xc[:nl], wq_c)
-            kv_c = ops.linear(xc, wkv_c)
-            q_r = ops.linear(xr[:nl], wq_r)
-            kv_r = ops.linear(xr, wkv_r)
-            tiles = ops.mca_tiles(ppf, lframe, xc.device)
-            xcat_c, cat3_c, xcat_r, cat3_r, _ = ops.mca_attention(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, m.scale,
-                                                                  sim_thresh, conf_thresh)
-            ops.linear(xcat_c, w_lin, b_lin, out=cat3_c[:, W:])
-            t_cls = ops.linear(cat3_c, w_out, b_out)
-            if not need_reg:
-                return t_cls
-            ops.linear(xcat_r, w_linr, b_linr, out=cat3_r[:, W:])
-            return t_cls, ops.linear(cat3_r, w_obj, b_obj)
-
-        def torch_fn(xc, xr, sc, *ws):
-            return _mca_torch(xc, xr, sc, *[half(w) for w in ws], *args)
-
-        out = hip_op(hip_fn, torch_fn, x_cls.to(torch.float16), x_reg.to(torch.float16), cls_score, *params)
-        if need_reg:
-            return out
-        return out, None
+        cfg = (ppf, lframe, float(m.scale), float(sim_thresh), float(conf_thresh), need_reg)
+        out = _MCAFunction.apply(cfg, x_cls.to(torch.float16), x_reg.to(torch.float16), cls_score, *params)
+        return out if need_reg else (out, None)

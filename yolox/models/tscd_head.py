@@ -59,6 +59,16 @@ EAGER_CLASS_BRANCH = os.environ.get("TSCD_EAGER_CLASS_BRANCH", "1") != "0"
 _SIDE_STREAMS = {}      # device -> [torch.cuda.Stream]; process-wide (module attributes must stay deep-copyable for ModelEMA)
 
 
+_EAGER_SEED = {}        # device -> 0-dim fp32 tensor: loss scale the eager class branch is seeded with when no scaler scale is given
+
+
+def _eager_seed(dev):
+    t = _EAGER_SEED.get(dev)
+    if t is None:
+        t = _EAGER_SEED[dev] = torch.full((), 65536.0, dtype=torch.float32, device=dev)      # GradScaler's default init_scale
+    return t
+
+
 def _side_streams(dev, n):
     st = _SIDE_STREAMS.get(dev)
     if st is None or len(st) < n:
@@ -136,6 +146,7 @@ class TSCDHead(nn.Module):
         self.ota_mode = True
         self.max_gt = 128          # SimOTA cost planes are sized for this many boxes per frame
         self.debug = None          # tests set a dict here to capture intermediates
+        self.loss_scale = None     # 0-dim fp32 device tensor: the GradScaler's current scale (set by the training loop per step)
 
     def initialize_biases(self, prior_prob):
         for convs in (self.cls_preds, self.obj_preds):
@@ -300,8 +311,13 @@ class TSCDHead(nn.Module):
                     fcm, cp = class_branch(fc, fr, cs)
                     return class_loss(cp), (fcm.detach(), cp.detach())
 
+                # seed = the loss scale of this step: `self.loss_scale` when the training loop provides it (a device tensor,
+                # e.g. scaler.scale(ones)); otherwise a tracked copy of the upstream gradient of the previous step
+                seed, track = self.loss_scale, False
+                if seed is None:
+                    seed, track = _eager_seed(dev), True
                 loss_r_cls, features_cls_matched, cls_preds = eager_branch(
-                    branch, [f_cls, f_reg, cls_scores], list(self.agg.parameters()) + list(self.cls_pred.parameters()))
+                    branch, [f_cls, f_reg, cls_scores], list(self.agg.parameters()) + list(self.cls_pred.parameters()), seed, track)
             else:
                 loss_r_cls = class_loss(cls_preds)
             base = pred_rows[:nl, :4].float()
@@ -319,7 +335,8 @@ class TSCDHead(nn.Module):
             obj_refined = features_reg
         m_obj = hip_linear(obj_refined, self.matcher_obj_pred)
         m_reg = hip_linear(matched4, self.matcher_reg_pred)
-        self._dbg(cls_preds=cls_preds, matcher_obj_preds=m_obj, matcher_reg_preds=m_reg)
+        self._dbg(cls_preds=cls_preds, matcher_obj_preds=m_obj, matcher_reg_preds=m_reg, cls_scores=cls_scores, matched4=matched4,
+                  obj_refined=obj_refined, hungarian_rows=list(self.local_reg_matcher.last_hungarian_rows))
 
         if not training:
             res, res_ori, keep = nms_frames(pred_rows[:nl], ppf[:lframe], nc, cls_preds, m_obj, m_reg, 0.001, nms_thresh,
@@ -333,7 +350,7 @@ class TSCDHead(nn.Module):
         loss_m_iou = (sl1 * rmask.unsqueeze(-1)).sum() / num_fg_local
         loss_m_obj = torch.where(loss_m_obj > 15, loss_m_obj / loss_m_obj.detach() * 15, loss_m_obj)
         loss = 3.0 * loss_iou + loss_obj + loss_cls + loss_r_cls + loss_m_obj + 6.0 * loss_m_iou
-        self._dbg(fg_mask=fg_mask, matched_gt=matched_gt, num_fg=num_fg_b)
+        self._dbg(fg_mask=fg_mask, matched_gt=matched_gt, pred_iou=pred_iou, num_fg=num_fg_b, refined_fg_rows=rmask.sum())
         return (loss, 3.0 * loss_iou, loss_obj, loss_cls, 0.0, num_fg / num_gts.clamp(min=1), loss_r_cls, loss_m_obj,
                 6.0 * loss_m_iou)
 

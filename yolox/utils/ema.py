@@ -25,15 +25,22 @@ class ModelEMA:
         self.updates += 1
         d = self.decay(self.updates)
         inner = model.module if is_parallel(model) else model
-        # the (ema tensor, model tensor) pairs are collected once: parameters and buffers are updated in place, so the lists stay
-        # valid until the model is moved or cast (first parameter's address / dtype change) -- walking two state_dicts of ~900
-        # entries costs more host time per step than the update itself
-        p0 = next(inner.parameters())
-        key = (id(inner), p0.data_ptr(), p0.dtype, next(self.ema.parameters()).data_ptr())
-        if getattr(self, "_pairs_key", None) != key:
+        # The (ema tensor, model tensor) pairs are collected once: walking two state_dicts of ~900 entries costs ~3.5 ms of host
+        # time per step, more than the update itself.  They are re-collected when ANY parameter / buffer object of either model
+        # reports a new address (p.data = ..., .to(), .half(): ~0.1 ms per step to check) and, to notice replaced sub-modules,
+        # unconditionally every 128th update.  The cached aliases keep their storages alive, so a stale pair can never point
+        # at freed memory.
+        self._calls = getattr(self, "_calls", 0) + 1
+        objs = getattr(self, "_objs", None)
+        stale = objs is None or self._objs_of != id(inner) or self._calls % 128 == 0
+        if not stale:
+            stale = tuple(t.data_ptr() for t in objs) != self._ptrs
+        if stale:
             msd = inner.state_dict()
             self._pairs = [(v, msd[k].detach()) for k, v in self.ema.state_dict().items() if v.dtype.is_floating_point]
-            self._pairs_key = key
+            self._objs = list(inner.parameters()) + list(inner.buffers()) + list(self.ema.parameters()) + list(self.ema.buffers())
+            self._ptrs = tuple(t.data_ptr() for t in self._objs)
+            self._objs_of = id(inner)
         dst = [a for a, _ in self._pairs]
         src = [b if b.dtype == a.dtype else b.to(a.dtype) for a, b in self._pairs]
         if dst and all(a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous()
