@@ -194,7 +194,8 @@ def cpu_baseline(args, state_dict, clip):
     ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("TSCD_CPU_THREADS", "16")))
     torch.set_num_threads(ncores)
     cfg = O.TSCDConfig(num_classes=NUM_CLASSES, depth=args.depth, width=args.width, minimal_limit=50, maximal_limit=500,
-                       simota_autocast=True)      # assignment in the arithmetic of autocast training (what the product reproduces)
+                       simota_autocast=True,      # assignment in the arithmetic of autocast training (what the product reproduces)
+                       simota_matched_pair_iou=True)    # ... minus its NaN-poisoned IoU sum (simota.hip header): finite class targets
     sd = {}
     for k, v in state_dict.items():
         v = v.detach().cpu()

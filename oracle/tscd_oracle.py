@@ -50,6 +50,11 @@ class TSCDConfig:
     # training under autocast (tscd_trainer.py:159-176): images AND targets are cast to fp16 and the head's outputs are
     # fp16 tensors, so get_assignments evaluates its IoU chain in fp16 (see simota_assign).  False = the fp32 evaluation.
     simota_autocast: bool = False
+    # The product's one deliberate deviation inside SimOTA (simota.hip header): the matched IoU is read from
+    # the matched (gt, anchor) pair instead of (matching_matrix * ious).sum(0), whose fp16 evaluation returns NaN for every
+    # anchor that has a NaN IoU with ANY other gt (far-apart boxes: prod(br - tl) overflows fp16, times the zero overlap flag).
+    # False = the reference's expression (tscd_head.py:1540-1543).
+    simota_matched_pair_iou: bool = False
 
     @property
     def head_width(self):
@@ -219,7 +224,7 @@ def get_in_boxes_info(gt, strides_a, xs, ys, num_gt):
     return anchor, (is_in_boxes[:, anchor] & is_in_centers[:, anchor])
 
 
-def dynamic_k_matching(cost, ious, gt_classes, num_gt, fg_mask, vid_dk=10):
+def dynamic_k_matching(cost, ious, gt_classes, num_gt, fg_mask, vid_dk=10, matched_pair_iou=False):
     """tscd_head.py:1512-1544."""
     matching = torch.zeros_like(cost)
     n_cand = min(vid_dk, ious.size(1))
@@ -238,7 +243,12 @@ def dynamic_k_matching(cost, ious, gt_classes, num_gt, fg_mask, vid_dk=10):
     fg_mask = fg_mask.clone()
     fg_mask[fg_mask.clone()] = fg_in
     matched_gt_inds = matching[:, fg_in].argmax(0)
-    return num_fg, gt_classes[matched_gt_inds], (matching * ious).sum(0)[fg_in], matched_gt_inds, fg_mask
+    if matched_pair_iou:
+        cols = torch.nonzero(fg_in).flatten()
+        pred_ious = ious[matched_gt_inds, cols].to(matching.dtype)
+    else:
+        pred_ious = (matching * ious).sum(0)[fg_in]
+    return num_fg, gt_classes[matched_gt_inds], pred_ious, matched_gt_inds, fg_mask
 
 
 @torch.no_grad()
@@ -287,7 +297,7 @@ def simota_assign(outputs, labels, xs, ys, strides_a, cfg):
         cls_loss = F.binary_cross_entropy(p.sqrt_(), gt_onehot, reduction="none").sum(-1)
         cost = cls_loss + 3.0 * iou_loss + 100000.0 * (~in_bc)
         n_fg_img, matched_cls, pred_ious, matched_inds, fg_mask = dynamic_k_matching(
-            cost, ious, gt_cls, G, fg_mask, cfg.vid_dk)
+            cost, ious, gt_cls, G, fg_mask, cfg.vid_dk, cfg.simota_matched_pair_iou)
         num_fg += n_fg_img
         fg_ids.append(torch.where(fg_mask)[0])
         cls_t.append(F.one_hot(matched_cls.to(torch.int64), nc) * pred_ious.unsqueeze(-1))

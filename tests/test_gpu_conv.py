@@ -231,6 +231,9 @@ DMA_CASES = [
     (2, 9, 11, 64, 256, 3, 1),       # one 64-channel chunk per tap, ragged M (128 x 256 variant: 9 k-tiles)
     (1, 5, 5, 128, 384, 1, 1),       # Cout padded to 384: not a multiple of 256 -> stays on the 128-wide tiles
     (2, 8, 8, 192, 256, 3, 2),       # stride 2, 3 chunks per tap
+    (2, 72, 72, 256, 256, 3, 1),     # the dominant shape's geometry (72 k-tiles of 32, 81 M-tiles)
+    (1, 3, 5, 32, 256, 1, 1),        # a single k-tile on the 256-wide tiles (ring prologue longer than the loop)
+    (1, 7, 9, 96, 512, 3, 1),        # 27 k-tiles, two N-tiles of 256, ragged M
 ]
 
 
@@ -253,11 +256,13 @@ def test_conv_lds_dma_variant_bit_identical_to_register_staging(case):
         y1, st1 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
         lib.tscd_conv_set_variant(3)              # the 128 x 256 / BK=64 variant wherever the shape allows it
         y2, st2 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
+        lib.tscd_conv_set_variant(4)              # 128 x 256 / BK=32, staggered wave groups, wherever the shape allows it
+        y3, st3 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
     finally:
         lib.tscd_conv_set_variant(-1)
     torch.cuda.synchronize()
-    assert torch.equal(y0, y1) and torch.equal(y0, y2)
-    assert torch.equal(st0, st1) and torch.equal(st0, st2)
+    assert torch.equal(y0, y1) and torch.equal(y0, y2) and torch.equal(y0, y3)
+    assert torch.equal(st0, st1) and torch.equal(st0, st2) and torch.equal(st0, st3)
     ref = F.conv2d(x.float(), w.float(), None, s, (k - 1) // 2)
     assert_close(y1.permute(0, 3, 1, 2), ref)
 

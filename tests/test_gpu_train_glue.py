@@ -39,18 +39,18 @@ def test_ema_forward_sees_updated_weights(golden):
     ema.decay = lambda n: 0.5                                    # a large step so that stale packs would be far off
     ema.ema.head.debug = {}
     with torch.no_grad():
-        ema.ema(imgs, time_embedding=temb, **kw)                  # packs every weight of the EMA model
-        before = ema.ema.head.debug["cls_preds"].float().clone()
+        ema.ema(imgs, time_embedding=temb, **kw)                  # packs every weight of the EMA model; `det` = decoded head output [B,A,7+NC]
+        before = ema.ema.head.debug["det"].float().clone()
         for p in m.parameters():                                  # move the source model, then one EMA update
             p.mul_(1.5)
         ema.update(m)
         ema.ema(imgs, time_embedding=temb, **kw)
-        after = ema.ema.head.debug["cls_preds"].float().clone()
+        after = ema.ema.head.debug["det"].float().clone()
         fresh = build_model(golden[0]).cuda().eval()
         fresh.load_state_dict(ema.ema.state_dict(), strict=True)
         fresh.head.debug = {}
         fresh(imgs, time_embedding=temb, **kw)
-        want = fresh.head.debug["cls_preds"].float()
+        want = fresh.head.debug["det"].float()
     torch.cuda.synchronize()
     assert not torch.allclose(before, want, rtol=1e-2, atol=1e-2)            # the update did move the outputs
     assert after.shape == want.shape and torch.equal(after, want)            # same weights, same kernels: identical

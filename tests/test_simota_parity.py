@@ -102,7 +102,12 @@ def test_hip_simota_bit_exact_both_modes(cases, emu16):
         known = want_iou != 0                 # the golden recovers the class from onehot * iou: undefined where the IoU is 0
         assert np.array_equal(got_cls[known], want_cls[known]), (ci, emu16)
         if emu16:
-            assert np.array_equal(pi, want_iou, equal_nan=True), (ci, emu16)                # fp16 values: exact
+            # fp16 values: exact wherever the reference's value is a number.  Where it is NaN -- (matching * ious).sum(0) picks
+            # up 0 * NaN from the anchor's pair with ANOTHER, far-away gt (fp16 overflow of prod(br - tl)) and poisons the class
+            # target -- the kernel deliberately keeps the matched pair's own IoU (simota.hip header).
+            num = ~np.isnan(want_iou)
+            assert np.array_equal(pi[num], want_iou[num]), (ci, emu16)
+            assert np.isfinite(pi[~num]).all() and (pi[~num] >= 0).all() and (pi[~num] <= 1).all(), (ci, emu16)
         else:
             np.testing.assert_allclose(pi, want_iou, rtol=1e-5, atol=1e-6)
         assert nfg.cpu().tolist() == want_fg.sum(1).tolist()

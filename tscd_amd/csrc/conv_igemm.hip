@@ -601,6 +601,176 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(ConvParams p) {
   conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
 }
 
+// ====================================================================================================================
+// Main-loop variant 4 (Cin % 32 == 0, Cout > 128): 128 x 256 tile, 8 waves, BK = 32 stages in a 6-deep LDS-DMA ring, the two
+// wave groups of a workgroup STAGGERED by one barrier interval.
+//
+// Why: variants 2 / 3 run their two co-resident waves per SIMD in lockstep -- both fetch fragments, then both queue on the
+// SIMD's one matrix pipe, then both wait -- and measure 650-700 TFLOP/s on the dominant shape (760-840 with every operand
+// L1-hot: the loop structure, not memory, is the first limit).  Here waves 0-3 (group 0) and waves 4-7 (group 1: the waves
+// that share SIMDs with 0-3) alternate roles every barrier interval:
+//
+//   interval      2u          2u+1        2u+2        2u+3
+//   group 0     L(u)        M(u)        L(u+1)      M(u+1)         L(t) = 8 ds_read_b128 of k-tile t's fragments + this wave's
+//   group 1     M(u-1)      L(u)        M(u)        L(u+1)                3 LDS-DMA pieces of a later tile;  M(t) = 8 MFMAs
+//
+// so in every interval one wave of each SIMD feeds the matrix pipe (256 cycles of v_mfma_f32_32x32x16_f16) while its partner
+// fetches fragments and issues DMA -- matrix beside memory (MI355X_MICROARCH.md, "Two waves per SIMD").  Synchronisation by
+// construction (one raw s_barrier per interval, counted vmcnt, no __syncthreads in the loop):
+//   RAW  k-tile t is read by group 0 in interval 2t and by group 1 in 2t+1.  Every wave retires ITS OWN pieces of tile t with a
+//        counted s_waitcnt vmcnt at the end of an M segment that lies before barrier 2t: group 0 waits for tile u+1 at the end of
+//        M(u) (interval 2u+1), group 1 for tile u+2 at the end of M(u) (interval 2u+2).
+//   WAR  the fragment reads of tile t are retired (lgkmcnt(0) right behind the barrier that opens the M segment) by barrier 2t+2
+//        at the latest; the stage is refilled -- tile t+6 -- by group 1 in L(t+1) (interval 2t+3) and by group 0 in L(t+2)
+//        (interval 2t+4), i.e. at least one full barrier after the last reader has its data in registers.
+//   Each wave keeps 3 tiles (9 pieces) of its own DMA in flight across the barriers; the ring holds 6 x 24 KB = 144 KB.
+// K order and MFMA shape are those of variants 0-3, so outputs (and the BatchNorm partial sums) are bit-identical.
+// ====================================================================================================================
+template <int N> __device__ __forceinline__ void wait_vmcnt9() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 1) void conv_igemm_v4_kernel(ConvParams p) {
+  constexpr int BM = 128, BN = 256, NS = 6, WAVES_M = 2, WAVES_N = 4, TM = 2, TN = 2, WM = 64, WN = 64;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;      // 8 KB + 16 KB per k-tile of 32
+  constexpr int B_LD = 2;                                                              // pieces (16 rows x 64 B) per wave: 1 A + 2 B
+  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                          // 0: waves 0-3, 1: waves 4-7 (SIMD partners of 0-3)
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-lane DMA source state (as variant 2): slot s = lane&3 of row lane>>2 in a 16-row piece holds chunk s ^ ((row>>2)&3)
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const f16* a_src;
+  unsigned a_mask;
+  {
+    const int m = m0 + wave * 16 + (lane >> 2);
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / (p.Ho * p.Wo);
+    const int rem = mm - b * (p.Ho * p.Wo);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+    a_src = p.x + ((long)(b * p.H + hi0) * p.W + wi0) * p.ldx + chunk * 8;
+    unsigned mask = 0;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw)
+        if (ok && (unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W) mask |= 1u << (kh * p.KW + kw);
+    a_mask = mask;
+  }
+  const f16* b_src[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) b_src[j] = p.w + (long)(n0 + wave * 32 + j * 16 + (lane >> 2)) * p.Kpad + chunk * 8;
+
+  const int nk = p.Kpad >> 5;
+  int ld_tile = 0, ld_tap = 0, ld_cin = 0, ld_kw = 0, ld_soff = 0;     // wave-uniform position of the NEXT k-tile this wave issues
+  long ld_tapoff = 0;
+  auto issue = [&]() __attribute__((always_inline)) {
+    char* sbase = smem + ld_soff;
+    const f16* src = ((a_mask >> ld_tap) & 1u) ? a_src + ld_tapoff + ld_cin : g_zero_chunk;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sbase + wave * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[j],
+                                       (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wave * 2 + j) * 1024), 16, 0, 0);
+      b_src[j] += 32;
+    }
+    ++ld_tile;
+    ld_soff += STAGE;
+    if (ld_soff == NS * STAGE) ld_soff = 0;
+    ld_cin += 32;
+    if (ld_cin == p.Cin) {
+      ld_cin = 0;
+      ++ld_tap;
+      if (++ld_kw == p.KW) { ld_kw = 0; ld_tapoff += (long)(p.W - p.KW + 1) * p.ldx; } else ld_tapoff += p.ldx;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read offsets inside a stage: row r, chunk c -> r*64 + ((c ^ ((r>>2)&3)) * 16)
+  const int frow = lane & 31, fsw = (frow >> 2) & 3, fk = lane >> 5;
+  int a_off[TM][2], b_off[TN][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_off[i][ks] = (wm * WM + i * 32 + frow) * 64 + (((ks * 2 + fk) ^ fsw) * 16);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_off[j][ks] = A_BYTES + (wn * WN + j * 32 + frow) * 64 + (((ks * 2 + fk) ^ fsw) * 16);
+  }
+
+  // prologue: group 0 starts 4 tiles, group 1 5 tiles (their steady-state issue distances: L(u) issues tile u+4 / u+5)
+  const int ahead = 4 + grp;
+  for (int t = 0; t < ahead; ++t)
+    if (ld_tile < nk) issue();
+  // retire this wave's pieces of tile 0 (and tile 1 for group 1, which never gets another chance before tile 1 is read)
+  auto wait_own = [&](int t) __attribute__((always_inline)) {      // this wave's pieces of tiles <= t have landed
+    if (t >= nk) t = nk - 1;
+    const int younger = ld_tile - 1 - t;                            // tiles of this wave still allowed in flight
+    if (younger >= 3) wait_vmcnt9<9>();
+    else if (younger == 2) wait_vmcnt9<6>();
+    else if (younger == 1) wait_vmcnt9<3>();
+    else wait_vmcnt9<0>();
+  };
+  wait_own(grp);
+  __builtin_amdgcn_s_barrier();                                     // barrier 0
+  if (grp == 1) __builtin_amdgcn_s_barrier();                       // the stagger: group 1 runs one interval behind
+
+  f16x8 fa[2][TM], fb[2][TN];
+  int rd_soff = 0;
+  for (int u = 0; u < nk; ++u) {
+    // ---------------- L(u): fragments of k-tile u, DMA of a later tile ----------------
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const char* sb = smem + rd_soff;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[ks][i] = *(const f16x8*)(sb + a_off[i][ks]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[ks][j] = *(const f16x8*)(sb + b_off[j][ks]);
+      }
+      rd_soff += STAGE;
+      if (rd_soff == NS * STAGE) rd_soff = 0;
+    }
+    if (ld_tile < nk) issue();             // group 0: tile u+4 (stage of tile u-2), group 1: tile u+5 (stage of tile u-1)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- M(u) ----------------
+    __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): the fragments are in registers (retires this wave's reads of tile u)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_own(u + 1 + grp);                 // group 0: tile u+1, group 1: tile u+2 (both precede the barrier their readers need)
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();                       // even out the barrier count of the two groups
+  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
+}
+
 // Tile choice: BN follows Cout (128 / 64 / 32); BM = 128.  Packed weights and BatchNorm partials are padded to a multiple of
 // this BN.  (A 128 x 256 tile with 8 waves was measured: no faster on the 72x72 level -- the limit is bytes in flight per CU
 // against the ~2 us loaded MALL latency, not bytes per FLOP -- and slower on the small levels, which get half the workgroups.)
@@ -649,15 +819,20 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
   // the 128 x 256 / BK=64 variant pays off (+7 %) only when its half-as-many, twice-as-large workgroups still cover the
   // chip at least twice (measured: 72x72 level x1.07, 36x36 x1.01, 18x18 x0.77); g_conv_variant == 3 forces it (tests)
   const bool v3_shape = Cin % 64 == 0 && Cout > 128 && cout_pad % 256 == 0;
-  const bool v3_ok = dma_ok && v3_shape && g_conv_variant != 1 &&
+  const bool v3_ok = dma_ok && v3_shape && g_conv_variant != 1 && g_conv_variant != 4 &&
                      (g_conv_variant == 3 || (long)cdiv(M, 128) * cdiv(Cout, 256) >= 512);
-  const int BN = v3_ok ? 256 : BNP;
+  // variant 4 (staggered wave groups): the same 128 x 256 tile; needs only Cin % 32 == 0.  Selected by tscd_conv_set_variant(4)
+  // while it is being measured against variant 3.
+  const bool v4_ok = dma_ok && Cout > 128 && cout_pad % 256 == 0 && g_conv_variant == 4;
+  const int BN = (v3_ok || v4_ok) ? 256 : BNP;
   p.mtiles = cdiv(M, BM);
   p.ntiles = cdiv(Cout, BN);
   p.cstride = cdiv(Cout, BNP) * BNP;
-  dim3 grid(p.mtiles * p.ntiles), block(v3_ok ? 512 : 256);
+  dim3 grid(p.mtiles * p.ntiles), block((v3_ok || v4_ok) ? 512 : 256);
   hipStream_t s = (hipStream_t)stream;
-  if (v3_ok)
+  if (v4_ok)
+    hipLaunchKernelGGL(conv_igemm_v4_kernel, grid, block, 0, s, p);
+  else if (v3_ok)
     hipLaunchKernelGGL(conv_igemm_v3_kernel, grid, block, 0, s, p);
   else if (dma_ok && BN == 128)
     hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 2>), grid, block, 0, s, p);

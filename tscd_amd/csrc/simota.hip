@@ -8,6 +8,10 @@
 //                   smallest-cost anchors (ties -> lower anchor index)
 //   simota_resolve  thread per (image, anchor): anchors claimed by several gts go to the gt of minimum cost (first
 //                   minimum), emits fg mask, matched gt index and the matched IoU
+// pred_iou is the IoU of the matched (gt, anchor) pair.  The reference forms it as (matching_matrix * pair_wise_ious).sum(0)
+// (tscd_head.py:1540-1543): in fp16 the IoU of two boxes that are far apart in both axes is NaN (prod(br - tl) overflows to inf,
+// times the zero overlap flag), and 0 * NaN = NaN then poisons the sum of every anchor that has such a pair with ANY other gt --
+// NaN class targets, a NaN loss and a skipped optimizer step.  Deliberate deviation: finite, the matched pair.
 // `emu16` reproduces the reference's fp16 arithmetic under autocast (IoU chain evaluated on fp16 tensors with per-op
 // rounding, fp16 sigmoid of the objectness); with emu16 = 0 the same fp16 inputs are evaluated in fp32.
 #include "common.h"
@@ -171,10 +175,12 @@ __global__ __launch_bounds__(1024) void simota_match_kernel(SimotaParams p, int 
   int k = (sum != sum) ? 1 : (int)sum;   // .int() truncates; NaN -> implementation garbage, clamp below
   if (k < 1) k = 1;
   if (k > topk) k = topk;
-  // k smallest costs
+  // k smallest costs.  +inf is a legal cost (a gt whose fp16 area overflows has IoU 0 with everything: -log(0) = inf) and
+  // torch.topk(largest=False) then still returns k entries -- the lowest indices among the ties -- so the running best
+  // starts AT +inf with an out-of-range index instead of below it.
   int nm = 0;
   for (int round = 0; round < k; ++round) {
-    float bv = 3.4e38f;
+    float bv = __builtin_inff();
     int bi = 0x7fffffff;
     for (int a = tid; a < p.A; a += blockDim.x) {
       if (iou[a] < 0.f && !(iou[a] != iou[a])) continue;
@@ -210,12 +216,12 @@ __global__ void simota_resolve_kernel(SimotaParams p, int topk, const int* __res
   }
   int mg = first;
   if (cnt > 1) {
-    // torch.min(cost[:, a], dim=0): first minimum over ALL gts
-    float bv = 3.4e38f;
+    // torch.min(cost[:, a], dim=0) over ALL gts: the first NaN if there is one (NaN propagates), else the first minimum
+    float bv = p.cost[((long)b * p.G) * p.A + a];
     mg = 0;
-    for (int g = 0; g < G; ++g) {
+    for (int g = 1; g < G; ++g) {
       float v = p.cost[((long)b * p.G + g) * p.A + a];
-      if (v < bv) { bv = v; mg = g; }
+      if (!(bv != bv) && (v != v || v < bv)) { bv = v; mg = g; }
     }
   }
   long o = (long)b * p.A + a;
