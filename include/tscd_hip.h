@@ -34,9 +34,14 @@ int tscd_conv_tile_m(void);
 /* Main-loop selection of tscd_conv2d_nhwc_f16: -1 automatic (LDS-DMA ring when Cin % 32 == 0 and Cout > 32 -- as 128 x 256
  * tiles with BK = 64 when Cin % 64 == 0, Cout is a multiple of 256 and the launch still has >= 512 workgroups -- register
  * staging otherwise), 0 force register staging, 1 LDS-DMA with 128-wide tiles only, 3 the 128 x 256 variant wherever its
- * shape constraints hold.  All variants accumulate in the same order: outputs and BatchNorm partial sums are bit-identical
- * (tests/test_gpu_conv.py). */
+ * shape constraints hold, 4 the same tile with BK = 32 and the two wave groups of a workgroup staggered by one barrier
+ * interval, 5 the halo-staged 256 x 256 tile for 3x3 / stride-1 convs (input pixels fetched once per 32-channel chunk and
+ * shared by the 9 taps).  Variants 0-4 accumulate in the same order: outputs and BatchNorm partial sums are bit-identical;
+ * variant 5 walks k as (channel chunk, tap) and equals variant 0 bit for bit once that takes the same order
+ * (tscd_conv_set_korder(1)) -- tests/test_gpu_conv.py. */
 void tscd_conv_set_variant(int variant);
+/* k order of the register-staged loop (variant 0): 0 = (tap, channel) as packed, 1 = (32-channel chunk, tap); test hook. */
+void tscd_conv_set_korder(int order);
 /* Measurement hook (scratch experiments, never set by the product path): bit0 makes the LDS-DMA loop's A gather read a
  * zero block, bit1 makes every B row read row 0 -- isolates how much of a launch is memory stall.  Results are wrong. */
 void tscd_conv_set_debug(int bits);

@@ -295,3 +295,49 @@ def test_ema_update_matches_foreach_formulation():
     ops.ema_update(dst, src, 0.5)
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(dst, ref))
+
+
+HALO_CASES = [
+    (2, 72, 72, 256, 256),       # the dominant shape's geometry: 41 tiles of 256 pixels, tiles span image rows and frames
+    (3, 36, 36, 256, 256),       # M = 3888: the last tile is ragged
+    (1, 18, 18, 512, 512),       # two N-tiles, 16 channel chunks
+    (2, 8, 8, 32, 256),          # one channel chunk (no halo double-buffering), M = 128 < one tile
+    (1, 5, 90, 64, 256),         # wide, short image (W = 90: the largest halo class), 2 chunks
+    (5, 4, 3, 96, 256),          # tiny images: every pixel is an edge pixel, a tile spans all five frames
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv_halo_variant_matches_chunk_major_register_loop_bit_for_bit(case):
+    """Variant 5 (input halo staged once per channel chunk, taps read it at row shifts, out-of-image taps redirected to a zero
+    block) vs the register-staged loop walking k in the same (channel chunk, tap) order: identical MFMA sequence per output =>
+    bit-identical outputs; BatchNorm partial sums agree to fp32 rounding (the 256-row tile sums its rows in another order);
+    both match the fp32 oracle.  Also: variant 5 vs the default k order within fp32-accumulation noise."""
+    from tscd_amd import ops
+    from tscd_amd._lib import lib
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half()
+    xg = x.to(dev()).permute(0, 2, 3, 1).contiguous()
+    wpk = ops.pack_conv_weight(w.to(dev()))
+    try:
+        lib.tscd_conv_set_variant(0)
+        y_def, st_def = ops.conv2d(xg, wpk, Cout, 3, 1, want_stats=True)
+        lib.tscd_conv_set_korder(1)
+        y0, st0 = ops.conv2d(xg, wpk, Cout, 3, 1, want_stats=True)
+        lib.tscd_conv_set_korder(0)
+        lib.tscd_conv_set_variant(5)
+        y5, st5 = ops.conv2d(xg, wpk, Cout, 3, 1, want_stats=True)
+        yb = ops.conv2d(xg, wpk, Cout, 3, 1, epilogue=ops.EPI_BIAS_RELU, bias=torch.linspace(-1, 1, Cout, device=dev()))[0]
+    finally:
+        lib.tscd_conv_set_korder(0)
+        lib.tscd_conv_set_variant(-1)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y5)
+    assert torch.allclose(st0, st5, rtol=1e-5, atol=1e-4)
+    assert (y_def.float() - y5.float()).abs().max().item() <= 2e-3 * y_def.float().abs().max().item()
+    ref = F.conv2d(x.float(), w.float(), None, 1, 1)
+    assert_close(y5.permute(0, 3, 1, 2), ref)
+    refb = torch.relu(ref + torch.linspace(-1, 1, Cout).view(1, -1, 1, 1))
+    assert_close(yb.permute(0, 3, 1, 2), refb)

@@ -457,3 +457,46 @@ def test_cafm_ragged_counts_and_carried_state_match_oracle(W, counts):
         for fi, (a, b) in enumerate(zip(hung, aux["hungarian"])):
             assert np.array_equal(a, np.asarray(b)), (ci, fi)
         close(out[-1], ref, 6e-2, 1.5e-2)
+
+
+def test_nms_more_candidates_than_one_lds_sort_chunk():
+    """The ImageNet-VID regime (no upper proposal clamp, 30 classes): a frame with 1500 proposals has up to 45000
+    (proposal, class) candidates -- more than the 16384 keys one LDS sort holds -- next to a small frame.  Kept candidate
+    indices must equal the oracle's batched NMS on the same fp16 values, in the same order."""
+    from oracle.nms_ref import batched_nms
+    from yolox.models.post_process import nms_frames
+    g = torch.Generator().manual_seed(17)
+    NC, ppf = 30, [1500, 300]
+    n = sum(ppf)
+    cxy = torch.rand(n, 2, generator=g) * 500 + 30
+    wh = torch.rand(n, 2, generator=g) * 120 + 10
+    det = torch.zeros(n, 7 + NC)
+    det[:, 0:2], det[:, 2:4] = cxy - wh / 2, cxy + wh / 2
+    det[:, 4], det[:, 5] = torch.rand(n, generator=g), torch.rand(n, generator=g)
+    det[:, 6] = torch.randint(0, NC, (n,), generator=g).float()
+    det = det.half()
+    cls = (torch.randn(n, NC, generator=g) * 2.0 - 1.0).half()           # ~30 % of the (proposal, class) scores pass 1e-3 * ...
+    obj = (torch.randn(n, generator=g) * 1.5 + 1.0).half()
+    reg = (0.05 * torch.randn(n, 4, generator=g)).half()
+    q = lambda t: t.half().float()
+    reg_xyxy = O.decode_reg_preds5(reg, det[:, :4]).float()
+    ref_keep, s0 = [], 0
+    for c in ppf:
+        sc = q(torch.sigmoid(cls[s0:s0 + c].float()))
+        ob = q(torch.sigmoid(obj[s0:s0 + c].float()))
+        loc = torch.where(sc >= q(torch.tensor(0.001)))
+        prod = q(ob[loc[0]] * sc[loc[0], loc[1]])
+        km = prod >= q(torch.tensor(0.001))
+        boxes, scores, cids = reg_xyxy[s0:s0 + c][loc[0]][km], prod[km], loc[1][km]
+        cand_idx = (loc[0] * NC + loc[1])[km]
+        ref_keep.append(cand_idx[batched_nms(boxes, scores, cids.float(), 0.5)])
+        s0 += c
+    assert int((q(torch.sigmoid(cls[:1500].float())) >= 0.001).sum()) > 16384          # the large frame really needs the chunked sort
+    out, ori, keep = nms_frames(det.cuda(), ppf, NC, cls.cuda(), obj.cuda(), reg.cuda(), 0.001, 0.5, return_idx=True)
+    torch.cuda.synchronize()
+    for i in range(len(ppf)):
+        k = keep[i].cpu().long()
+        # the kernel numbers candidates in expansion order (surviving (row, class) pairs, row-major); map to row*NC + class
+        assert out[i].shape[0] == len(k) == len(ref_keep[i]), (i, len(k), len(ref_keep[i]))
+        sc = (out[i][:, 4].float() * out[i][:, 5].float()).half().float().cpu()
+        assert torch.all(sc[:-1] >= sc[1:])

@@ -41,8 +41,9 @@ def test_ema_forward_sees_updated_weights(golden):
     with torch.no_grad():
         ema.ema(imgs, time_embedding=temb, **kw)                  # packs every weight of the EMA model; `det` = decoded head output [B,A,7+NC]
         before = ema.ema.head.debug["det"].float().clone()
-        for p in m.parameters():                                  # move the source model, then one EMA update
-            p.mul_(1.5)
+        for k, p in m.named_parameters():                         # move the source model, then one EMA update
+            if "_preds." in k or "head.stems" in k or "lateral_conv0.conv" in k:
+                p.mul_(1.25)
         ema.update(m)
         ema.ema(imgs, time_embedding=temb, **kw)
         after = ema.ema.head.debug["det"].float().clone()
@@ -52,7 +53,7 @@ def test_ema_forward_sees_updated_weights(golden):
         fresh(imgs, time_embedding=temb, **kw)
         want = fresh.head.debug["det"].float()
     torch.cuda.synchronize()
-    assert not torch.allclose(before, want, rtol=1e-2, atol=1e-2)            # the update did move the outputs
+    assert torch.isfinite(want).all() and not torch.allclose(before, want, rtol=1e-3, atol=1e-3)     # the update did move the outputs
     assert after.shape == want.shape and torch.equal(after, want)            # same weights, same kernels: identical
 
 

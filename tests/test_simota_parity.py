@@ -99,7 +99,7 @@ def test_hip_simota_bit_exact_both_modes(cases, emu16):
         assert np.array_equal(fg, want_fg), (ci, emu16, int(fg.sum()), int(want_fg.sum()), int((fg != want_fg).sum()))
         lab_cls = c["labels"][..., 0].astype(np.int64)
         got_cls = np.where(fg, np.take_along_axis(lab_cls, np.clip(mg, 0, None), 1), -1)
-        known = want_iou != 0                 # the golden recovers the class from onehot * iou: undefined where the IoU is 0
+        known = np.isfinite(want_iou) & (want_iou != 0)      # the golden recovers the class from onehot * iou: undefined where that is 0 / NaN
         assert np.array_equal(got_cls[known], want_cls[known]), (ci, emu16)
         if emu16:
             # fp16 values: exact wherever the reference's value is a number.  Where it is NaN -- (matching * ious).sum(0) picks

@@ -37,7 +37,7 @@ def run(x, wpk, cout, k, variant, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="1,3,4,-1")
+    ap.add_argument("--variants", default="1,3,4,5")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
@@ -57,7 +57,8 @@ def main():
             torch.cuda.synchronize()
             if ref is None:
                 ref = (y.clone(), st.clone())
-            same[v] = bool(torch.equal(y, ref[0]) and torch.equal(st, ref[1]))
+            same[v] = "==" if bool(torch.equal(y, ref[0]) and torch.equal(st, ref[1])) else (
+                "~=" if (y.float() - ref[0].float()).abs().max().item() <= 2e-3 * ref[0].float().abs().max().item() else "DIFF")
         lib.tscd_conv_set_variant(-1)
         ts = {v: [] for v in variants}
         for _ in range(args.rounds):
@@ -66,7 +67,7 @@ def main():
         cells = []
         for v in variants:
             mn, md = min(ts[v]), statistics.median(ts[v])
-            cells.append(f"v{v}: {mn:7.1f} us (med {md:7.1f}) {fl / mn / 1e6:6.0f} TF/s {'==' if same[v] else 'DIFF'}")
+            cells.append(f"v{v}: {mn:7.1f} us (med {md:7.1f}) {fl / mn / 1e6:6.0f} TF/s {same[v]}")
         print((B, H, W, Cin, Cout, k), " | ".join(cells), flush=True)
 
 

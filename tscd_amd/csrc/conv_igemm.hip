@@ -30,6 +30,8 @@ struct ConvParams {
   int K, Kpad, M;
   int epilogue;
   int mtiles, ntiles, cstride;
+  int mtiles_stat;   // BatchNorm partials are kept per 128 output pixels whatever the tile height (bn_finalize's layout)
+  int korder;        // 0: k runs (tap, cin) as packed; 1: (32-channel chunk, tap) -- variant 5's order (Cin % 32 == 0 only)
   int debug;   // experiments only: bit0 = A gather reads the zero chunk, bit1 = B rows all read row 0
 };
 
@@ -39,7 +41,7 @@ enum { EPI_RAW = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BN_SILU = 3, EPI_BN = 4
 // The finished fp16 tile is staged in LDS (row pitch BN+8 halves: the two half-waves of a ds_write land on disjoint bank
 // quarters, the 16-B read-back of a row is conflict-free) and leaves as 16-byte stores, 16 lanes per 256-B row segment,
 // instead of 64 two-byte stores per lane; the per-channel BatchNorm sums stay in the MFMA layout (in-lane over 16 rows).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int TM, int TN>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SPLIT_STATS = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], f16* smem, int m0, int n0, int mt, int tid,
                                               int lane, int wm, int wn) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, CP = BN + 8, NT = 64 * WAVES_M * WAVES_N;
@@ -120,15 +122,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
   }
   if (stats && tid < BN) {
-    float a = 0.f, b = 0.f;
+    if constexpr (SPLIT_STATS) {
+      // 256-row tile, each wave row-group = 128 rows = one entry of the per-128-pixel partial table
 #pragma unroll
-    for (int w = 0; w < WAVES_M; ++w) {
-      a += red[(w * BN + tid) * 2 + 0];
-      b += red[(w * BN + tid) * 2 + 1];
+      for (int w = 0; w < WAVES_M; ++w) {
+        const int ms = mt * WAVES_M + w;
+        if (ms < p.mtiles_stat) {
+          p.bn_partial[(long)(n0 + tid) * p.mtiles_stat + ms] = red[(w * BN + tid) * 2 + 0];
+          p.bn_partial[((long)p.cstride + n0 + tid) * p.mtiles_stat + ms] = red[(w * BN + tid) * 2 + 1];
+        }
+      }
+    } else {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) {
+        a += red[(w * BN + tid) * 2 + 0];
+        b += red[(w * BN + tid) * 2 + 1];
+      }
+      // channel-major [2][cstride][mtiles]: bn_finalize's wave-per-channel reduction then reads contiguous floats
+      p.bn_partial[(long)(n0 + tid) * p.mtiles + mt] = a;
+      p.bn_partial[((long)p.cstride + n0 + tid) * p.mtiles + mt] = b;
     }
-    // channel-major [2][cstride][mtiles]: bn_finalize's wave-per-channel reduction then reads contiguous floats
-    p.bn_partial[(long)(n0 + tid) * p.mtiles + mt] = a;
-    p.bn_partial[((long)p.cstride + n0 + tid) * p.mtiles + mt] = b;
   }
 }
 
@@ -175,11 +189,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     cin -= p.Cin;
     if (++kw == p.KW) { kw = 0; ++kh; }
   }
+  // korder 1 (Cin % 32 == 0): k-tile kt = (32-channel chunk kt / ntaps, tap kt % ntaps); the weight columns of that tile
+  // sit at tap * Cin + chunk * 32 of the packed row
+  const bool chunk_major = p.korder == 1;
+  const int ntaps = p.KH * p.KW;
+  int cm_chunk = 0, cm_tap = 0;
 
   f16x8 a_reg[A_CH], b_reg[B_CH];
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   auto load_tiles = [&](int kt) {
+    if (chunk_major) {
+      kh = cm_tap / p.KW;
+      kw = cm_tap - kh * p.KW;
+      cin = cm_chunk * 32 + a_chunk * 8;
+    }
+    const int kcol = chunk_major ? cm_tap * p.Cin + cm_chunk * 32 : kt * 32;
     const bool kvalid = kh < p.KH;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
@@ -190,12 +215,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
     for (int j = 0; j < B_CH; ++j) {
       int idx = tid + j * 256;
-      if (idx < BN * 4) b_reg[j] = *(const f16x8*)(p.w + (long)(n0 + (idx >> 2)) * p.Kpad + kt * 32 + (idx & 3) * 8);
+      if (idx < BN * 4) b_reg[j] = *(const f16x8*)(p.w + (long)(n0 + (idx >> 2)) * p.Kpad + kcol + (idx & 3) * 8);
     }
-    cin += 32;
-    while (cin >= p.Cin) {
-      cin -= p.Cin;
-      if (++kw == p.KW) { kw = 0; ++kh; }
+    if (chunk_major) {
+      if (++cm_tap == ntaps) { cm_tap = 0; ++cm_chunk; }
+    } else {
+      cin += 32;
+      while (cin >= p.Cin) {
+        cin -= p.Cin;
+        if (++kw == p.KW) { kw = 0; ++kh; }
+      }
     }
   };
   auto store_tiles = [&](int buf) {
@@ -771,6 +800,224 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_v4_kernel(ConvParams p) {
   conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
 }
 
+// ====================================================================================================================
+// Main-loop variant 5: 3x3 / stride 1 / 'same' convolutions with Cin % 32 == 0, Cout a multiple of 256 -- the head towers
+// (33 % of all FLOPs at 72x72) and the 256 / 512-channel 3x3 convs of the backbone.  256 x 256 tile, 8 waves, INPUT HALO staged
+// once per 32-channel chunk and re-used by all 9 taps.
+//
+// Why: variants 1-4 all measure 650-700 TFLOP/s on the dominant shape whatever their loop structure (lockstep, staggered,
+// BK 32 / 64, 128- or 256-wide tiles): the limit is the volume that has to come in through the per-CU LDS-DMA path, ~42 GB/s
+// per CU as used here (24 KB per 128x256x32 step: A 8 KB gathered again for every tap + B 16 KB).  An implicit GEMM fetches
+// each input pixel 9 times (once per tap) and each weight row once per 128 output pixels.  Here
+//   * the tile is 256 consecutive output pixels x 256 channels: weights are fetched once per 256 pixels (half the B volume);
+//   * per 32-channel chunk the 256 + 2W + 2 input pixels the 9 taps touch (flattened pixel range [m0 - W - 1, m0 + 256 + W])
+//     are staged ONCE (26 KB at W = 72, double-buffered) and tap (kh, kw) reads its A fragments at a row shift of kh*W + kw:
+//     A volume / 4.5.  Taps that fall outside the image (left / right / top / bottom edge, other frame) are handled at
+//     fragment-read time: the lane's LDS address is redirected to a zero block (one v_cndmask per read);
+//   => 170 KB of LDS-DMA per 9 k-steps of a 256 x 256 tile instead of 432 KB for the same work with 128 x 256 tiles.
+// LDS image (A halo and B ring): [16-row piece][4 chunks of 16 B][16 rows] -- a ds_read_b128 of 16 consecutive rows of one chunk
+// is 256 contiguous bytes at any row offset (two runs that wrap by 1 KiB = 0 mod 64 banks), so every fragment read is
+// conflict-free at every tap shift without a swizzle; the LDS-DMA destination stays lane-linear (lane l fills slot l of its
+// piece: row l & 15, chunk l >> 4).
+// K order is chunk-major ((cin chunk, tap) instead of (tap, cin chunk)): the same products summed in a different order, so
+// results agree with variants 0-4 to fp32 rounding, not bit for bit; variant 0 takes the same order with
+// tscd_conv_set_korder(1), and then the two ARE bit-identical (tests/test_gpu_conv.py).
+// Schedule: the staggered wave groups of variant 4 (L / M segments of 12 fragment reads + 2-6 DMA pieces / 16 MFMAs); B ring of 6
+// k-steps; the A halo of chunk c+1 is issued during the first two steps of chunk c, into the buffer chunk c-1 has left.
+// ====================================================================================================================
+template <int N> __device__ __forceinline__ void wait_vmcnt_v5() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+
+template <int MAXP>   // MAXP = A pieces per wave (ceil(halo pieces / 8)): 4 covers W <= 110, 6 covers W <= 238
+__global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, int HRP) {
+  constexpr int BM = 256, BN = 256, NS = 6, WAVES_M = 2, WAVES_N = 4, TM = 4, TN = 2, WM = 128, WN = 64;
+  constexpr int B_BYTES = BN * 64;                       // 16 KB per k-step
+  constexpr int SMEM_BYTES = 1024 + 2 * 480 * 64 + NS * B_BYTES;         // HRP <= 480 (W <= 111); also >= the epilogue's 139264 B
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
+  // layout: [zero block 1 KB][A halo 0][A halo 1][B ring NS x 16 KB]
+  const int A_BYTES = HRP * 64;
+  char* const zero_blk = smem;
+  char* const a_buf = smem + 1024;
+  char* const b_ring = smem + 1024 + 2 * A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int W = p.W, HW = p.H * p.W;
+
+  if (tid < 64) ((f16x8*)zero_blk)[tid] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+
+  // ---- DMA sources.  A: halo piece pc covers flattened input pixels m0 - W - 1 + 16 pc + (lane & 15), chunk lane >> 4 ----
+  const int NP = HRP >> 4;
+  const f16* a_src[MAXP];
+  bool a_ok[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int pc = wave + 8 * i;
+    const long pix = (long)m0 - W - 1 + pc * 16 + (lane & 15);
+    a_ok[i] = pc < NP && pix >= 0 && pix < p.M;
+    a_src[i] = p.x + (a_ok[i] ? pix : 0) * p.ldx + (lane >> 4) * 8;
+  }
+  // B: piece = 16 weight rows; wave w fills rows 32 w .. 32 w + 31 (2 pieces); lane: row lane & 15, chunk lane >> 4
+  const f16* b_src[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b_src[j] = p.w + (long)(n0 + wave * 32 + j * 16 + (lane & 15)) * p.Kpad + (lane >> 4) * 8;
+
+  const int nchunks = p.Cin >> 5, nk = nchunks * 9;
+  int ld_tile = 0, ld_tap = 0, ld_cin = 0, ld_soff = 0;      // next B k-step this wave issues: (chunk ld_cin/32, tap ld_tap)
+  auto issue_b = [&]() __attribute__((always_inline)) {
+    char* sbase = b_ring + ld_soff;
+    const int koff = ld_tap * p.Cin + ld_cin;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(sbase + (wave * 2 + j) * 1024), 16, 0, 0);
+    ++ld_tile;
+    ld_soff += B_BYTES;
+    if (ld_soff == NS * B_BYTES) ld_soff = 0;
+    if (++ld_tap == 9) { ld_tap = 0; ld_cin += 32; }
+  };
+  auto issue_a = [&](int chunk_idx) __attribute__((always_inline)) {      // the whole halo of channel chunk chunk_idx
+    char* sbase = a_buf + (chunk_idx & 1) * A_BYTES;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      if (wave + 8 * i < NP) {                                             // wave-uniform
+        const f16* src = a_ok[i] ? a_src[i] + chunk_idx * 32 : g_zero_chunk;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sbase + (wave + 8 * i) * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- fragment addressing.  row-tile i of this wave: output pixel mloc = wm*128 + 32 i + (lane & 31); tap (kh, kw) reads halo
+  // row mloc + kh W + kw; byte offset of (halo row hr, chunk c) = (hr >> 4) * 1024 + c * 256 + (hr & 15) * 16
+  const int frow = lane & 31, fk = lane >> 5;
+  unsigned vmask[TM];
+  int a_t16[TM];                                        // (halo row of tap (0,0)) * 16
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int mloc = wm * WM + i * 32 + frow;
+    const int m = m0 + mloc;
+    unsigned mask = 0;
+    if (m < p.M) {
+      const int rem = m % HW;
+      const int h = rem / W, w = rem - h * W;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          if ((unsigned)(h + kh - 1) < (unsigned)p.H && (unsigned)(w + kw - 1) < (unsigned)W) mask |= 1u << (kh * 3 + kw);
+    }
+    vmask[i] = mask;
+    a_t16[i] = mloc * 16;
+  }
+  const int a_lane = fk * 256 + 1024;                                   // chunk half of this lane + the zero block in front
+  int b_off[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * WN + j * 32 + frow;
+    b_off[j] = (row >> 4) * 1024 + fk * 256 + (row & 15) * 16;
+  }
+
+  // ---- prologue ----
+  issue_a(0);
+  const int ahead = 4 + grp;
+  for (int t = 0; t < ahead; ++t)
+    if (ld_tile < nk) issue_b();
+  int na_wave = 0;                                                   // halo pieces this wave issues per chunk
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) na_wave += (wave + 8 * i < NP) ? 1 : 0;
+  // this wave's B pieces of k-steps <= t (and every older DMA) have landed.  `halo_young`: a halo burst was issued AFTER the
+  // B pieces of step t (it is younger than them): up to 3 more pieces may then stay in flight
+  auto wait_own = [&](int t, int halo_young) __attribute__((always_inline)) {
+    if (t >= nk) t = nk - 1;
+    const int younger = ld_tile - 1 - t;
+    if (younger >= 3) { if (halo_young && na_wave >= 3) wait_vmcnt_v5<9>(); else wait_vmcnt_v5<6>(); }
+    else if (younger == 2) wait_vmcnt_v5<4>();
+    else if (younger == 1) wait_vmcnt_v5<2>();
+    else wait_vmcnt_v5<0>();
+  };
+  wait_own(grp, 0);                                                  // also retires the halo of chunk 0 (issued first)
+  __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): the zero block is written
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();                        // stagger
+
+  f16x8 fa[2][TM], fb[2][TN];
+  int rd_soff = 0, tap = 0, chunk_idx = 0, shift16 = 0, kw_ = 0;     // shift16 = (kh W + kw) * 16 of the current tap
+  for (int u = 0; u < nk; ++u) {
+    // ---------------- L(u) ----------------
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const char* sa = smem + (chunk_idx & 1) * A_BYTES;             // a_lane carries the +1024 of the zero block
+      const char* sb = b_ring + rd_soff;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int t16 = a_t16[i] + shift16;
+        const int hi = t16 & ~255;
+        int off = (hi << 2) + (t16 & 255) + a_lane;                  // (hr >> 4) * 1024 + (hr & 15) * 16 + chunk half
+        const bool ok = (vmask[i] >> tap) & 1u;
+        const char* ptr = ok ? sa + off : zero_blk + (lane & 15) * 16;   // zero block: 1 KB, covers the +512 of ks = 1
+        fa[0][i] = *(const f16x8*)(ptr);
+        fa[1][i] = *(const f16x8*)(ptr + 512);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        fb[0][j] = *(const f16x8*)(sb + b_off[j]);
+        fb[1][j] = *(const f16x8*)(sb + b_off[j] + 512);
+      }
+      rd_soff += B_BYTES;
+      if (rd_soff == NS * B_BYTES) rd_soff = 0;
+    }
+    if (ld_tile < nk) issue_b();
+    if (tap == 1 - grp && chunk_idx + 1 < nchunks) issue_a(chunk_idx + 1);   // group 1 at tap 0, group 0 at tap 1 (WAR, see header)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- M(u) ----------------
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      // the halo burst of this chunk was issued in the L segment of tap (1 - grp): it is younger than the B pieces waited for
+      // here during that step and the 3 that follow
+      const int since = tap - (1 - grp);
+      wait_own(u + 1 + grp, (since >= 0 && since <= 3 && chunk_idx + 1 < nchunks) ? 1 : 0);
+    }
+    __builtin_amdgcn_s_barrier();
+    // next tap
+    ++tap;
+    if (++kw_ == 3) { kw_ = 0; shift16 += (W - 2) * 16; } else shift16 += 16;
+    if (tap == 9) { tap = 0; kw_ = 0; shift16 = 0; ++chunk_idx; }
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN, true>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
+}
+
 // Tile choice: BN follows Cout (128 / 64 / 32); BM = 128.  Packed weights and BatchNorm partials are padded to a multiple of
 // this BN.  (A 128 x 256 tile with 8 waves was measured: no faster on the 72x72 level -- the limit is bytes in flight per CU
 // against the ~2 us loaded MALL latency, not bytes per FLOP -- and slower on the small levels, which get half the workgroups.)
@@ -781,6 +1028,8 @@ extern "C" int tscd_conv_tile_m(void) { return 128; }
 
 static int g_conv_debug = 0;
 extern "C" void tscd_conv_set_debug(int v) { g_conv_debug = v; }
+static int g_conv_korder = 0;     // tests: 1 = chunk-major k order in the register-staged loop (variant 5's order)
+extern "C" void tscd_conv_set_korder(int v) { g_conv_korder = v; }
 static int g_conv_variant = -1;   // -1 auto, 0 register staging, 1 LDS-DMA 128-wide tiles only, 3 128x256 variant wherever its shape allows (tests / A-B timing)
 extern "C" void tscd_conv_set_variant(int v) { g_conv_variant = v; }
 
@@ -824,7 +1073,22 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
   // variant 4 (staggered wave groups): the same 128 x 256 tile; needs only Cin % 32 == 0.  Selected by tscd_conv_set_variant(4)
   // while it is being measured against variant 3.
   const bool v4_ok = dma_ok && Cout > 128 && cout_pad % 256 == 0 && g_conv_variant == 4;
-  const int BN = (v3_ok || v4_ok) ? 256 : BNP;
+  // variant 5 (input halo staged once per channel chunk, 256 x 256 tiles): 3x3 stride-1 convs; selected by
+  // tscd_conv_set_variant(5) while it is being measured
+  const int hrp = (256 + 2 * W + 2 + 15) / 16 * 16;
+  const bool v5_shape = dma_ok && ksize == 3 && stride == 1 && Cout > 128 && cout_pad % 256 == 0 && hrp <= 480;
+  const bool v5_ok = v5_shape && g_conv_variant == 5;
+  const int BN = (v3_ok || v4_ok || v5_ok) ? 256 : BNP;
+  p.korder = (g_conv_korder == 1 && Cin % 32 == 0) ? 1 : 0;
+  p.mtiles_stat = cdiv(M, 128);
+  if (v5_ok) {
+    p.mtiles = cdiv(M, 256);
+    p.ntiles = cdiv(Cout, 256);
+    p.cstride = cdiv(Cout, BNP) * BNP;
+    hipLaunchKernelGGL((conv_igemm_halo_kernel<4>), dim3(p.mtiles * p.ntiles), dim3(512), 0, (hipStream_t)stream, p, hrp);
+    TSCD_CHECK_LAUNCH("conv2d (halo)");
+    return TSCD_OK;
+  }
   p.mtiles = cdiv(M, BM);
   p.ntiles = cdiv(Cout, BN);
   p.cstride = cdiv(Cout, BNP) * BNP;

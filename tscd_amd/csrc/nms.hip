@@ -5,8 +5,8 @@
 //                sig(refined cls); every (proposal, class) with score >= thr and obj*score >= thr becomes a
 //                candidate (row-major order, as torch.where).  Mode 1 builds the "original detections" set instead
 //                (one candidate per proposal: class = argmax id, score = obj * cls_conf).
-//   nms_sort     one workgroup per frame: bitonic sort of <= 16384 candidates in LDS by (score desc, candidate
-//                index asc) -- torchvision visits boxes in decreasing score order.
+//   nms_sort     one workgroup per frame: bitonic sort by (score desc, candidate index asc) -- torchvision visits boxes in
+//                decreasing score order; <= 16384 candidates entirely in LDS, up to 65536 with global-memory cross-chunk steps.
 //   nms_greedy   one workgroup per (frame, class): class-aware NMS == independent greedy NMS per class (what the
 //                coordinate-offset trick of batched_nms implements); <= 2048 boxes of the class are pulled from the
 //                sorted list into LDS and suppressed greedily with IoU > thr (fp32 arithmetic).
@@ -15,7 +15,7 @@
 // torchvision is absent from the reference tree, so NMS parity is pinned by oracle/nms_ref.py's restatement only.
 #include "common.h"
 
-#define NMS_MAXC 16384    // candidates per frame handled by the LDS sort
+#define NMS_MAXC 65536    // candidates per frame (16-bit index field of the sort key)
 #define NMS_MAXPC 2048    // boxes per (frame, class)
 
 // ---- candidate record arrays, all [L][capM] -------------------------------------------------------------
@@ -105,36 +105,74 @@ __global__ __launch_bounds__(256) void nms_expand_kernel(const f16* __restrict__
   if (tid == 0) c.count[f] = base < capM ? base : capM;
 }
 
-// Bitonic sort of (score desc, index asc) keys in LDS.  Scores are fp16-representable and non-negative, so their
-// fp16 bit pattern orders them: key = fp16 bits << 16 | (0xFFFF - index), larger key first (<= 64 KiB of LDS).
+// Bitonic sort of (score desc, index asc) keys.  Scores are fp16-representable and non-negative, so their fp16 bit pattern
+// orders them: key = fp16 bits << 16 | (0xFFFF - index), larger key first.  Up to 16384 surviving candidates of a frame are
+// sorted entirely in LDS (64 KiB).  Frames with more (the ImageNet-VID exp has no upper proposal clamp: 2000 proposals x 30
+// classes = 60000 candidates) keep their keys in a global workspace: compare-exchange steps whose stride reaches across
+// 16384-key chunks run on global memory (L2-resident, <= 256 KiB per frame), every run of smaller strides is done chunk by
+// chunk in LDS.  Same network, same keys => the same order as the single-chunk sort.  Limit: 65536 candidates per frame (the
+// index field of the key).
+#define NMS_CHUNK 16384
+__device__ __forceinline__ void bitonic_lds_steps(unsigned int* keys, int base, int n, int size, int first_stride, int tid) {
+  // strides first_stride .. 1 of the merge of width `size`, for the n keys (n a power of two <= NMS_CHUNK) at global offset `base`
+  for (int stride = first_stride; stride > 0; stride >>= 1) {
+    for (int i = tid; i < (n >> 1); i += 1024) {
+      int lo = (i / stride) * (stride << 1) + (i % stride), hi = lo + stride;
+      bool desc = (((base + lo) & size) == 0);   // descending runs first => overall descending
+      unsigned int a = keys[lo], b = keys[hi];
+      if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ score, const int* __restrict__ count, int capM,
-                                                       int* __restrict__ order) {
+                                                       unsigned int* __restrict__ gkeys, int gstride, int* __restrict__ order) {
   extern __shared__ unsigned int keys[];
   const int f = blockIdx.x, tid = threadIdx.x;
   const int M = count[f];
   int P = 1;
   while (P < M) P <<= 1;
-  for (int i = tid; i < P; i += 1024) {
-    unsigned int k = 0u;   // padding sorts last (real keys have a non-zero low half)
-    if (i < M) {
-      f16 h = (f16)score[(long)f * capM + i];
-      k = ((unsigned int)__builtin_bit_cast(unsigned short, h) << 16) | (unsigned)(0xFFFFu - (unsigned)i);
-    }
-    keys[i] = k;
+  auto make_key = [&](int i) -> unsigned int {
+    if (i >= M) return 0u;   // padding sorts last (real keys have a non-zero low half ... or a non-zero score)
+    f16 h = (f16)score[(long)f * capM + i];
+    return ((unsigned int)__builtin_bit_cast(unsigned short, h) << 16) | (unsigned)(0xFFFFu - (unsigned)i);
+  };
+  if (P <= NMS_CHUNK) {
+    for (int i = tid; i < P; i += 1024) keys[i] = make_key(i);
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) bitonic_lds_steps(keys, 0, P, size, size >> 1, tid);
+    for (int i = tid; i < M; i += 1024) order[(long)f * capM + i] = (int)(0xFFFFu - (keys[i] & 0xFFFFu));
+    return;
   }
-  __syncthreads();
-  for (int size = 2; size <= P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+  unsigned int* gk = gkeys + (long)f * gstride;
+  // chunks: fill + all merges that stay inside a chunk
+  for (int c0 = 0; c0 < P; c0 += NMS_CHUNK) {
+    for (int i = tid; i < NMS_CHUNK; i += 1024) keys[i] = make_key(c0 + i);
+    __syncthreads();
+    for (int size = 2; size <= NMS_CHUNK; size <<= 1) bitonic_lds_steps(keys, c0, NMS_CHUNK, size, size >> 1, tid);
+    for (int i = tid; i < NMS_CHUNK; i += 1024) gk[c0 + i] = keys[i];
+    __syncthreads();
+  }
+  for (int size = 2 * NMS_CHUNK; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride >= NMS_CHUNK; stride >>= 1) {       // across chunks: global memory
       for (int i = tid; i < (P >> 1); i += 1024) {
         int lo = (i / stride) * (stride << 1) + (i % stride), hi = lo + stride;
-        bool desc = ((lo & size) == 0);   // descending runs first => overall descending
-        unsigned int a = keys[lo], b = keys[hi];
-        if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+        bool desc = ((lo & size) == 0);
+        unsigned int a = gk[lo], b = gk[hi];
+        if ((a < b) == desc) { gk[lo] = b; gk[hi] = a; }
       }
+      __syncthreads();                                                        // same workgroup, same CU: stores visible after the barrier
+    }
+    for (int c0 = 0; c0 < P; c0 += NMS_CHUNK) {                               // strides < chunk: chunk by chunk in LDS
+      for (int i = tid; i < NMS_CHUNK; i += 1024) keys[i] = gk[c0 + i];
+      __syncthreads();
+      bitonic_lds_steps(keys, c0, NMS_CHUNK, size, NMS_CHUNK >> 1, tid);
+      for (int i = tid; i < NMS_CHUNK; i += 1024) gk[c0 + i] = keys[i];
       __syncthreads();
     }
   }
-  for (int i = tid; i < M; i += 1024) order[(long)f * capM + i] = (int)(0xFFFFu - (keys[i] & 0xFFFFu));
+  for (int i = tid; i < M; i += 1024) order[(long)f * capM + i] = (int)(0xFFFFu - (gk[i] & 0xFFFFu));
 }
 
 // Greedy NMS for one (frame, class).  keep[f][sorted position] = 1 for survivors.
@@ -231,8 +269,15 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
   if (tid == 0) out_count[f] = base;
 }
 
+static int nms_pow2(int capM) {
+  int P = 1;
+  while (P < capM) P <<= 1;
+  return P;
+}
+
 extern "C" long tscd_nms_workspace_bytes(int L, int capM) {
-  long per = (long)capM * (16 + 4 + 6 + 4 + 4 + 1) + 64;
+  long per = (long)capM * (16 + 4 + 6 + 4 + 4 + 1) + 64 + 7 * 256;
+  if (capM > NMS_CHUNK) per += 4L * nms_pow2(capM);        // global sort keys of frames with more than one LDS chunk
   return (long)L * per + 4096;
 }
 
@@ -246,7 +291,7 @@ extern "C" int tscd_batched_nms(const void* det, int ndet, const int* frame_off,
                                 int* out_count, int* overflow_flag, void* stream) {
   TSCD_CHECK_ARG(det && frame_off && workspace && out && out_idx && out_count && overflow_flag, "batched_nms: null pointer");
   TSCD_CHECK_ARG(mode == 1 || (cls_logit && obj_logit && reg_delta), "batched_nms: mode 0 needs refined predictions");
-  TSCD_CHECK_ARG(capM > 0 && capM <= NMS_MAXC, "batched_nms: capM=%d exceeds the %d-candidate LDS sort", capM, NMS_MAXC);
+  TSCD_CHECK_ARG(capM > 0 && capM <= NMS_MAXC, "batched_nms: capM=%d exceeds the %d candidates per frame the sort key can index", capM, NMS_MAXC);
   TSCD_CHECK_ARG(workspace_bytes >= tscd_nms_workspace_bytes(L, capM), "batched_nms: workspace too small");
   if (L == 0) return TSCD_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -264,9 +309,10 @@ extern "C" int tscd_batched_nms(const void* det, int ndet, const int* frame_off,
   hipLaunchKernelGGL(nms_expand_kernel, dim3(L), dim3(256), 0, st, (const f16*)det, ndet, frame_off, (const f16*)cls_logit,
                      (const f16*)obj_logit, (const f16*)reg_delta, NC, conf_thresh, capM, mode, logf(736.0f / 32.0f), c);
   TSCD_CHECK_LAUNCH("nms_expand");
-  int P = 1;
-  while (P < capM) P <<= 1;
-  hipLaunchKernelGGL(nms_sort_kernel, dim3(L), dim3(1024), (size_t)P * 4, st, c.score, c.count, capM, order);
+  const int P = nms_pow2(capM);
+  unsigned int* gkeys = capM > NMS_CHUNK ? (unsigned int*)take(4L * L * P) : nullptr;
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(L), dim3(1024), (size_t)(P < NMS_CHUNK ? P : NMS_CHUNK) * 4, st, c.score, c.count, capM,
+                     gkeys, P, order);
   TSCD_CHECK_LAUNCH("nms_sort");
   hipLaunchKernelGGL(nms_greedy_kernel, dim3(L, NC), dim3(256), 0, st, c.box, c.cls, order, c.count, capM, iou_thresh, keep,
                      overflow_flag);

@@ -8,7 +8,7 @@ import torch
 
 from tscd_amd import ops
 
-MAX_CANDIDATES = 16384
+MAX_CANDIDATES = 65536        # 16-bit candidate index in nms.hip's sort key (frames above 16384 candidates sort through global memory)
 
 
 def nms_frames(det_rows, frame_counts, num_classes, cls_logits=None, obj_logits=None, reg_deltas=None, conf_thre=0.001,
@@ -26,8 +26,9 @@ def nms_frames(det_rows, frame_counts, num_classes, cls_logits=None, obj_logits=
         return [None] * L, [None] * L
     cap0 = nmax * num_classes
     if cap0 > MAX_CANDIDATES:
-        raise NotImplementedError(f"{nmax} proposals x {num_classes} classes exceeds the {MAX_CANDIDATES}-candidate LDS sort "
-                                  "(VID exp without maximal_limit; documented limit, DESIGN.md)")
+        raise NotImplementedError(f"{nmax} proposals x {num_classes} classes exceeds the {MAX_CANDIDATES} candidates per frame the NMS "
+                                  "sort can index (ImageNet-VID exp without maximal_limit: set maximal_limit <= "
+                                  f"{MAX_CANDIDATES // num_classes}; documented limit, DESIGN.md)")
     det_rows = det_rows.contiguous()
     half = lambda t: t.to(torch.float16).contiguous()
     rows0, idx0, cnt0, ovf0 = ops.batched_nms(det_rows, frame_off, L, num_classes, conf_thre, nms_thre, cap0, 0,
