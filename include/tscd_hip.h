@@ -42,6 +42,12 @@ int tscd_conv_tile_m(void);
 void tscd_conv_set_variant(int variant);
 /* k order of the register-staged loop (variant 0): 0 = (tap, channel) as packed, 1 = (32-channel chunk, tap); test hook. */
 void tscd_conv_set_korder(int order);
+/* 1: launches that qualify (3x3, stride 1, Cin % 32 == 0, Cout % 256 == 0, at least one tile per CU) take the halo-staged
+ * variant automatically (variant -1); 6 forces its 192-pixel tile, 5 its 256-pixel tile. */
+void tscd_conv_set_halo_auto(int on);
+/* Per-channel BatchNorm partial-sum entries a raw-epilogue launch of this shape writes (= its number of M-tiles, which
+ * depends on the main-loop variant it takes): the `mtiles` argument of tscd_bn_finalize.  M = B*Ho*Wo, W = output width. */
+int tscd_conv_stat_tiles(long M, int W, int Cin, int Cout, int ksize, int stride);
 /* Measurement hook (scratch experiments, never set by the product path): bit0 makes the LDS-DMA loop's A gather read a
  * zero block, bit1 makes every B row read row 0 -- isolates how much of a launch is memory stall.  Results are wrong. */
 void tscd_conv_set_debug(int bits);

@@ -51,6 +51,18 @@ int64_t tscd_lap_chain_spec_hits(int reset);
 /* Diagnostics: relaxation passes executed by the fixed-point solver since the last reset. */
 int64_t tscd_lap_debug_steps(int reset);
 
+/* COCO bounding-box evaluation (replaces the reference's pybind11 extension
+ * yolox/layers/cocoeval/cocoeval.cpp:59-199,370-502 and its pycocotools fallback, ovis_evaluator_v2.py:397-402).
+ * Boxes are xywh; image and category ids are dense indices 0..n-1; gt_area is the annotation's "area" field.
+ * stats12 receives the 12 numbers of COCOeval.summarize() (AP@[.5:.95], AP50, AP75, AP small / medium / large, AR@1 / 10 / 100,
+ * AR small / medium / large; -1 where undefined).  Optional outputs: precision [10][101][n_cat][4][3] and recall
+ * [10][n_cat][4][3] (IoU threshold, recall threshold, category, area range {all, small, medium, large}, maxDets {1,10,100}),
+ * -1 = no ground truth.  Returns 0, 1 on bad sizes, 2 on an out-of-range image / category index. */
+int tscd_cocoeval_bbox(const float* gt_box, const int* gt_img, const int* gt_cat, const unsigned char* gt_crowd,
+                       const float* gt_area, long n_gt, const float* dt_box, const int* dt_img, const int* dt_cat,
+                       const float* dt_score, long n_dt, int n_img, int n_cat, float* stats12, float* precision_out,
+                       float* recall_out);
+
 #ifdef __cplusplus
 }
 #endif

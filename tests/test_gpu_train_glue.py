@@ -39,19 +39,19 @@ def test_ema_forward_sees_updated_weights(golden):
     ema.decay = lambda n: 0.5                                    # a large step so that stale packs would be far off
     ema.ema.head.debug = {}
     with torch.no_grad():
-        ema.ema(imgs, time_embedding=temb, **kw)                  # packs every weight of the EMA model; `det` = decoded head output [B,A,7+NC]
-        before = ema.ema.head.debug["det"].float().clone()
+        ema.ema(imgs, time_embedding=temb, **kw)                  # packs every weight of the EMA model; `score` = obj * max cls per anchor [B,A]
+        before = ema.ema.head.debug["score"].float().clone()
         for k, p in m.named_parameters():                         # move the source model, then one EMA update
             if "_preds." in k or "head.stems" in k or "lateral_conv0.conv" in k:
                 p.mul_(1.25)
         ema.update(m)
         ema.ema(imgs, time_embedding=temb, **kw)
-        after = ema.ema.head.debug["det"].float().clone()
+        after = ema.ema.head.debug["score"].float().clone()
         fresh = build_model(golden[0]).cuda().eval()
         fresh.load_state_dict(ema.ema.state_dict(), strict=True)
         fresh.head.debug = {}
         fresh(imgs, time_embedding=temb, **kw)
-        want = fresh.head.debug["det"].float()
+        want = fresh.head.debug["score"].float()
     torch.cuda.synchronize()
     assert torch.isfinite(want).all() and not torch.allclose(before, want, rtol=1e-3, atol=1e-3)     # the update did move the outputs
     assert after.shape == want.shape and torch.equal(after, want)            # same weights, same kernels: identical

@@ -89,3 +89,29 @@ def lap_chain_f16(base_ptr, shapes, kinds, before=None):
         a += int(npair[i])
         b += int(nc[i])
     return out
+
+
+_lib.tscd_cocoeval_bbox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.tscd_cocoeval_bbox.restype = C.c_int
+
+
+def cocoeval_bbox(gt_box, gt_img, gt_cat, gt_crowd, gt_area, dt_box, dt_img, dt_cat, dt_score, n_img, n_cat, full=False):
+    """COCO bbox evaluation (csrc_host/cocoeval.cpp).  Boxes xywh float32 [n,4]; image / category ids dense int32 indices.
+    -> stats [12] (COCOeval.summarize order) and, with ``full``, precision [10,101,K,4,3] and recall [10,K,4,3]."""
+    f32 = lambda a, shape: np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(shape))
+    i32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(-1))
+    gt_box, dt_box = f32(gt_box, (-1, 4)), f32(dt_box, (-1, 4))
+    gt_img, gt_cat, dt_img, dt_cat = i32(gt_img), i32(gt_cat), i32(dt_img), i32(dt_cat)
+    gt_crowd = np.ascontiguousarray(np.asarray(gt_crowd, dtype=np.uint8).reshape(-1))
+    gt_area, dt_score = f32(gt_area, (-1,)), f32(dt_score, (-1,))
+    stats = np.empty(12, np.float32)
+    prec = np.empty((10, 101, n_cat, 4, 3), np.float32) if full else None
+    rec = np.empty((10, n_cat, 4, 3), np.float32) if full else None
+    st = _lib.tscd_cocoeval_bbox(gt_box.ctypes.data, gt_img.ctypes.data, gt_cat.ctypes.data, gt_crowd.ctypes.data, gt_area.ctypes.data,
+                                 len(gt_img), dt_box.ctypes.data, dt_img.ctypes.data, dt_cat.ctypes.data, dt_score.ctypes.data,
+                                 len(dt_img), n_img, n_cat, stats.ctypes.data, None if prec is None else prec.ctypes.data,
+                                 None if rec is None else rec.ctypes.data)
+    if st:
+        raise ValueError("cocoeval_bbox failed (status %d)" % st)
+    return (stats, prec, rec) if full else stats

@@ -13,16 +13,16 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-Wno-unused-result", "-I", CSRC]
 
 
-HOST_SRC = os.path.join(HERE, "csrc_host", "lap.cpp")
+HOST_SRCS = sorted(glob.glob(os.path.join(HERE, "csrc_host", "*.cpp")))      # lap.cpp (assignment solver), cocoeval.cpp (COCO bbox AP)
 HOST_LIB = os.path.join(LIBDIR, "libtscd_host.so")
 
 
 def build_host(force=False, verbose=True):
-    """g++ build of the host-side assignment solver (no -march flags: SIMD variants are selected at run time)."""
-    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) > os.path.getmtime(HOST_SRC):
+    """g++ build of the host-side code (no -march flags: SIMD variants are selected at run time)."""
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) > max(os.path.getmtime(s) for s in HOST_SRCS):
         return HOST_LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-pthread", HOST_SRC, "-o", HOST_LIB]
+    cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-pthread"] + HOST_SRCS + ["-o", HOST_LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -833,11 +833,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_v5() {
   else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 }
 
-template <int MAXP>   // MAXP = A pieces per wave (ceil(halo pieces / 8)): 4 covers W <= 110, 6 covers W <= 238
+// TM = 32-row MFMA tiles per wave: 3 -> 192-pixel tiles, 4 -> 256-pixel tiles (the host picks whichever leaves the smaller
+// idle tail for the launch's M).  The tap loop is unrolled (tap is a compile-time constant in every step: shifts, validity
+// bits and the halo issue slots fold) and every channel chunk but the last runs without tail logic (fixed DMA distance,
+// fixed vmcnt): the L segment's instruction count, not the MFMAs, bounded the first version of this loop.
+template <int TM>
 __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, int HRP) {
-  constexpr int BM = 256, BN = 256, NS = 6, WAVES_M = 2, WAVES_N = 4, TM = 4, TN = 2, WM = 128, WN = 64;
+  constexpr int MAXP = 4;                                // A pieces per wave: halo of <= 512 rows
+  constexpr int BM = 64 * TM, BN = 256, NS = 6, WAVES_M = 2, WAVES_N = 4, TN = 2, WM = 32 * TM, WN = 64;
   constexpr int B_BYTES = BN * 64;                       // 16 KB per k-step
-  constexpr int SMEM_BYTES = 1024 + 2 * 480 * 64 + NS * B_BYTES;         // HRP <= 480 (W <= 111); also >= the epilogue's 139264 B
+  constexpr int SMEM_BYTES = 1024 + 2 * 480 * 64 + NS * B_BYTES;         // HRP <= 480; also >= the epilogue's staging tile
   __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
   // layout: [zero block 1 KB][A halo 0][A halo 1][B ring NS x 16 KB]
   const int A_BYTES = HRP * 64;
@@ -861,13 +866,16 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
   const int NP = HRP >> 4;
   const f16* a_src[MAXP];
   bool a_ok[MAXP];
+  int na_wave = 0;                                       // halo pieces this wave issues per chunk
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
     const int pc = wave + 8 * i;
     const long pix = (long)m0 - W - 1 + pc * 16 + (lane & 15);
     a_ok[i] = pc < NP && pix >= 0 && pix < p.M;
     a_src[i] = p.x + (a_ok[i] ? pix : 0) * p.ldx + (lane >> 4) * 8;
+    na_wave += pc < NP ? 1 : 0;
   }
+  const bool burst_big = na_wave >= 3;
   // B: piece = 16 weight rows; wave w fills rows 32 w .. 32 w + 31 (2 pieces); lane: row lane & 15, chunk lane >> 4
   const f16* b_src[2];
 #pragma unroll
@@ -907,8 +915,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // ---- fragment addressing.  row-tile i of this wave: output pixel mloc = wm*128 + 32 i + (lane & 31); tap (kh, kw) reads halo
+  // ---- fragment addressing.  row-tile i of this wave: output pixel mloc = wm*WM + 32 i + (lane & 31); tap (kh, kw) reads halo
   // row mloc + kh W + kw; byte offset of (halo row hr, chunk c) = (hr >> 4) * 1024 + c * 256 + (hr & 15) * 16
+  //                                                            = 16 hr + 3 * ((16 hr) & ~255) + c * 256
   const int frow = lane & 31, fk = lane >> 5;
   unsigned vmask[TM];
   int a_t16[TM];                                        // (halo row of tap (0,0)) * 16
@@ -930,51 +939,57 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
     a_t16[i] = mloc * 16;
   }
   const int a_lane = fk * 256 + 1024;                                   // chunk half of this lane + the zero block in front
+  const int zero_lane = (lane & 15) * 16;
   int b_off[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int row = wn * WN + j * 32 + frow;
     b_off[j] = (row >> 4) * 1024 + fk * 256 + (row & 15) * 16;
   }
+  const int w16 = W * 16;
 
   // ---- prologue ----
   issue_a(0);
   const int ahead = 4 + grp;
   for (int t = 0; t < ahead; ++t)
     if (ld_tile < nk) issue_b();
-  int na_wave = 0;                                                   // halo pieces this wave issues per chunk
-#pragma unroll
-  for (int i = 0; i < MAXP; ++i) na_wave += (wave + 8 * i < NP) ? 1 : 0;
-  // this wave's B pieces of k-steps <= t (and every older DMA) have landed.  `halo_young`: a halo burst was issued AFTER the
-  // B pieces of step t (it is younger than them): up to 3 more pieces may then stay in flight
-  auto wait_own = [&](int t, int halo_young) __attribute__((always_inline)) {
+  // tail form of the wait: this wave's B pieces of k-steps <= t (and every older DMA) have landed
+  auto wait_tail = [&](int t) __attribute__((always_inline)) {
     if (t >= nk) t = nk - 1;
     const int younger = ld_tile - 1 - t;
-    if (younger >= 3) { if (halo_young && na_wave >= 3) wait_vmcnt_v5<9>(); else wait_vmcnt_v5<6>(); }
+    if (younger >= 3) wait_vmcnt_v5<6>();
     else if (younger == 2) wait_vmcnt_v5<4>();
     else if (younger == 1) wait_vmcnt_v5<2>();
     else wait_vmcnt_v5<0>();
   };
-  wait_own(grp, 0);                                                  // also retires the halo of chunk 0 (issued first)
+  wait_tail(grp);                                                    // also retires the halo of chunk 0 (issued first)
   __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): the zero block is written
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();                        // stagger
 
   f16x8 fa[2][TM], fb[2][TN];
-  int rd_soff = 0, tap = 0, chunk_idx = 0, shift16 = 0, kw_ = 0;     // shift16 = (kh W + kw) * 16 of the current tap
-  for (int u = 0; u < nk; ++u) {
+  int rd_soff = 0;
+  // one k-step = one (chunk, tap).  STEADY: not in the last chunk -- the DMA distance is full and a next chunk exists.
+  auto step = [&](auto tapc, auto steadyc, int chunk_idx, int u) __attribute__((always_inline)) {
+    constexpr int TAP = decltype(tapc)::value;
+    constexpr bool STEADY = decltype(steadyc)::value;
+    constexpr int KH = TAP / 3, KW = TAP % 3;
     // ---------------- L(u) ----------------
     __builtin_amdgcn_sched_barrier(0);
     {
       const char* sa = smem + (chunk_idx & 1) * A_BYTES;             // a_lane carries the +1024 of the zero block
       const char* sb = b_ring + rd_soff;
+      const int shift16 = KH * w16 + KW * 16;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int t16 = a_t16[i] + shift16;
-        const int hi = t16 & ~255;
-        int off = (hi << 2) + (t16 & 255) + a_lane;                  // (hr >> 4) * 1024 + (hr & 15) * 16 + chunk half
-        const bool ok = (vmask[i] >> tap) & 1u;
-        const char* ptr = ok ? sa + off : zero_blk + (lane & 15) * 16;   // zero block: 1 KB, covers the +512 of ks = 1
+        int base16 = a_t16[i];
+        asm volatile("" : "+v"(base16));                               // keep the 9 x TM tap addresses out of registers: recompute per step
+        const int t16 = base16 + shift16;
+        const int off = t16 + 3 * (t16 & ~255) + a_lane;
+        unsigned vm = vmask[i];
+        asm volatile("" : "+v"(vm));                                   // likewise: do not keep 9 x TM lane masks in SGPR pairs
+        const bool ok = (vm >> TAP) & 1u;
+        const char* ptr = ok ? sa + off : zero_blk + zero_lane;       // zero block: 1 KB, covers the +512 of ks = 1
         fa[0][i] = *(const f16x8*)(ptr);
         fa[1][i] = *(const f16x8*)(ptr + 512);
       }
@@ -986,8 +1001,11 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
       rd_soff += B_BYTES;
       if (rd_soff == NS * B_BYTES) rd_soff = 0;
     }
-    if (ld_tile < nk) issue_b();
-    if (tap == 1 - grp && chunk_idx + 1 < nchunks) issue_a(chunk_idx + 1);   // group 1 at tap 0, group 0 at tap 1 (WAR, see header)
+    if (STEADY || ld_tile < nk) issue_b();
+    // halo of the next chunk: group 1 in the step of tap 0, group 0 in the step of tap 1 (WAR on the buffer chunk c-1 has left)
+    if constexpr (STEADY && (TAP == 0 || TAP == 1)) {
+      if (grp == 1 - TAP) issue_a(chunk_idx + 1);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---------------- M(u) ----------------
@@ -1002,20 +1020,33 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    {
-      // the halo burst of this chunk was issued in the L segment of tap (1 - grp): it is younger than the B pieces waited for
-      // here during that step and the 3 that follow
-      const int since = tap - (1 - grp);
-      wait_own(u + 1 + grp, (since >= 0 && since <= 3 && chunk_idx + 1 < nchunks) ? 1 : 0);
+    if constexpr (STEADY) {
+      // 3 k-steps of B (6 pieces) stay in flight; for the 4 waits that follow this wave's halo burst (issued at tap 1 - grp)
+      // the burst is younger than the pieces waited for and may stay in flight too (3 of its pieces are accounted)
+      if constexpr (TAP >= 1 && TAP <= 3) {
+        if (burst_big) wait_vmcnt_v5<9>(); else wait_vmcnt_v5<6>();
+      } else if constexpr (TAP == 0 || TAP == 4) {
+        if (burst_big && grp == (TAP == 0 ? 1 : 0)) wait_vmcnt_v5<9>(); else wait_vmcnt_v5<6>();
+      } else {
+        wait_vmcnt_v5<6>();
+      }
+    } else {
+      wait_tail(u + 1 + grp);
     }
     __builtin_amdgcn_s_barrier();
-    // next tap
-    ++tap;
-    if (++kw_ == 3) { kw_ = 0; shift16 += (W - 2) * 16; } else shift16 += 16;
-    if (tap == 9) { tap = 0; kw_ = 0; shift16 = 0; ++chunk_idx; }
-  }
+  };
+#define HALO_CHUNK(STEADYT, CI)                                                                         \
+  step(std::integral_constant<int, 0>{}, STEADYT{}, CI, (CI) * 9 + 0); step(std::integral_constant<int, 1>{}, STEADYT{}, CI, (CI) * 9 + 1); \
+  step(std::integral_constant<int, 2>{}, STEADYT{}, CI, (CI) * 9 + 2); step(std::integral_constant<int, 3>{}, STEADYT{}, CI, (CI) * 9 + 3); \
+  step(std::integral_constant<int, 4>{}, STEADYT{}, CI, (CI) * 9 + 4); step(std::integral_constant<int, 5>{}, STEADYT{}, CI, (CI) * 9 + 5); \
+  step(std::integral_constant<int, 6>{}, STEADYT{}, CI, (CI) * 9 + 6); step(std::integral_constant<int, 7>{}, STEADYT{}, CI, (CI) * 9 + 7); \
+  step(std::integral_constant<int, 8>{}, STEADYT{}, CI, (CI) * 9 + 8);
+  int ci = 0;
+  for (; ci + 1 < nchunks; ++ci) { HALO_CHUNK(std::true_type, ci) }
+  { HALO_CHUNK(std::false_type, ci) }
+#undef HALO_CHUNK
   if (grp == 0) __builtin_amdgcn_s_barrier();
-  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN, true>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
+  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
 }
 
 // Tile choice: BN follows Cout (128 / 64 / 32); BM = 128.  Packed weights and BatchNorm partials are padded to a multiple of
@@ -1027,10 +1058,44 @@ extern "C" int tscd_conv_tile_n(int cout) { return pick_bn(cout); }
 extern "C" int tscd_conv_tile_m(void) { return 128; }
 
 static int g_conv_debug = 0;
-extern "C" void tscd_conv_set_debug(int v) { g_conv_debug = v; }
 static int g_conv_korder = 0;     // tests: 1 = chunk-major k order in the register-staged loop (variant 5's order)
+static int g_conv_variant = -1;   // -1 auto, 0 register staging, 1 LDS-DMA 128-wide tiles only, 3 / 4: 128x256 variants wherever their shape allows, 5 / 6: halo variant with 256- / 192-pixel tiles wherever its shape allows (tests / A-B timing)
+
+// Tile height (output pixels) of the halo-staged variant for this launch, 0 = the launch does not take it.
+// Shape: 3x3, stride 1, Cin % 32 == 0, Cout a multiple of 256, halo (tile + 2W + 2 pixels) <= 480 rows.  Automatic selection:
+// only when the launch has enough tiles to give every CU one (its 1-workgroup-per-CU tiles cannot share a CU with anything),
+// and then the height (192 / 256) whose last round leaves fewer CUs idle.
+static int g_halo_auto = 0;      // automatic selection of the halo variant (tscd_conv_set_halo_auto)
+extern "C" void tscd_conv_set_halo_auto(int v) { g_halo_auto = v; }
+static int halo_tile_m(long M, int W, int Cin, int Cout, int ksize, int stride) {
+  if (g_conv_variant != -1 && g_conv_variant != 5 && g_conv_variant != 6) return 0;
+  if (g_conv_variant == -1 && !g_halo_auto) return 0;
+  if (ksize != 3 || stride != 1 || Cin % 32 != 0 || Cout % 256 != 0) return 0;
+  auto fits = [&](int bm) { return (bm + 2 * W + 2 + 15) / 16 * 16 <= 480; };
+  if (g_conv_variant == 5) return fits(256) ? 256 : 0;
+  if (g_conv_variant == 6) return fits(192) ? 192 : 0;
+  const long nt = Cout / 256;
+  int best = 0;
+  double best_cost = 1e30;
+  for (int bm : {192, 256}) {
+    if (!fits(bm)) continue;
+    const long tiles = (M + bm - 1) / bm * nt;
+    if (tiles < 224) continue;                               // fewer tiles than CUs: the 128-row variants' finer grain wins
+    const double cost = (double)((tiles + 255) / 256) * bm;  // rounds x rows per tile
+    if (cost < best_cost) { best_cost = cost; best = bm; }
+  }
+  return best;
+}
+
+// Number of per-channel partial-sum entries a raw-epilogue launch writes (one per M-tile of the variant it takes):
+// bn_finalize must be told this count.
+extern "C" int tscd_conv_stat_tiles(long M, int W, int Cin, int Cout, int ksize, int stride) {
+  const int bm = halo_tile_m(M, W, Cin, Cout, ksize, stride);
+  return cdiv(M, bm > 0 ? bm : 128);
+}
+
+extern "C" void tscd_conv_set_debug(int v) { g_conv_debug = v; }
 extern "C" void tscd_conv_set_korder(int v) { g_conv_korder = v; }
-static int g_conv_variant = -1;   // -1 auto, 0 register staging, 1 LDS-DMA 128-wide tiles only, 3 128x256 variant wherever its shape allows (tests / A-B timing)
 extern "C" void tscd_conv_set_variant(int v) { g_conv_variant = v; }
 
 extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* bias, const float* scale,
@@ -1073,19 +1138,21 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
   // variant 4 (staggered wave groups): the same 128 x 256 tile; needs only Cin % 32 == 0.  Selected by tscd_conv_set_variant(4)
   // while it is being measured against variant 3.
   const bool v4_ok = dma_ok && Cout > 128 && cout_pad % 256 == 0 && g_conv_variant == 4;
-  // variant 5 (input halo staged once per channel chunk, 256 x 256 tiles): 3x3 stride-1 convs; selected by
-  // tscd_conv_set_variant(5) while it is being measured
-  const int hrp = (256 + 2 * W + 2 + 15) / 16 * 16;
-  const bool v5_shape = dma_ok && ksize == 3 && stride == 1 && Cout > 128 && cout_pad % 256 == 0 && hrp <= 480;
-  const bool v5_ok = v5_shape && g_conv_variant == 5;
+  // variant 5 (input halo staged once per channel chunk, 192- or 256-pixel x 256-channel tiles): 3x3 stride-1 convs
+  const int v5_tm = halo_tile_m(M, W, Cin, Cout, ksize, stride);
+  const bool v5_ok = v5_tm > 0;
   const int BN = (v3_ok || v4_ok || v5_ok) ? 256 : BNP;
   p.korder = (g_conv_korder == 1 && Cin % 32 == 0) ? 1 : 0;
   p.mtiles_stat = cdiv(M, 128);
   if (v5_ok) {
-    p.mtiles = cdiv(M, 256);
+    const int hrp = (v5_tm + 2 * W + 2 + 15) / 16 * 16;
+    p.mtiles = cdiv(M, v5_tm);
     p.ntiles = cdiv(Cout, 256);
     p.cstride = cdiv(Cout, BNP) * BNP;
-    hipLaunchKernelGGL((conv_igemm_halo_kernel<4>), dim3(p.mtiles * p.ntiles), dim3(512), 0, (hipStream_t)stream, p, hrp);
+    if (v5_tm == 192)
+      hipLaunchKernelGGL((conv_igemm_halo_kernel<3>), dim3(p.mtiles * p.ntiles), dim3(512), 0, (hipStream_t)stream, p, hrp);
+    else
+      hipLaunchKernelGGL((conv_igemm_halo_kernel<4>), dim3(p.mtiles * p.ntiles), dim3(512), 0, (hipStream_t)stream, p, hrp);
     TSCD_CHECK_LAUNCH("conv2d (halo)");
     return TSCD_OK;
   }

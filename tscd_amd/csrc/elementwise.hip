@@ -493,6 +493,7 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
                                     float* bn_partial, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int ldx, int ldy,
                                     int epilogue, void* stream);
 extern "C" int tscd_conv_tile_m(void);
+extern "C" int tscd_conv_stat_tiles(long M, int W, int Cin, int Cout, int ksize, int stride);
 extern "C" int tscd_conv_bn_act_train_f16(const void* x, const void* wpk, void* raw, int ldraw, float* partial, int cstride, int B, int H,
                                           int W, int Cin, int Cout, int ksize, int stride, int ldx, const float* gamma, const float* beta,
                                           float eps, float momentum, float* running_mean, float* running_var, float* small, void* out,
@@ -503,8 +504,7 @@ extern "C" int tscd_conv_bn_act_train_f16(const void* x, const void* wpk, void* 
   const long M = (long)B * Ho * Wo;
   int st = tscd_conv2d_nhwc_f16(x, wpk, raw, nullptr, nullptr, nullptr, partial, B, H, W, Cin, Cout, ksize, stride, ldx, ldraw, 0, stream);
   if (st != TSCD_OK) return st;
-  const int tm = tscd_conv_tile_m();
-  const int mtiles = (int)((M + tm - 1) / tm);
+  const int mtiles = tscd_conv_stat_tiles(M, W, Cin, Cout, ksize, stride);     // partial-sum entries the conv launch wrote
   st = tscd_bn_finalize(partial, mtiles, cstride, Cout, M, gamma, beta, eps, momentum, running_mean, running_var, small, small + 2 * (long)Cout,
                         small + 3 * (long)Cout, stream);
   if (st != TSCD_OK) return st;

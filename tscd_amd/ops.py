@@ -129,7 +129,7 @@ def conv2d(x, wpk, cout, ksize, stride=1, epilogue=EPI_RAW, bias=None, scale_shi
     assert wpk.shape[1] == kpad and wpk.shape[0] >= cout, (wpk.shape, kpad, cout)
     partial = None
     if want_stats:
-        mt = (B * Ho * Wo + lib.tscd_conv_tile_m() - 1) // lib.tscd_conv_tile_m()
+        mt = lib.tscd_conv_stat_tiles(B * Ho * Wo, Wo, Cin, cout, ksize, stride)     # one partial-sum entry per M-tile of the variant taken
         partial = torch.empty((2, wpk.shape[0], mt), dtype=torch.float32, device=x.device)
     scale = shift = None
     if scale_shift is not None:

@@ -1,0 +1,310 @@
+"""Clip datasets and loaders of TSCD (interface of the reference's yolox/data/datasets/vid.py: ``OVIS`` :560-717 on top of
+``Arg_VID`` :345-557, the samplers :758-830, ``collate_fn_ovis`` :917-937, the loader factories :940-960,
+``DataPrefetcher`` :963-1012, ``get_timing_signal_1d`` :1015-1023).
+
+One training iteration = one clip = ``lframe`` consecutive local frames + ``gframe`` frames sampled from the rest of the
+video; the batch is the clip (tensor contract: imgs [B,3,H,W] float 0..255 letterboxed, targets [B,100,5]
+(cls,cx,cy,w,h; zero rows = padding), img infos, raw targets, paths, time embedding [B,256] of the frame index parsed from
+``..._<idx>.jpg``).  On-disk format: the "vid"-style COCO json the reference reads (``videos``, ``images`` with ``sid`` /
+``file_name``, ``annotations``, ``categories``), read with a small own index (pycocotools is not in this image) and decoded
+with Pillow (OpenCV is not either).
+
+New relative to the reference: the train sampler is RANK-AWARE -- every rank shuffles the clip list with
+the same (seed, epoch) generator and takes clips rank, rank + world, ... -- the reference shuffles the full list identically
+on every rank, so its multi-GPU runs would train every rank on the same clips."""
+import copy
+import json
+import math
+import os
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset as torchDataset
+from torch.utils.data.sampler import BatchSampler, Sampler, SequentialSampler
+
+IMAGE_EXT = [".jpg", ".jpeg", ".webp", ".bmp", ".png"]
+
+
+def get_timing_signal_1d(index_squence, channels, min_timescale=1.0, max_timescale=1.0e4):
+    """Sinusoidal embedding of the frame indices: [n] -> [n, channels] (sin | cos halves)."""
+    n = channels // 2
+    inc = torch.tensor(math.log(max_timescale / min_timescale) / (n - 1))
+    inv = min_timescale * torch.exp(torch.arange(0, n) * -inc)
+    st = torch.unsqueeze(index_squence, 1) * torch.unsqueeze(inv, 0)
+    return torch.cat([torch.sin(st), torch.cos(st)], dim=1)
+
+
+def imread_bgr(path):
+    """Decode an image file to HxWx3 uint8 in BGR channel order (what cv2.imread returns)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        rgb = np.asarray(im.convert("RGB"))
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+class CocoIndex:
+    """The few lookups the datasets need from a COCO-style annotation file."""
+
+    def __init__(self, path):
+        with open(path, "r") as fh:
+            self.dataset = json.load(fh)
+        self.imgs = {im["id"]: im for im in self.dataset.get("images", [])}
+        self.cats = {c["id"]: c for c in self.dataset.get("categories", [])}
+        self.anns_of = {}
+        for a in self.dataset.get("annotations", []):
+            self.anns_of.setdefault(a["image_id"], []).append(a)
+
+    def img_ids(self):
+        return sorted(self.imgs)
+
+    def cat_ids(self):
+        return sorted(self.cats)
+
+    def anns(self, img_id, iscrowd=False):
+        return [a for a in self.anns_of.get(img_id, []) if bool(a.get("iscrowd", 0)) == iscrowd]
+
+
+class OVIS(torchDataset):
+    """OVIS in "vid" COCO format.  ``self.res`` = list of clips (each a list of lframe + gframe file names);
+    ``dataset[file_name]`` -> (img, target, (h, w), file_name) after ``preproc``."""
+
+    def __init__(self, data_dir="", img_size=(576, 576), preproc=None, lframe=0, gframe=16, val=False, mode="random", COCO_anno="",
+                 name="train", training=False):
+        super().__init__()
+        if not os.path.isfile(COCO_anno):
+            raise FileNotFoundError(f"OVIS annotation file {COCO_anno!r} not found (set exp.data_dir / train_ann / val_ann)")
+        self.input_dim = self.img_size = img_size
+        self.name, self.val, self.data_dir, self.coco_anno_path = name, val, data_dir, COCO_anno
+        self.mode, self.preproc, self.training = mode, preproc, training
+        self.coco = CocoIndex(COCO_anno)
+        self.name_id_dic = {im["file_name"]: im["id"] for im in self.coco.dataset["images"]}
+        self.ids = self.coco.img_ids()
+        self.class_ids = self.coco.cat_ids()
+        self._classes = tuple(self.coco.cats[c]["name"] for c in self.class_ids)
+        self._pos = {i: n for n, i in enumerate(self.ids)}
+        self.annotations = [self.load_anno_from_ids(i) for i in self.ids]
+        self.res = self.photo_to_sequence(lframe, gframe)
+
+    def __len__(self):
+        return len(self.res)
+
+    def load_anno_from_ids(self, id_):
+        im = self.coco.imgs[id_]
+        width, height = im["width"], im["height"]
+        objs = []
+        for obj in self.coco.anns(id_):
+            x1, y1 = max(0, obj["bbox"][0]), max(0, obj["bbox"][1])
+            x2 = min(width, x1 + max(0, obj["bbox"][2]))
+            y2 = min(height, y1 + max(0, obj["bbox"][3]))
+            if obj.get("area", 1) > 0 and x2 >= x1 and y2 >= y1:
+                objs.append(([x1, y1, x2, y2], self.class_ids.index(obj["category_id"])))
+        res = np.zeros((len(objs), 5))
+        for ix, (box, cls) in enumerate(objs):
+            res[ix, :4], res[ix, 4] = box, cls
+        r = min(self.img_size[0] / height, self.img_size[1] / width)
+        res[:, :4] *= r
+        file_name = im["file_name"] if "file_name" in im else "{:012}".format(id_) + ".jpg"
+        return res, (height, width), (int(height * r), int(width * r)), file_name
+
+    def _has_labels(self, file_name):
+        return len(self.annotations[self._pos[self.name_id_dic[file_name]]][0]) > 0
+
+    def photo_to_sequence(self, lframe, gframe):
+        """Clip sampling (vid.py:601-685).  'random' with lframe > 0: every run of `lframe` consecutive frames of a video is
+        one clip, completed by `gframe` frames drawn from the rest of that video; training skips clips whose local frames
+        carry no label."""
+        nvid = len(self.coco.dataset.get("videos", [])) or 1 + max(im["sid"] for im in self.coco.dataset["images"])
+        videos = [[] for _ in range(nvid)]
+        for im in self.coco.dataset["images"]:
+            videos[im["sid"]].append(im["file_name"])
+        res = []
+        for element in videos:
+            if not element:
+                continue
+            while len(element) < lframe + gframe:              # short videos: repeat the last frame
+                element.append(element[-1])
+            n = len(element)
+            if self.mode == "random":
+                if lframe == 0:
+                    random.shuffle(element)
+                    res += [element[i * gframe:(i + 1) * gframe] for i in range(n // gframe)]
+                else:
+                    split = n // lframe
+                    local_all = element[:split * lframe]
+                    for i in np.arange(split) * lframe:
+                        l_frame = local_all[i:i + lframe]
+                        if self.training and not any(self._has_labels(f) for f in l_frame):
+                            continue
+                        res.append(l_frame + random.sample(element[:i] + element[i + lframe:], gframe))
+            elif self.mode == "uniform":
+                split = n // gframe
+                uni = element[:split * gframe]
+                res += [uni[i::split] for i in range(split)]
+            elif self.mode == "gl":
+                split = n // lframe
+                local_all = element[:split * lframe]
+                for i in range(split):
+                    g_frame = random.sample(element[:i * lframe] + element[(i + 1) * lframe:], gframe)
+                    res.append(local_all[i * lframe:(i + 1) * lframe] + g_frame)
+            else:
+                raise ValueError(f"unsupported clip sampling mode {self.mode!r}")
+        if not self.val:
+            random.shuffle(res)
+        return res
+
+    def pull_item(self, path):
+        annos, _, _, img_path = self.annotations[self._pos[self.name_id_dic[path]]]
+        from ..data_augment import resize_bilinear
+        img = imread_bgr(os.path.join(self.data_dir, self.name, img_path))
+        h, w = img.shape[:2]
+        r = min(self.img_size[0] / h, self.img_size[1] / w)
+        return resize_bilinear(img, int(h * r), int(w * r)), annos.copy(), (h, w), img_path
+
+    def __getitem__(self, path):
+        img, target, img_info, path = self.pull_item(path)
+        if self.preproc is not None:
+            img, target = self.preproc(img, target, self.input_dim)
+        return img, target, img_info, path
+
+
+class VIDDataset(torchDataset):
+    """ImageNet-VID sequences (reference: vid.py:60-342, ``.npy`` lists of frame paths + XML annotations).  The constructor
+    contract is kept for the exp files; reading the XML annotations is not built."""
+
+    def __init__(self, file_path="train_seq.npy", img_size=(576, 576), preproc=None, lframe=0, gframe=16, val=False, mode="random",
+                 dataset_pth="", tnum=-1, formal=False, traj_linking=False, local_stride=1):
+        super().__init__()
+        raise NotImplementedError("ImageNet-VID (npy sequence lists + XML annotations) is not built; OVIS-style COCO json is "
+                                  "(yolox.data.datasets.vid.OVIS)")
+
+
+class TrainSampler(Sampler):
+    """Yields clips (lists of file names).  Rank-aware: all ranks draw the same permutation from (seed, epoch) and keep every
+    world-th clip starting at their rank; call ``set_epoch`` once per epoch."""
+
+    def __init__(self, data_source, rank=None, world_size=None, seed=0):
+        self.data_source = data_source
+        if rank is None or world_size is None:
+            import torch.distributed as dist
+            on = dist.is_available() and dist.is_initialized()
+            rank, world_size = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+        self.rank, self.world, self.seed, self.epoch = rank, world_size, seed, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def _mine(self):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + self.epoch)
+        order = torch.randperm(len(self.data_source.res), generator=g).tolist()
+        return [self.data_source.res[i] for i in order[self.rank::self.world]]
+
+    def __iter__(self):
+        self.epoch += 1
+        return iter(self._mine())
+
+    def __len__(self):
+        return (len(self.data_source.res) - self.rank + self.world - 1) // self.world
+
+
+class TestSampler(SequentialSampler):
+    """Clips in dataset order (the evaluator carries CAFM state from clip to clip of a video).  With ``world_size`` > 1 the
+    clips are sharded by VIDEO, never inside one: rank r gets the videos r, r + world, ..."""
+
+    def __init__(self, data_source, rank=0, world_size=1):
+        super().__init__(data_source)
+        self.data_source, self.rank, self.world = data_source, rank, world_size
+
+    def _mine(self):
+        if self.world == 1:
+            return list(self.data_source.res)
+        vid_of = lambda clip: os.path.dirname(clip[0])
+        vids = sorted({vid_of(c) for c in self.data_source.res})
+        mine = set(vids[self.rank::self.world])
+        return [c for c in self.data_source.res if vid_of(c) in mine]
+
+    def __iter__(self):
+        return iter(self._mine())
+
+    def __len__(self):
+        return len(self._mine())
+
+
+class VIDBatchSampler(BatchSampler):
+    """Flattens the sampler's clips into batches of `batch_size` file names (batch_size = lframe + gframe: one clip)."""
+
+    def __iter__(self):
+        batch = []
+        for clip in self.sampler:
+            for filename in clip:
+                batch.append(filename)
+                if len(batch) == self.batch_size:
+                    yield batch
+                    batch = []
+        if batch and not self.drop_last:
+            yield batch
+
+    def __len__(self):
+        return len(self.sampler)
+
+
+class VIDBatchSampler_Test(VIDBatchSampler):
+    pass
+
+
+def collate_fn_ovis(batch):
+    tar, imgs, ims_info, tar_ori, path, seq = [], [], [], [], [], []
+    for img, target, info, p in batch:
+        t = torch.zeros([100, 5])
+        imgs.append(torch.as_tensor(img))
+        tar_ori.append(torch.as_tensor(copy.deepcopy(target)))
+        t[:target.shape[0]] = torch.as_tensor(target)
+        tar.append(t)
+        ims_info.append(info)
+        path.append(p)
+        seq.append(int(p[p.rfind("/") + 1:p.rfind(".")].split("_")[-1]))
+    return torch.stack(imgs), torch.stack(tar), ims_info, tar_ori, path, get_timing_signal_1d(torch.tensor(seq), 256)
+
+
+def _loader(dataset, sampler, data_num_workers):
+    return torch.utils.data.DataLoader(dataset, num_workers=data_num_workers, pin_memory=torch.cuda.is_available(),
+                                       batch_sampler=sampler, collate_fn=collate_fn_ovis)
+
+
+def ovis_get_trans_loader(batch_size, data_num_workers, dataset, rank=None, world_size=None, seed=0):
+    return _loader(dataset, VIDBatchSampler(TrainSampler(dataset, rank, world_size, seed), batch_size, drop_last=False), data_num_workers)
+
+
+def ovis_vid_val_loader(batch_size, data_num_workers, dataset, rank=0, world_size=1):
+    return _loader(dataset, VIDBatchSampler_Test(TestSampler(dataset, rank, world_size), batch_size, drop_last=False), data_num_workers)
+
+
+class DataPrefetcher:
+    """Double buffering of the loader's batches: the next clip's H2D copy runs on a side stream from pinned memory while the
+    current step computes; ``next()`` -> (imgs, targets, time_embedding) on the device (None at the end of the epoch)."""
+
+    def __init__(self, loader):
+        self.loader = iter(loader)
+        self.max_iter = len(loader)
+        self.stream = torch.cuda.Stream()
+        self.preload()
+
+    def preload(self):
+        try:
+            self.next_input, self.next_target, _, _, _, self.time_embedding = next(self.loader)
+        except StopIteration:
+            self.next_input = self.next_target = self.time_embedding = None
+            return
+        with torch.cuda.stream(self.stream):
+            self.next_input = self.next_input.cuda(non_blocking=True)
+            self.next_target = self.next_target.cuda(non_blocking=True)
+            self.time_embedding = self.time_embedding.cuda(non_blocking=True)
+
+    def next(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        out = (self.next_input, self.next_target, self.time_embedding)
+        for t in out:
+            if t is not None:
+                t.record_stream(torch.cuda.current_stream())
+        self.preload()
+        return out
