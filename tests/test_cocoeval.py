@@ -1,0 +1,78 @@
+"""COCO bbox evaluation on the host (tscd_amd/csrc_host/cocoeval.cpp) vs the plain-Python restatement of
+the published algorithm (oracle/cocoeval_ref.py) and hand-computed cases.  pycocotools is absent from the reference tree and
+from this image: parity with pycocotools itself is unpinned (stated in both files)."""
+import numpy as np
+import pytest
+
+from oracle import cocoeval_ref as R
+
+
+def run_cpp(gts, dts, n_img, n_cat, full=True):
+    from tscd_amd._host import cocoeval_bbox
+    g = lambda k: [x[k] for x in gts]
+    d = lambda k: [x[k] for x in dts]
+    return cocoeval_bbox(np.array(g("bbox"), np.float32).reshape(-1, 4), g("img"), g("cat"), g("iscrowd"), g("area"),
+                         np.array(d("bbox"), np.float32).reshape(-1, 4), d("img"), d("cat"), d("score"), n_img, n_cat, full=full)
+
+
+def test_hand_computed_cases():
+    gt = lambda img, cat, box, crowd=0: dict(img=img, cat=cat, bbox=box, iscrowd=crowd, area=box[2] * box[3])
+    dt = lambda img, cat, box, s: dict(img=img, cat=cat, bbox=box, score=s)
+    # perfect detection of one medium box
+    s, p, r = run_cpp([gt(0, 0, [10, 10, 50, 50])], [dt(0, 0, [10, 10, 50, 50], 0.9)], 1, 1)
+    assert s[0] == 1 and s[1] == 1 and s[4] == 1 and s[3] == -1 and s[5] == -1 and s[8] == 1
+    # two gts, one found (IoU 1), one false positive ranked FIRST: precision at recall <= .5 is 1/2, beyond it 0
+    #   -> AP = (51 recall thresholds * 0.5) / 101 at every IoU threshold
+    gts = [gt(0, 0, [0, 0, 40, 40]), gt(0, 0, [100, 100, 40, 40])]
+    dts = [dt(0, 0, [200, 200, 40, 40], 0.9), dt(0, 0, [0, 0, 40, 40], 0.8)]
+    s, p, r = run_cpp(gts, dts, 1, 1)
+    assert abs(s[0] - 51 * 0.5 / 101) < 1e-6 and abs(s[8] - 0.5) < 1e-6 and abs(s[6] - 0.0) < 1e-6   # AR@1: the top detection is the FP
+    # IoU 0.6 detection: counts as TP for thresholds .50 .55 .60 only -> AP = 3/10, AP50 = 1, AP75 = 0
+    #   boxes [0,0,100,100] vs [0,0,100,60]: inter 6000, union 10000
+    s, p, r = run_cpp([gt(0, 0, [0, 0, 100, 100])], [dt(0, 0, [0, 0, 100, 60], 0.5)], 1, 1)
+    assert abs(s[0] - 0.3) < 1e-6 and s[1] == 1 and s[2] == 0
+    # a detection on a crowd region is ignored (neither TP nor FP); the real gt is still found
+    gts = [gt(0, 0, [0, 0, 40, 40]), gt(0, 0, [100, 100, 80, 80], crowd=1)]
+    dts = [dt(0, 0, [110, 110, 30, 30], 0.95), dt(0, 0, [0, 0, 40, 40], 0.5)]
+    s, p, r = run_cpp(gts, dts, 1, 1)
+    assert s[0] == 1 and s[1] == 1
+    # categories are evaluated independently and averaged; a category without gt is left out of the mean
+    gts = [gt(0, 0, [0, 0, 40, 40])]
+    dts = [dt(0, 0, [0, 0, 40, 40], 0.9), dt(0, 1, [0, 0, 40, 40], 0.9)]
+    s, p, r = run_cpp(gts, dts, 1, 3)
+    assert s[0] == 1 and (p[:, :, 1] == -1).all() and (p[:, :, 2] == -1).all()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_matches_restatement_on_random_scenes(seed):
+    rng = np.random.default_rng(seed)
+    n_img, n_cat = 6, 4
+    gts, dts = [], []
+    for im in range(n_img):
+        for _ in range(int(rng.integers(0, 9))):
+            w, h = rng.uniform(8, 200, 2)
+            box = [float(rng.uniform(0, 400)), float(rng.uniform(0, 400)), float(w), float(h)]
+            gts.append(dict(img=im, cat=int(rng.integers(0, n_cat)), bbox=box, iscrowd=int(rng.random() < 0.15), area=float(w * h)))
+        for x in [g for g in gts if g["img"] == im]:
+            if rng.random() < 0.8:           # a jittered copy of the gt, sometimes of another class
+                j = rng.normal(0, 6, 4)
+                box = [x["bbox"][0] + j[0], x["bbox"][1] + j[1], max(2.0, x["bbox"][2] + j[2]), max(2.0, x["bbox"][3] + j[3])]
+                cat = x["cat"] if rng.random() < 0.85 else int(rng.integers(0, n_cat))
+                dts.append(dict(img=im, cat=cat, bbox=[float(v) for v in box], score=float(np.round(rng.random(), 2))))   # rounded: ties
+        for _ in range(int(rng.integers(0, 40 if im == 0 else 6))):   # clutter; image 0 exceeds maxDets = 100 with its duplicates below
+            w, h = rng.uniform(4, 150, 2)
+            dts.append(dict(img=im, cat=int(rng.integers(0, n_cat)), bbox=[float(rng.uniform(0, 400)), float(rng.uniform(0, 400)), float(w), float(h)],
+                            score=float(np.round(rng.random(), 2))))
+    dts += [dict(d, score=float(np.round(rng.random(), 2))) for d in dts if d["img"] == 0 and d["cat"] == 0] * 12
+    # float32 views of everything (what the C ABI receives), so that both sides see identical numbers
+    for x in gts + dts:
+        x["bbox"] = [float(np.float32(v)) for v in x["bbox"]]
+    for x in gts:
+        x["area"] = float(np.float32(x["area"]))
+    for x in dts:
+        x["score"] = float(np.float32(x["score"]))
+    s_ref, p_ref, r_ref = R.evaluate(gts, dts, n_img, n_cat)
+    s, p, r = run_cpp(gts, dts, n_img, n_cat)
+    np.testing.assert_allclose(p, p_ref, atol=1e-6)
+    np.testing.assert_allclose(r, r_ref, atol=1e-6)
+    np.testing.assert_allclose(s, s_ref, atol=1e-6)

@@ -37,7 +37,7 @@ def run(x, wpk, cout, k, variant, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="3,5,6")
+    ap.add_argument("--variants", default="3,6,-1")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()

@@ -842,13 +842,12 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
   constexpr int MAXP = 4;                                // A pieces per wave: halo of <= 512 rows
   constexpr int BM = 64 * TM, BN = 256, NS = 6, WAVES_M = 2, WAVES_N = 4, TN = 2, WM = 32 * TM, WN = 64;
   constexpr int B_BYTES = BN * 64;                       // 16 KB per k-step
-  constexpr int SMEM_BYTES = 1024 + 2 * 480 * 64 + NS * B_BYTES;         // HRP <= 480; also >= the epilogue's staging tile
+  constexpr int SMEM_BYTES = 2 * (1024 + 480 * 64) + NS * B_BYTES;         // HRP <= 480; also >= the epilogue's staging tile
   __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
-  // layout: [zero block 1 KB][A halo 0][A halo 1][B ring NS x 16 KB]
-  const int A_BYTES = HRP * 64;
-  char* const zero_blk = smem;
-  char* const a_buf = smem + 1024;
-  char* const b_ring = smem + 1024 + 2 * A_BYTES;
+  // layout: [A buffer 0][A buffer 1][B ring NS x 16 KB]; an A buffer = [zero block 1 KB][halo rows]: the per-lane fragment offsets
+  // (halo row or zero block) are then relative to the buffer and the same for both buffers
+  const int A_BYTES = 1024 + HRP * 64;
+  char* const b_ring = smem + 2 * A_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
@@ -860,7 +859,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
   const int m0 = mt * BM, n0 = nt * BN;
   const int W = p.W, HW = p.H * p.W;
 
-  if (tid < 64) ((f16x8*)zero_blk)[tid] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (tid < 128) ((f16x8*)(smem + (tid >> 6) * A_BYTES))[tid & 63] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 
   // ---- DMA sources.  A: halo piece pc covers flattened input pixels m0 - W - 1 + 16 pc + (lane & 15), chunk lane >> 4 ----
   const int NP = HRP >> 4;
@@ -896,7 +895,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
     if (++ld_tap == 9) { ld_tap = 0; ld_cin += 32; }
   };
   auto issue_a = [&](int chunk_idx) __attribute__((always_inline)) {      // the whole halo of channel chunk chunk_idx
-    char* sbase = a_buf + (chunk_idx & 1) * A_BYTES;
+    char* sbase = smem + (chunk_idx & 1) * A_BYTES + 1024;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       if (wave + 8 * i < NP) {                                             // wave-uniform
@@ -919,34 +918,31 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
   // row mloc + kh W + kw; byte offset of (halo row hr, chunk c) = (hr >> 4) * 1024 + c * 256 + (hr & 15) * 16
   //                                                            = 16 hr + 3 * ((16 hr) & ~255) + c * 256
   const int frow = lane & 31, fk = lane >> 5;
-  unsigned vmask[TM];
-  int a_t16[TM];                                        // (halo row of tap (0,0)) * 16
+  // a_pre[tap][i]: byte offset inside an A buffer of this lane's fragment for row-tile i at tap `tap` -- the halo row, or the
+  // zero block when the tap falls outside the image for this lane's output pixel (9 x TM registers, computed once)
+  int a_pre[9][TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int mloc = wm * WM + i * 32 + frow;
     const int m = m0 + mloc;
-    unsigned mask = 0;
-    if (m < p.M) {
-      const int rem = m % HW;
-      const int h = rem / W, w = rem - h * W;
+    const bool live = m < p.M;
+    const int rem = live ? m % HW : 0;
+    const int h = rem / W, w = rem - h * W;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-          if ((unsigned)(h + kh - 1) < (unsigned)p.H && (unsigned)(w + kw - 1) < (unsigned)W) mask |= 1u << (kh * 3 + kw);
-    }
-    vmask[i] = mask;
-    a_t16[i] = mloc * 16;
+      for (int kw = 0; kw < 3; ++kw) {
+        const bool ok = live && (unsigned)(h + kh - 1) < (unsigned)p.H && (unsigned)(w + kw - 1) < (unsigned)W;
+        const int t16 = (mloc + kh * W + kw) * 16;
+        a_pre[kh * 3 + kw][i] = ok ? 1024 + t16 + 3 * (t16 & ~255) + fk * 256 : (lane & 15) * 16;
+      }
   }
-  const int a_lane = fk * 256 + 1024;                                   // chunk half of this lane + the zero block in front
-  const int zero_lane = (lane & 15) * 16;
   int b_off[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int row = wn * WN + j * 32 + frow;
     b_off[j] = (row >> 4) * 1024 + fk * 256 + (row & 15) * 16;
   }
-  const int w16 = W * 16;
 
   // ---- prologue ----
   issue_a(0);
@@ -973,23 +969,14 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
   auto step = [&](auto tapc, auto steadyc, int chunk_idx, int u) __attribute__((always_inline)) {
     constexpr int TAP = decltype(tapc)::value;
     constexpr bool STEADY = decltype(steadyc)::value;
-    constexpr int KH = TAP / 3, KW = TAP % 3;
     // ---------------- L(u) ----------------
     __builtin_amdgcn_sched_barrier(0);
     {
-      const char* sa = smem + (chunk_idx & 1) * A_BYTES;             // a_lane carries the +1024 of the zero block
+      const char* sa = smem + (chunk_idx & 1) * A_BYTES;
       const char* sb = b_ring + rd_soff;
-      const int shift16 = KH * w16 + KW * 16;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        int base16 = a_t16[i];
-        asm volatile("" : "+v"(base16));                               // keep the 9 x TM tap addresses out of registers: recompute per step
-        const int t16 = base16 + shift16;
-        const int off = t16 + 3 * (t16 & ~255) + a_lane;
-        unsigned vm = vmask[i];
-        asm volatile("" : "+v"(vm));                                   // likewise: do not keep 9 x TM lane masks in SGPR pairs
-        const bool ok = (vm >> TAP) & 1u;
-        const char* ptr = ok ? sa + off : zero_blk + zero_lane;       // zero block: 1 KB, covers the +512 of ks = 1
+        const char* ptr = sa + a_pre[TAP][i];
         fa[0][i] = *(const f16x8*)(ptr);
         fa[1][i] = *(const f16x8*)(ptr + 512);
       }
@@ -1065,7 +1052,7 @@ static int g_conv_variant = -1;   // -1 auto, 0 register staging, 1 LDS-DMA 128-
 // Shape: 3x3, stride 1, Cin % 32 == 0, Cout a multiple of 256, halo (tile + 2W + 2 pixels) <= 480 rows.  Automatic selection:
 // only when the launch has enough tiles to give every CU one (its 1-workgroup-per-CU tiles cannot share a CU with anything),
 // and then the height (192 / 256) whose last round leaves fewer CUs idle.
-static int g_halo_auto = 0;      // automatic selection of the halo variant (tscd_conv_set_halo_auto)
+static int g_halo_auto = 1;      // automatic selection of the halo variant (tscd_conv_set_halo_auto)
 extern "C" void tscd_conv_set_halo_auto(int v) { g_halo_auto = v; }
 static int halo_tile_m(long M, int W, int Cin, int Cout, int ksize, int stride) {
   if (g_conv_variant != -1 && g_conv_variant != 5 && g_conv_variant != 6) return 0;
@@ -1080,7 +1067,7 @@ static int halo_tile_m(long M, int W, int Cin, int Cout, int ksize, int stride) 
   for (int bm : {192, 256}) {
     if (!fits(bm)) continue;
     const long tiles = (M + bm - 1) / bm * nt;
-    if (tiles < 224) continue;                               // fewer tiles than CUs: the 128-row variants' finer grain wins
+    if (tiles < 200) continue;                               // clearly fewer tiles than CUs: the 128-row variants' finer grain wins
     const double cost = (double)((tiles + 255) / 256) * bm;  // rounds x rows per tile
     if (cost < best_cost) { best_cost = cost; best = bm; }
   }
