@@ -1,7 +1,7 @@
 """Base experiment of TSCD on the MI355X kernels: the configuration surface of the reference's
 exps/TSCD_OVIS/tscd_base.py:16-499 (same attribute names and defaults, same factory methods), building this
-repository's yolox.models classes.  Dataset loaders / evaluators are rows N1/N2 of SURVEY.md 8f and are not built; the
-loaders fall back to yolox.data.SyntheticClipLoader when ``data_dir`` does not exist."""
+repository's yolox.models classes.  The loaders read OVIS ("vid" COCO json) when ``data_dir`` holds it and fall back to
+yolox.data.SyntheticClipLoader otherwise; the evaluator is yolox.evaluators.ovis_evaluator_v2.OVISEvaluator."""
 import os
 import random
 
@@ -9,6 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from yolox.data.data_augment import Vid_Val_Transform
+from yolox.data.datasets import vid
 from yolox.exp import BaseExp
 
 
@@ -142,27 +144,68 @@ class Exp(BaseExp):
             targets[..., 2::2] = targets[..., 2::2] * sy
         return inputs, targets
 
-    # ------------------------------------------------------------------ data / eval (rows N1 / N2, synthetic stand-in)
+    # ------------------------------------------------------------------ data / eval
     def _synthetic(self, frames, size, is_distributed=False):
         from yolox.data import SyntheticClipLoader
         rank = dist.get_rank() if is_distributed and dist.is_initialized() else 0
         world = dist.get_world_size() if is_distributed and dist.is_initialized() else 1
         return SyntheticClipLoader(frames, size, rank=rank, world_size=world, seed=self.seed or 0)
 
+    def _ann(self, name):
+        return os.path.join(self.data_dir, getattr(self, name, ""))
+
     def get_data_loader(self, batch_size, is_distributed, no_aug=False, cache_img=False):
-        if os.path.isdir(self.data_dir):
-            raise NotImplementedError("the OVIS / ImageNet-VID input pipeline is row N1 of SURVEY.md 8f (not built)")
+        """OVIS clips (tscd_base.py:199-219 / ovis_tscd_large.py:199-217) behind the device prefetcher when ``data_dir`` holds the
+        dataset; a synthetic clip source with the same tensor contract otherwise (smoke runs, benchmarks)."""
         assert batch_size == self.lframe + self.gframe, "one clip per iteration: -b must equal lframe + gframe"
-        return self._synthetic(batch_size, self.input_size[0], is_distributed)
+        if not os.path.isfile(self._ann("train_ann")):
+            return self._synthetic(batch_size, self.input_size[0], is_distributed)
+        from yolox.data import DataPrefetcher, TrainTransform
+        dataset = vid.OVIS(img_size=self.input_size, preproc=TrainTransform(max_labels=50, flip_prob=self.flip_prob, hsv_prob=self.hsv_prob),
+                           mode="random", lframe=self.lframe, gframe=self.gframe, data_dir=self.data_dir, name="train",
+                           COCO_anno=self._ann("train_ann"), training=True)
+        loader = vid.ovis_get_trans_loader(batch_size=batch_size, data_num_workers=self.data_num_workers, dataset=dataset,
+                                           seed=self.seed or 0)
+        return _Prefetched(loader)
 
     def get_eval_loader(self, batch_size, tnum=None, data_num_workers=8, formal=False):
-        if os.path.isdir(self.data_dir):
-            raise NotImplementedError("the OVIS / ImageNet-VID input pipeline is row N1 of SURVEY.md 8f (not built)")
         assert batch_size == self.lframe_val + self.gframe_val
-        return self._synthetic(batch_size, self.test_size[0])
+        if not os.path.isfile(self._ann("val_ann")):
+            return self._synthetic(batch_size, self.test_size[0])
+        dataset = vid.OVIS(data_dir=self.data_dir, img_size=self.test_size, mode="random", COCO_anno=self._ann("val_ann"), name="train",
+                           lframe=self.lframe_val, gframe=self.gframe_val, preproc=Vid_Val_Transform(), val=True)
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        return vid.ovis_vid_val_loader(batch_size=batch_size, data_num_workers=data_num_workers, dataset=dataset, rank=rank, world_size=world)
 
     def get_evaluator(self, val_loader):
-        raise NotImplementedError("OVISEvaluator / COCOeval is row N2 of SURVEY.md 8f (not built)")
+        from yolox.evaluators.ovis_evaluator_v2 import OVISEvaluator
+        return OVISEvaluator(dataloader=val_loader, img_size=self.test_size, confthre=self.test_conf, nmsthre=self.nmsthre,
+                             num_classes=self.num_classes, lframe=self.lframe_val, gframe=self.gframe_val, first_only=False)
+
+    def get_trainer(self, args):
+        from yolox.core import Trainer
+        return Trainer(self, args)
 
     def eval(self, model, evaluator, is_distributed, half=False):
         return evaluator.evaluate(model, is_distributed, half)
+
+
+class _Prefetched:
+    """The trainer's clip source contract -- ``next()`` -> (imgs, targets, time_embedding) on the device, ``len()`` = iterations per
+    epoch -- over a torch DataLoader: a DataPrefetcher (pinned H2D on a side stream) that is re-armed at the end of every epoch."""
+
+    def __init__(self, loader):
+        from yolox.data import DataPrefetcher
+        self.loader, self._mk = loader, DataPrefetcher
+        self.pf = DataPrefetcher(loader)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def next(self):
+        out = self.pf.next()
+        if out[0] is None:                 # epoch exhausted: the sampler reshuffles (rank-aware, seeded by the epoch) on re-iteration
+            self.pf = self._mk(self.loader)
+            out = self.pf.next()
+        return out

@@ -203,6 +203,26 @@ int tscd_batched_nms(const void* det, int ndet, const int* frame_off, int L, con
                      int mode, void* workspace, long workspace_bytes, void* out, int* out_idx, int* out_count,
                      int* overflow_flag, void* stream);
 
+/* Fused losses (tscd_amd/csrc/loss.hip; reference: TSCDHead.get_matcher_refined_losses yolox/models/tscd_head.py:1008-1203,
+ * IOUloss yolox/models/losses.py:9-53, encode_reg_preds tscd_head.py:951-974).  Sums are returned un-normalised (the caller
+ * divides by the foreground counts, device scalars); per-block partials are reduced in a fixed order (deterministic).
+ * tscd_loss_dense_f16: raw [B][A][5+NC] logits, outputs [B][A][5+NC] decoded (cx,cy,w,h,..), SimOTA results fg_mask / matched_gt /
+ * pred_iou [B][A], labels [B][Lmax][5] fp32 -> sums[3] = {sum over foreground of 1 - IoU^2, sum over all anchors of the
+ * objectness BCE (target = foreground), sum over foreground of the class BCE (target = onehot * matched IoU)}; d_logit (or NULL)
+ * [B][A][1+NC] fp16 = gradient of (sums[1] + sums[2]) w.r.t. the raw objectness | class logits.
+ * tscd_loss_rows_f16: N refined rows, row n = anchor row_a[n] of frame row_b[n]; part bit 0 class BCE of cls_logit [N][NC]
+ * (foreground rows, target gathered through the assignment), bit 1 BCE of obj_logit [N] (target = row is foreground), bit 2
+ * SmoothL1 (beta 1) of reg_delta [N][4] against encode_reg_preds(matched box, base xyxy = columns 0..3 of base [N][ndet]) on the
+ * foreground rows -> sums[3] and the gradients d_cls / d_obj / d_reg (fp16, NULL to skip). */
+long tscd_loss_workspace_bytes(long B, long A, long N);
+int tscd_loss_dense_f16(const void* raw, const void* outputs, const unsigned char* fg_mask, const int* matched_gt,
+                        const float* pred_iou, const float* labels, int B, int A, int NC, int Lmax, void* workspace,
+                        long workspace_bytes, float* sums, void* d_logit, void* stream);
+int tscd_loss_rows_f16(const int* row_b, const int* row_a, int N, int A, int NC, int Lmax, const unsigned char* fg_mask,
+                       const int* matched_gt, const float* pred_iou, const float* labels, const void* cls_logit,
+                       const void* obj_logit, const void* reg_delta, const void* base, int ndet, int part, void* workspace,
+                       long workspace_bytes, float* sums, void* d_cls, void* d_obj, void* d_reg, void* stream);
+
 /* ---- SimOTA label assignment: get_fg_idx / get_assignments / get_in_boxes_info / dynamic_k_matching
  * (tscd_head.py:1712-1851,1330-1544), bboxes_iou (yolox/utils/boxes.py:131-154). */
 long tscd_simota_workspace_bytes(int B, int A, int G, int topk);

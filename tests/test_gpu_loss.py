@@ -1,0 +1,102 @@
+"""Fused loss kernels (tscd_amd/csrc/loss.hip) vs the oracle's loss expressions (oracle/tscd_oracle.py
+iou_loss / encode_reg_preds and the BCE / SmoothL1 calls of tscd_head, i.e. the reference's tscd_head.py:1008-1203,
+losses.py:9-53) evaluated in fp32 on the same fp16 inputs: sums within 1e-3 relative, logit gradients within 2e-3 of the
+largest gradient (they are written as fp16)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tscd_oracle as O
+
+
+def _scene(B, A, NC, Lmax, seed):
+    g = torch.Generator().manual_seed(seed)
+    raw = (torch.randn(B, A, 5 + NC, generator=g) * 2).half()
+    outputs = raw.clone()
+    outputs[..., 0:2] = (torch.rand(B, A, 2, generator=g) * 500).half()
+    outputs[..., 2:4] = (torch.rand(B, A, 2, generator=g) * 300 + 4).half()          # up to 304 px: areas above the fp16 range
+    labels = torch.zeros(B, Lmax, 5)
+    ngt = 7
+    labels[:, :ngt, 0] = torch.randint(0, NC, (B, ngt), generator=g).float()
+    labels[:, :ngt, 1:3] = torch.rand(B, ngt, 2, generator=g) * 500
+    labels[:, :ngt, 3:5] = torch.rand(B, ngt, 2, generator=g) * 250 + 6
+    labels = labels.half().float()
+    fg = torch.rand(B, A, generator=g) < 0.02
+    fg[1] = False                                                                     # a frame without foreground
+    mg = torch.where(fg, torch.randint(0, ngt, (B, A), generator=g), torch.full((B, A), -1)).int()
+    pi = torch.where(fg, torch.rand(B, A, generator=g), torch.zeros(B, A)).half().float()
+    # make some predictions overlap their gt well
+    for b in range(B):
+        idx = torch.nonzero(fg[b]).flatten()[::2]
+        outputs[b, idx, :4] = (labels[b, mg[b, idx].long(), 1:5] * (1 + 0.1 * torch.randn(len(idx), 4, generator=g))).half()
+    return raw, outputs, labels, fg, mg, pi
+
+
+@pytest.mark.parametrize("B,A,NC", [(3, 336, 25), (4, 6804, 30)])
+def test_dense_loss_matches_oracle_expressions(B, A, NC):
+    from tscd_amd import functional as TF
+    raw, outputs, labels, fg, mg, pi = _scene(B, A, NC, 20, B + NC)
+    r32 = raw.float().requires_grad_()
+    gt = torch.gather(labels[..., 1:5], 1, mg.clamp(min=0).long().unsqueeze(-1).expand(-1, -1, 4))
+    gcls = torch.gather(labels[..., 0], 1, mg.clamp(min=0).long()).long()
+    iou_l = O.iou_loss(outputs[..., :4].float().reshape(-1, 4)[fg.reshape(-1)], gt.reshape(-1, 4)[fg.reshape(-1)]).sum()
+    obj_l = F.binary_cross_entropy_with_logits(r32[..., 4], fg.float(), reduction="sum")
+    cls_t = F.one_hot(gcls, NC).float() * pi.unsqueeze(-1)
+    cls_l = F.binary_cross_entropy_with_logits(r32[..., 5:][fg], cls_t[fg], reduction="sum")
+    (2.0 * obj_l + 3.0 * cls_l).backward()
+    rd = raw.cuda().requires_grad_()
+    sums = TF.dense_loss(rd, outputs.cuda().contiguous(), fg.to(torch.uint8).cuda(), mg.cuda(), pi.cuda(), labels.cuda().contiguous(), NC)
+    (2.0 * sums[1] + 3.0 * sums[2]).backward()
+    torch.cuda.synchronize()
+    got = sums.detach().cpu()
+    for v, ref in zip(got.tolist(), (iou_l.item(), obj_l.item(), cls_l.item())):
+        assert abs(v - ref) <= 1e-3 * abs(ref) + 1e-3, (v, ref)
+    gd, gr = rd.grad.float().cpu(), r32.grad
+    assert torch.all(gd[..., :4] == 0)
+    assert (gd - gr).abs().max().item() <= 2e-3 * gr.abs().max().item()
+    # deterministic: a second evaluation gives the same bits
+    sums2 = TF.dense_loss(raw.cuda(), outputs.cuda().contiguous(), fg.to(torch.uint8).cuda(), mg.cuda(), pi.cuda(), labels.cuda().contiguous(), NC)
+    assert torch.equal(sums2.cpu(), got)
+
+
+@pytest.mark.parametrize("B,A,NC,N", [(3, 336, 25, 150), (4, 6804, 30, 2000)])
+def test_row_losses_match_oracle_expressions(B, A, NC, N):
+    from tscd_amd import functional as TF
+    raw, outputs, labels, fg, mg, pi = _scene(B, A, NC, 20, B + N)
+    g = torch.Generator().manual_seed(N)
+    # rows: half of them sit on foreground anchors
+    fgi = torch.nonzero(fg)
+    pick = fgi[torch.randint(0, len(fgi), (N // 2,), generator=g)]
+    rb = torch.cat((pick[:, 0], torch.randint(0, B, (N - N // 2,), generator=g)))
+    ra = torch.cat((pick[:, 1], torch.randint(0, A, (N - N // 2,), generator=g)))
+    cls = (torch.randn(N, NC, generator=g) * 2).half()
+    obj = (torch.randn(N, 1, generator=g) * 2).half()
+    reg = (torch.randn(N, 4, generator=g) * 1.5).half()
+    base = torch.zeros(N, 7 + NC)
+    base[:, 0:2] = torch.rand(N, 2, generator=g) * 400
+    base[:, 2:4] = base[:, 0:2] + torch.rand(N, 2, generator=g) * 200 + 5
+    base = base.half()
+    rmask = fg[rb, ra]
+    gt = labels[rb, mg[rb, ra].clamp(min=0).long()]
+    c32, o32, g32 = cls.float().requires_grad_(), obj.float().requires_grad_(), reg.float().requires_grad_()
+    t_cls = F.one_hot(gt[:, 0].long(), NC).float() * pi[rb, ra].unsqueeze(-1)
+    l_cls = F.binary_cross_entropy_with_logits(c32[rmask], t_cls[rmask], reduction="sum")
+    l_obj = F.binary_cross_entropy_with_logits(o32.view(-1), rmask.float(), reduction="sum")
+    tgt = O.encode_reg_preds(gt[rmask, 1:5], base[rmask, :4].float())
+    l_reg = F.smooth_l1_loss(g32[rmask], tgt, reduction="sum")
+    (l_cls + 2.0 * l_obj + 3.0 * l_reg).backward()
+    dev = lambda t: t.cuda()
+    args = (dev(rb.int()), dev(ra.int()), A, NC, dev(fg.to(torch.uint8)), dev(mg), dev(pi), dev(labels).contiguous())
+    cd, od, gd = dev(cls).requires_grad_(), dev(obj).requires_grad_(), dev(reg).requires_grad_()
+    s1 = TF.row_loss(*args, cls_logit=cd)
+    s2 = TF.row_loss(*args, obj_logit=od.reshape(-1), reg_delta=gd, base=dev(base)[:N])
+    (s1[0] + 2.0 * s2[1] + 3.0 * s2[2]).backward()
+    torch.cuda.synchronize()
+    for v, ref in ((s1[0], l_cls), (s2[1], l_obj), (s2[2], l_reg)):
+        assert abs(v.item() - ref.item()) <= 1e-3 * abs(ref.item()) + 1e-3, (v.item(), ref.item())
+    assert s1[1].item() == 0 and s1[2].item() == 0 and s2[0].item() == 0
+    for got, ref in ((cd.grad, c32.grad), (od.grad, o32.grad), (gd.grad, g32.grad)):
+        assert (got.float().cpu() - ref).abs().max().item() <= 2e-3 * max(ref.abs().max().item(), 1e-6)

@@ -1,0 +1,162 @@
+"""The import surface the reference's entry points and exp files rely on, performed against THIS package, and
+the clip input pipeline behind it on a tiny OVIS-style dataset written by the test.  CPU only.
+
+Import lists checked (reference file:line):
+  tools/tscd_train.py:17-23, tools/tscd_eval.py:18-24       yolox.core.launch, yolox.core.tscd_trainer.Trainer, yolox.exp.get_exp,
+                                                             yolox.utils.{configure_nccl,configure_omp,get_num_devices},
+                                                             yolox.data.data_augment.{ValTransform,Vid_Val_Transform}, yolox.data.datasets.vid
+  exps/TSCD_OVIS/tscd_base.py:10-12,214,321,462,477          yolox.data.datasets.vid, yolox.exp.base_exp.BaseExp, Vid_Val_Transform,
+                                                             yolox.models.{YOLOPAFPN}, tscd_head.TSCDHead, tscd.TSCD, yolox.data.TrainTransform,
+                                                             yolox.evaluators.ovis_evaluator_v2.OVISEvaluator, yolox.utils.LRScheduler
+  exps/TSCD_OVIS/ovis_tscd_large.py:6-9                      exps.TSCD_OVIS.tscd_base.Exp, vid, Vid_Val_Transform
+  tools/demo.py:17-22                                        ValTransform, vid_classes.{VID_classes,OVIS_classes}, get_exp,
+                                                             yolox.utils.{fuse_model,get_model_info,postprocess,vis}
+(loguru and cv2, which those files also import, are third-party packages, not part of this surface.)"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_reference_entry_point_imports_resolve():
+    from yolox.core import launch                                                    # noqa: F401
+    from yolox.core.tscd_trainer import Trainer                                      # noqa: F401
+    from yolox.exp import get_exp                                                    # noqa: F401
+    from yolox.utils import configure_nccl, configure_omp, get_num_devices           # noqa: F401
+    from yolox.data.data_augment import ValTransform, Vid_Val_Transform              # noqa: F401
+    from yolox.data.datasets import vid
+    from yolox.exp.base_exp import BaseExp                                           # noqa: F401
+    from yolox.models import YOLOPAFPN, YOLOX, YOLOXHead                             # noqa: F401
+    from yolox.models.tscd_head import TSCDHead                                      # noqa: F401
+    from yolox.models.tscd import TSCD                                               # noqa: F401
+    from yolox.data import TrainTransform                                            # noqa: F401
+    from yolox.evaluators.ovis_evaluator_v2 import OVISEvaluator                     # noqa: F401
+    from yolox.utils import LRScheduler                                              # noqa: F401
+    from yolox.data.datasets.vid_classes import VID_classes, OVIS_classes
+    from yolox.utils import fuse_model, get_model_info, postprocess, vis             # noqa: F401
+    for name in ("OVIS", "VIDDataset", "ovis_get_trans_loader", "ovis_vid_val_loader", "DataPrefetcher", "get_timing_signal_1d",
+                 "collate_fn_ovis", "TrainSampler", "TestSampler", "VIDBatchSampler"):
+        assert hasattr(vid, name), name
+    assert len(VID_classes) == 30 and len(OVIS_classes) == 25
+
+
+def test_exp_files_and_tools_load():
+    import importlib.util
+    from yolox.exp import get_exp
+    for f, nc, frames in (("exps/TSCD_OVIS/ovis_tscd_large.py", 25, (4, 12, 8, 24)), ("exps/TSCD_OVIS/ovis_tscd_base.py", 25, None),
+                          ("exps/TSCD_VID/vid_tscd_large.py", 30, (4, 12, 1, 31)), ("exps/TSCD_VID/vid_tscd_large_32f.py", 30, (8, 24, 8, 24)),
+                          ("exps/default/yolox_s.py", 80, None)):
+        exp = get_exp(f)
+        assert exp.num_classes == nc, f
+        if frames:
+            assert (exp.lframe, exp.gframe, exp.lframe_val, exp.gframe_val) == frames, f        # reference: vid_tscd_large.py:27-30
+    vid_exp = get_exp("exps/TSCD_VID/vid_tscd_large.py")
+    assert vid_exp.maximal_limit == 0 and vid_exp.minimal_limit == 50                           # :42, no upper clamp
+    m = get_exp("exps/default/yolox_s.py").get_model()
+    assert abs(sum(p.numel() for p in m.parameters()) / 1e6 - 8.97) < 0.05
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tool in ("tscd_train.py", "tscd_eval.py", "demo.py"):
+        spec = importlib.util.spec_from_file_location("tool_" + tool[:-3], os.path.join(root, "tools", tool))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)                                                             # imports resolve, parser builds
+        assert hasattr(mod, "make_parser")
+
+
+@pytest.fixture()
+def tiny_ovis(tmp_path):
+    """3 videos (7, 5, 2 frames) of 60x80 images, file names <video>/img_<frame>.png, 2 categories."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    images, anns, aid = [], [], 1
+    for sid, nframes in enumerate((7, 5, 2)):
+        os.makedirs(tmp_path / "train" / f"v{sid}", exist_ok=True)
+        for fidx in range(nframes):
+            name = f"v{sid}/img_{fidx}.png"
+            img = rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)
+            Image.fromarray(img).save(tmp_path / "train" / name)
+            iid = len(images) + 1
+            images.append({"id": iid, "sid": sid, "fid": fidx, "file_name": name, "width": 80, "height": 60})
+            if not (sid == 1 and fidx >= 3):                      # a few unlabeled frames
+                anns.append({"id": aid, "image_id": iid, "category_id": 1 + (fidx % 2), "bbox": [10 + fidx, 8, 30, 20], "area": 600, "iscrowd": 0})
+                aid += 1
+    ann = {"videos": [{"id": i} for i in range(3)], "images": images, "annotations": anns,
+           "categories": [{"id": 1, "name": "a"}, {"id": 2, "name": "b"}]}
+    with open(tmp_path / "ann.json", "w") as fh:
+        json.dump(ann, fh)
+    return tmp_path
+
+
+def test_ovis_clip_pipeline_contract(tiny_ovis):
+    from yolox.data import TrainTransform
+    from yolox.data.data_augment import Vid_Val_Transform
+    from yolox.data.datasets import vid
+    L, G = 2, 3
+    ds = vid.OVIS(data_dir=str(tiny_ovis), img_size=(64, 64), preproc=TrainTransform(max_labels=50), mode="random", lframe=L, gframe=G,
+                  name="train", COCO_anno=str(tiny_ovis / "ann.json"), training=True)
+    assert len(ds) > 0 and all(len(c) == L + G for c in ds.res)
+    for clip in ds.res:                                            # local frames: consecutive frames of one video
+        vids = {c.split("/")[0] for c in clip}
+        assert len(vids) == 1
+        idx = [int(c.rsplit("_", 1)[1].split(".")[0]) for c in clip[:L]]
+        assert idx == list(range(idx[0], idx[0] + L)) or len(set(idx)) == 1      # (a 2-frame video is padded by repetition)
+    loader = vid.ovis_get_trans_loader(batch_size=L + G, data_num_workers=0, dataset=ds, rank=0, world_size=1, seed=3)
+    imgs, targets, infos, raw, paths, temb = next(iter(loader))
+    assert imgs.shape == (L + G, 3, 64, 64) and imgs.dtype == torch.float32 and float(imgs.max()) <= 255
+    assert targets.shape == (L + G, 100, 5) and temb.shape == (L + G, 256)
+    frame_idx = torch.tensor([int(p.rsplit("_", 1)[1].split(".")[0]) for p in paths])
+    assert torch.allclose(temb, vid.get_timing_signal_1d(frame_idx, 256))
+    lab = targets[0][targets[0].sum(-1) > 0]
+    assert lab.shape[0] == 1 and 0 <= lab[0, 0] <= 1                      # (cls, cx, cy, w, h), class index 0/1
+    r = min(64 / 60, 64 / 80)
+    assert abs(float(lab[0, 3]) - 30 * r) < 1e-3 and abs(float(lab[0, 4]) - 20 * r) < 1e-3
+    # letterbox: the image occupies the top-left 48x64 region, the rest is the 114 fill
+    assert torch.all(imgs[0][:, int(60 * r):, :] == 114)
+    # validation transform keeps corner boxes
+    dv = vid.OVIS(data_dir=str(tiny_ovis), img_size=(64, 64), preproc=Vid_Val_Transform(), mode="random", lframe=L, gframe=G, name="train",
+                  COCO_anno=str(tiny_ovis / "ann.json"), val=True)
+    img, tgt, info, path = dv[dv.res[0][0]]
+    assert img.shape == (3, 64, 64) and tgt.shape[1] == 5 and info == (60, 80)
+
+
+def test_train_sampler_is_rank_aware_and_eval_sharding_is_video_affine(tiny_ovis):
+    from yolox.data.data_augment import Vid_Val_Transform
+    from yolox.data.datasets import vid
+    ds = vid.OVIS(data_dir=str(tiny_ovis), img_size=(64, 64), preproc=Vid_Val_Transform(), mode="random", lframe=1, gframe=1, name="train",
+                  COCO_anno=str(tiny_ovis / "ann.json"), val=True)
+    n = len(ds.res)
+    a, b = vid.TrainSampler(ds, rank=0, world_size=2, seed=1), vid.TrainSampler(ds, rank=1, world_size=2, seed=1)
+    ca, cb = [tuple(c) for c in a], [tuple(c) for c in b]
+    assert len(ca) + len(cb) == n and not (set(ca) & set(cb))                   # disjoint cover of the epoch's clips
+    ca2 = [tuple(c) for c in a]
+    assert ca2 != ca or n < 3                                                   # reshuffled in the next epoch
+    # evaluation: clips of one video never leave their rank (CAFM state flows clip -> clip inside a video)
+    e0, e1 = vid.TestSampler(ds, 0, 2), vid.TestSampler(ds, 1, 2)
+    v0 = {c[0].split("/")[0] for c in e0}
+    v1 = {c[0].split("/")[0] for c in e1}
+    assert not (v0 & v1) and len(list(e0)) + len(list(e1)) == n
+    order = [c[0] for c in e0]
+    assert order == [c[0] for c in ds.res if c[0].split("/")[0] in v0]           # dataset order kept inside the shard
+
+
+def test_letterbox_and_transforms():
+    from yolox.data.data_augment import TrainTransform, ValTransform, preproc, resize_bilinear
+    img = np.zeros((30, 40, 3), np.uint8)
+    img[:, 20:] = 200
+    out, r = preproc(img, (64, 64))
+    assert out.shape == (3, 64, 64) and abs(r - 1.6) < 1e-9
+    assert out[0, 0, 0] == 0 and out[0, 0, 63] == 200 and out[0, 47, 5] == 0 and out[0, 48, 5] == 114
+    # bilinear resampling: a constant image stays constant, a horizontal ramp stays monotone
+    assert np.all(resize_bilinear(np.full((7, 9, 3), 77, np.uint8), 20, 33) == 77)
+    ramp = np.tile(np.arange(0, 250, 10, dtype=np.uint8)[None, :, None], (5, 1, 3))
+    rr = resize_bilinear(ramp, 5, 60)
+    assert np.all(np.diff(rr[0, :, 0].astype(int)) >= 0) and rr[0, 0, 0] == 0 and rr[0, -1, 0] == 240
+    v, lab = ValTransform()(img, None, (64, 64))
+    assert v.shape == (3, 64, 64) and lab.shape == (1, 5)
+    t = TrainTransform(max_labels=7, flip_prob=1.0, hsv_prob=0.0)
+    boxes = np.array([[4.0, 5.0, 14.0, 25.0, 1.0]])
+    timg, tl = t(img.copy(), boxes, (64, 64))
+    assert tl.shape == (7, 5) and tl[0, 0] == 1
+    # flipped horizontally: cx' = (W - cx) * r
+    assert abs(tl[0, 1] - (40 - 9.0) * 1.6) < 1e-4 and abs(tl[0, 3] - 10 * 1.6) < 1e-4 and abs(tl[0, 4] - 20 * 1.6) < 1e-4

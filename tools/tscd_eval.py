@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """TSCD evaluation entry (CLI of the reference's tools/tscd_eval.py:28-183).  Runs the eval forward over the clips of
 the val loader in fp16 (the reference's OVISEvaluator calls model.half(), ovis_evaluator_v2.py:167-170), carrying the
-CAFM state across the clips of a video with ``resume``.  mAP scoring (COCOeval) is row N2 of SURVEY.md 8f; this script
-reports detections per clip and throughput."""
+CAFM state across the clips of a video with ``resume``.  With a dataset under ``exp.data_dir`` the exp's OVISEvaluator scores
+the detections (COCO bbox AP via tscd_amd's C++ COCOeval); without one the synthetic clip source is run and detections per
+clip and throughput are reported."""
 import argparse
 import os
 import sys
@@ -34,8 +35,13 @@ def main():
     model = exp.get_model().cuda().eval()
     if args.ckpt:
         model.load_state_dict(torch.load(args.ckpt, map_location="cuda", weights_only=True)["model"])
-    model.half()
     loader = exp.get_eval_loader(exp.lframe_val + exp.gframe_val)
+    if not hasattr(loader, "next"):                      # a real val loader: score with the exp's evaluator (N2)
+        ap50_95, ap50, summary = exp.eval(model, exp.get_evaluator(loader), False, half=True)
+        print(summary)
+        print(f"AP50:95 = {ap50_95:.4f}  AP50 = {ap50:.4f}")
+        return
+    model.half()
     t0 = time.time()
     for i in range(args.clips):
         imgs, _, temb = loader.next()

@@ -46,12 +46,14 @@ SIGNATURES = {
     "tscd_bias_relu_bwd_f16": [P, I, P, I, P, I, L, I, P, P, L, P],
     "tscd_linear_bwd_f16": [P, I, P, I, P, I, I, I, I, I, P, P, P, P, L, P],
     "tscd_simota_assign": [P, P, I, I, I, I, I, P, P, P, I, I, P, L, P, P, P, P, P, P],
+    "tscd_loss_dense_f16": [P, P, P, P, P, P, I, I, I, I, P, L, P, P, P],
+    "tscd_loss_rows_f16": [P, P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, L, P, P, P, P, P],
 }
 PLAIN = {"tscd_ema_chunk_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
          "tscd_bn_silu_bwd_workspace_bytes": ([L, I], L), "tscd_linear_bwd_workspace_bytes": ([I, I, I], L),
          "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
          "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),
-         "tscd_nms_workspace_bytes": ([I, I], L), "tscd_simota_workspace_bytes": ([I, I, I, I], L),
+         "tscd_nms_workspace_bytes": ([I, I], L), "tscd_simota_workspace_bytes": ([I, I, I, I], L), "tscd_loss_workspace_bytes": ([L, L, L], L),
          "tscd_conv_set_variant": ([I], None), "tscd_conv_set_korder": ([I], None), "tscd_conv_set_halo_auto": ([I], None), "tscd_conv_stat_tiles": ([L, I, I, I, I, I], I), "tscd_mca_backward_set_paired": ([I], I), "tscd_conv_wgrad_set_variant": ([I], I), "tscd_conv_set_debug": ([I], None), "tscd_cos_attn_mfma_supported": ([I], I), "tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
          "tscd_last_error": ([], C.c_char_p)}
 

@@ -1,0 +1,201 @@
+// Fused TSCD losses (reference: TSCDHead.get_matcher_refined_losses yolox/models/tscd_head.py:1008-1203, IOUloss
+// yolox/models/losses.py:9-53 (loss_type "iou": 1 - IoU^2), encode_reg_preds tscd_head.py:951-974).
+//
+// The reference evaluates the losses with boolean-mask gathers over per-image lists; the first port of this repository used
+// ~100 small device-PyTorch launches per step (where / one_hot / gather / mul / div / sum ...).  Here:
+//   loss_dense   one thread per (frame, anchor) over [B, A, 5+NC]:  IoU loss of the SimOTA-foreground anchors against their
+//                matched box, objectness BCE of every anchor (target = foreground), class BCE of the foreground anchors
+//                (target = onehot(matched class) * matched IoU) -- forward sums AND the gradients w.r.t. the raw obj / cls
+//                logits in the same pass (sigmoid(x) - t, masked), nothing intermediate in HBM;
+//   loss_rows    one wave per refined local proposal row:  class BCE of the refined class logits (target gathered from the
+//                same assignment through the row's (frame, anchor)), objectness BCE of the matched-objectness logit (target =
+//                "this proposal is a foreground anchor"), SmoothL1 of the box deltas against encode_reg_preds(gt, base box);
+//                sums + gradients in one pass;
+//   reduce       fixed-order reduction of the per-block partial sums (deterministic: two runs give bit-identical losses).
+// All arithmetic in fp32 on the fp16 inputs (the documented deviation of DESIGN.md section 2: the reference's fp16 prod
+// overflows for boxes above 65504 px^2).  Normalisation (1 / num_fg, the clip of the matched-objectness loss at 15, the loss
+// weights 3 / 6) is applied by the caller from the returned sums -- they are scalars on the device.
+#include "common.h"
+
+__device__ __forceinline__ float bce_logits(float x, float t) {
+  // max(x,0) - x t + log1p(exp(-|x|))  (torch.nn.functional.binary_cross_entropy_with_logits)
+  return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// partial [gridDim.x][3]: iou, obj, cls sums of the block.  d_logit [B][A][1+NC] fp16: d(obj_sum + cls_sum) / d raw logit
+// (channel 0 = objectness, 1.. = classes), un-normalised.
+__global__ __launch_bounds__(256) void loss_dense_kernel(const f16* __restrict__ raw, const f16* __restrict__ outputs,
+                                                        const unsigned char* __restrict__ fg, const int* __restrict__ matched_gt,
+                                                        const float* __restrict__ pred_iou, const float* __restrict__ labels,
+                                                        int B, int A, int NC, int Lmax, float* __restrict__ partial,
+                                                        f16* __restrict__ d_logit) {
+  __shared__ float red[4];
+  const long total = (long)B * A;
+  const int nch = 5 + NC;
+  float s_iou = 0.f, s_obj = 0.f, s_cls = 0.f;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int b = (int)(idx / A);
+    const f16* r = raw + idx * nch;
+    const bool f = fg[idx] != 0;
+    const float xo = (float)r[4];
+    s_obj += bce_logits(xo, f ? 1.f : 0.f);
+    f16* d = d_logit ? d_logit + idx * (1 + NC) : nullptr;
+    if (d) d[0] = (f16)(1.0f / (1.0f + expf(-xo)) - (f ? 1.f : 0.f));
+    if (f) {
+      const float* L = labels + ((long)b * Lmax + matched_gt[idx]) * 5;
+      const f16* o = outputs + idx * nch;
+      // IOUloss: boxes as (cx, cy, w, h)
+      const float px = (float)o[0], py = (float)o[1], pw = (float)o[2], ph = (float)o[3];
+      const float gx = L[1], gy = L[2], gw = L[3], gh = L[4];
+      const float tlx = fmaxf(px - pw * 0.5f, gx - gw * 0.5f), tly = fmaxf(py - ph * 0.5f, gy - gh * 0.5f);
+      const float brx = fminf(px + pw * 0.5f, gx + gw * 0.5f), bry = fminf(py + ph * 0.5f, gy + gh * 0.5f);
+      const float en = (tlx < brx && tly < bry) ? 1.f : 0.f;
+      const float ai = (brx - tlx) * (bry - tly) * en;
+      const float iou = ai / (pw * ph + gw * gh - ai + 1e-16f);
+      s_iou += 1.0f - iou * iou;
+      int gc = (int)L[0];
+      gc = gc < 0 ? 0 : (gc >= NC ? NC - 1 : gc);
+      const float tiou = pred_iou[idx];
+      for (int c = 0; c < NC; ++c) {
+        const float x = (float)r[5 + c], t = c == gc ? tiou : 0.f;
+        s_cls += bce_logits(x, t);
+        if (d) d[1 + c] = (f16)(1.0f / (1.0f + expf(-x)) - t);
+      }
+    } else if (d) {
+      for (int c = 0; c < NC; ++c) d[1 + c] = (f16)0.f;
+    }
+  }
+  const float a = block_sum_256(s_iou, red), o2 = block_sum_256(s_obj, red), c2 = block_sum_256(s_cls, red);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 3 + 0] = a;
+    partial[blockIdx.x * 3 + 1] = o2;
+    partial[blockIdx.x * 3 + 2] = c2;
+  }
+}
+
+// One wave per refined row n (a local-frame proposal): (b, a) = (row_b[n], row_a[n]).
+//   part bit 0: class BCE of cls_logit[n][NC]       -> partial[.][0], d_cls [N][NC]
+//   part bit 1: objectness BCE of obj_logit[n]      -> partial[.][1], d_obj [N]
+//   part bit 2: SmoothL1 of reg_delta[n][4]         -> partial[.][2], d_reg [N][4]      (beta = 1)
+// base: pred rows [N][ndet] with the base xyxy box in columns 0..3.
+__global__ __launch_bounds__(256) void loss_rows_kernel(const int* __restrict__ row_b, const int* __restrict__ row_a, int N, int A, int NC,
+                                                       int Lmax, const unsigned char* __restrict__ fg, const int* __restrict__ matched_gt,
+                                                       const float* __restrict__ pred_iou, const float* __restrict__ labels,
+                                                       const f16* __restrict__ cls_logit, const f16* __restrict__ obj_logit,
+                                                       const f16* __restrict__ reg_delta, const f16* __restrict__ base, int ndet, int part,
+                                                       float* __restrict__ partial, f16* __restrict__ d_cls, f16* __restrict__ d_obj,
+                                                       f16* __restrict__ d_reg) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float s_cls = 0.f, s_obj = 0.f, s_reg = 0.f;
+  for (int n = blockIdx.x * 4 + wv; n < N; n += gridDim.x * 4) {
+    const long idx = (long)row_b[n] * A + row_a[n];
+    const bool f = fg[idx] != 0;
+    const float* L = labels + ((long)row_b[n] * Lmax + (f ? matched_gt[idx] : 0)) * 5;
+    if (part & 1) {
+      int gc = (int)L[0];
+      gc = gc < 0 ? 0 : (gc >= NC ? NC - 1 : gc);
+      const float tiou = f ? pred_iou[idx] : 0.f;
+      for (int c = lane; c < NC; c += 64) {
+        const float x = (float)cls_logit[(long)n * NC + c], t = c == gc ? tiou : 0.f;
+        if (f) s_cls += bce_logits(x, t);
+        if (d_cls) d_cls[(long)n * NC + c] = f ? (f16)(1.0f / (1.0f + expf(-x)) - t) : (f16)0.f;
+      }
+    }
+    if ((part & 2) && lane == 0) {
+      const float x = (float)obj_logit[n], t = f ? 1.f : 0.f;
+      s_obj += bce_logits(x, t);
+      if (d_obj) d_obj[n] = (f16)(1.0f / (1.0f + expf(-x)) - t);
+    }
+    if ((part & 4) && lane < 4) {
+      float g = 0.f;
+      if (f) {
+        const f16* bb = base + (long)n * ndet;
+        const float x1 = (float)bb[0], y1 = (float)bb[1], x2 = (float)bb[2], y2 = (float)bb[3];
+        const float w = x2 - x1, h = y2 - y1, cx = x1 + 0.5f * w, cy = y1 + 0.5f * h;
+        // encode_reg_preds: ((gx - cx) / w, (gy - cy) / h, log(gw / w + 1e-8), log(gh / h + 1e-8))
+        float t;
+        if (lane == 0) t = (L[1] - cx) / w;
+        else if (lane == 1) t = (L[2] - cy) / h;
+        else if (lane == 2) t = logf(L[3] / w + 1e-8f);
+        else t = logf(L[4] / h + 1e-8f);
+        const float dlt = (float)reg_delta[(long)n * 4 + lane] - t, ad = fabsf(dlt);
+        s_reg += ad < 1.f ? 0.5f * dlt * dlt : ad - 0.5f;
+        g = ad < 1.f ? dlt : (dlt > 0.f ? 1.f : -1.f);
+      }
+      if (d_reg) d_reg[(long)n * 4 + lane] = (f16)g;
+    }
+  }
+  const float a = block_sum_256(s_cls, red), b2 = block_sum_256(s_obj, red), c2 = block_sum_256(s_reg, red);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 3 + 0] = a;
+    partial[blockIdx.x * 3 + 1] = b2;
+    partial[blockIdx.x * 3 + 2] = c2;
+  }
+}
+
+// sums[3] = sum over blocks of partial[block][3], fixed order (one wave per column, lanes stride the blocks, then a shuffle tree).
+__global__ void loss_reduce_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ sums) {
+  const int col = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (col >= 3) return;
+  float s = 0.f;
+  for (int i = lane; i < nblocks; i += 64) s += partial[i * 3 + col];
+  s = wave_sum(s);
+  if (lane == 0) sums[col] = s;
+}
+
+static int loss_blocks(long items, int per_block) {
+  long nb = (items + per_block - 1) / per_block;
+  return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+}
+
+extern "C" long tscd_loss_workspace_bytes(long B, long A, long N) {
+  return 3L * 4 * 1024 * 2 + 256;
+}
+
+// sums[3] (fp32, device): iou / obj / cls sums; d_logit [B][A][1+NC] fp16 or NULL.
+extern "C" int tscd_loss_dense_f16(const void* raw, const void* outputs, const unsigned char* fg_mask, const int* matched_gt,
+                                   const float* pred_iou, const float* labels, int B, int A, int NC, int Lmax, void* workspace,
+                                   long workspace_bytes, float* sums, void* d_logit, void* stream) {
+  TSCD_CHECK_ARG(raw && outputs && fg_mask && matched_gt && pred_iou && labels && workspace && sums, "loss_dense: null pointer");
+  TSCD_CHECK_ARG(B > 0 && A > 0 && NC > 0 && Lmax > 0, "loss_dense: bad sizes");
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_loss_workspace_bytes(B, A, 0), "loss_dense: workspace too small");
+  const int nb = loss_blocks((long)B * A, 256);
+  hipLaunchKernelGGL(loss_dense_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f16*)raw, (const f16*)outputs, fg_mask,
+                     matched_gt, pred_iou, labels, B, A, NC, Lmax, (float*)workspace, (f16*)d_logit);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(192), 0, (hipStream_t)stream, (const float*)workspace, nb, sums);
+  TSCD_CHECK_LAUNCH("loss_dense");
+  return TSCD_OK;
+}
+
+// sums[3]: refined class BCE / matched-objectness BCE / SmoothL1 sums over the N rows (parts not selected give 0).
+extern "C" int tscd_loss_rows_f16(const int* row_b, const int* row_a, int N, int A, int NC, int Lmax, const unsigned char* fg_mask,
+                                  const int* matched_gt, const float* pred_iou, const float* labels, const void* cls_logit,
+                                  const void* obj_logit, const void* reg_delta, const void* base, int ndet, int part, void* workspace,
+                                  long workspace_bytes, float* sums, void* d_cls, void* d_obj, void* d_reg, void* stream) {
+  TSCD_CHECK_ARG(row_b && row_a && fg_mask && matched_gt && pred_iou && labels && workspace && sums, "loss_rows: null pointer");
+  TSCD_CHECK_ARG(!(part & 1) || cls_logit, "loss_rows: class part without logits");
+  TSCD_CHECK_ARG(!(part & 2) || obj_logit, "loss_rows: objectness part without logits");
+  TSCD_CHECK_ARG(!(part & 4) || (reg_delta && base && ndet >= 4), "loss_rows: box part without deltas / base rows");
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_loss_workspace_bytes(0, 0, N), "loss_rows: workspace too small");
+  if (N <= 0) {
+    (void)hipMemsetAsync(sums, 0, 12, (hipStream_t)stream);
+    return TSCD_OK;
+  }
+  const int nb = loss_blocks(N, 4);
+  hipLaunchKernelGGL(loss_rows_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, row_b, row_a, N, A, NC, Lmax, fg_mask, matched_gt,
+                     pred_iou, labels, (const f16*)cls_logit, (const f16*)obj_logit, (const f16*)reg_delta, (const f16*)base, ndet, part,
+                     (float*)workspace, (f16*)d_cls, (f16*)d_obj, (f16*)d_reg);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(192), 0, (hipStream_t)stream, (const float*)workspace, nb, sums);
+  TSCD_CHECK_LAUNCH("loss_rows");
+  return TSCD_OK;
+}

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void nms_expand_kernel(const f16* __restrict__
   const f16 thr16 = (f16)thr;
   if (tid == 0) base = 0;
   __syncthreads();
-  const int per_row = mode == 0 ? NC : 1;
+  const int per_row = mode == 0 ? NC : 1;          // modes 1 / 2: one candidate per row (class = arg-max id)
   const long total = (long)n * per_row;
   for (long i0 = 0; i0 < total; i0 += 256) {
     long i = i0 + tid;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void nms_expand_kernel(const f16* __restrict__
         c.box[o * 4 + 0] = bx[0]; c.box[o * 4 + 1] = bx[1]; c.box[o * 4 + 2] = bx[2]; c.box[o * 4 + 3] = bx[3];
         c.score[o] = sc;
         c.aux[o * 3 + 0] = a_obj; c.aux[o * 3 + 1] = a_cs; c.aux[o * 3 + 2] = (f16)(float)cid;
-        c.cls[o] = cid;
+        c.cls[o] = mode == 2 ? 0 : cid;            // mode 2: class-agnostic suppression (utils/boxes.py:59-64), the row keeps its class
       }
     }
     __syncthreads();
@@ -282,7 +282,8 @@ extern "C" long tscd_nms_workspace_bytes(int L, int capM) {
 }
 
 // det [N,ndet] rows of the local frames (pred_result), frame_off [L+1] row offsets.
-// mode 0: refined set (needs cls_logit [N,NC], obj_logit [N], reg_delta [N,4]); mode 1: original detections.
+// mode 0: refined set (needs cls_logit [N,NC], obj_logit [N], reg_delta [N,4]); mode 1: original detections (one candidate per
+// row, class-aware); mode 2: the same with class-agnostic suppression (YOLOX demo postprocess).
 // out [L][capM][7] fp16, out_idx [L][capM] (kept candidate index = row*NC + class in mode 0, row in mode 1),
 // out_count [L].  Returns TSCD_ERR_ARG if a frame exceeds the LDS sort capacity.
 extern "C" int tscd_batched_nms(const void* det, int ndet, const int* frame_off, int L, const void* cls_logit,
@@ -290,7 +291,7 @@ extern "C" int tscd_batched_nms(const void* det, int ndet, const int* frame_off,
                                 int capM, int mode, void* workspace, long workspace_bytes, void* out, int* out_idx,
                                 int* out_count, int* overflow_flag, void* stream) {
   TSCD_CHECK_ARG(det && frame_off && workspace && out && out_idx && out_count && overflow_flag, "batched_nms: null pointer");
-  TSCD_CHECK_ARG(mode == 1 || (cls_logit && obj_logit && reg_delta), "batched_nms: mode 0 needs refined predictions");
+  TSCD_CHECK_ARG(mode == 1 || mode == 2 || (cls_logit && obj_logit && reg_delta), "batched_nms: mode 0 needs refined predictions");
   TSCD_CHECK_ARG(capM > 0 && capM <= NMS_MAXC, "batched_nms: capM=%d exceeds the %d candidates per frame the sort key can index", capM, NMS_MAXC);
   TSCD_CHECK_ARG(workspace_bytes >= tscd_nms_workspace_bytes(L, capM), "batched_nms: workspace too small");
   if (L == 0) return TSCD_OK;
@@ -314,7 +315,7 @@ extern "C" int tscd_batched_nms(const void* det, int ndet, const int* frame_off,
   hipLaunchKernelGGL(nms_sort_kernel, dim3(L), dim3(1024), (size_t)(P < NMS_CHUNK ? P : NMS_CHUNK) * 4, st, c.score, c.count, capM,
                      gkeys, P, order);
   TSCD_CHECK_LAUNCH("nms_sort");
-  hipLaunchKernelGGL(nms_greedy_kernel, dim3(L, NC), dim3(256), 0, st, c.box, c.cls, order, c.count, capM, iou_thresh, keep,
+  hipLaunchKernelGGL(nms_greedy_kernel, dim3(L, mode == 2 ? 1 : NC), dim3(256), 0, st, c.box, c.cls, order, c.count, capM, iou_thresh, keep,
                      overflow_flag);
   TSCD_CHECK_LAUNCH("nms_greedy");
   hipLaunchKernelGGL(nms_compact_kernel, dim3(L), dim3(256), 0, st, c.box, c.aux, order, keep, c.count, capM, (f16*)out,

@@ -77,9 +77,9 @@ class _ConvBnSiluTrain(torch.autograd.Function):
 
 
 def conv_bn_silu(x, weight, gamma, beta, running_mean, running_var, stride, training, out=None, residual=None,
-                 eps=ops.BN_EPS, momentum=ops.BN_MOMENTUM):
+                 eps=ops.BN_EPS, momentum=ops.BN_MOMENTUM, folded=None):
     """BaseConv forward (network_blocks.py:36-61).  x NHWC fp16.  ``out`` / ``residual`` (channel slices) are only
-    allowed on the no-grad path."""
+    allowed on the no-grad path.  ``folded``: eval-mode scale / shift [2,C] computed ahead of time (yolox.utils.fuse_model)."""
     if training and _needs_grad(x, weight, gamma, beta):
         assert out is None and residual is None
         return _ConvBnSiluTrain.apply(x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum)
@@ -89,7 +89,7 @@ def conv_bn_silu(x, weight, gamma, beta, running_mean, running_var, stride, trai
     if training:
         return ops.conv_bn_act_train(x, wpk, cout, k, stride, gamma, beta, running_mean, running_var, eps, momentum, ops.ACT_SILU,
                                      residual=residual, out=out)[0]
-    ss = ops.bn_fold(gamma, beta, running_mean, running_var, eps)
+    ss = folded if folded is not None else ops.bn_fold(gamma, beta, running_mean, running_var, eps)
     if residual is None:
         y, _ = ops.conv2d(x, wpk, cout, k, stride, ops.EPI_BN_SILU, scale_shift=ss, out=out)
         return y
@@ -171,3 +171,58 @@ def haar_hf(x):
 
 def haar_idwt_mul(hf, content):
     return _HaarIdwtMul.apply(hf, content) if _needs_grad(hf, content) else ops.haar_idwt_mul(hf.contiguous(), content)
+
+
+# ----------------------------------------------------------------------------------------------------
+# fused losses (tscd_amd/csrc/loss.hip): forward sums and the gradients w.r.t. the logits come out of ONE pass; backward only
+# scales the stored gradients by the upstream scalars
+# ----------------------------------------------------------------------------------------------------
+class _DenseLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes):
+        want = ctx.needs_input_grad[0]
+        sums, d = ops.loss_dense(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes, want_grad=want)
+        ctx.save_for_backward(d)
+        ctx.nc = num_classes
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        if d is None:
+            return (None,) * 7
+        nc = ctx.nc
+        # channel 0 (objectness) scales with d sums[1], channels 1.. (classes) with d sums[2]; the 4 box channels get no gradient
+        gv = torch.cat((g[1:2], g[2:3].expand(nc))).to(torch.float16)
+        return torch.nn.functional.pad(d * gv, (4, 0)), None, None, None, None, None, None
+
+
+def dense_loss(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes):
+    """-> fp32 [3]: IoU-loss sum (no gradient: the decoded boxes are detached), objectness BCE sum, class BCE sum."""
+    return _DenseLoss.apply(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes)
+
+
+class _RowLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls_logit, obj_logit, reg_delta, base, row_b, row_a, A, num_classes, fg_mask, matched_gt, pred_iou, labels):
+        c = lambda t: None if t is None else t.to(torch.float16).contiguous()
+        cls_l, obj_l, reg_d = c(cls_logit), c(obj_logit), c(reg_delta)
+        want = any(ctx.needs_input_grad[:3])
+        sums, d_cls, d_obj, d_reg = ops.loss_rows(row_b, row_a, A, num_classes, fg_mask, matched_gt, pred_iou, labels, cls_l, obj_l, reg_d,
+                                                  base, want_grad=want)
+        ctx.save_for_backward(d_cls, d_obj, d_reg)
+        ctx.shapes = [None if t is None else t.shape for t in (cls_logit, obj_logit, reg_delta)]
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        d_cls, d_obj, d_reg = ctx.saved_tensors
+        gh = g.to(torch.float16)
+        out = [None if d is None else (d * gh[i]).reshape(shp) for i, (d, shp) in enumerate(zip((d_cls, d_obj, d_reg), ctx.shapes))]
+        return (out[0], out[1], out[2]) + (None,) * 9
+
+
+def row_loss(row_b, row_a, A, num_classes, fg_mask, matched_gt, pred_iou, labels, cls_logit=None, obj_logit=None, reg_delta=None, base=None):
+    """-> fp32 [3]: refined class BCE sum (rows that are SimOTA foreground), matched-objectness BCE sum (all rows), SmoothL1 sum
+    of the box deltas (foreground rows); a part whose logits are None is 0."""
+    return _RowLoss.apply(cls_logit, obj_logit, reg_delta, base, row_b, row_a, A, num_classes, fg_mask, matched_gt, pred_iou, labels)

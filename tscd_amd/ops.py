@@ -748,6 +748,50 @@ def simota_assign(outputs, labels, geo, num_classes, max_gt, topk=10, emu16=True
 
 
 # ----------------------------------------------------------------------------------------------------
+# fused losses (loss.hip)
+# ----------------------------------------------------------------------------------------------------
+def loss_dense(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes, want_grad=True):
+    """Base-detector losses over [B,A,5+NC]: -> (sums fp32 [3] = IoU-loss / objectness-BCE / class-BCE sums (un-normalised),
+    d_logit fp16 [B,A,1+NC] = d(obj_sum + cls_sum) / d raw obj|cls logits, or None)."""
+    B, A, nch = raw_all.shape
+    dev = raw_all.device
+    assert raw_all.is_contiguous() and outputs.is_contiguous() and raw_all.dtype == torch.float16 and outputs.dtype == torch.float16
+    assert labels.dtype == torch.float32 and labels.is_contiguous() and pred_iou.dtype == torch.float32
+    ws_bytes = lib.tscd_loss_workspace_bytes(B, A, 0)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    sums = torch.empty((3,), dtype=torch.float32, device=dev)
+    d = torch.empty((B, A, 1 + num_classes), dtype=torch.float16, device=dev) if want_grad else None
+    call("tscd_loss_dense_f16", raw_all.data_ptr(), outputs.data_ptr(), fg_mask.data_ptr(), matched_gt.data_ptr(), pred_iou.data_ptr(),
+         labels.data_ptr(), B, A, num_classes, labels.shape[1], ws.data_ptr(), ws_bytes, sums.data_ptr(), _ptr(d), _stream())
+    return sums, d
+
+
+def loss_rows(row_b, row_a, A, num_classes, fg_mask, matched_gt, pred_iou, labels, cls_logit=None, obj_logit=None, reg_delta=None,
+              base=None, want_grad=True):
+    """Refined-head losses over the N local proposal rows (row n = anchor row_a[n] of frame row_b[n], int32): -> (sums fp32 [3] =
+    class BCE / matched-objectness BCE / SmoothL1 sums of the parts whose logits are given, d_cls, d_obj, d_reg (fp16 or None))."""
+    N = row_b.shape[0]
+    dev = row_b.device
+    part = (1 if cls_logit is not None else 0) | (2 if obj_logit is not None else 0) | (4 if reg_delta is not None else 0)
+    for t in (cls_logit, obj_logit, reg_delta):
+        assert t is None or (t.is_contiguous() and t.dtype == torch.float16)
+    assert row_b.dtype == torch.int32 and row_a.dtype == torch.int32 and row_b.is_contiguous() and row_a.is_contiguous()
+    ws_bytes = lib.tscd_loss_workspace_bytes(0, 0, N)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    sums = torch.empty((3,), dtype=torch.float32, device=dev)
+    mk = lambda t: torch.empty_like(t) if (t is not None and want_grad) else None
+    d_cls, d_obj, d_reg = mk(cls_logit), mk(obj_logit), mk(reg_delta)
+    ndet = 0
+    if base is not None:
+        assert base.dtype == torch.float16 and base.stride(1) == 1
+        ndet = base.stride(0)
+    call("tscd_loss_rows_f16", row_b.data_ptr(), row_a.data_ptr(), N, A, num_classes, labels.shape[1], fg_mask.data_ptr(),
+         matched_gt.data_ptr(), pred_iou.data_ptr(), labels.data_ptr(), _ptr(cls_logit), _ptr(obj_logit), _ptr(reg_delta), _ptr(base), ndet,
+         part, ws.data_ptr(), ws_bytes, sums.data_ptr(), _ptr(d_cls), _ptr(d_obj), _ptr(d_reg), _stream())
+    return sums, d_cls, d_obj, d_reg
+
+
+# ----------------------------------------------------------------------------------------------------
 # backward kernels of the trainable head convs
 # ----------------------------------------------------------------------------------------------------
 def conv_wgrad(x, dy, cin, cout, ksize):

@@ -1,34 +1,41 @@
-"""IOUloss (interface of the reference's yolox/models/losses.py:9-53); elementwise on device tensors."""
+"""``IOUloss`` -- the plugin-surface class of the reference's yolox/models/losses.py:9-53 (constructor arguments ``reduction`` /
+``loss_type``, boxes as (cx, cy, w, h) rows).  The TSCD head does not call it: its IoU loss is one term of the fused loss
+kernel (tscd_amd/csrc/loss.hip).  The module stays for code that instantiates it directly; the arithmetic is restated here
+from the definition (1 - IoU^2, or 1 - GIoU)."""
 import torch
 import torch.nn as nn
+
+
+def _corners(b):
+    half = b[:, 2:4] * 0.5
+    return b[:, 0:2] - half, b[:, 0:2] + half
 
 
 class IOUloss(nn.Module):
     def __init__(self, reduction="none", loss_type="iou"):
         super().__init__()
-        self.reduction = reduction
-        self.loss_type = loss_type
+        if loss_type not in ("iou", "giou"):
+            raise ValueError(f"unknown loss_type {loss_type!r}")
+        self.reduction, self.loss_type = reduction, loss_type
 
     def forward(self, pred, target):
-        assert pred.shape[0] == target.shape[0]
-        pred, target = pred.view(-1, 4), target.view(-1, 4)
-        tl = torch.max(pred[:, :2] - pred[:, 2:] / 2, target[:, :2] - target[:, 2:] / 2)
-        br = torch.min(pred[:, :2] + pred[:, 2:] / 2, target[:, :2] + target[:, 2:] / 2)
-        area_p, area_g = torch.prod(pred[:, 2:], 1), torch.prod(target[:, 2:], 1)
-        en = (tl < br).type(tl.type()).prod(dim=1)
-        area_i = torch.prod(br - tl, 1) * en
-        area_u = area_p + area_g - area_i
-        iou = area_i / (area_u + 1e-16)
+        if pred.shape[0] != target.shape[0]:
+            raise ValueError("pred / target row counts differ")
+        p, t = pred.reshape(-1, 4), target.reshape(-1, 4)
+        (p_lo, p_hi), (t_lo, t_hi) = _corners(p), _corners(t)
+        lo, hi = torch.maximum(p_lo, t_lo), torch.minimum(p_hi, t_hi)
+        overlap = (hi - lo).clamp(min=0)
+        inter = overlap[:, 0] * overlap[:, 1]
+        union = p[:, 2] * p[:, 3] + t[:, 2] * t[:, 3] - inter
+        iou = inter / (union + 1e-16)
         if self.loss_type == "iou":
-            loss = 1 - iou ** 2
-        elif self.loss_type == "giou":
-            c_tl = torch.min(pred[:, :2] - pred[:, 2:] / 2, target[:, :2] - target[:, 2:] / 2)
-            c_br = torch.max(pred[:, :2] + pred[:, 2:] / 2, target[:, :2] + target[:, 2:] / 2)
-            area_c = torch.prod(c_br - c_tl, 1)
-            giou = iou - (area_c - area_u) / area_c.clamp(1e-16)
-            loss = 1 - giou.clamp(min=-1.0, max=1.0)
+            loss = 1.0 - iou * iou
+        else:
+            hull = torch.maximum(p_hi, t_hi) - torch.minimum(p_lo, t_lo)
+            hull_area = (hull[:, 0] * hull[:, 1]).clamp(min=1e-16)
+            loss = 1.0 - (iou - (hull_area - union) / hull_area).clamp(-1.0, 1.0)
         if self.reduction == "mean":
-            loss = loss.mean()
-        elif self.reduction == "sum":
-            loss = loss.sum()
+            return loss.mean()
+        if self.reduction == "sum":
+            return loss.sum()
         return loss

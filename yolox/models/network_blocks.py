@@ -81,7 +81,8 @@ class BaseConv(nn.Module):
         y = TF.conv_bn_silu(x, self.conv.weight, bn.weight.float(), bn.bias.float(),
                             bn.running_mean if bn.running_mean.dtype == torch.float32 else bn.running_mean.float(),
                             bn.running_var if bn.running_var.dtype == torch.float32 else bn.running_var.float(),
-                            self.stride, training, out=out, residual=residual, eps=bn.eps, momentum=bn.momentum)
+                            self.stride, training, out=out, residual=residual, eps=bn.eps, momentum=bn.momentum,
+                            folded=None if training else getattr(self, "_folded", None))
         return y
 
     fuseforward = forward

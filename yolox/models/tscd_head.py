@@ -24,7 +24,6 @@ from tscd_amd import functional as TF
 from tscd_amd import ops
 from tscd_amd.autograd import eager_branch
 
-from .losses import IOUloss
 from .network_blocks import BaseConv
 from .post_process import nms_frames
 from .post_trans import MCA_tscd_g2l_reg
@@ -140,7 +139,8 @@ class TSCDHead(nn.Module):
         self.use_l1 = False
         self.l1_loss = nn.L1Loss(reduction="none")
         self.bcewithlog_loss = nn.BCEWithLogitsLoss(reduction="none")
-        self.iou_loss = IOUloss(reduction="none")
+        from .losses import IOUloss
+        self.iou_loss = IOUloss(reduction="none")      # attribute kept for the reference's module tree; the head's IoU loss runs in loss.hip
         self.smooth_l1_loss = nn.SmoothL1Loss(reduction="none")
         self.strides = strides
         self.ota_mode = True
@@ -240,8 +240,10 @@ class TSCDHead(nn.Module):
         if not training and B == 1:
             pr = [pred_rows[off[i]:off[i + 1]] for i in range(B)]
             return pr, pr
-        a_idx = torch.cat([sel_idx[b, :ppf[b]] for b in range(B)]).long()
+        a_idx32 = torch.cat([sel_idx[b, :ppf[b]] for b in range(B)])                    # int32 anchor id of every proposal row
+        a_idx = a_idx32.long()
         b_idx = torch.repeat_interleave(torch.arange(B, device=dev), ops.h2d(ppf, torch.long, dev), output_size=N)
+        b_idx32 = b_idx.int()
 
         def gather(feature_maps):
             maps = [m.contiguous() for m in feature_maps]
@@ -282,27 +284,20 @@ class TSCDHead(nn.Module):
         if training:
             # ---------------- losses (get_matcher_refined_losses, tscd_head.py:1008-1203), dense + masked: everything that
             # does not involve the matcher's outputs is queued here, inside the assignment window ----------------
-            raw_f = raw_all.float()
+            # fused loss kernels (tscd_amd/csrc/loss.hip): sums + logit gradients in one pass each
             fg = fg_mask.bool()
-            lab = labels.float()
-            mg = matched_gt.clamp(min=0).long()
-            gt_box = torch.gather(lab[..., 1:5], 1, mg.unsqueeze(-1).expand(-1, -1, 4))          # [B,A,4] cxcywh of matched gt
-            gt_cls = torch.gather(lab[..., 0], 1, mg).long().clamp(0, nc - 1)
+            lab = labels.float().contiguous()
             num_fg = num_fg_b.sum().float().clamp(min=1)
             num_gts = ngt_b.sum().float()
-            iou_l = self.iou_loss(outputs[..., :4].float().reshape(-1, 4), gt_box.reshape(-1, 4)).view(B, -1)
-            loss_iou = torch.where(fg, iou_l, torch.zeros_like(iou_l)).sum() / num_fg
-            loss_obj = self.bcewithlog_loss(raw_f[..., 4], fg.float()).sum() / num_fg
-            cls_t = F.one_hot(gt_cls, nc).float() * pred_iou.unsqueeze(-1)
-            loss_cls = (self.bcewithlog_loss(raw_f[..., 5:], cls_t) * fg.unsqueeze(-1)).sum() / num_fg
+            dense = TF.dense_loss(raw_all.contiguous(), outputs, fg_mask, matched_gt, pred_iou, lab, nc)   # IoU / obj / cls sums
+            loss_iou, loss_obj, loss_cls = dense[0] / num_fg, dense[1] / num_fg, dense[2] / num_fg
             # refined heads: local-frame proposals that SimOTA marked foreground
-            lb, la = b_idx[:nl], a_idx[:nl]
-            rmask = fg[lb, la]
+            row_b, row_a = b_idx32[:nl].contiguous(), a_idx32[:nl].contiguous()
             num_fg_local = num_fg_b[:lframe].sum().float()
-            r_cls_t = cls_t[lb, la]
+            rowargs = (row_b, row_a, geo.A, nc, fg_mask, matched_gt, pred_iou, lab)
 
             def class_loss(cp):
-                return (self.bcewithlog_loss(cp.float(), r_cls_t) * rmask.unsqueeze(-1)).sum() / num_fg_local
+                return TF.row_loss(*rowargs, cls_logit=cp)[0] / num_fg_local
 
             if eager:
                 # first MCA -> cls_pred -> refined class loss, forward AND backward, queued inside the assignment window
@@ -320,8 +315,6 @@ class TSCDHead(nn.Module):
                     branch, [f_cls, f_reg, cls_scores], list(self.agg.parameters()) + list(self.cls_pred.parameters()), seed, track)
             else:
                 loss_r_cls = class_loss(cls_preds)
-            base = pred_rows[:nl, :4].float()
-            tgt = self._encode_reg(gt_box[lb, la], base, rmask)
         hook = getattr(self, "window_hook", None)
         if hook is not None:          # queued behind the window's own work: the next clip's frozen backbone pass (tscd.py)
             hook()
@@ -345,24 +338,10 @@ class TSCDHead(nn.Module):
             return res, res_ori
 
         # ---------------- refined-head losses (the rest was queued inside the assignment window) ----------------
-        loss_m_obj = self.bcewithlog_loss(m_obj.float().view(-1), rmask.float()).sum() / num_fg_local
-        sl1 = self.smooth_l1_loss(torch.where(rmask.unsqueeze(-1), m_reg.float(), torch.zeros_like(tgt)), tgt)
-        loss_m_iou = (sl1 * rmask.unsqueeze(-1)).sum() / num_fg_local
+        rows = TF.row_loss(*rowargs, obj_logit=m_obj.reshape(-1), reg_delta=m_reg, base=pred_rows[:nl])
+        loss_m_obj, loss_m_iou = rows[1] / num_fg_local, rows[2] / num_fg_local
         loss_m_obj = torch.where(loss_m_obj > 15, loss_m_obj / loss_m_obj.detach() * 15, loss_m_obj)
         loss = 3.0 * loss_iou + loss_obj + loss_cls + loss_r_cls + loss_m_obj + 6.0 * loss_m_iou
-        self._dbg(fg_mask=fg_mask, matched_gt=matched_gt, pred_iou=pred_iou, num_fg=num_fg_b, refined_fg_rows=rmask.sum())
+        self._dbg(fg_mask=fg_mask, matched_gt=matched_gt, pred_iou=pred_iou, num_fg=num_fg_b, refined_fg_rows=fg[b_idx[:nl], a_idx[:nl]].sum())
         return (loss, 3.0 * loss_iou, loss_obj, loss_cls, 0.0, num_fg / num_gts.clamp(min=1), loss_r_cls, loss_m_obj,
                 6.0 * loss_m_iou)
-
-    @staticmethod
-    def _encode_reg(gt_cxcywh, base_xyxy, mask, eps=1e-8):
-        """encode_reg_preds (tscd_head.py:951-974); rows outside ``mask`` are neutralised to avoid NaNs."""
-        w = base_xyxy[:, 2] - base_xyxy[:, 0]
-        h = base_xyxy[:, 3] - base_xyxy[:, 1]
-        cx, cy = base_xyxy[:, 0] + 0.5 * w, base_xyxy[:, 1] + 0.5 * h
-        one = torch.ones_like(w)
-        w_, h_ = torch.where(mask, w, one), torch.where(mask, h, one)
-        gw, gh = torch.where(mask, gt_cxcywh[:, 2], one), torch.where(mask, gt_cxcywh[:, 3], one)
-        t = torch.stack(((gt_cxcywh[:, 0] - cx) / w_, (gt_cxcywh[:, 1] - cy) / h_, torch.log(gw / w_ + eps),
-                         torch.log(gh / h_ + eps)), dim=1)
-        return torch.where(mask.unsqueeze(-1), t, torch.zeros_like(t))
