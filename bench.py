@@ -43,10 +43,24 @@ def parse():
     ap.add_argument("--lr", type=float, default=1e-6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-only-baseline", action="store_true", help=argparse.SUPPRESS)
-    return ap.parse_args()
+    # BASELINE.json configs other than the headline one (c3): same step, other model / clip / mode.  c2 = TSCD-S, 8 frames (2+6)
+    # @576^2, evaluation in .half() incl. the final NMS; c4 = TSCD-L, 32 frames (8+24), 30 classes, up to 2000 proposals per frame
+    # (ImageNet-VID regime, one clip per GPU); c5 = "TSCD-X" (depth 1.33, width 1.25), 32 frames @704^2, one clip per GPU.
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--classes", type=int, default=25)
+    ap.add_argument("--max-props", type=int, default=500)
+    ap.add_argument("--mode", default="train", choices=["train", "eval"])
+    a = ap.parse_args()
+    preset = {"c2": dict(frames=8, lframe=2, size=576, depth=0.33, width=0.5, mode="eval"),
+              "c4": dict(frames=32, lframe=8, size=576, classes=30, max_props=2000),
+              "c5": dict(frames=32, lframe=8, size=704, depth=1.33, width=1.25)}.get(a.config, {})
+    for k, v in preset.items():
+        setattr(a, k, v)
+    return a
 
 
-NUM_CLASSES = 25
+NUM_CLASSES = 25          # overwritten from --classes / --config in main()
+MAX_PROPS = 500
 
 
 def build_model(depth, width, props):
@@ -61,7 +75,7 @@ def build_model(depth, width, props):
     more = dict(use_ffn=True, use_time_emd=False, use_loc_emd=True, loc_fuse_type="identity", use_qkv=True, local_mask=False,
                 local_mask_branch="", pure_pos_emb=False, loc_conf=False, iou_base=False, reconf=True, ota_mode=True, ota_cls=False,
                 traj_linking=False, iou_window=0, globalBlocks=1, use_pre_nms=False, cat_ota_fg=False, agg_type="mca",
-                minimal_limit=50, maximal_limit=500, conf_sim_thresh=0.99, decouple_reg=True)
+                minimal_limit=50, maximal_limit=MAX_PROPS, conf_sim_thresh=0.99, decouple_reg=True)
     head = TSCDHead(NUM_CLASSES, width, in_channels=in_channels, heads=4, drop=0.0, use_score=True, defualt_p=30, sim_thresh=0.75,
                     pre_nms=0.75, ave=True, defulat_pre=750, test_conf=0.001, use_mask=False, gmode=True, lmode=True,
                     both_mode=False, localBlocks=1, **more)
@@ -193,7 +207,7 @@ def cpu_baseline(args, state_dict, clip):
     from oracle import tscd_oracle as O
     ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("TSCD_CPU_THREADS", "16")))
     torch.set_num_threads(ncores)
-    cfg = O.TSCDConfig(num_classes=NUM_CLASSES, depth=args.depth, width=args.width, minimal_limit=50, maximal_limit=500,
+    cfg = O.TSCDConfig(num_classes=NUM_CLASSES, depth=args.depth, width=args.width, minimal_limit=50, maximal_limit=MAX_PROPS,
                        simota_autocast=True,      # assignment in the arithmetic of autocast training (what the product reproduces)
                        simota_matched_pair_iou=True)    # ... minus its NaN-poisoned IoU sum (simota.hip header): finite class targets
     sd = {}
@@ -212,10 +226,15 @@ def cpu_baseline(args, state_dict, clip):
                         clip[2][:n])
     imgs, targets, temb = sub(nf, nl)
     t0 = time.time()
-    out = O.tscd_forward(sd, cfg, imgs.float(), targets.float(), temb.float(), 0.5, nl, nf - nl, False, True, O.MatcherState(), None)
-    out["total_loss"].backward()
+    train = args.mode == "train"
+    if train:
+        out = O.tscd_forward(sd, cfg, imgs.float(), targets.float(), temb.float(), 0.5, nl, nf - nl, False, True, O.MatcherState(), None)
+        out["total_loss"].backward()
+    else:
+        with torch.no_grad():
+            out = O.tscd_forward(sd, cfg, imgs.float(), None, temb.float(), 0.5, nl, nf - nl, False, False, O.MatcherState(), None)
     dt = (time.time() - t0) * div
-    if div > 1 and dt < 40.0:     # cheap enough: measure the whole clip instead of extrapolating
+    if div > 1 and dt < 40.0 and train:     # cheap enough: measure the whole clip instead of extrapolating
         div, nf, nl = 1, args.frames, args.lframe
         for v in sd.values():
             v.grad = None
@@ -225,12 +244,12 @@ def cpu_baseline(args, state_dict, clip):
         out["total_loss"].backward()
         dt = time.time() - t0
     losses = None
-    if div == 1:      # whole clip, same weights and inputs as the GPU's first step: keep the losses as a full-size parity signal
+    if div == 1 and train:      # whole clip, same weights and inputs as the GPU's first step: keep the losses as a full-size parity signal
         losses = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in out.items() if k in ("total_loss", "iou_loss", "conf_loss", "cls_loss", "num_fg",
                                                                 "loss_matched_cls", "loss_matched_obj", "loss_matched_iou")}
     return {"value": 1.0 / dt, "unit": "clips/s", "cores": ncores, "kind": "port", "losses_step0": losses,
             "sample": f"{nf} of {args.frames} frames ({nl} local + {nf - nl} global) @{args.size}^2, TSCD d{args.depth}/w{args.width}, "
-                      f"fwd+bwd, {args.props} props/frame, measured {dt / div:.1f} s x{div} = {dt:.1f} s per clip; "
+                      f"{'fwd+bwd' if train else 'eval fwd'}, {args.props} props/frame, measured {dt / div:.1f} s x{div} = {dt:.1f} s per clip; "
                       f"oracle/tscd_oracle.py, torch {torch.__version__} fp32, {ncores} threads"}
 
 
@@ -305,11 +324,17 @@ LOSS_TERMS = ("total_loss", "iou_loss", "conf_loss", "cls_loss", "num_fg", "loss
 
 
 def conv_flops_per_clip(args):
-    """Algorithmic conv FLOPs of one TSCD-L train step ([probe]): 3.776 TFLOP at 16 frames @576^2, scaling with
-    frames x pixels; None for other widths/depths (no probe figure)."""
-    if args.depth != 1.0 or args.width != 1.0:
-        return None
-    return 3.776e12 * (args.frames / 16.0) * (args.size / 576.0) ** 2
+    """Algorithmic conv FLOPs of one step ([probe] figures, scaling with frames x pixels): TSCD-L 3.776 TFLOP per
+    16-frame @576^2 train step, 2.684 forward only; TSCD-S 0.257 TFLOP per 8-frame @576^2 forward; "TSCD-X" 2 x 219.25 GMAC per
+    frame @704^2 forward.  None where SURVEY has no figure (S / X training, 30-class heads differ by < 0.1 %)."""
+    scale = (args.size / 576.0) ** 2
+    if (args.depth, args.width) == (1.0, 1.0):
+        return (3.776e12 if args.mode == "train" else 2.684e12) * (args.frames / 16.0) * scale
+    if (args.depth, args.width) == (0.33, 0.5) and args.mode == "eval":
+        return 0.257e12 * (args.frames / 8.0) * scale
+    if (args.depth, args.width) == (1.33, 1.25) and args.mode == "eval":
+        return 2 * 219.25e9 * args.frames * (args.size / 704.0) ** 2
+    return None
 
 
 def simota_check(head_dbg, targets, size):
@@ -342,6 +367,9 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    global NUM_CLASSES, MAX_PROPS
+    NUM_CLASSES, MAX_PROPS = args.classes, args.max_props
+    train = args.mode == "train"
     model = build_model(args.depth, args.width, args.props).to(device).train()
     opt = make_optimizer(model, lr=args.lr)
     # init_scale 2^10: the loss of the random-init head is ~2e3, so the default 2^16 overflows fp16 activation gradients and the
@@ -358,8 +386,17 @@ def main():
     one = torch.ones((), dtype=torch.float32, device=device)
     clip = {"targets": targets_on_top_proposals(model, imgs, targets0, temb, args.lframe, gframe)}
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    if not train:
+        # evaluation as the reference's OVISEvaluator runs it (ovis_evaluator_v2.py:167-170): model.eval().half(), no autocast;
+        # one call = backbone + head + proposal stage + refined heads + the final class-wise NMS of the local frames
+        net = model = model.eval().half()
 
-    def step():
+    def step_eval():
+        with torch.no_grad():
+            res, ori = net(imgs, time_embedding=temb, lframe=args.lframe, gframe=gframe, resume=False)
+        return torch.as_tensor(float(sum(0 if r is None else r.shape[0] for r in res)))     # detections of the local frames
+
+    def step_train():
         # next_x: the following clip (here the same synthetic tensor); its frozen backbone pass runs inside this step's
         # assignment window (yolox/models/tscd.py) and is consumed by the next call -- one backbone pass per step either way
         model.head.loss_scale = scaler.scale(one)      # this step's loss scale for the head's eager class branch (device tensor)
@@ -372,6 +409,8 @@ def main():
         model.join_prefetch()          # the EMA reads the backbone's running statistics: behind the prefetched pass that updates them
         ema.update()
         return loss
+
+    step = step_train if train else step_eval
 
     def sync():
         if world > 1:
@@ -402,7 +441,7 @@ def main():
 
     verbose = bool(os.environ.get("TSCD_BENCH_VERBOSE"))
     losses_step0, simota = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and train:
         # untimed: the loss terms and the assignment of the very first step (initial weights) for the full-size parity line below
         model.head.debug = {}
         out0 = net(imgs, clip["targets"], temb, lframe=args.lframe, gframe=gframe, resume=False)
@@ -426,7 +465,8 @@ def main():
     other = "50" if args.props == "500" else "500"
     set_regime(model, other)
     main_targets = clip["targets"]
-    clip["targets"] = targets_on_top_proposals(model, imgs, targets0, temb, args.lframe, gframe)
+    if train:
+        clip["targets"] = targets_on_top_proposals(model, imgs, targets0, temb, args.lframe, gframe)
     o_steps = max(5, args.steps // 2)
     o_dt, o_loss = timed(min(args.warmup, 5), o_steps)
     other_line = {"props": other, "value": world * o_steps / o_dt, "unit": "clips/s", "ms_per_step": o_dt / o_steps * 1e3, "steps": o_steps,
@@ -436,14 +476,17 @@ def main():
     clip["targets"] = main_targets
     if rank == 0:
         line = {
-            "metric": "clips/s (16f 576^2, TSCD-L train step)", "value": world * args.steps / dt, "unit": "clips/s", "n_gpus": world,
+            "metric": "clips/s (16f 576^2, TSCD-L train step)" if args.config == "c3" else
+                      f"clips/s ({args.frames}f {args.size}^2, TSCD d{args.depth}/w{args.width} {'train step' if train else 'eval clip incl. NMS'}, BASELINE config {args.config})",
+            "value": world * args.steps / dt, "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"TSCD d{args.depth}/w{args.width} train step (fwd+bwd+SGD+EMA), {args.frames}-frame {args.size}^2 clip per GPU, "
+            "config": {"workload": f"TSCD d{args.depth}/w{args.width} {'train step (fwd+bwd+SGD+EMA)' if train else 'evaluation clip (.half(), incl. final NMS)'}, {args.frames}-frame {args.size}^2 clip per GPU, "
                                    f"lframe {args.lframe}+gframe {gframe}, {args.props} proposals/frame, {NUM_CLASSES} classes, random init, "
-                                   f"6 boxes/frame placed on the initial model's top proposals",
+                                   f"6 boxes/frame placed on the initial model's top proposals, proposal cap {MAX_PROPS}",
                        "clips_per_step": world, "parallelism": f"dp{world}"},
-            "loss": final_loss, "lr": args.lr, "grad_scale": float(scaler.get_scale()), "roofline": roof, "other_regime": other_line,
+            "loss" if train else "detections_per_clip": final_loss, "lr": args.lr if train else None,
+            "grad_scale": float(scaler.get_scale()) if train else None, "roofline": roof, "other_regime": other_line,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -1,0 +1,269 @@
+"""BASELINE.json configs at their full workloads on the GPU, through size-independent properties (finite outputs, proposal counts
+inside the exp's clamps, detections in decreasing score order, BatchNorm statistics advancing once per step, every trainable
+tensor receiving a finite gradient), plus an oracle comparison of the YOLOX config at its real size and a 2-rank
+DistributedDataParallel check on the real forward.
+
+  C1  YOLOX-S, one 640x640 image, eval + class-agnostic postprocess (tools/demo.py path)
+  C2  TSCD-S, 8 frames (2 local + 6 global) @576^2, model.eval().half(), incl. the final NMS
+  C3  TSCD-L 16 frames train: tests/test_gpu_fullsize_c3.py (stage-by-stage oracle parity at full size)
+  C4  TSCD-L, 30 classes, 2000-proposal cap (ImageNet-VID regime): eval of a 1 + 7 frame clip -- 60000 NMS candidates per frame
+  C5  "TSCD-X" (depth 1.33, width 1.25, head width 320), 8 + 24 frames @704^2: one train step
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sorted_by_score(rows):
+    s = (rows[:, 4].float() * rows[:, 5].float()).half().float()
+    return bool(torch.all(s[:-1] >= s[1:]))
+
+
+def test_c1_yolox_s_640_eval_matches_oracle_and_postprocess():
+    from oracle import tscd_oracle as O
+    from yolox.exp import get_exp
+    from yolox.utils import fuse_model, postprocess
+    torch.manual_seed(0)
+    exp = get_exp("exps/default/yolox_s.py")
+    model = exp.get_model()
+    g = torch.Generator().manual_seed(1)
+    for m in model.modules():                       # condition the random init (see oracle/make_golden.py): O(1) eval-mode activations
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = 0.8 + 0.4 * torch.rand(m.weight.shape, generator=g)
+            m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=g)
+            m.running_var.data = 0.5 + torch.rand(m.running_var.shape, generator=g)
+    for conv in list(model.head.obj_preds) + list(model.head.cls_preds):
+        conv.bias.data.fill_(-2.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    img = (torch.rand(1, 3, 640, 640, generator=g) * 255).round()
+    # ---- oracle: backbone + head convs + decode, fp32 CPU (yolo_head.py:145-228,250-265) ----
+    cfg = O.TSCDConfig(num_classes=80, depth=0.33, width=0.5)
+    with torch.no_grad():
+        fpn = O.yolo_pafpn(sd, img, cfg, False)
+        outs = []
+        for k, x in enumerate(fpn):
+            x = O.base_conv(sd, f"head.stems.{k}", x)
+            cls_feat, reg_feat = O.tower(sd, f"head.cls_convs.{k}", x, False), O.tower(sd, f"head.reg_convs.{k}", x, False)
+            outs.append(torch.cat([O.conv_pred(sd, f"head.reg_preds.{k}", reg_feat), O.conv_pred(sd, f"head.obj_preds.{k}", reg_feat).sigmoid(),
+                                   O.conv_pred(sd, f"head.cls_preds.{k}", cls_feat).sigmoid()], 1).flatten(2))
+        hw = [t.shape[-2:] for t in fpn]
+        xs, ys, ss = O.make_grids(hw, cfg.strides)
+        t = torch.cat(outs, 2).permute(0, 2, 1)
+        ref = torch.cat(((t[..., :2] + torch.stack((xs, ys), 1)[None]) * ss[None, :, None], torch.exp(t[..., 2:4]) * ss[None, :, None], t[..., 4:]), -1)
+        # the reference arithmetic's own fp16 noise on this model: the oracle ops in fp16 on the device
+        sdh = {k: (v.cuda().half() if v.is_floating_point() else v.cuda()) for k, v in sd.items()}
+        fpn16 = O.yolo_pafpn(sdh, img.cuda().half(), cfg, False)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        out = model(img.cuda())
+        fpn_got = model.backbone(img.cuda())
+    torch.cuda.synchronize()
+    assert out.shape == (1, 8400, 85) and torch.isfinite(out).all()
+    for a, b, n in zip(fpn_got, fpn, fpn16):
+        err, nerr, scale = (a.float().cpu() - b).abs(), (n.float().cpu() - b).abs(), b.abs().max().item()
+        assert err.mean().item() <= max(1.5 * nerr.mean().item(), 5e-4 * scale), (err.mean().item(), nerr.mean().item())
+    got = out.float().cpu()
+    # probabilities: absolute; boxes: relative to the stride-scaled magnitude (fp16 through ~60 conv layers of a random-init net)
+    assert (got[..., 4:] - ref[..., 4:]).abs().mean().item() < 1e-2
+    rel = (got[..., :4] - ref[..., :4]).abs() / (ref[..., :4].abs() + 8.0)
+    assert rel.mean().item() < 3e-2, rel.mean().item()
+    # ---- postprocess (class-agnostic NMS, tools/demo.py): against the oracle's NMS on the product's own predictions ----
+    from oracle.nms_ref import nms
+    pred = out.clone()
+    dets = postprocess(out, 80, 0.25, 0.45, class_agnostic=True)
+    torch.cuda.synchronize()
+    p = pred.float().cpu()[0]
+    box = torch.cat((p[:, :2] - p[:, 2:4] / 2, p[:, :2] + p[:, 2:4] / 2), 1).half().float()
+    conf, cid = p[:, 5:].max(1)
+    score = (p[:, 4].half() * conf.half()).float()
+    keepm = score >= torch.tensor(0.25).half().float()
+    if keepm.sum() == 0:
+        assert dets[0] is None
+    else:
+        idx = torch.nonzero(keepm).flatten()
+        k = nms(box[idx], score[idx], 0.45)
+        assert dets[0] is not None and dets[0].shape[0] == len(k)
+        assert torch.allclose(dets[0][:, :4].float().cpu(), box[idx][k], atol=0.26)        # fp16 box corners
+        assert torch.equal(dets[0][:, 6].long().cpu(), cid[idx][k])
+        assert _sorted_by_score(dets[0])
+    # fuse_model caches the folded BatchNorm: identical outputs
+    with torch.no_grad():
+        out2 = fuse_model(model)(img.cuda())
+    assert torch.equal(out2, pred)
+
+
+def _tscd(depth, width, classes, max_props, props="500"):
+    import bench
+    bench.NUM_CLASSES, bench.MAX_PROPS = classes, max_props
+    try:
+        return bench.build_model(depth, width, props)
+    finally:
+        bench.NUM_CLASSES, bench.MAX_PROPS = 25, 500
+
+
+@pytest.mark.parametrize("props", ["500", "50"])
+def test_c2_tscd_s_8f_576_eval_half(props):
+    import bench
+    model = _tscd(0.33, 0.5, 25, 500, props).cuda().eval().half()
+    imgs, _, temb = bench.synth_clip(8, 576, "cuda")
+    model.head.debug = {}
+    with torch.no_grad():
+        res, ori = model(imgs, time_embedding=temb, lframe=2, gframe=6, resume=False)
+        res2, _ = model(imgs, time_embedding=temb, lframe=2, gframe=6, resume=True)       # a following clip of the same video
+    torch.cuda.synchronize()
+    ppf = model.head.debug["preds_per_frame"]
+    assert len(ppf) == 8 and all(50 <= n <= 500 for n in ppf)
+    assert (ppf == [500] * 8) if props == "500" else (ppf == [50] * 8)
+    assert len(res) == 2 and len(res2) == 2
+    for r in list(res) + list(ori) + list(res2):
+        assert r is None or (r.shape[1] == 7 and torch.isfinite(r[:, 4:]).all() and _sorted_by_score(r))
+    assert any(r is not None and r.shape[0] > 0 for r in res)
+
+
+def test_c4_vid_regime_eval_2000_proposals_30_classes():
+    import bench
+    model = _tscd(1.0, 1.0, 30, 2000).cuda().eval().half()
+    imgs, _, temb = bench.synth_clip(8, 576, "cuda")
+    model.head.debug = {}
+    with torch.no_grad():
+        res, ori = model(imgs, time_embedding=temb, lframe=1, gframe=7, resume=False)       # reference: lframe_val 1 (+31 global)
+    torch.cuda.synchronize()
+    ppf = model.head.debug["preds_per_frame"]
+    assert ppf == [2000] * 8
+    assert res[0] is not None and res[0].shape[1] == 7 and _sorted_by_score(res[0]) and torch.isfinite(res[0][:, 4:]).all()
+    assert int(res[0][:, 6].max()) <= 29
+
+
+def test_c5_tscd_x_32f_704_train_step():
+    import bench
+    model = _tscd(1.33, 1.25, 25, 500).cuda().train()
+    assert model.head.width == 320
+    imgs, t0, temb = bench.synth_clip(32, 704, "cuda")
+    targets = bench.targets_on_top_proposals(model, imgs, t0, temb, 8, 24)
+    nbt0 = int(model.backbone.backbone.stem.conv.bn.num_batches_tracked)
+    rm0 = model.backbone.backbone.dark5[0].bn.running_mean.clone()
+    model.head.debug = {}
+    scale = torch.full((), 256.0, device="cuda")
+    model.head.loss_scale = scale
+    out = model(imgs, targets, temb, lframe=8, gframe=24, resume=False)
+    (out["total_loss"] * scale).backward()
+    torch.cuda.synchronize()
+    ppf = model.head.debug["preds_per_frame"]
+    assert len(ppf) == 32 and ppf == [500] * 32
+    for k in ("total_loss", "iou_loss", "conf_loss", "cls_loss", "loss_matched_cls", "loss_matched_obj", "loss_matched_iou"):
+        assert torch.isfinite(torch.as_tensor(out[k])).all(), k
+    assert int(model.backbone.backbone.stem.conv.bn.num_batches_tracked) == nbt0 + 1
+    assert not torch.equal(rm0, model.backbone.backbone.dark5[0].bn.running_mean)
+    got = {k for k, p in model.named_parameters() if p.grad is not None}
+    want = {k for k, p in model.named_parameters() if p.requires_grad}
+    assert got == want, (sorted(want - got)[:5], sorted(got - want)[:5])
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+    from test_state_dict_compat import build_model
+    from oracle.tscd_oracle import TSCDConfig
+    g = os.path.join(root, "tests", "golden")
+    meta = {k: v.item() for k, v in np.load(os.path.join(g, "tscd_tiny_meta.npz")).items()}
+    sd = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(g, "tscd_tiny_weights.npz")).items()}
+    vec = np.load(os.path.join(g, "tscd_tiny_vectors.npz"))
+    cfg = TSCDConfig(num_classes=int(meta["num_classes"]), depth=float(meta["depth"]), width=float(meta["width"]),
+                     minimal_limit=int(meta["minimal_limit"]), maximal_limit=int(meta["maximal_limit"]))
+    torch.cuda.set_device(0)                                    # both ranks share the one GPU of the box (gloo: no RCCL needed)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yolox.core.tscd_trainer import DEAD_PARAMS
+
+    def fresh():
+        m = build_model(cfg)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().train()
+        for p in m.backbone.parameters():
+            p.requires_grad = False
+        for mod in (m.head.stems, m.head.reg_convs, m.head.cls_convs, m.head.reg_preds):
+            for p in mod.parameters():
+                p.requires_grad = False
+        for k, p in m.named_parameters():
+            if any(d in k for d in DEAD_PARAMS):
+                p.requires_grad = False
+        return m
+
+    clips = [torch.from_numpy(vec["evalA_imgs"]).float().cuda().half(), torch.from_numpy(vec["evalB_imgs"]).float().cuda().half()]
+    labels = torch.from_numpy(vec["train_labels"]).cuda().half()
+    temb = torch.from_numpy(vec["time_embedding"]).cuda().half()
+    kw = dict(lframe=int(meta["lframe"]), gframe=int(meta["gframe"]), resume=False)
+    scale = torch.full((), 64.0, device="cuda")
+    model = fresh()
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True)
+    model.head.loss_scale = scale
+    out = ddp(clips[rank], labels, temb, **kw)               # eager class branch + level streams on (defaults)
+    (out["total_loss"] * scale).backward()
+    torch.cuda.synchronize()
+    got = {k: p.grad.float().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    res = None
+    if rank == 0:
+        # the same two clips in one process, no DDP: the all-reduced gradient must be their mean
+        acc = None
+        for c in clips:
+            m = fresh()
+            m.head.loss_scale = scale
+            o = m(c, labels, temb, **kw)
+            (o["total_loss"] * scale).backward()
+            torch.cuda.synchronize()
+            gr = {k: p.grad.float().cpu() for k, p in m.named_parameters() if p.grad is not None}
+            acc = gr if acc is None else {k: acc[k] + gr[k] for k in acc}
+        worst = (1.0, "")
+        assert set(acc) == set(got)
+        for k in acc:
+            want = acc[k] / 2
+            if want.norm() == 0:
+                continue
+            cos = torch.nn.functional.cosine_similarity(got[k].flatten(), want.flatten(), dim=0).item()
+            ratio = (got[k].norm() / want.norm()).item()
+            if cos < worst[0]:
+                worst = (cos, k)
+            assert cos > 0.99 and abs(ratio - 1) < 0.05, (k, cos, ratio)
+        res = (len(acc), worst)
+    q.put((rank, res, float(out["total_loss"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_real_forward_gradient_is_the_mean_of_the_two_clips():
+    """Two gloo ranks on the one GPU, DistributedDataParallel over the product model (frozen backbone / base head, the never-used
+    parameters frozen), each rank its own clip, the head's eager class branch and level streams enabled: every parameter's
+    all-reduced gradient equals the mean of the two single-process gradients (fp16 kernels are deterministic; the tolerance
+    covers the bucketed fp32 all-reduce vs a plain sum)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0 = [r for r in res if r[0] == 0][0]
+    assert r0[1] is not None and r0[1][0] > 60, r0            # > 60 trainable tensors compared
+    assert all(np.isfinite(r[2]) for r in res)
