@@ -41,6 +41,14 @@ struct McaBwdParams {
   float* dscore;             // [N]
   int N, N_L, Npad, WP, S;
   float scale, sim_thresh, conf_thresh;
+  // split passes (mode 2): per (query tile, key block) 32x32 blocks written by pass 1, read by the dq / dkv passes
+  float *dMq, *dMk;          // dM, [tile][maxblk][32 q][32 key] and [tile][maxblk][32 key][32 q]
+  f16 *Ack, *Ark;            // sim_round2 weights, [tile][maxblk][32 key][32 q]
+  const float* score_pad;    // [Npad] fp32 (0 beyond N)
+  float* rowstat;            // [tile][HEADS][4][32]: 1/l_c, 1/l_r, delta_c, delta_r (0 on padded rows)
+  float* dscore_part;        // [S3 * HEADS][Npad]
+  int maxblk, S2, S3;
+  long dq_stride, dk_stride; // floats between the partial sums of consecutive splits
 };
 
 __device__ __forceinline__ f16x8 tr_frag16(const f16* tile_row0_col0, int ldst, int lane) {
@@ -58,10 +66,11 @@ __device__ __forceinline__ f16x8 tr_frag16(const f16* tile_row0_col0, int ldst, 
 // per-tile transposed q^) -- rows follow mca_prep_kernel's conventions.
 __global__ void mca_bwd_layout_kernel(const f16* __restrict__ kn_c, const f16* __restrict__ kn_r, const f16* __restrict__ kv_c,
                                       const f16* __restrict__ kv_r, int N, int Npad, int W, int d, int DP, f16* vraw_c,
-                                      f16* vraw_r, f16* kt_c, f16* kt_r) {
+                                      f16* vraw_r, f16* kt_c, f16* kt_r, const f16* __restrict__ score, float* score_pad) {
   int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   int n = wave >> 1, br = wave & 1;
   if (n >= Npad) return;
+  if (br == 0 && lane == 0) score_pad[n] = n < N ? (float)score[n] : 0.f;
   const int WP = MCA_HEADS * DP;
   const f16* kn = br ? kn_r : kn_c;
   const f16* kv = br ? kv_r : kv_c;
@@ -119,7 +128,7 @@ __global__ void mca_bwd_tiles_kernel(const McaTile* __restrict__ tiles, int ntil
 }
 
 // ------------------------------------------------------------------------------------------------ core
-template <int DP, bool NEED_REG, int PASS>
+template <int DP, bool NEED_REG, int PASS, bool STORE = false>
 __global__ __launch_bounds__(256, PASS == 1 ? 2 : 1) void mca_bwd_core_kernel(McaBwdParams p) {
   constexpr int KS = DP / 16, NT = DP / 32;
   constexpr int PST = 33, HST = 40;
@@ -251,8 +260,21 @@ __global__ __launch_bounds__(256, PASS == 1 ? 2 : 1) void mca_bwd_core_kernel(Mc
         float dar = X[2][0][row][cc] + X[2][1][row][cc] + X[2][2][row][cc] + X[2][3][row][cc];
         X[0][0][row][cc] = A32[0][row][cc] * (dac - gdt[0][row]) + A32[1][row][cc] * (dar - gdt[1][row]);   // dM
       }
+      if (STORE) {
+        const long blk = ((long)tile * p.maxblk + j) * 1024;
+        *(f32x4*)(p.dMq + blk + row * 32 + c0) =
+            f32x4{X[0][0][row][c0], X[0][0][row][c0 + 1], X[0][0][row][c0 + 2], X[0][0][row][c0 + 3]};
+      }
     }
     __syncthreads();
+    if (STORE) {   // key-major copies for the key-stationary pass (X[0][0] and A32 stay untouched until the next visit)
+      const int kk = tid >> 3, q0 = (tid & 7) * 4;
+      const long blk = ((long)tile * p.maxblk + j) * 1024 + kk * 32 + q0;
+      *(f32x4*)(p.dMk + blk) = f32x4{X[0][0][q0][kk], X[0][0][q0 + 1][kk], X[0][0][q0 + 2][kk], X[0][0][q0 + 3][kk]};
+      *(f16x4*)(p.Ack + blk) = f16x4{(f16)A32[0][q0][kk], (f16)A32[0][q0 + 1][kk], (f16)A32[0][q0 + 2][kk], (f16)A32[0][q0 + 3][kk]};
+      if (NEED_REG)
+        *(f16x4*)(p.Ark + blk) = f16x4{(f16)A32[1][q0][kk], (f16)A32[1][q0 + 1][kk], (f16)A32[1][q0 + 2][kk], (f16)A32[1][q0 + 3][kk]};
+    }
     float dsco = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -615,6 +637,227 @@ __global__ __launch_bounds__(256) void mca_bwd_pair_kernel(McaBwdParams p, int n
   }
 }
 
+// ------------------------------------------------------------------------------------------------ split passes (mode 2)
+// Pass 2 without atomics and without workgroup barriers.  Everything that couples the four heads of a (query tile, key block)
+// pair -- dM and the sim_round2 weights Ac / Ar -- is written once by pass 1 (mca_bwd_core_kernel<.., 1, true>: 12 KB per
+// pair, ~100 MB per call at 16 x 500 proposals, far below what HBM moves in the time the pair's MFMAs take).  With those in
+// memory a head is independent of the others, so a WAVE owns its output and keeps it in registers:
+//   dq  pass (mca_bwd_dq_kernel):  wave = (query tile, head, split of the key blocks); S^T = K Q^T puts the query on the
+//        lane axis, so dS^T leaves the MFMA already in A-operand order for dq = dS K (no LDS transpose);
+//   dkv pass (mca_bwd_dkv_kernel): wave = (32-key block, head, split of the query tiles); S = Q K^T puts the key on the
+//        lane axis, and P / dS / Ac / Ar are A operands of dk = dS^T Q, dv = P^T dO + A^T dsoft as they are.
+// The contraction index of those second products is the C-register order of the first (rows 8i + 4*half + j), and the B
+// operand is fetched in the same order from the transposed copies (k^T, per-tile q^T / dO^T / dsoft^T): two 8-byte loads.
+// Splits write separate partial sums; mca_bwd_finish_kernel adds them in a fixed order (deterministic, nothing to zero).
+__global__ void mca_bwd_rowstat_kernel(const McaTile* __restrict__ tiles, const float* __restrict__ stats,
+                                       const float* __restrict__ delta_part, int S, int N_L, float* __restrict__ rowstat) {
+  const int tile = blockIdx.x, tid = threadIdx.x, h = tid >> 6, br = (tid >> 5) & 1, row = tid & 31;
+  const McaTile t = tiles[tile];
+  const bool ok = row < t.nrows;
+  const float l = ok ? stats[((long)h * 2 + br) * N_L + t.row0 + row] : 0.f;
+  float dsum = 0.f;
+  if (ok)
+    for (int ss = 0; ss < S; ++ss) dsum += delta_part[(((long)ss * MCA_HEADS + h) * 2 + br) * N_L + t.row0 + row];
+  float* o = rowstat + ((long)tile * MCA_HEADS + h) * 128;
+  o[br * 32 + row] = l > 0.f ? 1.0f / l : 0.f;
+  o[(2 + br) * 32 + row] = dsum;
+}
+
+__device__ __forceinline__ f16x8 ld_2x4(const f16* p) {   // 4 halves at p, 4 at p + 8 (the C-register row order of a 16-slab)
+  f16x4 lo = *(const f16x4*)p, hi = *(const f16x4*)(p + 8);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int DP, bool NEED_REG>
+__global__ __launch_bounds__(256) void mca_bwd_dq_kernel(McaBwdParams p) {
+  constexpr int KS = DP / 16, NT = DP / 32;
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+  const int tile = blockIdx.x, s = blockIdx.y;
+  const McaTile t = p.tiles[tile];
+  const int n_local = ((t.loc_end + 31) >> 5) - (t.loc_start >> 5);
+  const int n_glob = ((p.N + 31) >> 5) - (p.N_L >> 5);
+  const int nblk = n_local + n_glob;
+  const int qi = lane & 31, half = lane >> 5;
+  const int qrow = t.row0 + (qi < t.nrows ? qi : 0);
+  const float* rs = p.rowstat + ((long)tile * MCA_HEADS + h) * 128;
+  const float il_c = rs[qi], il_r = rs[32 + qi], dl_c = rs[64 + qi], dl_r = rs[96 + qi];
+  f16x8 qc[KS], qr[KS], gOc[KS], gOr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const long o = (long)qrow * p.WP + h * DP + ks * 16 + half * 8;
+    qc[ks] = *(const f16x8*)(p.qn_c + o);
+    qr[ks] = *(const f16x8*)(p.qn_r + o);
+    gOc[ks] = *(const f16x8*)(p.gO_c + o);
+    if (NEED_REG) gOr[ks] = *(const f16x8*)(p.gO_r + o);
+  }
+  f32x16 dqc[NT], dqr[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dqc[n][e] = dqr[n][e] = 0.f;
+
+  for (int j = s; j < nblk; j += p.S2) {
+    int key0, lo, hi;
+    block_range(t, p.N_L, p.N, j, key0, lo, hi, n_local);
+    const long blk = ((long)tile * p.maxblk + j) * 1024;
+    f32x16 sc, sr, gvc, gvr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sc[e] = sr[e] = gvc[e] = gvr[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {      // rows = keys (A), columns = queries (B)
+      const long o = (long)(key0 + qi) * p.WP + h * DP + ks * 16 + half * 8;
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.kn_c + o), qc[ks], sc, 0, 0, 0);
+      sr = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.kn_r + o), qr[ks], sr, 0, 0, 0);
+      gvc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.vraw_c + o), gOc[ks], gvc, 0, 0, 0);
+      if (NEED_REG) gvr = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.vraw_r + o), gOr[ks], gvr, 0, 0, 0);
+    }
+    f16x8 tc[2], tr[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kb = key0 + 8 * i + 4 * half;
+      const f32x4 dm = *(const f32x4*)(p.dMq + blk + qi * 32 + 8 * i + 4 * half);
+      const f32x4 ks4 = *(const f32x4*)(p.score_pad + kb);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int e = 4 * i + jj;
+        const bool valid = kb + jj >= lo && kb + jj < hi;
+        const float pc = valid ? __expf(p.scale * ks4[jj] * sc[e] - p.scale) * il_c : 0.f;
+        const float pr = valid ? __expf(p.scale * sr[e] - p.scale) * il_r : 0.f;
+        const float hdp = 0.5f * (gvc[e] + gvr[e] + 0.25f * dm[jj]);
+        tc[i >> 1][(i & 1) * 4 + jj] = (f16)(pc * (hdp - dl_c) * p.scale * ks4[jj]);
+        tr[i >> 1][(i & 1) * 4 + jj] = (f16)(pr * (hdp - dl_r) * p.scale);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const long o = (long)(h * DP + n * 32 + qi) * p.Npad + key0 + 16 * m + 4 * half;
+        dqc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tc[m], ld_2x4(p.kt_c + o), dqc[n], 0, 0, 0);
+        dqr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tr[m], ld_2x4(p.kt_r + o), dqr[n], 0, 0, 0);
+      }
+  }
+  float* oc = p.dqn_c + (long)s * p.dq_stride;
+  float* orr = p.dqn_r + (long)s * p.dq_stride;
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+      if (row < t.nrows) {
+        const long o = (long)(t.row0 + row) * p.WP + h * DP + n * 32 + qi;
+        oc[o] = dqc[n][e];
+        orr[o] = dqr[n][e];
+      }
+    }
+}
+
+template <int DP, bool NEED_REG>
+__global__ __launch_bounds__(256) void mca_bwd_dkv_kernel(McaBwdParams p, int ntiles) {
+  constexpr int KS = DP / 16, NT = DP / 32;
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int key0 = b * 32, col = lane & 31, half = lane >> 5, key = key0 + col;
+  const int gb0 = p.N_L >> 5, gb1 = (p.N + 31) >> 5;
+  const bool is_glob = b >= gb0 && b < gb1;
+  const float kscore = p.score_pad[key];
+  f16x8 kc[KS], kr[KS], vc[KS], vr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const long o = (long)key * p.WP + h * DP + ks * 16 + half * 8;
+    kc[ks] = *(const f16x8*)(p.kn_c + o);
+    kr[ks] = *(const f16x8*)(p.kn_r + o);
+    vc[ks] = *(const f16x8*)(p.vraw_c + o);
+    if (NEED_REG) vr[ks] = *(const f16x8*)(p.vraw_r + o);
+  }
+  f32x16 akc[NT], akr[NT], avc[NT], avr[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) akc[n][e] = akr[n][e] = avc[n][e] = avr[n][e] = 0.f;
+  float dsco = 0.f;
+
+  auto visit = [&](const int tt, const McaTile& t, const int j, const int lo, const int hi) __attribute__((always_inline)) {
+    const bool valid = key >= lo && key < hi;
+    const int qrow = t.row0 + (col < t.nrows ? col : 0);
+    f32x16 sc, sr, gvc, gvr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sc[e] = sr[e] = gvc[e] = gvr[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {      // rows = queries (A), columns = keys (B)
+      const long o = (long)qrow * p.WP + h * DP + ks * 16 + half * 8;
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.qn_c + o), kc[ks], sc, 0, 0, 0);
+      sr = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.qn_r + o), kr[ks], sr, 0, 0, 0);
+      gvc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.gO_c + o), vc[ks], gvc, 0, 0, 0);
+      if (NEED_REG) gvr = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.gO_r + o), vr[ks], gvr, 0, 0, 0);
+    }
+    const long blk = ((long)tt * p.maxblk + j) * 1024 + col * 32;
+    const float* rs = p.rowstat + ((long)tt * MCA_HEADS + h) * 128;
+    f16x8 tc[2], tr[2], pp[2], ac[2], ar[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r0 = 8 * i + 4 * half;
+      const f32x4 dm = *(const f32x4*)(p.dMk + blk + r0);
+      const f16x4 a_c = *(const f16x4*)(p.Ack + blk + r0);
+      f16x4 a_r = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+      if (NEED_REG) a_r = *(const f16x4*)(p.Ark + blk + r0);
+      const f32x4 il_c = *(const f32x4*)(rs + r0), il_r = *(const f32x4*)(rs + 32 + r0);
+      const f32x4 dl_c = *(const f32x4*)(rs + 64 + r0), dl_r = *(const f32x4*)(rs + 96 + r0);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int e = 4 * i + jj, u = (i & 1) * 4 + jj;
+        const float pc = valid ? __expf(p.scale * kscore * sc[e] - p.scale) * il_c[jj] : 0.f;   // il = 0 on padded rows
+        const float pr = valid ? __expf(p.scale * sr[e] - p.scale) * il_r[jj] : 0.f;
+        const float hdp = 0.5f * (gvc[e] + gvr[e] + 0.25f * dm[jj]);
+        const float dsc = pc * (hdp - dl_c[jj]), dsr = pr * (hdp - dl_r[jj]);
+        dsco += dsc * p.scale * sc[e];
+        tc[i >> 1][u] = (f16)(dsc * p.scale * kscore);
+        tr[i >> 1][u] = (f16)(dsr * p.scale);
+        pp[i >> 1][u] = (f16)(0.5f * (pc + pr));
+        ac[i >> 1][u] = a_c[jj];
+        ar[i >> 1][u] = a_r[jj];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const long o = ((long)tt * p.WP + h * DP + n * 32 + col) * 32 + 16 * m + 4 * half;
+        akc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tc[m], ld_2x4(p.qT_c + o), akc[n], 0, 0, 0);
+        akr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tr[m], ld_2x4(p.qT_r + o), akr[n], 0, 0, 0);
+        avc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pp[m], ld_2x4(p.gOT_c + o), avc[n], 0, 0, 0);
+        avc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ac[m], ld_2x4(p.gST_c + o), avc[n], 0, 0, 0);
+        if (NEED_REG) {
+          avr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pp[m], ld_2x4(p.gOT_r + o), avr[n], 0, 0, 0);
+          avr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[m], ld_2x4(p.gST_r + o), avr[n], 0, 0, 0);
+        }
+      }
+  };
+
+  for (int tt = s; tt < ntiles; tt += p.S3) {
+    const McaTile t = p.tiles[tt];
+    const int lb0 = t.loc_start >> 5, lb1 = (t.loc_end + 31) >> 5;
+    if (b >= lb0 && b < lb1) visit(tt, t, b - lb0, t.loc_start, t.loc_end);
+    if (is_glob) visit(tt, t, lb1 - lb0 + b - gb0, p.N_L, p.N);
+  }
+  dsco += __shfl_xor(dsco, 32, 64);
+  if (half == 0) p.dscore_part[((long)s * MCA_HEADS + h) * p.Npad + key] = dsco;
+  float* okc = p.dkn_c + (long)s * p.dk_stride;
+  float* okr = p.dkn_r + (long)s * p.dk_stride;
+  float* ovc = p.dv_c + (long)s * p.dk_stride;
+  float* ovr = p.dv_r + (long)s * p.dk_stride;
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long o = (long)(key0 + (e & 3) + 8 * (e >> 2) + 4 * half) * p.WP + h * DP + n * 32 + col;
+      okc[o] = akc[n][e];
+      okr[o] = akr[n][e];
+      ovc[o] = avc[n][e];
+      if (NEED_REG) ovr[o] = avr[n][e];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ normalisation backward
 // One wave per (row, branch): x^ = x/||x||  =>  dx = (dx^ - x^ (x^.dx^)) / ||x||  per head, for q and k; v passes through
 // (+ the gradient of the "x_ori" rows, i.e. d xcat[:, W:2W], for local rows).  Outputs fp16 dq [N_L,W], dkv [N,2W].
@@ -623,11 +866,18 @@ __global__ void mca_bwd_finish_kernel(const f16* __restrict__ q_c, const f16* __
                                       const float* __restrict__ dkn_c, const float* __restrict__ dkn_r, const float* __restrict__ dv_c,
                                       const float* __restrict__ dv_r, const f16* __restrict__ dvloc_c, const f16* __restrict__ dvloc_r,
                                       int ld_dvloc, int N, int N_L, int W, int d, int DP, int need_reg, f16* dq_c, f16* dkv_c,
-                                      f16* dq_r, f16* dkv_r) {
+                                      f16* dq_r, f16* dkv_r, int nsq, long dq_stride, int nsk, long dk_stride,
+                                      const float* __restrict__ dscore_part, int nds, int Npad, float* __restrict__ dscore) {
   int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   int n = wave >> 1, br = wave & 1;
   if (n >= N) return;
   const int WP = MCA_HEADS * DP;
+  if (dscore_part && br == 0) {     // split passes: dscore = fixed-order sum of the (split, head) partials
+    float a = 0.f;
+    for (int i = lane; i < nds; i += 64) a += dscore_part[(long)i * Npad + n];
+    a = wave_sum(a);
+    if (lane == 0) dscore[n] = a;
+  }
   const f16* q = br ? q_r : q_c;
   const f16* kv = br ? kv_r : kv_c;
   const float* dqn = br ? dqn_r : dqn_c;
@@ -645,10 +895,10 @@ __global__ void mca_bwd_finish_kernel(const f16* __restrict__ q_c, const f16* __
       int j = lane + rnd * 64;
       if (j < d) {
         kx[rnd] = (float)kv[(long)n * 2 * W + h * d + j];
-        dk[rnd] = dkn[(long)n * WP + h * DP + j];
+        for (int ss = 0; ss < nsk; ++ss) dk[rnd] += dkn[ss * dk_stride + (long)n * WP + h * DP + j];
         if (n < N_L) {
           qx[rnd] = (float)q[(long)n * W + h * d + j];
-          dqq[rnd] = dqn[(long)n * WP + h * DP + j];
+          for (int ss = 0; ss < nsq; ++ss) dqq[rnd] += dqn[ss * dq_stride + (long)n * WP + h * DP + j];
         }
       }
       sk += kx[rnd] * kx[rnd]; sq += qx[rnd] * qx[rnd];
@@ -662,7 +912,9 @@ __global__ void mca_bwd_finish_kernel(const f16* __restrict__ q_c, const f16* __
       if (j < d) {
         // x^.dx^ = (x.dx^)/||x||  =>  dx = dx^/||x|| - x (x.dx^)/||x||^3
         dkv[(long)n * 2 * W + h * d + j] = (f16)(dk[rnd] * ik - kx[rnd] * kd * ik * ik * ik);
-        float g = vgrad ? dv[(long)n * WP + h * DP + j] : 0.f;
+        float g = 0.f;
+        if (vgrad)
+          for (int ss = 0; ss < nsk; ++ss) g += dv[ss * dk_stride + (long)n * WP + h * DP + j];
         if (n < N_L && vgrad) g += (float)dvloc[(long)n * ld_dvloc + h * d + j];
         dkv[(long)n * 2 * W + W + h * d + j] = (f16)g;
         if (n < N_L) dq[(long)n * W + h * d + j] = (f16)(dqq[rnd] * iq - qx[rnd] * qd * iq * iq * iq);
@@ -672,18 +924,44 @@ __global__ void mca_bwd_finish_kernel(const f16* __restrict__ q_c, const f16* __
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI
-static int g_mca_bwd_pair = 1;
-// 1 (default): pass 2 walks the key blocks once for two query tiles of a frame (half the dk / dv atomics); 0: one tile per
-// workgroup (the cross-check).  Returns the previous setting.
+static int g_mca_bwd_pair = 2;
+// Pass 2 of the backward.  2 (default): split passes -- dM / Ac / Ar blocks through memory, a wave-private dq pass and a
+// key-stationary dk / dv pass, no atomics (falls back to 1 when the blocks would need more than 24 GB); 1: query-stationary,
+// two query tiles of a frame per workgroup, dk / dv by float atomics; 0: the same with one tile per workgroup (the
+// cross-checks).  Returns the previous setting.
 extern "C" int tscd_mca_backward_set_paired(int on) { int o = g_mca_bwd_pair; g_mca_bwd_pair = on; return o; }
+
+namespace {
+struct McaSplitPlan { bool on; int maxblk, nkb, S2, S3; long blocks; };
+McaSplitPlan mca_split_plan(int N, int N_L, int ntiles) {
+  McaSplitPlan pl;
+  pl.maxblk = (N + 31) / 32 + 2;                     // >= blocks of one frame + global blocks of any tile
+  pl.nkb = (N + 31) / 32;
+  pl.blocks = (long)ntiles * pl.maxblk;
+  pl.on = pl.blocks * 1024 * 12 <= (24L << 30);
+  auto clampi = [](long v, long lo, long hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); };
+  pl.S2 = clampi((2048 + ntiles * 4 - 1) / (ntiles * 4), 1, 16);
+  pl.S3 = clampi((2048 + pl.nkb * 4 - 1) / (pl.nkb * 4), 1, ntiles < 8 ? ntiles : 8);
+  return pl;
+}
+}  // namespace
+
 extern "C" long tscd_mca_backward_workspace_bytes(int N, int N_L, int W, int S, int ntiles) {
   int d = W / MCA_HEADS, DP = (d + 31) / 32 * 32, WP = MCA_HEADS * DP;
   long Npad = (N + 31) / 32 * 32 + 32;
   long halves = 2L * N_L * WP + 4L * Npad * WP + 2L * WP * Npad          // forward prep layouts
                 + 2L * Npad * WP + 2L * WP * Npad                       // vraw, kt
                 + 4L * N_L * WP + 6L * ntiles * WP * 32;                // gO/gS padded, qT/gOT/gST per tile
-  long floats = 2L * N_L + (long)S * MCA_HEADS * 2 * N_L + 2L * N_L * WP + 4L * Npad * WP;
-  return halves * 2 + floats * 4 + 8192;
+  const McaSplitPlan pl = mca_split_plan(N, N_L, ntiles);
+  const long nsq = pl.on ? pl.S2 : 1, nsk = pl.on ? pl.S3 : 1;
+  long floats = 2L * N_L + (long)S * MCA_HEADS * 2 * N_L + nsq * 2L * N_L * WP + nsk * 4L * Npad * WP;
+  if (pl.on) {
+    floats += Npad + (long)ntiles * MCA_HEADS * 128 + (long)pl.S3 * MCA_HEADS * Npad + 2L * pl.blocks * 1024;
+    halves += 2L * pl.blocks * 1024;
+  } else {
+    floats += Npad;
+  }
+  return halves * 2 + floats * 4 + 16384;
 }
 
 // defined in mca.hip
@@ -724,15 +1002,30 @@ extern "C" int tscd_mca_backward(const void* q_c, const void* kv_c, const void* 
   f16* gOT_c = (f16*)take(tb); f16* gOT_r = (f16*)take(tb); f16* gST_c = (f16*)take(tb); f16* gST_r = (f16*)take(tb);
   float* gdot = (float*)take(4L * 2 * N_L);
   float* delta_part = (float*)take(4L * S * MCA_HEADS * 2 * N_L);
-  // atomic targets (one contiguous region, zeroed together with dscore)
-  long acc_floats = 2L * N_L * WP + 4L * Npad * WP;
+  const McaSplitPlan pl = mca_split_plan(N, N_L, ntiles);
+  const bool split = g_mca_bwd_pair == 2 && pl.on;
+  const int nsq = split ? pl.S2 : 1, nsk = split ? pl.S3 : 1;
+  const long dq_stride = (long)N_L * WP, dk_stride = (long)Npad * WP;
+  // accumulators: [split][rows][WP] per array; atomic targets (zeroed together with dscore) unless the passes are split
+  long acc_floats = nsq * 2L * dq_stride + nsk * 4L * dk_stride;
   float* acc = (float*)take(4L * acc_floats);
+  float* score_pad = (float*)take(4L * Npad);
+  float *rowstat = nullptr, *dscore_part = nullptr, *dMq = nullptr, *dMk = nullptr;
+  f16 *Ack = nullptr, *Ark = nullptr;
+  if (split) {
+    rowstat = (float*)take(4L * ntiles * MCA_HEADS * 128);
+    dscore_part = (float*)take(4L * pl.S3 * MCA_HEADS * Npad);
+    dMq = (float*)take(4L * pl.blocks * 1024); dMk = (float*)take(4L * pl.blocks * 1024);
+    Ack = (f16*)take(2L * pl.blocks * 1024); Ark = (f16*)take(2L * pl.blocks * 1024);
+  }
   TSCD_CHECK_ARG(ws - (char*)workspace <= workspace_bytes, "mca_backward: workspace carve-out overflow");
-  float* dqn_c = acc; float* dqn_r = dqn_c + (long)N_L * WP;
-  float* dkn_c = dqn_r + (long)N_L * WP; float* dkn_r = dkn_c + (long)Npad * WP;
-  float* dv_c = dkn_r + (long)Npad * WP; float* dv_r = dv_c + (long)Npad * WP;
-  (void)hipMemsetAsync(acc, 0, 4L * acc_floats, st);
-  (void)hipMemsetAsync(dscore, 0, 4L * N, st);
+  float* dqn_c = acc; float* dqn_r = dqn_c + nsq * dq_stride;
+  float* dkn_c = dqn_r + nsq * dq_stride; float* dkn_r = dkn_c + nsk * dk_stride;
+  float* dv_c = dkn_r + nsk * dk_stride; float* dv_r = dv_c + nsk * dk_stride;
+  if (!split) {
+    (void)hipMemsetAsync(acc, 0, 4L * acc_floats, st);
+    (void)hipMemsetAsync(dscore, 0, 4L * N, st);
+  }
 
   {
     long waves = 2L * Npad;
@@ -740,7 +1033,7 @@ extern "C" int tscd_mca_backward(const void* q_c, const void* kv_c, const void* 
     mca_launch_prep(st, (const f16*)q_c, (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, N, N_L, Npad, W, d, DP, qn_c, kn_c, vn_c,
                     vt_c, qn_r, kn_r, vn_r, vt_r, nullptr, nullptr);
     hipLaunchKernelGGL(mca_bwd_layout_kernel, dim3(grid), dim3(256), 0, st, kn_c, kn_r, (const f16*)kv_c, (const f16*)kv_r, N, Npad,
-                       W, d, DP, vraw_c, vraw_r, kt_c, kt_r);
+                       W, d, DP, vraw_c, vraw_r, kt_c, kt_r, (const f16*)score, score_pad);
     hipLaunchKernelGGL(mca_bwd_tiles_kernel, dim3(ntiles), dim3(256), 0, st, (const McaTile*)tiles, ntiles, qn_c, qn_r,
                        (const f16*)dxcat_c, 2 * W, (const f16*)dxcat_r, (const f16*)dsoft_c, ld_dsoft, (const f16*)dsoft_r,
                        (const f16*)soft_c, (const f16*)soft_r, ld_soft, N_L, W, d, DP, need_reg, qT_c, qT_r, gO_c, gO_r, gS_c, gS_r,
@@ -755,11 +1048,22 @@ extern "C" int tscd_mca_backward(const void* q_c, const void* kv_c, const void* 
   p.dqn_c = dqn_c; p.dqn_r = dqn_r; p.dkn_c = dkn_c; p.dkn_r = dkn_r; p.dv_c = dv_c; p.dv_r = dv_r; p.dscore = dscore;
   p.N = N; p.N_L = N_L; p.Npad = Npad; p.WP = WP; p.S = S;
   p.scale = scale; p.sim_thresh = sim_thresh; p.conf_thresh = conf_thresh;
+  p.dMq = dMq; p.dMk = dMk; p.Ack = Ack; p.Ark = Ark; p.score_pad = score_pad; p.rowstat = rowstat; p.dscore_part = dscore_part;
+  p.maxblk = pl.maxblk; p.S2 = pl.S2; p.S3 = pl.S3; p.dq_stride = dq_stride; p.dk_stride = dk_stride;
   dim3 grid(ntiles, S), block(256);
   dim3 pgrid((ntiles + 1) / 2, S);      // pass 2: two same-frame query tiles per workgroup (mca_bwd_pair_kernel)
+#define MCAS(DPV, REG)                                                                                             \
+  do {                                                                                                             \
+    hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, REG, 1, true>), grid, block, 0, st, p);                           \
+    hipLaunchKernelGGL(mca_bwd_rowstat_kernel, dim3(ntiles), block, 0, st, p.tiles, stats, delta_part, S, N_L, rowstat); \
+    hipLaunchKernelGGL((mca_bwd_dq_kernel<DPV, REG>), dim3(ntiles, pl.S2), block, 0, st, p);                       \
+    hipLaunchKernelGGL((mca_bwd_dkv_kernel<DPV, REG>), dim3(pl.nkb, pl.S3), block, 0, st, p, ntiles);              \
+  } while (0)
 #define MCAB(DPV)                                                                            \
   do {                                                                                       \
-    if (need_reg) {                                                                          \
+    if (split) {                                                                             \
+      if (need_reg) MCAS(DPV, true); else MCAS(DPV, false);                                  \
+    } else if (need_reg) {                                                                   \
       hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, true, 1>), grid, block, 0, st, p);        \
       if (g_mca_bwd_pair) hipLaunchKernelGGL((mca_bwd_pair_kernel<DPV, true>), pgrid, block, 0, st, p, ntiles); \
       else hipLaunchKernelGGL((mca_bwd_core_kernel<DPV, true, 2>), grid, block, 0, st, p);   \
@@ -773,13 +1077,15 @@ extern "C" int tscd_mca_backward(const void* q_c, const void* kv_c, const void* 
   else if (DP == 64) MCAB(64);
   else MCAB(96);
 #undef MCAB
+#undef MCAS
   TSCD_CHECK_LAUNCH("mca_backward core");
   {
     long waves = 2L * N;
     hipLaunchKernelGGL(mca_bwd_finish_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st, (const f16*)q_c,
                        (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, dqn_c, dqn_r, dkn_c, dkn_r, dv_c, dv_r,
                        (const f16*)dxcat_c + W, need_reg ? (const f16*)dxcat_r + W : (const f16*)dxcat_c + W, 2 * W, N, N_L, W, d, DP,
-                       need_reg, (f16*)dq_c, (f16*)dkv_c, (f16*)dq_r, (f16*)dkv_r);
+                       need_reg, (f16*)dq_c, (f16*)dkv_c, (f16*)dq_r, (f16*)dkv_r, nsq, dq_stride, nsk, dk_stride, dscore_part,
+                       pl.S3 * MCA_HEADS, Npad, dscore);
     TSCD_CHECK_LAUNCH("mca_backward finish");
   }
   return TSCD_OK;
