@@ -152,9 +152,7 @@ int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q_r, const v
  * projected q / (k|v) rows and the key scores.  stats = stats_out of the forward call; dxcat_* [N_L,2W], dsoft_* / soft_* the
  * first W columns of the [N_L,3W] concat (row strides ld_dsoft / ld_soft). */
 long tscd_mca_backward_workspace_bytes(int N, int N_L, int W, int S, int ntiles);
-/* Pass 2 of tscd_mca_backward: 1 (default) two same-frame query tiles per workgroup share each key block's dk / dv flush (half
- * the float atomics), 0 one tile per workgroup (cross-check).  Returns the previous setting. */
-int tscd_mca_backward_set_paired(int on);
+/* Three passes without atomics (delta + dM/Ac/Ar blocks; dq per query tile; dk/dv/dscore per key block): deterministic. */
 int tscd_mca_backward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
                       const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale, float sim_thresh,
                       float conf_thresh, const float* stats, const void* dxcat_c, const void* dxcat_r, const void* dsoft_c,

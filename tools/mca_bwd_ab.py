@@ -1,7 +1,5 @@
 #!/usr/bin/env python3
-"""MCA backward, same box A/B: split passes (mode 2, default) vs the atomic query-stationary passes (mode 1 paired, 0 single) at
-the bench clip's sizes (16 frames, 4 local, 500 / 50 proposals per frame, W 256).  Prints the time per call and the largest
-difference between the modes' outputs."""
+"""MCA backward timing at the bench clip's sizes (16 frames, 4 local, 500 / 50 proposals per frame, W 256), per call."""
 import os
 import sys
 
@@ -9,7 +7,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from tscd_amd import ops
-from tscd_amd._lib import lib
 
 d = torch.device("cuda")
 torch.manual_seed(0)
@@ -32,20 +29,13 @@ for P in (500, 50):
         a = (g2(), g2() if need_reg else None, g3(), g3() if need_reg else None)
         f = lambda: ops.mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, 25.0, 0.75, 0.99, stats, a[0], a[1], a[2], a[3],
                                      cat3_c, cat3_r)
-        outs = {}
         for rnd in range(2):
-            for mode in (2, 1, 0):
-                lib.tscd_mca_backward_set_paired(mode)
-                for _ in range(2):
-                    outs[mode] = f()
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                for _ in range(5):
-                    f()
-                e.record()
-                torch.cuda.synchronize()
-                print(f"P {P} need_reg {need_reg} round {rnd} mode {mode}: {s.elapsed_time(e) / 5 * 1e3:8.1f} us per call", flush=True)
-        for other in (1, 0):
-            diff = [float((x.float() - y.float()).abs().max() / (y.float().abs().max() + 1e-20)) for x, y in zip(outs[2], outs[other]) if x is not None]
-            print(f"   mode 2 vs {other}: max |diff| / max |ref| per output = {['%.2e' % v for v in diff]}", flush=True)
-lib.tscd_mca_backward_set_paired(2)
+            for _ in range(2):
+                f()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(5):
+                f()
+            e.record()
+            torch.cuda.synchronize()
+            print(f"P {P} need_reg {need_reg} round {rnd}: {s.elapsed_time(e) / 5 * 1e3:8.1f} us per call", flush=True)
