@@ -42,6 +42,7 @@ def parse():
     # bench.py fails if the final loss is not finite.
     ap.add_argument("--lr", type=float, default=1e-6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-table", action="store_true", help="print the per-shape conv launch table of the instrumented steps to stderr")
     ap.add_argument("--cpu-only-baseline", action="store_true", help=argparse.SUPPRESS)
     # BASELINE.json configs other than the headline one (c3): same step, other model / clip / mode.  c2 = TSCD-S, 8 frames (2+6)
     # @576^2, evaluation in .half() incl. the final NMS; c4 = TSCD-L, 32 frames (8+24), 30 classes, up to 2000 proposals per frame
@@ -278,7 +279,21 @@ def roofline_dominant_kernel(args, device, step):
         head_mod.LEVEL_STREAMS = streams
         tscd_mod.PREFETCH_BACKBONE = prefetch
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-    sel = [(f, e0.elapsed_time(e1) * 1e-3) for (bn, cin, f, e0, e1) in prof if bn == 128 and cin % 32 == 0]
+    sel = [(f, e0.elapsed_time(e1) * 1e-3) for (bn, cin, f, e0, e1, _) in prof if bn == 128 and cin % 32 == 0]
+    if args.conv_table:        # per-shape table of every conv / GEMM launch of the instrumented steps (stderr)
+        import collections
+        tab = collections.defaultdict(lambda: [0, 0.0, 0.0])
+        for (bn, cin, f, e0, e1, shape) in prof:
+            r = tab[shape]
+            r[0] += 1
+            r[1] += e0.elapsed_time(e1) * 1e-3
+            r[2] += f
+        tot = sum(r[1] for r in tab.values())
+        print(f"conv launches per step {len(prof) / nsteps:.0f}, conv ms per step {tot / nsteps * 1e3:.3f}", file=sys.stderr)
+        print("   n/step   us/launch   TFLOP/s  ms/step  share   (B, H, W, Cin, Cout, k, stride)", file=sys.stderr)
+        for shape, r in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+            print(f"  {r[0] / nsteps:6.1f}  {r[1] / r[0] * 1e6:9.1f}  {r[2] / r[1] / 1e12:8.1f}  {r[1] / nsteps * 1e3:7.3f}  {r[1] / tot:5.3f}   {shape}",
+                  file=sys.stderr)
     flops, secs = sum(f for f, _ in sel), sum(t for _, t in sel)
     W = int(256 * args.width)
     B, h = args.frames, args.size // 8

@@ -48,6 +48,9 @@ void tscd_conv_set_halo_auto(int on);
 /* Per-channel BatchNorm partial-sum entries a raw-epilogue launch of this shape writes (= its number of M-tiles, which
  * depends on the main-loop variant it takes): the `mtiles` argument of tscd_bn_finalize.  M = B*Ho*Wo, W = output width. */
 int tscd_conv_stat_tiles(long M, int W, int Cin, int Cout, int ksize, int stride);
+/* Tile height of the 128-channel-wide LDS-DMA variant: 0 = automatic (64 / 128 / 192 rows by how the grid fills 256 CUs),
+ * 64 / 128 / 192 = forced (tests, A/B timing).  Returns the previous setting. */
+int tscd_conv_set_tile_m(int rows);
 /* Measurement hook (scratch experiments, never set by the product path): bit0 makes the LDS-DMA loop's A gather read a
  * zero block, bit1 makes every B row read row 0 -- isolates how much of a launch is memory stall.  Results are wrong. */
 void tscd_conv_set_debug(int bits);

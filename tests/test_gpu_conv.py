@@ -249,7 +249,9 @@ def test_conv_lds_dma_variant_bit_identical_to_register_staging(case):
     w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).half()
     xg = x.to(dev()).permute(0, 2, 3, 1).contiguous()
     wpk = ops.pack_conv_weight(w.to(dev()))
+    tall = {}
     try:
+        lib.tscd_conv_set_tile_m(128)
         lib.tscd_conv_set_variant(0)
         y0, st0 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
         lib.tscd_conv_set_variant(1)              # 128-wide LDS-DMA tiles only
@@ -258,11 +260,22 @@ def test_conv_lds_dma_variant_bit_identical_to_register_staging(case):
         y2, st2 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
         lib.tscd_conv_set_variant(4)              # 128 x 256 / BK=32, staggered wave groups, wherever the shape allows it
         y3, st3 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
+        lib.tscd_conv_set_variant(1)
+        for bm in (64, 192):                      # the other tile heights of the 128-wide LDS-DMA variant
+            lib.tscd_conv_set_tile_m(bm)
+            tall[bm] = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
     finally:
         lib.tscd_conv_set_variant(-1)
+        lib.tscd_conv_set_tile_m(0)
     torch.cuda.synchronize()
     assert torch.equal(y0, y1) and torch.equal(y0, y2) and torch.equal(y0, y3)
     assert torch.equal(st0, st1) and torch.equal(st0, st2) and torch.equal(st0, st3)
+    for bm, (yb, stb) in tall.items():            # same MFMA sequence per output; the statistics are grouped by other row blocks
+        assert torch.equal(y0, yb), bm
+        M = B * yb.shape[1] * yb.shape[2]
+        if lib.tscd_conv_tile_n(Cout) == 128 and Cin % 32 == 0:
+            assert stb.shape[-1] == (M + bm - 1) // bm, (bm, stb.shape)
+        assert torch.allclose(stb.sum(-1), st0.sum(-1), rtol=2e-5, atol=1e-3), bm
     ref = F.conv2d(x.float(), w.float(), None, s, (k - 1) // 2)
     assert_close(y1.permute(0, 3, 1, 2), ref)
 

@@ -54,7 +54,7 @@ PLAIN = {"tscd_ema_chunk_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": 
          "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
          "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),
          "tscd_nms_workspace_bytes": ([I, I], L), "tscd_simota_workspace_bytes": ([I, I, I, I], L), "tscd_loss_workspace_bytes": ([L, L, L], L),
-         "tscd_conv_set_variant": ([I], None), "tscd_conv_set_korder": ([I], None), "tscd_conv_set_halo_auto": ([I], None), "tscd_conv_stat_tiles": ([L, I, I, I, I, I], I), "tscd_conv_wgrad_set_variant": ([I], I), "tscd_conv_set_debug": ([I], None), "tscd_cos_attn_mfma_supported": ([I], I), "tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
+         "tscd_conv_set_variant": ([I], None), "tscd_conv_set_korder": ([I], None), "tscd_conv_set_halo_auto": ([I], None), "tscd_conv_set_tile_m": ([I], I), "tscd_conv_stat_tiles": ([L, I, I, I, I, I], I), "tscd_conv_wgrad_set_variant": ([I], I), "tscd_conv_set_debug": ([I], None), "tscd_cos_attn_mfma_supported": ([I], I), "tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
          "tscd_last_error": ([], C.c_char_p)}
 
 

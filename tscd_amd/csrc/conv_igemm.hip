@@ -299,17 +299,22 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
 // Tiles: 128 x 256 with 8 waves (Cout > 128: the A gather is fetched once for 256 output channels -- the per-CU vector
 // memory path, not the MFMA, bounds the 128 x 128 tile at ~64 FLOP per loaded byte), 128 x 128 and 128 x 64 with 4 waves.
-template <int BN, int WAVES_N>
-__global__ __launch_bounds__(128 * WAVES_N, (BN == 256 ? 1 : 2)) void conv_igemm_glds_kernel(ConvParams p) {
-  constexpr int BM = 128, NS = 4, WAVES_M = 2, NW = WAVES_M * WAVES_N, NT = 64 * NW;
+// Tile height BM: 128 by default; 192 x 128 when that puts one workgroup on most CUs in a single round (36x36 level: 216
+// workgroups instead of 324 half-filling a second round), 64 x 128 when 128-row tiles leave most CUs empty (18x18 level).
+template <int BM, int BN, int WAVES_N>
+__global__ __launch_bounds__(128 * WAVES_N, (BM == 64 ? 3 : 2)) void conv_igemm_glds_kernel(ConvParams p) {
+  constexpr int NS = 4, WAVES_M = 2, NW = WAVES_M * WAVES_N, NT = 64 * NW;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_LD = 8 / NW, B_LD = BN / 16 / NW;       // glds wave-instructions (16 rows each) per wave and k-tile
+  constexpr int A_LD = BM / 16 / NW, B_LD = BN / 16 / NW;       // glds wave-instructions (16 rows each) per wave and k-tile
+  static_assert(BM % (16 * NW) == 0 && BM % 64 == 0, "tile height");
   constexpr int LD = A_LD + B_LD;
   static_assert(A_LD >= 1 && B_LD >= 1, "tile / wave split");
   __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
@@ -1074,11 +1079,48 @@ static int halo_tile_m(long M, int W, int Cin, int Cout, int ksize, int stride) 
   return best;
 }
 
+// 128 x 256 tiles: 3 = the BK=64 variant, 4 = the staggered one, 0 = neither (shared by the launch and tscd_conv_stat_tiles).
+// Variant 3 pays off (+7 %) only when its half-as-many, twice-as-large workgroups still cover the chip at least twice
+// (measured: 72x72 level x1.07, 36x36 x1.01, 18x18 x0.77); tscd_conv_set_variant(3 / 4) forces one (tests).
+static int wide_variant(long M, int Cin, int Cout) {
+  const int BNP = pick_bn(Cout);
+  const bool dma_ok = Cin % 32 == 0 && BNP >= 64 && g_conv_variant != 0;
+  const int cout_pad = cdiv(Cout, BNP) * BNP;
+  if (!dma_ok || Cout <= 128 || cout_pad % 256 != 0) return 0;
+  if (g_conv_variant == 4) return 4;
+  if (Cin % 64 == 0 && g_conv_variant != 1 && (g_conv_variant == 3 || (long)cdiv(M, 128) * cdiv(Cout, 256) >= 512)) return 3;
+  return 0;
+}
+
+// Tile height of the LDS-DMA 128-channel-wide variant for this launch, from same-box A/B timing of the bench clip's shapes
+// (tools/conv_tile_ab.py, profiles/r02_conv_tile_ab.txt; t128 = workgroups with 128-row tiles, 2 of which share a CU):
+//   * t128 <= 200 (18x18 level: 82 / 164 workgroups): 64-row tiles, 3 per CU -- 31.4 -> 22.5 us (256 ch 3x3), 54 -> 48 us (512 ch);
+//   * short K loops (<= 32 k-tiles: the 1x1 convs) up to 700 workgroups: 64-row tiles (prologue and epilogue of co-resident
+//     workgroups overlap) -- 14.1 -> 12.2, 18.0 -> 16.6, 20.9 -> 16.5 us;
+//   * long K loops whose 128-row grid needs a second, partly filled round while 192-row tiles fit 2 per CU in one
+//     (72x72 128 -> 128 3x3: 648 -> 432 workgroups): 192-row tiles -- 49.4 -> 42.7 us;
+//   * otherwise 128 (36x36 256 ch 3x3: 45 us with 128, 46 with 192, 52 with 64).
+// tscd_conv_set_tile_m(64 / 128 / 192) forces a height (tests, A/B).
+static int g_conv_tile_m = 0;
+extern "C" int tscd_conv_set_tile_m(int v) { int o = g_conv_tile_m; g_conv_tile_m = v; return o; }
+static int pick_bm(long M, int Cin, int Cout, int ksize) {
+  if (Cin % 32 != 0 || pick_bn(Cout) != 128 || g_conv_variant == 0) return 128;      // only the <*, 128, 2> instantiations vary BM
+  if (g_conv_tile_m == 64 || g_conv_tile_m == 128 || g_conv_tile_m == 192) return g_conv_tile_m;
+  const long nt = cdiv(Cout, 128), nk = (long)ksize * ksize * Cin / 32;
+  const long t128 = cdiv(M, 128) * nt, t192 = cdiv(M, 192) * nt;
+  if (t128 <= 200) return 64;
+  if (nk <= 32 && t128 <= 700) return 64;
+  if (nk > 32 && t128 > 512 && t192 <= 512) return 192;
+  return 128;
+}
+
 // Number of per-channel partial-sum entries a raw-epilogue launch writes (one per M-tile of the variant it takes):
 // bn_finalize must be told this count.
 extern "C" int tscd_conv_stat_tiles(long M, int W, int Cin, int Cout, int ksize, int stride) {
   const int bm = halo_tile_m(M, W, Cin, Cout, ksize, stride);
-  return cdiv(M, bm > 0 ? bm : 128);
+  if (bm > 0) return cdiv(M, bm);
+  if (wide_variant(M, Cin, Cout) != 0) return cdiv(M, 128);      // the 128 x 256 variants keep 128-row tiles
+  return cdiv(M, pick_bm(M, Cin, Cout, ksize));
 }
 
 extern "C" void tscd_conv_set_debug(int v) { g_conv_debug = v; }
@@ -1114,21 +1156,16 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
   p.M = (int)M;
   p.epilogue = epilogue;
   p.debug = g_conv_debug;
-  const int BM = 128, BNP = pick_bn(Cout);
+  const int BNP = pick_bn(Cout);
   const bool dma_ok = Cin % 32 == 0 && BNP >= 64 && g_conv_variant != 0;
   const int cout_pad = cdiv(Cout, BNP) * BNP;
-  // the 128 x 256 / BK=64 variant pays off (+7 %) only when its half-as-many, twice-as-large workgroups still cover the
-  // chip at least twice (measured: 72x72 level x1.07, 36x36 x1.01, 18x18 x0.77); g_conv_variant == 3 forces it (tests)
-  const bool v3_shape = Cin % 64 == 0 && Cout > 128 && cout_pad % 256 == 0;
-  const bool v3_ok = dma_ok && v3_shape && g_conv_variant != 1 && g_conv_variant != 4 &&
-                     (g_conv_variant == 3 || (long)cdiv(M, 128) * cdiv(Cout, 256) >= 512);
-  // variant 4 (staggered wave groups): the same 128 x 256 tile; needs only Cin % 32 == 0.  Selected by tscd_conv_set_variant(4)
-  // while it is being measured against variant 3.
-  const bool v4_ok = dma_ok && Cout > 128 && cout_pad % 256 == 0 && g_conv_variant == 4;
+  const int wv = wide_variant(M, Cin, Cout);
+  const bool v3_ok = wv == 3, v4_ok = wv == 4;
   // variant 5 (input halo staged once per channel chunk, 192- or 256-pixel x 256-channel tiles): 3x3 stride-1 convs
   const int v5_tm = halo_tile_m(M, W, Cin, Cout, ksize, stride);
   const bool v5_ok = v5_tm > 0;
   const int BN = (v3_ok || v4_ok || v5_ok) ? 256 : BNP;
+  const int BM = (v3_ok || v4_ok || !dma_ok) ? 128 : pick_bm(M, Cin, Cout, ksize);
   p.korder = (g_conv_korder == 1 && Cin % 32 == 0) ? 1 : 0;
   p.mtiles_stat = cdiv(M, 128);
   if (v5_ok) {
@@ -1153,9 +1190,11 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
   else if (v3_ok)
     hipLaunchKernelGGL(conv_igemm_v3_kernel, grid, block, 0, s, p);
   else if (dma_ok && BN == 128)
-    hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 2>), grid, block, 0, s, p);
+    if (BM == 64) hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 128, 2>), grid, block, 0, s, p);
+    else if (BM == 192) hipLaunchKernelGGL((conv_igemm_glds_kernel<192, 128, 2>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128, 2>), grid, block, 0, s, p);
   else if (dma_ok && BN == 64)
-    hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 2>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 64, 2>), grid, block, 0, s, p);
   else if (BN == 128)
     hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2>), grid, block, 0, s, p);
   else if (BN == 64)

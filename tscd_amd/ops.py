@@ -142,7 +142,8 @@ def conv2d(x, wpk, cout, ksize, stride=1, epilogue=EPI_RAW, bias=None, scale_shi
          _ptr(partial), B, H, W, Cin, cout, ksize, stride, ldx, ldy, epilogue, _stream())
     if prof is not None:
         e1.record()
-        prof.append((lib.tscd_conv_tile_n(cout), Cin, 2.0 * B * Ho * Wo * cout * ksize * ksize * Cin, e0, e1))
+        prof.append((lib.tscd_conv_tile_n(cout), Cin, 2.0 * B * Ho * Wo * cout * ksize * ksize * Cin, e0, e1,
+                     (B, H, W, Cin, cout, ksize, stride)))
     return out, partial
 
 
@@ -174,7 +175,7 @@ def conv_bn_act_train(x, wpk, cout, ksize, stride, gamma, beta, running_mean, ru
     if out is None:
         out = empty_nhwc(B, Ho, Wo, cout, dev)
     raw = empty_nhwc(B, Ho, Wo, cout, dev) if keep_raw else out
-    mt = (B * Ho * Wo + lib.tscd_conv_tile_m() - 1) // lib.tscd_conv_tile_m()
+    mt = lib.tscd_conv_stat_tiles(B * Ho * Wo, Wo, Cin, cout, ksize, stride)     # one partial-sum entry per M-tile of the variant taken
     partial = torch.empty((2, wpk.shape[0], mt), dtype=torch.float32, device=dev)
     small = torch.empty((4, cout), dtype=torch.float32, device=dev)
     call("tscd_conv_bn_act_train_f16", x.data_ptr(), wpk.data_ptr(), raw.data_ptr(), nhwc_ld(raw), partial.data_ptr(), wpk.shape[0],
