@@ -4,6 +4,8 @@ import os
 import torch
 import torch.nn as nn
 
+from tscd_amd import graphs
+
 from .network_blocks import defer_bn_ticks
 
 # Cross-step overlap (training, frozen backbone): while the host solves the clip's assignments the device has ~3 ms with
@@ -46,6 +48,8 @@ class TSCD(nn.Module):
             for t in hit[1]:
                 t.record_stream(torch.cuda.current_stream())
             return hit[1]
+        if not torch.is_grad_enabled() or (not self.training and not any(p.requires_grad for p in self.backbone.parameters())):
+            return graphs.frozen_pass(self.backbone, x)
         return self.backbone(x)
 
     def join_prefetch(self):
@@ -59,7 +63,7 @@ class TSCD(nn.Module):
         side = _prefetch_stream(next_x.device)
         side.wait_stream(torch.cuda.current_stream())            # next_x and every buffer the pass recycles are settled
         with torch.cuda.stream(side), torch.no_grad():
-            outs = self.backbone(next_x)
+            outs = graphs.frozen_pass(self.backbone, next_x)      # hipGraph replay after the first clip of a shape
             ev = torch.cuda.Event()
             ev.record(side)
         _PREFETCHED[id(self)] = (next_x, outs, ev)
