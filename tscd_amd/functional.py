@@ -104,7 +104,7 @@ class _ConvBias(torch.autograd.Function):
     def forward(ctx, x, weight, bias, relu):
         wpk = ops.WEIGHTS.get(weight)
         y, _ = ops.conv2d(x, wpk, weight.shape[0], weight.shape[-1], 1, ops.EPI_BIAS_RELU if relu else ops.EPI_BIAS,
-                          bias=bias.float())
+                          bias=ops.f32(bias))
         ctx.save_for_backward(x, weight, y)
         ctx.relu = relu
         return y
@@ -136,7 +136,7 @@ def conv_bias(x, weight, bias, relu=False):
         return _ConvBias.apply(x, weight, bias, relu)
     wpk = ops.WEIGHTS.get(weight)
     y, _ = ops.conv2d(x, wpk, weight.shape[0], weight.shape[-1], 1, ops.EPI_BIAS_RELU if relu else ops.EPI_BIAS,
-                      bias=bias.float())
+                      bias=ops.f32(bias))
     return y
 
 

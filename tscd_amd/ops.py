@@ -110,6 +110,27 @@ WEIGHTS = WeightCache()
 CONV_PROFILE = None
 
 
+_F32_CACHE = {}     # id(parameter) -> (weakref, version, data_ptr, fp32 copy)
+
+
+def f32(t):
+    """fp32 view of a small parameter (bias, norm weight) for kernels that take fp32 vectors.  For an nn.Parameter that autograd
+    does not have to see, the converted copy is kept until the parameter is written (a .half() evaluation model paid one
+    conversion kernel per call and layer otherwise)."""
+    if t is None or t.dtype == torch.float32:
+        return t
+    if not isinstance(t, torch.nn.Parameter) or (t.requires_grad and torch.is_grad_enabled()):
+        return t.float()
+    ent = _F32_CACHE.get(id(t))
+    if ent is not None and ent[0]() is t and ent[1] == t._version and ent[2] == t.data_ptr():
+        return ent[3]
+    if len(_F32_CACHE) > 8192:
+        _F32_CACHE.clear()
+    v = t.detach().float()
+    _F32_CACHE[id(t)] = (weakref.ref(t), t._version, t.data_ptr(), v)
+    return v
+
+
 def conv_out_hw(H, W, ksize, stride):
     pad = (ksize - 1) // 2
     return (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1

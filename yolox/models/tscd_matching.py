@@ -36,7 +36,7 @@ def _wait_copy(device_index, event):
 
 
 def _f32(t):
-    return t if t.dtype == torch.float32 else t.float()
+    return ops.f32(t)
 
 
 # ------------------------------------------------------------------------------------------------- device ops

@@ -65,6 +65,7 @@ def fuse_model(model):
         if isinstance(m, BaseConv) and m.conv.weight.is_cuda:
             bn = m.bn
             m._folded = ops.bn_fold(bn.weight.float(), bn.bias.float(), bn.running_mean.float(), bn.running_var.float(), bn.eps)
+            m._folded_ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.data_ptr())
     return model
 
 
