@@ -157,7 +157,11 @@ def make_optimizer(model, lr=0.002 / 64 * 16, momentum=0.9, weight_decay=5e-4, s
     # fused=True: one multi-tensor launch per group AND the GradScaler inf check stays on the device (found_inf is handed to the
     # fused step), so the host does not drain the GPU once per step; same SGD update rule (TSCD_FUSED_SGD=0: foreach path)
     fused = bool(tr(pg0)) and tr(pg0)[0].is_cuda and os.environ.get("TSCD_FUSED_SGD", "1") != "0"
-    opt = torch.optim.SGD(tr(pg0), lr=lr, momentum=momentum, nesterov=True, fused=fused)
+    if fused:
+        from tscd_amd.optim import FusedSGD      # the trainer's optimizer (exps/TSCD_OVIS/tscd_base.py get_optimizer): one launch, EMA included
+        opt = FusedSGD(tr(pg0), lr=lr, momentum=momentum, nesterov=True)
+    else:
+        opt = torch.optim.SGD(tr(pg0), lr=lr, momentum=momentum, nesterov=True)
     opt.add_param_group({"params": tr(pg1), "weight_decay": weight_decay})
     opt.add_param_group({"params": tr(pg2)})
     if tr(pg3):
@@ -166,17 +170,34 @@ def make_optimizer(model, lr=0.002 / 64 * 16, momentum=0.9, weight_decay=5e-4, s
 
 
 class FusedEMA:
-    """ModelEMA.update (yolox/utils/ema.py:48-60) over every floating state tensor, as one launch."""
+    """ModelEMA.update (yolox/utils/ema.py:48-60) without the deep copy of the module: EMA tensors of the state that can change.  As in
+    the trainer (ModelEMA.attach_to), the EMA of the parameters the optimizer steps rides in the optimizer's launch, frozen parameters
+    are skipped (they equal their copies), and update() covers the buffers (BatchNorm statistics of the whole network)."""
 
-    def __init__(self, model, decay=0.9998):
-        self.src = [v for v in model.state_dict().values() if v.dtype.is_floating_point]
+    def __init__(self, model, decay=0.9998, optimizer=None):
+        named = dict(model.named_parameters())
+        stepped = {id(p) for g in optimizer.param_groups for p in g["params"]} if optimizer is not None and hasattr(optimizer, "attach_ema") else set()
+        skip = {k for k, p in named.items() if id(p) in stepped or (stepped and not p.requires_grad)}
+        sd = model.state_dict()
+        self.src = [v for k, v in sd.items() if v.dtype.is_floating_point and k not in skip]
         self.ema = [v.detach().clone() for v in self.src]
         self.updates = 0
         self.decay = lambda x: decay * (1 - math.exp(-x / 2000))
+        self._pending = False
+        if stepped:
+            optimizer.attach_ema({p: p.detach().clone() for k, p in named.items() if id(p) in stepped}, self._next_decay)
+
+    def _next_decay(self):
+        self.updates += 1
+        self._pending = True
+        return self.decay(self.updates)
 
     @torch.no_grad()
     def update(self):
-        self.updates += 1
+        if self._pending:
+            self._pending = False
+        else:
+            self.updates += 1
         d = self.decay(self.updates)
         if self.ema and self.ema[0].is_cuda and all(v.dtype == torch.float32 for v in self.ema):
             from tscd_amd import ops
@@ -391,7 +412,7 @@ def main():
     # scaler would spend its first ~8 steps skipping (found_inf) while it backs off; start where it settles so that every timed
     # step applies its update
     scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
-    ema = FusedEMA(model)
+    ema = FusedEMA(model, optimizer=opt)
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,

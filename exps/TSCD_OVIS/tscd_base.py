@@ -111,7 +111,12 @@ class Exp(BaseExp):
             # fused multi-tensor SGD on the GPU: same update rule; with amp the GradScaler's inf check then stays on the
             # device instead of draining the GPU once per step (tscd_trainer.py:171-176 semantics unchanged)
             fused = bool(pg0) and pg0[0].is_cuda
-            opt = torch.optim.SGD(pg0, lr=lr, momentum=self.momentum, nesterov=True, fused=fused)
+            if fused:
+                # one launch for all groups, with the EMA of the trained parameters in the same pass (tscd_amd/optim.py, row N3)
+                from tscd_amd.optim import FusedSGD
+                opt = FusedSGD(pg0, lr=lr, momentum=self.momentum, nesterov=True)
+            else:
+                opt = torch.optim.SGD(pg0, lr=lr, momentum=self.momentum, nesterov=True)
             opt.add_param_group({"params": pg1, "weight_decay": self.weight_decay})
             opt.add_param_group({"params": pg2})
             if pg3:

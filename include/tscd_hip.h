@@ -127,6 +127,13 @@ int tscd_haar_idwt_mul_nhwc_f16(const void* hf, const void* content, int ldc, vo
  * array of nchunks records {float* dst; const float* src; long n} with n <= tscd_ema_chunk_elems() (one workgroup per record). */
 int tscd_ema_chunk_elems(void);
 int tscd_ema_update_f32(const void* table, long nchunks, float d, float one_minus_d, void* stream);
+/* Step tail in one launch (reference ovis_tscd_large.py:164-197, tscd_trainer.py:171-178, ema.py:48-60): Nesterov SGD
+ * with GradScaler unscale + skip-on-overflow and the EMA of the same parameters.  table: device array of nchunks records
+ * {float* p, const float* grad, float* momentum_buffer (zero before the first step), float* ema or NULL, long n, long group}
+ * (<= tscd_ema_chunk_elems() elements each); lr / wd: per-group host arrays (<= 8 groups); grad_scale / found_inf: device scalars or
+ * NULL; d, one_minus_d: EMA decay of this step. */
+int tscd_sgd_ema_step_f32(const void* table, long nchunks, const float* lr, const float* wd, int ngroups, float momentum, int nesterov,
+                          const float* grad_scale, const float* found_inf, float d, float one_minus_d, void* stream);
 int tscd_haar_idwt_mul_bwd_nhwc_f16(const void* d, const void* hf, const void* content, int ldc, void* dcontent, void* dhf,
                                     int B, int H, int W, int C, void* stream);
 

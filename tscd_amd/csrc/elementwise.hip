@@ -483,6 +483,80 @@ extern "C" int tscd_ema_update_f32(const void* table, long nchunks, float d, flo
 
 
 // ------------------------------------------------------------------------------------------------------
+// Step tail (reference: ovis_tscd_large.py:164-197 SGD groups, tscd_trainer.py:171-178, ema.py:48-60):
+// Nesterov-momentum SGD with the GradScaler's unscale and skip-on-overflow, AND the EMA update of the same parameter, in one
+// pass over the trainable parameters -- 4 reads + 3 writes per element instead of the 6 + 3 (fused SGD) plus 2 + 1 (EMA) of
+// the separate launches, and one launch instead of one per parameter group plus one.
+//   g = grad / grad_scale (+ wd * p);  buf = momentum * buf + g;  p -= lr * (g + momentum * buf)   [nesterov; buf = 0 before
+//   the first step, which makes the first step's buf = g as in torch.optim.SGD];  skipped when *found_inf != 0;
+//   ema = d * ema + (1 - d) * p   (always: the reference's ema.update runs after a skipped step too).
+// Chunk table like the EMA kernel's; each chunk names its parameter group (lr, weight decay per group as kernel arguments).
+// ------------------------------------------------------------------------------------------------------
+#define SGD_MAX_GROUPS 8
+struct SgdChunk { float* p; const float* g; float* buf; float* ema; long n; long group; };
+struct SgdGroups { float lr[SGD_MAX_GROUPS]; float wd[SGD_MAX_GROUPS]; };
+__global__ __launch_bounds__(256) void sgd_ema_kernel(const SgdChunk* __restrict__ table, SgdGroups grp, float momentum, int nesterov,
+                                                      const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
+                                                      float d, float omd) {
+  const SgdChunk c = table[blockIdx.x];
+  const float lr = grp.lr[c.group], wd = grp.wd[c.group];
+  const float inv = grad_scale ? 1.0f / *grad_scale : 1.0f;
+  const bool skip = found_inf && *found_inf != 0.f;
+  auto upd = [&](float& p, float g, float& buf, float& ema) {
+    if (!skip) {
+      g *= inv;
+      if (wd != 0.f) g = __builtin_fmaf(wd, p, g);
+      buf = __builtin_fmaf(momentum, buf, g);
+      g = nesterov ? __builtin_fmaf(momentum, buf, g) : buf;
+      p = __builtin_fmaf(-lr, g, p);
+    }
+    ema = __builtin_fmaf(omd, p, d * ema);
+  };
+  const bool has_ema = c.ema != nullptr;
+  if ((((uintptr_t)c.p | (uintptr_t)c.g | (uintptr_t)c.buf | (uintptr_t)c.ema) & 15) == 0) {
+    const long n4 = c.n >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+      float4 p = ((float4*)c.p)[i], b = ((float4*)c.buf)[i];
+      const float4 g = ((const float4*)c.g)[i];
+      float4 e = has_ema ? ((float4*)c.ema)[i] : float4{0.f, 0.f, 0.f, 0.f};
+      upd(p.x, g.x, b.x, e.x); upd(p.y, g.y, b.y, e.y); upd(p.z, g.z, b.z, e.z); upd(p.w, g.w, b.w, e.w);
+      if (!skip) { ((float4*)c.p)[i] = p; ((float4*)c.buf)[i] = b; }
+      if (has_ema) ((float4*)c.ema)[i] = e;
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) {
+      float p = c.p[i], b = c.buf[i], e = has_ema ? c.ema[i] : 0.f;
+      upd(p, c.g[i], b, e);
+      if (!skip) { c.p[i] = p; c.buf[i] = b; }
+      if (has_ema) c.ema[i] = e;
+    }
+  } else {
+    for (long i = threadIdx.x; i < c.n; i += 256) {
+      float p = c.p[i], b = c.buf[i], e = has_ema ? c.ema[i] : 0.f;
+      upd(p, c.g[i], b, e);
+      if (!skip) { c.p[i] = p; c.buf[i] = b; }
+      if (has_ema) c.ema[i] = e;
+    }
+  }
+}
+// table: device array of nchunks {float* p, const float* grad, float* momentum_buffer, float* ema (or null), long n, long group}
+// records (48 bytes); lr / wd: ngroups (<= 8) floats on the host; grad_scale / found_inf: device scalars or null.
+extern "C" int tscd_sgd_ema_step_f32(const void* table, long nchunks, const float* lr, const float* wd, int ngroups, float momentum,
+                                     int nesterov, const float* grad_scale, const float* found_inf, float d, float one_minus_d,
+                                     void* stream) {
+  TSCD_CHECK_ARG(table || nchunks == 0, "sgd_ema_step: null table");
+  TSCD_CHECK_ARG(lr && wd && ngroups > 0 && ngroups <= SGD_MAX_GROUPS, "sgd_ema_step: 1..%d parameter groups", SGD_MAX_GROUPS);
+  if (nchunks == 0) return TSCD_OK;
+  TSCD_CHECK_ARG(nchunks < (1L << 31), "sgd_ema_step: too many chunks");
+  SgdGroups g;
+  for (int i = 0; i < SGD_MAX_GROUPS; ++i) { g.lr[i] = i < ngroups ? lr[i] : 0.f; g.wd[i] = i < ngroups ? wd[i] : 0.f; }
+  hipLaunchKernelGGL(sgd_ema_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const SgdChunk*)table, g, momentum,
+                     nesterov, grad_scale, found_inf, d, one_minus_d);
+  TSCD_CHECK_LAUNCH("sgd_ema_step");
+  return TSCD_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
 // BaseConv in training mode as ONE host call: conv (raw output + per-tile BN partial sums) -> batch statistics
 // (scale/shift, saved mean / invstd, running statistics) -> apply + activation (+ residual).  Three launches, the same three
 // kernels as the separate entry points -- what it saves is the host side: one foreign call and one set of argument

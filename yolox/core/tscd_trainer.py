@@ -11,6 +11,7 @@ import time
 import torch
 from torch.nn.parallel import DistributedDataParallel as DDP
 
+from yolox.utils import checkpoint
 from yolox.utils import ModelEMA, all_reduce_norm, get_local_rank, get_rank, get_world_size, is_parallel, synchronize
 
 DEAD_PARAMS = ("transformer_self_attention_layers", "transformer_ffn_layers", "edge_feature_embedding", "attn.position_embedding",
@@ -54,6 +55,8 @@ class Trainer:
         if self.use_model_ema:
             self.ema_model = ModelEMA(model, 0.9998)
             self.ema_model.updates = self.max_iter * self.start_epoch
+            if hasattr(self.optimizer, "attach_ema"):
+                self.ema_model.attach_to(self.optimizer, model)      # EMA of the trained parameters inside the optimizer's launch
         self.model = model
         self.model.train()
 
@@ -62,14 +65,14 @@ class Trainer:
         ckpt_file = getattr(self.args, "ckpt", None)
         if getattr(self.args, "resume", False):
             ckpt_file = ckpt_file or os.path.join(self.file_name, "latest_ckpt.pth")
+            checkpoint.wait()
             ckpt = torch.load(ckpt_file, map_location=self.device, weights_only=True)
             model.load_state_dict(ckpt["model"])
             self.optimizer.load_state_dict(ckpt["optimizer"])
             self.start_epoch = ckpt.get("start_epoch", 0)
         elif ckpt_file:
             ckpt = torch.load(ckpt_file, map_location=self.device, weights_only=True)["model"]
-            own = model.state_dict()      # shape-tolerant fine-tune load (yolox/utils/checkpoint.py:11-33)
-            model.load_state_dict({k: v for k, v in ckpt.items() if k in own and own[k].shape == v.shape}, strict=False)
+            checkpoint.load_ckpt(model, ckpt)      # shape-tolerant fine-tune load (yolox/utils/checkpoint.py:11-33)
         return model
 
     # ------------------------------------------------------------------ loop
@@ -79,11 +82,33 @@ class Trainer:
             for self.epoch in range(self.start_epoch, self.max_epoch):
                 for self.iter in range(self.max_iter):
                     self.train_one_iter()
-                    if (self.progress_in_iter + 1) % 10 == 0 and getattr(self.exp, "multiscale_range", 0) > 0:
-                        self.input_size = self.exp.random_resize(self.train_loader, self.epoch, self.rank, self.is_distributed)
-                self.save_ckpt("latest")
+                    self.after_iter()
+                self.after_epoch()
         finally:
-            pass
+            checkpoint.wait()             # the last checkpoint's writer thread
+
+    def after_iter(self):
+        """Reference tscd_trainer.py:298-366: a ``latest`` checkpoint every 2000 iterations of an epoch (iteration 0 included),
+        multiscale resize every 10."""
+        if self.iter % 2000 == 0:
+            self.save_ckpt("latest")
+        if (self.progress_in_iter + 1) % 10 == 0 and getattr(self.exp, "multiscale_range", 0) > 0:
+            self.input_size = self.exp.random_resize(self.train_loader, self.epoch, self.rank, self.is_distributed)
+
+    def after_epoch(self):
+        """Reference :287-293, :394-425: ``latest`` after every epoch; every ``eval_interval`` epochs the (EMA) model is evaluated
+        and saved as ``last_epoch``, copied to ``best_ckpt.pth`` when its AP50:95 is the best so far."""
+        self.save_ckpt("latest")
+        if self.val_loader is not None and (self.epoch + 1) % max(1, getattr(self.exp, "eval_interval", 1)) == 0:
+            self.evaluate_and_save_model()
+
+    def evaluate_and_save_model(self):
+        summary = self.evaluate()
+        self.model.train()
+        ap50_95 = float(summary[0])
+        self.save_ckpt("last_epoch", ap50_95 > self.best_ap)
+        self.best_ap = max(self.best_ap, ap50_95)
+        return summary
 
     @property
     def progress_in_iter(self):
@@ -156,5 +181,6 @@ class Trainer:
             return
         model = self.ema_model.ema if self.use_model_ema else self.model
         model = model.module if is_parallel(model) else model
+        self._join_prefetch()             # a prefetched backbone pass may still be writing BatchNorm statistics
         state = {"start_epoch": self.epoch + 1, "model": model.state_dict(), "optimizer": self.optimizer.state_dict()}
-        torch.save(state, os.path.join(self.file_name, ckpt_name + "_ckpt.pth"))
+        checkpoint.save_checkpoint(state, update_best_ckpt, self.file_name, ckpt_name, non_blocking=getattr(self.args, "async_ckpt", True))

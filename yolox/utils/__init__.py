@@ -1,4 +1,5 @@
 from .boxes import adjust_box_anns, bboxes_iou, filter_box, postprocess, xyxy2cxcywh, xyxy2xywh
+from .checkpoint import load_ckpt, save_checkpoint
 from .dist import (all_reduce_norm, get_local_rank, get_local_size, get_num_devices, get_rank, get_world_size,
                    is_main_process, synchronize, time_synchronized)
 from .ema import ModelEMA, is_parallel

@@ -20,9 +20,33 @@ class ModelEMA:
         for p in self.ema.parameters():
             p.requires_grad_(False)
 
+    def attach_to(self, optimizer, model):
+        """Hands the EMA copies of the parameters ``optimizer`` (tscd_amd.optim.FusedSGD) steps to its fused pass; ``update`` then
+        covers the rest of the state that can change -- buffers, and parameters some other mechanism trains.  Frozen parameters
+        (requires_grad False, not in the optimizer) equal their copies at construction and stay equal: they are skipped, which is
+        what the full-state formula d * w + (1 - d) * w gives up to one rounding."""
+        inner = model.module if is_parallel(model) else model
+        ema_p = dict(self.ema.named_parameters())
+        stepped = {id(p) for g in optimizer.param_groups for p in g["params"]}
+        pairs = {p: ema_p[k] for k, p in inner.named_parameters() if id(p) in stepped}
+        optimizer.attach_ema(pairs, self._next_decay)
+        self._fused_keys = {k for k, p in inner.named_parameters() if id(p) in stepped}
+        self._skip_keys = self._fused_keys | {k for k, p in inner.named_parameters() if not p.requires_grad}
+        self._objs = None
+        self._fused_pending = False
+
+    def _next_decay(self):
+        # called by the optimizer's step: the EMA update counter advances there, update() must not advance it again
+        self.updates += 1
+        self._fused_pending = True
+        return self.decay(self.updates)
+
     @torch.no_grad()
     def update(self, model):
-        self.updates += 1
+        if getattr(self, "_fused_pending", False):
+            self._fused_pending = False           # the optimizer's pass already counted this update
+        else:
+            self.updates += 1
         d = self.decay(self.updates)
         inner = model.module if is_parallel(model) else model
         # The (ema tensor, model tensor) pairs are collected once: walking two state_dicts of ~900 entries costs ~3.5 ms of host
@@ -37,7 +61,8 @@ class ModelEMA:
             stale = tuple(t.data_ptr() for t in objs) != self._ptrs
         if stale:
             msd = inner.state_dict()
-            self._pairs = [(v, msd[k].detach()) for k, v in self.ema.state_dict().items() if v.dtype.is_floating_point]
+            skip = getattr(self, "_skip_keys", ())
+            self._pairs = [(v, msd[k].detach()) for k, v in self.ema.state_dict().items() if v.dtype.is_floating_point and k not in skip]
             self._objs = list(inner.parameters()) + list(inner.buffers()) + list(self.ema.parameters()) + list(self.ema.buffers())
             self._ptrs = tuple(t.data_ptr() for t in self._objs)
             self._objs_of = id(inner)
