@@ -346,7 +346,7 @@ def roofline_dominant_kernel(args, device, step):
             j = json.load(fh)
         traffic = j["all_launches"]["bytes_per_launch"]
         traffic_dom = (j.get("dominant_shape") or {}).get("bytes_per_launch")
-    return {"bound": "mfma", "kernel": "LDS-DMA implicit GEMM: conv_igemm_glds_kernel<128,2> + conv_igemm_v3_kernel (128x256 tiles on the 72x72 level)", "achieved": flops / secs / 1e12, "peak": peak,
+    return {"bound": "mfma", "kernel": "LDS-DMA implicit GEMM: conv_igemm_glds_kernel<64|128|192,128,2> + conv_igemm_halo_kernel<3> (halo-staged 192x256 tiles on the 72x72 level)", "achieved": flops / secs / 1e12, "peak": peak,
             "unit": "TFLOP/s", "frac": flops / secs / 1e12 / peak, "traffic": traffic,
             "traffic_unit": f"bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{pmc_name})",
             "launches_per_step": len(sel) / nsteps, "avg_launch_us": secs / len(sel) * 1e6, "gflop_per_launch": flops / len(sel) / 1e9,
@@ -535,7 +535,15 @@ def main():
                         "what": "loss terms of step 0 at the benchmark size, HIP product (fp16) vs CPU oracle (fp32) on identical "
                                 "weights/inputs; simota = the oracle's SimOTA in autocast arithmetic on the product's own fp16 outputs",
                         "gpu": losses_step0, "oracle": ref, "simota": simota,
-                        "max_rel_diff": max(abs(losses_step0[k] - ref[k]) / max(abs(ref[k]), 1e-6) for k in keys)}
+                        "rel_diff": {k: abs(losses_step0[k] - ref[k]) / max(abs(ref[k]), 1e-6) for k in keys},
+                        "max_rel_diff": max(abs(losses_step0[k] - ref[k]) / max(abs(ref[k]), 1e-6) for k in keys),
+                        "max_rel_diff_anchor_terms": max(abs(losses_step0[k] - ref[k]) / max(abs(ref[k]), 1e-6)
+                                                         for k in keys if k in ("iou_loss", "conf_loss", "cls_loss")),
+                        "reading": "the fp32 oracle and the fp16 product select different foreground anchors at random init (num_fg x 96 "
+                                   "boxes: see gpu / oracle; near-tied SimOTA costs), so the loss_matched_* terms -- means over the ~10 "
+                                   "refined foreground rows -- are different samples, not different arithmetic: `simota` shows the "
+                                   "assignment is identical on identical inputs, and tests/test_gpu_fullsize_c3.py checks every stage "
+                                   "(MCA, CAFM, loss kernels) on the product's own intermediates at this size"}
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)

@@ -57,6 +57,11 @@ void tscd_conv_set_debug(int bits);
 int tscd_conv_tile_n(int cout);
 int tscd_pack_conv_weight(const void* w, int src_is_f32, void* out, int Cout, int Cin, int CinPad, int KH, int KW,
                           int rows_pad, int Kpad, int mode, void* stream);
+/* The same packing for many weights in one launch (after an optimizer step).  jobs: device array of 56-byte records {const void* w;
+ * f16* out; int Cout, Cin, CinPad, KH, KW, rows_pad, Kpad, mode, src_is_f32, pad}; blockmap: one {int job, int block_in_job} per
+ * workgroup, each covering tscd_pack_block_elems() consecutive outputs of its job. */
+int tscd_pack_block_elems(void);
+int tscd_pack_conv_weights_batched(const void* jobs, const void* blockmap, long nblocks, void* stream);
 int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* bias, const float* scale,
                          const float* shift, float* bn_partial, int B, int H, int W, int Cin, int Cout, int ksize,
                          int stride, int ldx, int ldy, int epilogue, void* stream);

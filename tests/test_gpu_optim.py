@@ -116,3 +116,35 @@ def test_model_ema_attached_to_the_optimizer_equals_full_state_ema():
     a, b = ema.ema.state_dict(), ema_r.ema.state_dict()
     for k in a:
         assert torch.allclose(a[k].float(), b[k].float(), rtol=1e-5, atol=1e-7), k
+
+
+def test_packed_weight_copies_are_refreshed_in_place_by_the_step():
+    """After FusedSGD.step every cached packed copy (conv forward, conv data-gradient, linear forward / data-gradient) of a stepped
+    weight equals a fresh packing of the new values, is the same buffer as before, and a lookup launches nothing new."""
+    from tscd_amd import ops
+    from tscd_amd.optim import FusedSGD
+    torch.manual_seed(0)
+    conv_w = torch.nn.Parameter(torch.randn(40, 24, 3, 3, device="cuda"))
+    lin_w = torch.nn.Parameter(torch.randn(25, 64, device="cuda"))
+    frozen = torch.nn.Parameter(torch.randn(16, 16, 1, 1, device="cuda"), requires_grad=False)
+    copies = {"conv_f": ops.WEIGHTS.get(conv_w), "conv_d": ops.WEIGHTS.get(conv_w, None, 1), "lin_f": ops.LINEAR_WEIGHTS.get(lin_w),
+              "lin_d": ops.LINEAR_WEIGHTS.get(lin_w, mode=1), "frozen": ops.WEIGHTS.get(frozen)}
+    before = {k: v.clone() for k, v in copies.items()}
+    opt = FusedSGD([conv_w, lin_w], lr=0.5, momentum=0.9, nesterov=True)
+    conv_w.grad, lin_w.grad = torch.randn_like(conv_w), torch.randn_like(lin_w)
+    opt.step()
+    torch.cuda.synchronize()
+    fresh = {"conv_f": ops.pack_conv_weight(conv_w), "conv_d": ops.pack_conv_weight(conv_w, None, 1), "lin_f": ops.pack_linear_weight(lin_w),
+             "lin_d": ops.pack_conv_weight(lin_w.detach().reshape(25, 64, 1, 1), mode=1)}
+    again = {"conv_f": ops.WEIGHTS.get(conv_w), "conv_d": ops.WEIGHTS.get(conv_w, None, 1), "lin_f": ops.LINEAR_WEIGHTS.get(lin_w),
+             "lin_d": ops.LINEAR_WEIGHTS.get(lin_w, mode=1), "frozen": ops.WEIGHTS.get(frozen)}
+    for k in fresh:
+        assert again[k] is copies[k], k                       # no new buffer: the lookup hit the cache
+        assert torch.equal(again[k], fresh[k]), k             # and the buffer holds the new weights
+        assert not torch.equal(again[k], before[k]), k
+    assert again["frozen"] is copies["frozen"] and torch.equal(again["frozen"], before["frozen"])
+    # second step: table reused
+    conv_w.grad, lin_w.grad = torch.randn_like(conv_w), torch.randn_like(lin_w)
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(ops.WEIGHTS.get(conv_w), ops.pack_conv_weight(conv_w)) and ops.WEIGHTS.get(conv_w) is copies["conv_f"]

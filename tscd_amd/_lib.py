@@ -13,6 +13,7 @@ P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "tscd_conv2d_nhwc_f16": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "tscd_pack_conv_weight": [P, I, P, I, I, I, I, I, I, I, I, P],
+    "tscd_pack_conv_weights_batched": [P, P, L, P],
     "tscd_bn_finalize": [P, I, I, I, L, P, P, F, F, P, P, P, P, P, P],
     "tscd_bn_fold": [P, P, P, P, F, I, P, P],
     "tscd_bn_act_nhwc_f16": [P, I, P, I, P, P, I, L, I, I, P],
@@ -50,7 +51,7 @@ SIGNATURES = {
     "tscd_loss_dense_f16": [P, P, P, P, P, P, I, I, I, I, P, L, P, P, P],
     "tscd_loss_rows_f16": [P, P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, L, P, P, P, P, P],
 }
-PLAIN = {"tscd_ema_chunk_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
+PLAIN = {"tscd_ema_chunk_elems": ([], I), "tscd_pack_block_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
          "tscd_bn_silu_bwd_workspace_bytes": ([L, I], L), "tscd_linear_bwd_workspace_bytes": ([I, I, I], L),
          "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
          "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),

@@ -67,6 +67,41 @@ extern "C" int tscd_pack_conv_weight(const void* w, int src_is_f32, void* out, i
   return TSCD_OK;
 }
 
+// All trainable weights re-packed in ONE launch after the optimizer step (the per-weight launches above cost ~90 launches and
+// 0.4 ms per TSCD-L step: forward and data-gradient packing of ~45 convs / linears).  jobs: device array of PackJob; blockmap:
+// one {job, block-in-job} pair per workgroup, PACK_BLOCK_ELEMS outputs each.
+#define PACK_BLOCK_ELEMS 2048
+struct PackJob { const void* w; f16* out; int Cout, Cin, CinPad, KH, KW, rows_pad, Kpad, mode, src_f32, pad_; };
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, const int2* __restrict__ blockmap) {
+  const int2 bm = blockmap[blockIdx.x];
+  const PackJob j = jobs[bm.x];
+  const long total = (long)j.rows_pad * j.Kpad;
+  const long lo = (long)bm.y * PACK_BLOCK_ELEMS, hi = lo + PACK_BLOCK_ELEMS < total ? lo + PACK_BLOCK_ELEMS : total;
+  for (long idx = lo + threadIdx.x; idx < hi; idx += 256) {
+    const int row = idx / j.Kpad, k = idx % j.Kpad;
+    const int tap = k / j.CinPad, c = k % j.CinPad;
+    long src = -1;
+    if (j.mode == 0) {
+      if (row < j.Cout && tap < j.KH * j.KW && c < j.Cin) src = (((long)row * j.Cin + c) * j.KH + tap / j.KW) * j.KW + tap % j.KW;
+    } else if (row < j.Cin && tap < j.KH * j.KW && c < j.Cout) {
+      src = (((long)c * j.Cin + row) * j.KH + (j.KH - 1 - tap / j.KW)) * j.KW + (j.KW - 1 - tap % j.KW);
+    }
+    float v = 0.f;
+    if (src >= 0) v = j.src_f32 ? ((const float*)j.w)[src] : (float)((const f16*)j.w)[src];
+    j.out[idx] = (f16)v;
+  }
+}
+extern "C" int tscd_pack_block_elems(void) { return PACK_BLOCK_ELEMS; }
+extern "C" int tscd_pack_conv_weights_batched(const void* jobs, const void* blockmap, long nblocks, void* stream) {
+  TSCD_CHECK_ARG((jobs && blockmap) || nblocks == 0, "pack_conv_weights_batched: null table");
+  if (nblocks == 0) return TSCD_OK;
+  TSCD_CHECK_ARG(nblocks < (1L << 31), "pack_conv_weights_batched: too many blocks");
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs,
+                     (const int2*)blockmap);
+  TSCD_CHECK_LAUNCH("pack_conv_weights_batched");
+  return TSCD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Train-mode BatchNorm: reduce the conv kernel's per-M-tile partials ([2][cstride][mtiles], channel-major: a wave reads
 // contiguous floats) in a fixed order (one wave per channel,

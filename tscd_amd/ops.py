@@ -54,20 +54,19 @@ def empty_nhwc(B, H, W, C, device):
 # ----------------------------------------------------------------------------------------------------
 # weights
 # ----------------------------------------------------------------------------------------------------
+def _pack_dims(shape, cin_pad, mode):
+    Cout, Cin, KH, KW = shape
+    inner, rows = ((cin_pad or Cin), Cout) if mode == 0 else (Cout, Cin)
+    bn = lib.tscd_conv_tile_n(rows)
+    return Cout, Cin, inner, KH, KW, (rows + bn - 1) // bn * bn, (KH * KW * inner + 31) // 32 * 32
+
+
 def pack_conv_weight(w, cin_pad=None, mode=0):
     """torch [Cout,Cin,KH,KW] (fp32/fp16) -> packed fp16 [rows_pad, Kpad] for tscd_conv2d_nhwc_f16.
     mode=1 packs the matrix that makes the same kernel compute the data gradient of a stride-1 conv."""
     require_gpu(w, "weight")
-    Cout, Cin, KH, KW = w.shape
+    Cout, Cin, inner, KH, KW, rows_pad, kpad = _pack_dims(w.shape, cin_pad, mode)
     w = w.detach().contiguous()
-    if mode == 0:
-        inner = cin_pad or Cin
-        rows = Cout
-    else:
-        inner, rows = Cout, Cin
-    bn = lib.tscd_conv_tile_n(rows)
-    rows_pad = (rows + bn - 1) // bn * bn
-    kpad = (KH * KW * inner + 31) // 32 * 32
     out = torch.empty((rows_pad, kpad), dtype=torch.float16, device=w.device)
     assert w.dtype in (torch.float32, torch.float16)
     call("tscd_pack_conv_weight", w.data_ptr(), int(w.dtype == torch.float32), out.data_ptr(), Cout, Cin, inner, KH, KW,
@@ -86,18 +85,78 @@ class WeightCache:
     def _tag(w):
         return (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape))
 
-    def _lookup(self, key, w, make):
+    def _lookup(self, key, w, make, shape4=None, cin_pad=None, mode=0):
         # id() values are recycled once a tensor dies, so an entry is only valid while its weakref still points at `w`
         ent = self._c.get(key)
         if ent is None or ent[2]() is not w or ent[0] != self._tag(w):
             if len(self._c) > 4096:
                 self._c = {k: v for k, v in self._c.items() if v[2]() is not None}
-            ent = (self._tag(w), make(), weakref.ref(w))
+            # (tag, packed, weakref, [Cout, Cin, KH, KW] the packing sees, cin_pad, mode): the last three let refresh() repack in place
+            ent = (self._tag(w), make(), weakref.ref(w), tuple(shape4 if shape4 is not None else w.shape), cin_pad, mode)
             self._c[key] = ent
+            _REFRESH_TABLES.clear()
         return ent[1]
 
     def get(self, w, cin_pad=None, mode=0):
-        return self._lookup((id(w), mode, cin_pad), w, lambda: pack_conv_weight(w, cin_pad, mode))
+        return self._lookup((id(w), mode, cin_pad), w, lambda: pack_conv_weight(w, cin_pad, mode), None, cin_pad, mode)
+
+
+_REFRESH_TABLES = {}      # (ids of the stepped parameters) -> (signature, jobs, blockmap, nblocks, entries)
+
+
+def refresh_packed_weights(params):
+    """Re-packs, IN PLACE and in one launch, every cached packed copy (conv forward / data-gradient order, linear) of the given
+    parameters -- called by the optimizer right after its step, so the next forward and backward find every copy current and launch
+    no pack kernel (~90 per TSCD-L step otherwise).  Copies whose parameter was replaced or reshaped are left to the lazy path."""
+    import numpy as np
+    key = tuple(id(p) for p in params)
+    hit = _REFRESH_TABLES.get(key)
+    if hit is None:
+        want = set(key)
+        ents = []
+        for cache in (WEIGHTS, LINEAR_WEIGHTS):
+            for k, e in cache._c.items():
+                w = e[2]()
+                if w is not None and id(w) in want and w.is_cuda and w.is_contiguous() and w.dtype in (torch.float32, torch.float16):
+                    ents.append((cache, k))
+        if not ents:
+            _REFRESH_TABLES[key] = None
+            return 0
+        be = lib.tscd_pack_block_elems()
+        jobs, bmap, sig = [], [], []
+        for ji, (cache, k) in enumerate(ents):
+            tag, packed, ref, shape4, cin_pad, mode = cache._c[k]
+            w = ref()
+            Cout, Cin, inner, KH, KW, rows_pad, kpad = _pack_dims(shape4, cin_pad, mode)
+            assert tuple(packed.shape) == (rows_pad, kpad)
+            jobs.append((w.data_ptr(), packed.data_ptr(), Cout | (Cin << 32), inner | (KH << 32), KW | (rows_pad << 32), kpad | (mode << 32),
+                         int(w.dtype == torch.float32)))
+            nb = (rows_pad * kpad + be - 1) // be
+            bmap.extend((ji, b) for b in range(nb))
+            sig.append((w.data_ptr(), packed.data_ptr()))
+        dev = params[0].device
+        jt = torch.from_numpy(np.array(jobs, dtype=np.int64).reshape(-1, 7)).to(dev)
+        bt = torch.from_numpy(np.array(bmap, dtype=np.int32).reshape(-1, 2)).to(dev)
+        hit = _REFRESH_TABLES[key] = (tuple(sig), jt, bt, len(bmap), ents)
+    if hit is None:
+        return 0
+    sig, jt, bt, nb, ents = hit
+    live = []
+    for cache, k in ents:
+        e = cache._c.get(k)
+        w = e[2]() if e is not None else None
+        if w is None:
+            _REFRESH_TABLES.clear()
+            return 0
+        live.append((w.data_ptr(), e[1].data_ptr()))
+    if tuple(live) != sig:                       # a parameter or a packed copy moved: rebuild next time, lazy path now
+        _REFRESH_TABLES.clear()
+        return 0
+    call("tscd_pack_conv_weights_batched", jt.data_ptr(), bt.data_ptr(), nb, _stream())
+    for cache, k in ents:
+        e = cache._c[k]
+        cache._c[k] = (cache._tag(e[2]()),) + e[1:]
+    return len(ents)
 
 
 WEIGHTS = WeightCache()
@@ -296,8 +355,11 @@ def pack_linear_weight(w):
 
 
 class _LinearCache(WeightCache):
-    def get(self, w):
-        return self._lookup((id(w), "lin"), w, lambda: pack_linear_weight(w))
+    def get(self, w, mode=0):
+        shape4 = (w.shape[0], w.shape[1], 1, 1)
+        if mode == 0:
+            return self._lookup((id(w), "lin"), w, lambda: pack_linear_weight(w), shape4, None, 0)
+        return self._lookup((id(w), "lin_dgrad"), w, lambda: pack_conv_weight(w.detach().reshape(shape4), mode=1), shape4, None, 1)
 
 
 LINEAR_WEIGHTS = _LinearCache()
@@ -518,7 +580,7 @@ def linear_dgrad(dy, weight):
         d2 = dy.new_zeros((n, kp))
         d2[:, :out_f] = dy
         dy = d2
-    wpk = pack_conv_weight(weight.detach().reshape(out_f, in_f, 1, 1), mode=1)
+    wpk = LINEAR_WEIGHTS.get(weight, mode=1)        # data-gradient packing, cached per parameter version like the forward copy
     return linear(dy, None, out=torch.empty((n, in_f), dtype=torch.float16, device=dy.device), wpk=wpk)
 
 

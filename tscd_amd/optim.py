@@ -100,6 +100,7 @@ class FusedSGD(torch.optim.SGD):
         torch.autograd.graph.increment_version(params)
         if self._ema_of:
             torch.autograd.graph.increment_version([self._ema_of[id(p)] for p in params if id(p) in self._ema_of])
+        ops.refresh_packed_weights(params)       # every packed fp16 copy of the stepped weights, in place, one launch
         return loss
 
 
