@@ -243,6 +243,13 @@ int tscd_simota_assign(const void* outputs, const float* labels, int B, int A, i
                        const int* w3, const int* stride3, int topk, int emu16, void* workspace, long workspace_bytes,
                        unsigned char* fg_mask, int* matched_gt, float* pred_iou, int* num_fg, int* ngt, void* stream);
 
+/* Clip pre-processing on the device (reference: yolox/data/datasets/vid.py pull_item + data_augment.py:21-31,
+ * 196-203, 248-264): decoded uint8 BGR frames [B][hmax][wmax][3] -> letterboxed planar [B][3][H][W] (0..255; fp16 or fp32): bilinear
+ * resize to (nh, nw) in OpenCV's INTER_LINEAR geometry, optional 8-bit HSV jitter, optional horizontal flip, 114 fill.
+ * meta: device int32 [B][12] = {h, w, nh, nw, flip, hsv_on, hgain, sgain, vgain, bits of fp32(h/nh), bits of fp32(w/nw), 0}. */
+int tscd_clip_preproc_u8(const void* src, int B, int hmax, int wmax, const int* meta, void* out, int H, int W, int out_is_f16,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@ SIGNATURES = {
     "tscd_haar_idwt_mul_nhwc_f16": [P, P, I, P, I, I, I, I, I, P],
     "tscd_haar_idwt_mul_bwd_nhwc_f16": [P, P, P, I, P, P, I, I, I, I, P],
     "tscd_ema_update_f32": [P, L, F, F, P],
+    "tscd_clip_preproc_u8": [P, I, I, I, P, P, I, I, I, P],
     "tscd_sgd_ema_step_f32": [P, L, P, P, I, F, I, P, P, F, F, P],
     "tscd_conv_bn_act_train_f16": [P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, P, F, F, P, P, P, P, I, P, I, I, P],
     "tscd_decode_score": [P, P, P, P, P, P, I, I, P, P, P, P],

@@ -238,6 +238,106 @@ extern "C" int tscd_bn_act_nhwc_f16(const void* x, int ldx, void* y, int ldy, co
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Clip pre-processing on the device (reference: vid.py pull_item resize + data_augment.py:21-31 augment_hsv,
+// :196-203 _mirror, :248-264 preproc): decoded uint8 BGR frames [B][hmax][wmax][3] -> letterboxed planar [B][3][H][W] (0..255,
+// fp16 or fp32).  Per frame: bilinear resize to (nh, nw) with OpenCV's INTER_LINEAR geometry (half-pixel centres, edge clamp),
+// rounded to uint8; optional HSV jitter on the resized pixel (8-bit HSV: H 0..179); optional horizontal flip of the resized image;
+// paste top-left on a 114 canvas.  The same float32 arithmetic, in the same order, as yolox/data/data_augment.py's numpy
+// transforms, one thread per output pixel.  meta[b] = {h, w, nh, nw, flip, hsv_on, hgain, sgain, vgain, bits(fp32 h/nh), bits(fp32 w/nw), 0}.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hsv_jitter_u8(float& b, float& g, float& r, int hg, int sg, int vg) {
+#pragma clang fp contract(off)      // numpy rounds every product and sum: no fused multiply-add here
+  // _bgr2hsv
+  const float v = fmaxf(fmaxf(r, g), b), mn = fminf(fminf(r, g), b), d = v - mn;
+  float s = v > 0.f ? d / fmaxf(v, 1e-12f) * 255.0f : 0.f;
+  const float dd = fmaxf(d, 1e-12f);
+  float h = (v == r ? (g - b) / dd : (v == g ? 2.0f + (b - r) / dd : 4.0f + (r - g) / dd)) * 60.0f;
+  if (d == 0.f) h = 0.f;
+  if (h < 0.f) h += 360.0f;
+  h *= 0.5f;
+  int hi = ((int)rintf(h)) % 180, si = (int)rintf(s), vi = (int)v;
+  // gains
+  hi = (hi + hg) % 180;
+  if (hi < 0) hi += 180;
+  si = min(255, max(0, si + sg));
+  vi = min(255, max(0, vi + vg));
+  // _hsv2bgr
+  const float hh = (float)hi * 2.0f, ss = (float)si / 255.0f, vv = (float)vi;
+  const float c = vv * ss, hp = hh / 60.0f;
+  const float x = c * (1.f - fabsf(fmodf(hp, 2.f) - 1.f));
+  const int sel = ((int)floorf(hp)) % 6;
+  float rr, gg, bb;
+  switch (sel) {
+    case 0: rr = c; gg = x; bb = 0.f; break;
+    case 1: rr = x; gg = c; bb = 0.f; break;
+    case 2: rr = 0.f; gg = c; bb = x; break;
+    case 3: rr = 0.f; gg = x; bb = c; break;
+    case 4: rr = x; gg = 0.f; bb = c; break;
+    default: rr = c; gg = 0.f; bb = x; break;
+  }
+  const float m = vv - c;
+  b = fminf(255.f, fmaxf(0.f, rintf(bb + m)));
+  g = fminf(255.f, fmaxf(0.f, rintf(gg + m)));
+  r = fminf(255.f, fmaxf(0.f, rintf(rr + m)));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void clip_preproc_kernel(const unsigned char* __restrict__ src, long frame_stride, int wmax,
+                                                           const int* __restrict__ meta, T* __restrict__ out, int H, int W) {
+#pragma clang fp contract(off)      // numpy rounds every product and sum: no fused multiply-add here
+  const int b = blockIdx.z;
+  const int* m = meta + b * 12;
+  const int h = m[0], w = m[1], nh = m[2], nw = m[3], flip = m[4], hsv_on = m[5];
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  float vb = 114.f, vg = 114.f, vr = 114.f;
+  if (y < nh && x < nw) {
+    const int xs = flip ? nw - 1 - x : x;                    // the mirror acts on the RESIZED image
+    // scales h / nh, w / nw rounded to fp32 on the host exactly as numpy rounds them (meta[9], meta[10] carry the bits)
+    const float sy = ((float)y + 0.5f) * __int_as_float(m[9]) - 0.5f, sx = ((float)xs + 0.5f) * __int_as_float(m[10]) - 0.5f;
+    const float fy0 = floorf(sy), fx0 = floorf(sx);
+    const float fy = sy - fy0, fx = sx - fx0;
+    const int y0 = min(h - 1, max(0, (int)fy0)), y1 = min(h - 1, max(0, (int)fy0 + 1));
+    const int x0 = min(w - 1, max(0, (int)fx0)), x1 = min(w - 1, max(0, (int)fx0 + 1));
+    const unsigned char* f = src + b * frame_stride;
+    const unsigned char *p00 = f + ((long)y0 * wmax + x0) * 3, *p01 = f + ((long)y0 * wmax + x1) * 3;
+    const unsigned char *p10 = f + ((long)y1 * wmax + x0) * 3, *p11 = f + ((long)y1 * wmax + x1) * 3;
+    float v[3];
+    const bool same = h == nh && w == nw;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (same) {
+        v[c] = (float)p00[c];
+      } else {
+        const float top = (float)p00[c] * (1.f - fx) + (float)p01[c] * fx;
+        const float bot = (float)p10[c] * (1.f - fx) + (float)p11[c] * fx;
+        v[c] = fminf(255.f, fmaxf(0.f, rintf(top * (1.f - fy) + bot * fy)));
+      }
+    }
+    vb = v[0]; vg = v[1]; vr = v[2];
+    if (hsv_on) hsv_jitter_u8(vb, vg, vr, m[6], m[7], m[8]);
+  }
+  const long plane = (long)H * W, o = (long)b * 3 * plane + (long)y * W + x;
+  out[o] = (T)vb;
+  out[o + plane] = (T)vg;
+  out[o + 2 * plane] = (T)vr;
+}
+
+extern "C" int tscd_clip_preproc_u8(const void* src, int B, int hmax, int wmax, const int* meta, void* out, int H, int W, int out_is_f16,
+                                    void* stream) {
+  TSCD_CHECK_ARG(src && meta && out && B > 0 && hmax > 0 && wmax > 0 && H > 0 && W > 0, "clip_preproc: bad arguments");
+  dim3 grid(cdiv(W, 64), cdiv(H, 4), B), block(256);
+  const long fs = (long)hmax * wmax * 3;
+  if (out_is_f16)
+    hipLaunchKernelGGL(clip_preproc_kernel<f16>, grid, block, 0, (hipStream_t)stream, (const unsigned char*)src, fs, wmax, meta, (f16*)out, H, W);
+  else
+    hipLaunchKernelGGL(clip_preproc_kernel<float>, grid, block, 0, (hipStream_t)stream, (const unsigned char*)src, fs, wmax, meta, (float*)out, H,
+                       W);
+  TSCD_CHECK_LAUNCH("clip_preproc");
+  return TSCD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Focus (network_blocks.py:267-289): NCHW image -> NHWC [B, H/2, W/2, 16] with channels
 // (tl c0..2, bl c0..2, tr c0..2, br c0..2, 0, 0, 0, 0); the 4 zero channels keep Cin a multiple of 8.
 // ------------------------------------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-from .data_augment import TrainTransform, ValTransform, Vid_Val_Transform
+from .data_augment import TrainTransform, TrainTransformGPU, ValTransform, Vid_Val_Transform
 from .datasets import vid
 from .datasets.vid import DataPrefetcher
 from .synthetic import SyntheticClipLoader, get_timing_signal_1d

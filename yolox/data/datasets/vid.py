@@ -162,10 +162,35 @@ class OVIS(torchDataset):
         return resize_bilinear(img, int(h * r), int(w * r)), annos.copy(), (h, w), img_path
 
     def __getitem__(self, path):
+        from ..data_augment import TrainTransformGPU
+        if isinstance(self.preproc, TrainTransformGPU):
+            return self.pull_raw(path)
         img, target, img_info, path = self.pull_item(path)
         if self.preproc is not None:
             img, target = self.preproc(img, target, self.input_dim)
         return img, target, img_info, path
+
+    def pull_raw(self, path):
+        """Device-side pre-processing (row N1): the decoded frame as it is (uint8 HWC BGR), the transformed labels and the kernel's
+        per-frame record.  A frame whose letterbox needs the second resample of the host pipeline (pull_item resizes to (nh, nw),
+        preproc then maps that onto int(nh * r'), int(nw * r') with r' = min(H / nh, W / nw) -- the identity except when a float
+        truncation left nw one short of W) is transformed on the host and handed over as a finished H x W frame."""
+        from ..data_augment import TrainTransform, val_meta
+        annos, _, _, img_path = self.annotations[self._pos[self.name_id_dic[path]]]
+        img = imread_bgr(os.path.join(self.data_dir, self.name, img_path))
+        h, w = img.shape[:2]
+        H, W = self.input_dim
+        r = min(self.img_size[0] / h, self.img_size[1] / w)
+        nh, nw = int(h * r), int(w * r)
+        r2 = min(H / nh, W / nw)
+        if (int(nh * r2), int(nw * r2)) != (nh, nw):
+            host = TrainTransform(self.preproc.max_labels, self.preproc.flip_prob, self.preproc.hsv_prob)
+            from ..data_augment import resize_bilinear
+            chw, target = host(resize_bilinear(img, nh, nw), annos.copy(), self.input_dim)
+            done = np.ascontiguousarray(chw.transpose(1, 2, 0).astype(np.uint8))
+            return done, target, (h, w), img_path, val_meta((H, W), (H, W))
+        meta, target = self.preproc((h, w), (nh, nw), annos.copy(), self.input_dim)
+        return img, target, (h, w), img_path, meta
 
 
 class VIDDataset(torchDataset):
@@ -266,9 +291,30 @@ def collate_fn_ovis(batch):
     return torch.stack(imgs), torch.stack(tar), ims_info, tar_ori, path, get_timing_signal_1d(torch.tensor(seq), 256)
 
 
+def collate_fn_ovis_raw(batch):
+    """Clips of undecorated frames for the device-side transform: (frames uint8 [B,hmax,wmax,3], targets, infos, targets as lists, paths,
+    time embedding, per-frame kernel records int32 [B,12])."""
+    hmax, wmax = max(b[0].shape[0] for b in batch), max(b[0].shape[1] for b in batch)
+    frames = torch.zeros((len(batch), hmax, wmax, 3), dtype=torch.uint8)
+    tar, ims_info, tar_ori, path, seq, metas = [], [], [], [], [], []
+    for i, (img, target, info, p, meta) in enumerate(batch):
+        frames[i, :img.shape[0], :img.shape[1]] = torch.from_numpy(img)
+        t = torch.zeros([100, 5])
+        tar_ori.append(torch.as_tensor(copy.deepcopy(target)))
+        t[:target.shape[0]] = torch.as_tensor(target)
+        tar.append(t)
+        ims_info.append(info)
+        path.append(p)
+        metas.append(torch.from_numpy(meta))
+        seq.append(int(p[p.rfind("/") + 1:p.rfind(".")].split("_")[-1]))
+    return frames, torch.stack(tar), ims_info, tar_ori, path, get_timing_signal_1d(torch.tensor(seq), 256), torch.stack(metas)
+
+
 def _loader(dataset, sampler, data_num_workers):
+    from ..data_augment import TrainTransformGPU
+    raw = isinstance(getattr(dataset, "preproc", None), TrainTransformGPU)
     return torch.utils.data.DataLoader(dataset, num_workers=data_num_workers, pin_memory=torch.cuda.is_available(),
-                                       batch_sampler=sampler, collate_fn=collate_fn_ovis)
+                                       batch_sampler=sampler, collate_fn=collate_fn_ovis_raw if raw else collate_fn_ovis)
 
 
 def ovis_get_trans_loader(batch_size, data_num_workers, dataset, rank=None, world_size=None, seed=0):
@@ -283,20 +329,28 @@ class DataPrefetcher:
     """Double buffering of the loader's batches: the next clip's H2D copy runs on a side stream from pinned memory while the
     current step computes; ``next()`` -> (imgs, targets, time_embedding) on the device (None at the end of the epoch)."""
 
-    def __init__(self, loader):
+    def __init__(self, loader, input_size=None):
         self.loader = iter(loader)
         self.max_iter = len(loader)
+        self.input_size = input_size or getattr(getattr(loader, "dataset", None), "input_dim", None)
         self.stream = torch.cuda.Stream()
         self.preload()
 
     def preload(self):
         try:
-            self.next_input, self.next_target, _, _, _, self.time_embedding = next(self.loader)
+            batch = next(self.loader)
         except StopIteration:
             self.next_input = self.next_target = self.time_embedding = None
             return
+        self.next_input, self.next_target, self.time_embedding = batch[0], batch[1], batch[5]
         with torch.cuda.stream(self.stream):
-            self.next_input = self.next_input.cuda(non_blocking=True)
+            if len(batch) == 7:            # undecorated uint8 frames + kernel records: resize / HSV / flip / pad on the device
+                from ..data_augment import clip_preproc_gpu
+                frames = self.next_input.cuda(non_blocking=True)
+                self.next_input = clip_preproc_gpu(frames, batch[6].cuda(non_blocking=True), self.input_size, torch.float16)
+                frames.record_stream(self.stream)
+            else:
+                self.next_input = self.next_input.cuda(non_blocking=True)
             self.next_target = self.next_target.cuda(non_blocking=True)
             self.time_embedding = self.time_embedding.cuda(non_blocking=True)
 
