@@ -243,6 +243,14 @@ int tscd_simota_assign(const void* outputs, const float* labels, int B, int A, i
                        const int* w3, const int* stride3, int topk, int emu16, void* workspace, long workspace_bytes,
                        unsigned char* fg_mask, int* matched_gt, float* pred_iou, int* num_fg, int* ngt, void* stream);
 
+/* Backbone / neck backward helpers.  zero_insert2: dY [B,Ho,Wo,C] -> [B,2Ho,2Wo,C], dY at even positions: the
+ * data / weight gradient of a 3x3 stride-2 pad-1 conv is the stride-1 gradient on it (darknet.py:120-160 downsampling convs,
+ * yolo_pafpn.py bu_conv1/2).  maxpool5_bwd: gradient of SPP's stride-1 5x5 max pool (network_blocks.py:183-205), first maximum in scan
+ * order wins ties.  upsample2_bwd: gradient of PAFPN's nearest x2 upsample (sum of each 2x2 block). */
+int tscd_zero_insert2_nhwc_f16(const void* dy, int lddy, void* out, int ldo, int B, int Ho, int Wo, int C, void* stream);
+int tscd_maxpool5_bwd_nhwc_f16(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C, void* stream);
+int tscd_upsample2_bwd_nhwc_f16(const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C, void* stream);
+
 /* Clip pre-processing on the device (reference: yolox/data/datasets/vid.py pull_item + data_augment.py:21-31,
  * 196-203, 248-264): decoded uint8 BGR frames [B][hmax][wmax][3] -> letterboxed planar [B][3][H][W] (0..255; fp16 or fp32): bilinear
  * resize to (nh, nw) in OpenCV's INTER_LINEAR geometry, optional 8-bit HSV jitter, optional horizontal flip, 114 fill.

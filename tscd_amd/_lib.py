@@ -24,6 +24,9 @@ SIGNATURES = {
     "tscd_haar_idwt_mul_nhwc_f16": [P, P, I, P, I, I, I, I, I, P],
     "tscd_haar_idwt_mul_bwd_nhwc_f16": [P, P, P, I, P, P, I, I, I, I, P],
     "tscd_ema_update_f32": [P, L, F, F, P],
+    "tscd_zero_insert2_nhwc_f16": [P, I, P, I, I, I, I, I, P],
+    "tscd_maxpool5_bwd_nhwc_f16": [P, I, P, I, P, I, I, I, I, I, P],
+    "tscd_upsample2_bwd_nhwc_f16": [P, I, P, I, I, I, I, I, P],
     "tscd_clip_preproc_u8": [P, I, I, I, P, P, I, I, I, P],
     "tscd_sgd_ema_step_f32": [P, L, P, P, I, F, I, P, P, F, F, P],
     "tscd_conv_bn_act_train_f16": [P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, P, F, F, P, P, P, P, I, P, I, I, P],

@@ -238,6 +238,109 @@ extern "C" int tscd_bn_act_nhwc_f16(const void* x, int ldx, void* y, int ldy, co
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Backbone / neck backward helpers (the base detector trains its whole backbone).
+//   zero_insert2:   dY [B,Ho,Wo,C] -> [B,2Ho,2Wo,C] with dY at the even positions, zeros elsewhere.  A 3x3 / stride-2 / pad-1 conv
+//                   y[o] = sum_k x[2o+k-1] w[k] has dX = the stride-1 data gradient of the zero-inserted dY, and dW = the stride-1
+//                   weight gradient between x and the zero-inserted dY: both existing kernels, at 4x the FLOPs of the seven
+//                   stride-2 convs of CSPDarknet + PAFPN only.
+//   maxpool5_bwd:   gradient of the stride-1 5x5 max pool of SPP (network_blocks.py:183-205, pads act as -inf): dx[i] = sum of dy[o]
+//                   over the windows o whose FIRST maximum in scan order is i (torch's choice on ties); gather form, deterministic.
+//   upsample2_bwd:  gradient of the nearest-neighbour x2 upsample of PAFPN: dx[i] = sum of the 2x2 block of dy (fp32 sum).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zero_insert2_kernel(const f16* __restrict__ dy, int lddy, f16* __restrict__ out, int ldo, int B,
+                                                           int Ho, int Wo, int C) {
+  const int cv = C >> 3;
+  const long total = (long)B * 2 * Ho * 2 * Wo * cv;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c8 = idx % cv;
+    long t = idx / cv;
+    const int x = t % (2 * Wo);
+    t /= 2 * Wo;
+    const int y = t % (2 * Ho), b = t / (2 * Ho);
+    f16x8 v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (!(x & 1) && !(y & 1)) v = *(const f16x8*)(dy + (((long)b * Ho + (y >> 1)) * Wo + (x >> 1)) * lddy + c8 * 8);
+    *(f16x8*)(out + (((long)b * 2 * Ho + y) * 2 * Wo + x) * ldo + c8 * 8) = v;
+  }
+}
+extern "C" int tscd_zero_insert2_nhwc_f16(const void* dy, int lddy, void* out, int ldo, int B, int Ho, int Wo, int C, void* stream) {
+  TSCD_CHECK_ARG(dy && out && B > 0 && Ho > 0 && Wo > 0 && C % 8 == 0 && lddy % 8 == 0 && ldo % 8 == 0, "zero_insert2: bad arguments");
+  const long total = (long)B * 4 * Ho * Wo * (C >> 3);
+  hipLaunchKernelGGL(zero_insert2_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16*)dy, lddy, (f16*)out, ldo, B,
+                     Ho, Wo, C);
+  TSCD_CHECK_LAUNCH("zero_insert2");
+  return TSCD_OK;
+}
+
+__global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const f16* __restrict__ x, int ldx, const f16* __restrict__ dy, int lddy,
+                                                           f16* __restrict__ dx, int lddx, int B, int H, int W, int C) {
+  const long total = (long)B * H * W * C;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = idx % C;
+    long t = idx / C;
+    const int xx = t % W;
+    t /= W;
+    const int yy = t % H, b = t / H;
+    const f16* xb = x + (long)b * H * W * ldx + c;
+    const float me = (float)xb[((long)yy * W + xx) * ldx];
+    float acc = 0.f;
+    for (int oy = max(0, yy - 2); oy <= min(H - 1, yy + 2); ++oy)
+      for (int ox = max(0, xx - 2); ox <= min(W - 1, xx + 2); ++ox) {
+        // is (yy, xx) the first maximum of the window centred at (oy, ox)?
+        bool win = true;
+        for (int wy = max(0, oy - 2); wy <= min(H - 1, oy + 2) && win; ++wy)
+          for (int wx = max(0, ox - 2); wx <= min(W - 1, ox + 2); ++wx) {
+            const float v = (float)xb[((long)wy * W + wx) * ldx];
+            const bool before = wy < yy || (wy == yy && wx < xx);
+            if (v > me || (before && v == me)) { win = false; break; }
+          }
+        if (win) acc += (float)dy[(((long)b * H + oy) * W + ox) * lddy + c];
+      }
+    dx[(((long)b * H + yy) * W + xx) * lddx + c] = (f16)acc;
+  }
+}
+extern "C" int tscd_maxpool5_bwd_nhwc_f16(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C,
+                                          void* stream) {
+  TSCD_CHECK_ARG(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "maxpool5_bwd: bad arguments");
+  const long total = (long)B * H * W * C;
+  hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16*)x, ldx, (const f16*)dy, lddy,
+                     (f16*)dx, lddx, B, H, W, C);
+  TSCD_CHECK_LAUNCH("maxpool5_bwd");
+  return TSCD_OK;
+}
+
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const f16* __restrict__ dy, int lddy, f16* __restrict__ dx, int lddx, int B, int H,
+                                                            int W, int C) {
+  const int cv = C >> 3;
+  const long total = (long)B * H * W * cv;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c8 = idx % cv;
+    long t = idx / cv;
+    const int x = t % W;
+    t /= W;
+    const int y = t % H, b = t / H;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f16x8 v = *(const f16x8*)(dy + (((long)b * 2 * H + 2 * y + (q >> 1)) * 2 * W + 2 * x + (q & 1)) * lddy + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+    }
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)a[e];
+    *(f16x8*)(dx + (((long)b * H + y) * W + x) * lddx + c8 * 8) = o;
+  }
+}
+extern "C" int tscd_upsample2_bwd_nhwc_f16(const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C, void* stream) {
+  TSCD_CHECK_ARG(dy && dx && B > 0 && H > 0 && W > 0 && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "upsample2_bwd: bad arguments");
+  const long total = (long)B * H * W * (C >> 3);
+  hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const f16*)dy, lddy, (f16*)dx, lddx, B,
+                     H, W, C);
+  TSCD_CHECK_LAUNCH("upsample2_bwd");
+  return TSCD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Clip pre-processing on the device (reference: vid.py pull_item resize + data_augment.py:21-31 augment_hsv,
 // :196-203 _mirror, :248-264 preproc): decoded uint8 BGR frames [B][hmax][wmax][3] -> letterboxed planar [B][3][H][W] (0..255,
 // fp16 or fp32).  Per frame: bilinear resize to (nh, nw) with OpenCV's INTER_LINEAR geometry (half-pixel centres, edge clamp),

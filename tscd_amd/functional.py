@@ -33,9 +33,15 @@ def _pad8(dy):
 def _conv_backward(dy, x, weight, stride, need_dx, need_dw, dy_padded=None):
     """Stride-1 'same' conv gradients on the HIP kernels: dgrad = the forward MFMA kernel with dgrad-packed weights,
     wgrad = conv_wgrad.hip (pixel-axis GEMM, transposing LDS reads, deterministic split-K)."""
-    assert stride == 1, "only stride-1 convs are trainable on the TSCD path"
     cout, cin, k, _ = weight.shape
     dy = dy.to(torch.float16)
+    if stride == 2:
+        # 3x3 / stride 2 / pad 1 (the downsampling convs of CSPDarknet and PAFPN, row N4): y[o] = sum_k x[2o+k-1] w[k], so dX is the
+        # stride-1 data gradient of dY with zeros inserted between its pixels and dW the stride-1 weight gradient against it
+        assert k == 3 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and cout % 8 == 0, "stride-2 backward: 3x3 convs on even extents"
+        dy = ops.zero_insert2(dy.contiguous())
+    else:
+        assert stride == 1, "conv backward: stride 1 or 2"
     # prediction convs (Cout = 25 / 4 / 1): dY's channels zero-padded so rows stay 16-byte aligned
     dyp = dy_padded
     if dyp is None and cout % 8 and (need_dx or need_dw):
@@ -51,7 +57,8 @@ def _conv_backward(dy, x, weight, stride, need_dx, need_dw, dy_padded=None):
     dw = None
     if need_dw:
         dyp = dy.contiguous() if dyp is None else dyp
-        dw = ops.conv_wgrad(x, dyp, cin, dyp.shape[-1], k)[:cout].to(weight.dtype)
+        # x may carry zero-padded channels (Focus: 12 -> 16): their weight gradient is computed and dropped
+        dw = ops.conv_wgrad(x, dyp, x.shape[-1], dyp.shape[-1], k)[:cout, :cin].to(weight.dtype)
     return dx, dw
 
 
@@ -60,7 +67,7 @@ class _ConvBnSiluTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum):
-        wpk = ops.WEIGHTS.get(weight)
+        wpk = ops.WEIGHTS.get(weight, x.shape[-1] if x.shape[-1] != weight.shape[1] else None)     # Focus: 12 -> 16 input channels
         cout, k = weight.shape[0], weight.shape[-1]
         out, raw, ss, mean, invstd = ops.conv_bn_act_train(x, wpk, cout, k, stride, gamma, beta, running_mean, running_var, eps,
                                                            momentum, ops.ACT_SILU, keep_raw=True)
@@ -74,6 +81,45 @@ class _ConvBnSiluTrain(torch.autograd.Function):
         draw, dgamma, dbeta = ops.bn_silu_bwd(dy.to(torch.float16), raw, ss, mean, invstd, gamma.float())
         dx, dw = _conv_backward(draw, x, weight, ctx.stride, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dx, dw, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None
+
+
+class _MaxPool5(torch.autograd.Function):
+    """Stride-1 5x5 max pool (SPP), forward ops.maxpool, backward tscd_maxpool5_bwd (first maximum in scan order takes the gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        y = ops.maxpool(x, ops.empty_nhwc(B, H, W, C, x.device), 5)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool5_bwd(x, dy.to(torch.float16).contiguous())
+
+
+def maxpool5(x):
+    return _MaxPool5.apply(x) if _needs_grad(x) else ops.maxpool(x, ops.empty_nhwc(*x.shape[:3], x.shape[3], x.device), 5)
+
+
+class _Upsample2x(torch.autograd.Function):
+    """Nearest-neighbour x2 upsample (PAFPN), forward copy_slice(upsample=True), backward the 2x2 block sums."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        y = ops.empty_nhwc(B, 2 * H, 2 * W, C, x.device)
+        ops.copy_slice(x, y, upsample=True)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample2_bwd(dy.to(torch.float16).contiguous())
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)
 
 
 def conv_bn_silu(x, weight, gamma, beta, running_mean, running_var, stride, training, out=None, residual=None,

@@ -300,6 +300,28 @@ def copy_slice(src, dst, upsample=False):
     return dst
 
 
+def zero_insert2(dy):
+    """dY [B,Ho,Wo,C] -> [B,2Ho,2Wo,C] with dY at the even positions (stride-2 conv backward, elementwise.hip)."""
+    B, Ho, Wo, C = dy.shape
+    out = empty_nhwc(B, 2 * Ho, 2 * Wo, C, dy.device)
+    call("tscd_zero_insert2_nhwc_f16", dy.data_ptr(), nhwc_ld(dy), out.data_ptr(), nhwc_ld(out), B, Ho, Wo, C, _stream())
+    return out
+
+
+def maxpool5_bwd(x, dy):
+    B, H, W, C = x.shape
+    dx = empty_nhwc(B, H, W, C, x.device)
+    call("tscd_maxpool5_bwd_nhwc_f16", x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dx.data_ptr(), nhwc_ld(dx), B, H, W, C, _stream())
+    return dx
+
+
+def upsample2_bwd(dy):
+    B, H2, W2, C = dy.shape
+    dx = empty_nhwc(B, H2 // 2, W2 // 2, C, dy.device)
+    call("tscd_upsample2_bwd_nhwc_f16", dy.data_ptr(), nhwc_ld(dy), dx.data_ptr(), nhwc_ld(dx), B, H2 // 2, W2 // 2, C, _stream())
+    return dx
+
+
 def maxpool(src, dst, ks=5):
     B, H, W, C = src.shape
     call("tscd_maxpool_nhwc_f16", src.data_ptr(), nhwc_ld(src), dst.data_ptr(), nhwc_ld(dst), B, H, W, C, ks, _stream())

@@ -56,6 +56,12 @@ class defer_bn_ticks:
         return False
 
 
+def _grad_path(base_conv):
+    """True when this block has to run on the autograd path: gradients are enabled and its weights train (row N4; the TSCD exps
+    freeze the whole backbone and take the in-place no-grad path)."""
+    return torch.is_grad_enabled() and base_conv.conv.weight.requires_grad
+
+
 class BaseConv(nn.Module):
     """Conv2d(no bias, same pad) -> BatchNorm2d -> SiLU, one fused HIP pipeline."""
 
@@ -108,6 +114,9 @@ class Bottleneck(nn.Module):
         self.use_add = shortcut and in_channels == out_channels
 
     def forward(self, x, out=None):
+        if _grad_path(self.conv1):            # row N4: autograd path (new tensors, the residual add is an autograd op)
+            y = self.conv2(self.conv1(x))
+            return y + x if self.use_add else y
         return self.conv2(self.conv1(x), out=out, residual=x if self.use_add else None)
 
 
@@ -123,6 +132,12 @@ class SPPBottleneck(nn.Module):
         self.conv2 = BaseConv(hidden * (len(kernel_sizes) + 1), out_channels, 1, stride=1, act=activation)
 
     def forward(self, x):
+        if _grad_path(self.conv1):
+            x = self.conv1(x)
+            p1 = TF.maxpool5(x)
+            p2 = TF.maxpool5(p1)               # cascaded 5x5 pools = the 9x9 and 13x13 windows of the reference
+            p3 = TF.maxpool5(p2)
+            return self.conv2(torch.cat([x, p1, p2, p3], dim=-1))
         B, H, W, _ = x.shape
         h = self.conv1.conv.out_channels
         buf = ops.empty_nhwc(B, H, W, 4 * h, x.device)
@@ -142,6 +157,9 @@ class CSPLayer(nn.Module):
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
 
     def forward(self, x, out=None):
+        if _grad_path(self.conv1):
+            x1 = self.m(self.conv1(x))
+            return self.conv3(torch.cat([x1, self.conv2(x)], dim=-1))
         B, H, W, _ = x.shape
         h = self.conv1.conv.out_channels
         cat = ops.empty_nhwc(B, H, W, 2 * h, x.device)      # [m(conv1(x)) | conv2(x)]

@@ -58,14 +58,33 @@ class YOLOPAFPN(nn.Module):
         pan_out0 = self.C3_n4(n32)
         return pan_out2, pan_out1, pan_out0
 
+    def forward_nhwc_grad(self, img):
+        """The same network on the autograd path (the base detector trains backbone and neck): every block returns
+        a new tensor, concatenations are torch.cat, the upsample and the SPP pools are autograd Functions over their HIP kernels, the
+        stride-2 convs take their gradients from the stride-1 kernels on the zero-inserted dY (tscd_amd/functional.py)."""
+        from tscd_amd import functional as TF
+        ops.require_gpu(img, "input image")
+        if img.shape[2] % 32 or img.shape[3] % 32:
+            raise ValueError(f"input {img.shape[2]}x{img.shape[3]} must be a multiple of 32")
+        feats = self.backbone(img)
+        x2, x1, x0 = feats["dark3"], feats["dark4"], feats["dark5"]
+        fpn_out0 = self.lateral_conv0(x0)
+        f_out0 = self.C3_p4(torch.cat([TF.upsample2x(fpn_out0), x1], dim=-1))
+        fpn_out1 = self.reduce_conv1(f_out0)
+        pan_out2 = self.C3_p3(torch.cat([TF.upsample2x(fpn_out1), x2], dim=-1))
+        pan_out1 = self.C3_n3(torch.cat([self.bu_conv2(pan_out2), fpn_out1], dim=-1))
+        pan_out0 = self.C3_n4(torch.cat([self.bu_conv1(pan_out1), fpn_out0], dim=-1))
+        return pan_out2, pan_out1, pan_out0
+
     def forward(self, input):
         plist = self.__dict__.get("_plist")
         if plist is None:                       # flat parameter list, built once (Module.parameters() walks the module tree)
             plist = self.__dict__["_plist"] = list(self.parameters())
         if torch.is_grad_enabled() and any(p.requires_grad for p in plist):
-            raise NotImplementedError(
-                "backbone/neck backward is not built yet: every TSCD exp freezes it (ovis_tscd_large.py:116-117); "
-                "base-detector training is row N4 of SURVEY.md section 8f")
-        with torch.no_grad():
-            outs = self.forward_nhwc(input)
+            if not all(p.requires_grad for p in plist):
+                raise NotImplementedError("partially frozen backbone / neck: freeze all of it (TSCD exps) or none (base detector)")
+            outs = self.forward_nhwc_grad(input)
+        else:
+            with torch.no_grad():
+                outs = self.forward_nhwc(input)
         return tuple(o.permute(0, 3, 1, 2) for o in outs)
