@@ -231,6 +231,11 @@ long tscd_loss_workspace_bytes(long B, long A, long N);
 int tscd_loss_dense_f16(const void* raw, const void* outputs, const unsigned char* fg_mask, const int* matched_gt,
                         const float* pred_iou, const float* labels, int B, int A, int NC, int Lmax, void* workspace,
                         long workspace_bytes, float* sums, void* d_logit, void* stream);
+/* The same plus d_reg [B][A][4] fp16 = d(IoU-loss sum) / d raw box logits through the decode (cx = (r + grid) * stride, w = exp(r) *
+ * stride): base-detector training, where the box branch trains (yolo_head.py:267-434).  hw / stride: host int[3] per pyramid level. */
+int tscd_loss_dense_reg_f16(const void* raw, const void* outputs, const unsigned char* fg_mask, const int* matched_gt,
+                            const float* pred_iou, const float* labels, int B, int A, int NC, int Lmax, const int* hw, const int* stride,
+                            void* workspace, long workspace_bytes, float* sums, void* d_logit, void* d_reg, void* stream);
 int tscd_loss_rows_f16(const int* row_b, const int* row_a, int N, int A, int NC, int Lmax, const unsigned char* fg_mask,
                        const int* matched_gt, const float* pred_iou, const float* labels, const void* cls_logit,
                        const void* obj_logit, const void* reg_delta, const void* base, int ndet, int part, void* workspace,
@@ -242,6 +247,11 @@ long tscd_simota_workspace_bytes(int B, int A, int G, int topk);
 int tscd_simota_assign(const void* outputs, const float* labels, int B, int A, int NC, int Lmax, int G, const int* hw3,
                        const int* w3, const int* stride3, int topk, int emu16, void* workspace, long workspace_bytes,
                        unsigned char* fg_mask, int* matched_gt, float* pred_iou, int* num_fg, int* ngt, void* stream);
+/* The same with the centre-prior radius (in strides) as an argument: 4.5 in the TSCD head (what tscd_simota_assign uses), 2.5 in the
+ * YOLOX base head (yolo_head.py:594). */
+int tscd_simota_assign_r(const void* outputs, const float* labels, int B, int A, int NC, int Lmax, int G, const int* hw3, const int* w3,
+                         const int* stride3, int topk, int emu16, float center_radius, void* workspace, long workspace_bytes,
+                         unsigned char* fg_mask, int* matched_gt, float* pred_iou, int* num_fg, int* ngt, void* stream);
 
 /* Backbone / neck backward helpers.  zero_insert2: dY [B,Ho,Wo,C] -> [B,2Ho,2Wo,C], dY at even positions: the
  * data / weight gradient of a 3x3 stride-2 pad-1 conv is the stride-1 gradient on it (darknet.py:120-160 downsampling convs,

@@ -47,6 +47,7 @@ class TSCDConfig:
     maximal_limit: int = 500       # ovis_tscd_large.py:49 (0 = no upper clamp, vid_tscd_large.py)
     conf_thresh: float = 0.001     # tscd_head.py:1546
     vid_dk: int = 10               # tscd_head.py:1517
+    center_radius: float = 4.5     # tscd_head.py:1470 (the YOLOX base head: 2.5, yolo_head.py:594)
     # training under autocast (tscd_trainer.py:159-176): images AND targets are cast to fp16 and the head's outputs are
     # fp16 tensors, so get_assignments evaluates its IoU chain in fp16 (see simota_assign).  False = the fp32 evaluation.
     simota_autocast: bool = False
@@ -201,8 +202,8 @@ def bboxes_iou_cxcywh(a, b):
     return area_i / (area_a[:, None] + area_b - area_i)
 
 
-def get_in_boxes_info(gt, strides_a, xs, ys, num_gt):
-    """tscd_head.py:1428-1510. gt [G,4] cxcywh; strides_a/xs/ys [A]."""
+def get_in_boxes_info(gt, strides_a, xs, ys, num_gt, r=4.5):
+    """tscd_head.py:1428-1510 (centre radius 4.5 strides; yolo_head.py:560-620 is the same function with 2.5). gt [G,4] cxcywh; strides_a/xs/ys [A]."""
     xc = ((xs * strides_a) + 0.5 * strides_a)[None, :]
     yc = ((ys * strides_a) + 0.5 * strides_a)[None, :]
     gl = (gt[:, 0] - 0.5 * gt[:, 2])[:, None]
@@ -212,7 +213,6 @@ def get_in_boxes_info(gt, strides_a, xs, ys, num_gt):
     deltas = torch.stack([xc - gl, yc - gtop, gr - xc, gb - yc], 2)
     is_in_boxes = deltas.min(dim=-1).values > 0.0
     is_in_boxes_all = is_in_boxes.sum(dim=0) > 0
-    r = 4.5
     cl = gt[:, 0][:, None] - r * strides_a[None, :]
     cr = gt[:, 0][:, None] + r * strides_a[None, :]
     ct = gt[:, 1][:, None] - r * strides_a[None, :]
@@ -282,7 +282,7 @@ def simota_assign(outputs, labels, xs, ys, strides_a, cfg):
             continue
         gt = labels[b, :G, 1:5]
         gt_cls = labels[b, :G, 0]
-        fg_mask, in_bc = get_in_boxes_info(gt, strides_a, xs, ys, G)
+        fg_mask, in_bc = get_in_boxes_info(gt, strides_a, xs, ys, G, cfg.center_radius)
         boxes = outputs[b, :, :4][fg_mask]
         cls_p = outputs[b, :, 5:][fg_mask]
         obj_p = outputs[b, :, 4:5][fg_mask]
@@ -651,6 +651,53 @@ def tower(sd, p, x, training):
 
 def conv_pred(sd, p, x):
     return F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"])
+
+
+def yolox_head(sd, cfg, xin, labels=None, training=False, use_l1=False, p="head", strides=(8, 16, 32)):
+    """YOLOXHead.forward (yolo_head.py:166-265) and, in training, get_losses (:267-434) -- the base detector of SURVEY.md 8f row N4.
+    xin: the three NCHW pyramid maps.  Evaluation -> [B,A,5+NC] (decoded cx,cy,w,h | sigmoid obj | sigmoid cls); training ->
+    (loss, 5 * iou_loss, obj_loss, cls_loss, l1_loss, num_fg / max(num_gts, 1)).  Pinned by tests/golden/yolox_tiny.npz (the reference's
+    own YOLOX on CPU in fp32, oracle/make_golden_yolox.py)."""
+    nc = cfg.num_classes
+    outs = []
+    for k, x in enumerate(xin):
+        x = base_conv(sd, f"{p}.stems.{k}", x, 1, training)
+        cls_feat = tower(sd, f"{p}.cls_convs.{k}", x, training)
+        reg_feat = tower(sd, f"{p}.reg_convs.{k}", x, training)
+        outs.append(torch.cat([conv_pred(sd, f"{p}.reg_preds.{k}", reg_feat), conv_pred(sd, f"{p}.obj_preds.{k}", reg_feat),
+                               conv_pred(sd, f"{p}.cls_preds.{k}", cls_feat)], 1))
+    hw = [tuple(o.shape[-2:]) for o in outs]
+    xs, ys, ss = make_grids(hw, strides, outs[0].dtype)
+    xs, ys, ss = xs.to(outs[0].device), ys.to(outs[0].device), ss.to(outs[0].device)
+    flat = torch.cat([o.flatten(2) for o in outs], 2).permute(0, 2, 1)                   # [B,A,5+NC] raw
+    decoded = torch.cat([(flat[..., :2] + torch.stack([xs, ys], -1)) * ss[:, None], torch.exp(flat[..., 2:4]) * ss[:, None],
+                         flat[..., 4:]], -1)                                             # get_output_and_grid :226-248
+    if not training:
+        return torch.cat([decoded[..., :4], decoded[..., 4:].sigmoid()], -1)
+    with torch.no_grad():
+        import dataclasses
+        fg_ids, cls_t, reg_t, obj_t, fg_masks, num_fg, num_gts = simota_assign(decoded.detach(), labels, xs, ys, ss,
+                                                                               dataclasses.replace(cfg, center_radius=2.5))
+    fg = torch.cat(fg_masks, 0)
+    cls_targets, reg_targets, obj_targets = torch.cat(cls_t, 0), torch.cat(reg_t, 0), torch.cat(obj_t, 0)
+    loss_iou = iou_loss(decoded[..., :4].reshape(-1, 4)[fg], reg_targets).sum() / num_fg
+    loss_obj = F.binary_cross_entropy_with_logits(decoded[..., 4].reshape(-1, 1), obj_targets.to(decoded.dtype), reduction="none").sum() / num_fg
+    loss_cls = F.binary_cross_entropy_with_logits(decoded[..., 5:].reshape(-1, nc)[fg], cls_targets.to(decoded.dtype), reduction="none").sum() / num_fg
+    loss_l1 = decoded.new_zeros(())
+    if use_l1:                                                                           # get_l1_target :436-441
+        B, A = flat.shape[:2]
+        st, gx, gy = ss.repeat(B)[fg], xs.repeat(B)[fg], ys.repeat(B)[fg]
+        tgt = torch.stack([reg_targets[:, 0] / st - gx, reg_targets[:, 1] / st - gy, torch.log(reg_targets[:, 2] / st + 1e-8),
+                           torch.log(reg_targets[:, 3] / st + 1e-8)], -1)
+        loss_l1 = (flat[..., :4].reshape(-1, 4)[fg] - tgt).abs().sum() / num_fg
+    loss = 5.0 * loss_iou + loss_obj + loss_cls + loss_l1
+    return loss, 5.0 * loss_iou, loss_obj, loss_cls, loss_l1, num_fg / max(num_gts, 1)
+
+
+def yolox_forward(sd, cfg, x, targets=None, training=False, use_l1=False):
+    """YOLOX.forward (yolox.py:27-48): YOLOPAFPN -> YOLOXHead."""
+    fpn = yolo_pafpn(sd, x, cfg, training)
+    return yolox_head(sd, cfg, fpn, targets, training, use_l1)
 
 
 def tscd_head(sd, cfg, xin, labels=None, imgs=None, time_embedding=None, nms_thresh=0.5, lframe=0,

@@ -52,7 +52,9 @@ SIGNATURES = {
     "tscd_bias_relu_bwd_f16": [P, I, P, I, P, I, L, I, P, P, L, P],
     "tscd_linear_bwd_f16": [P, I, P, I, P, I, I, I, I, I, P, P, P, P, L, P],
     "tscd_simota_assign": [P, P, I, I, I, I, I, P, P, P, I, I, P, L, P, P, P, P, P, P],
+    "tscd_simota_assign_r": [P, P, I, I, I, I, I, P, P, P, I, I, F, P, L, P, P, P, P, P, P],
     "tscd_loss_dense_f16": [P, P, P, P, P, P, I, I, I, I, P, L, P, P, P],
+    "tscd_loss_dense_reg_f16": [P, P, P, P, P, P, I, I, I, I, P, P, P, L, P, P, P, P],
     "tscd_loss_rows_f16": [P, P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, L, P, P, P, P, P],
 }
 PLAIN = {"tscd_ema_chunk_elems": ([], I), "tscd_pack_block_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),

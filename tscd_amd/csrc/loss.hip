@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void loss_dense_kernel(const f16* __restrict__
                                                         const unsigned char* __restrict__ fg, const int* __restrict__ matched_gt,
                                                         const float* __restrict__ pred_iou, const float* __restrict__ labels,
                                                         int B, int A, int NC, int Lmax, float* __restrict__ partial,
-                                                        f16* __restrict__ d_logit) {
+                                                        f16* __restrict__ d_logit, f16* __restrict__ d_reg, int hw0, int hw1, float st0,
+                                                        float st1, float st2) {
   __shared__ float red[4];
   const long total = (long)B * A;
   const int nch = 5 + NC;
@@ -62,6 +63,28 @@ __global__ __launch_bounds__(256) void loss_dense_kernel(const f16* __restrict__
       const float ai = (brx - tlx) * (bry - tly) * en;
       const float iou = ai / (pw * ph + gw * gh - ai + 1e-16f);
       s_iou += 1.0f - iou * iou;
+      if (d_reg) {
+        // d(1 - IoU^2) / d raw box logits (base-detector training, row N4): the box is decoded as cx = (r0 + grid) * stride,
+        // w = exp(r2) * stride, so d/dr0 = stride * d/dcx and d/dr2 = w * d/dw; min / max pass the gradient to the active side
+        // (half to each on an exact tie, like torch)
+        const int a = (int)(idx - (long)b * A);
+        const float st = a < hw0 ? st0 : (a < hw0 + hw1 ? st1 : st2);
+        auto side = [](float p, float g, bool want_greater) { return p == g ? 0.5f : ((want_greater ? p > g : p < g) ? 1.f : 0.f); };
+        const float wax = side(px - pw * 0.5f, gx - gw * 0.5f, true), wbx = side(px + pw * 0.5f, gx + gw * 0.5f, false);
+        const float way = side(py - ph * 0.5f, gy - gh * 0.5f, true), wby = side(py + ph * 0.5f, gy + gh * 0.5f, false);
+        const float iw = brx - tlx, ih = bry - tly;
+        const float U = pw * ph + gw * gh - ai + 1e-16f;
+        // d ai: x-centre, y-centre, width, height of the predicted box
+        const float dai[4] = {en * ih * (wbx - wax), en * iw * (wby - way), en * ih * 0.5f * (wbx + wax), en * iw * 0.5f * (wby + way)};
+        const float dap[4] = {0.f, 0.f, ph, pw};
+        const float chain[4] = {st, st, pw, ph};
+        f16* dr = d_reg + idx * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float diou = (dai[q] * (U + ai) - ai * dap[q]) / (U * U);
+          dr[q] = (f16)(-2.0f * iou * diou * chain[q]);
+        }
+      }
       int gc = (int)L[0];
       gc = gc < 0 ? 0 : (gc >= NC ? NC - 1 : gc);
       const float tiou = pred_iou[idx];
@@ -70,8 +93,10 @@ __global__ __launch_bounds__(256) void loss_dense_kernel(const f16* __restrict__
         s_cls += bce_logits(x, t);
         if (d) d[1 + c] = (f16)(1.0f / (1.0f + expf(-x)) - t);
       }
-    } else if (d) {
-      for (int c = 0; c < NC; ++c) d[1 + c] = (f16)0.f;
+    } else {
+      if (d)
+        for (int c = 0; c < NC; ++c) d[1 + c] = (f16)0.f;
+      if (d_reg) *(f16x4*)(d_reg + idx * 4) = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
     }
   }
   const float a = block_sum_256(s_iou, red), o2 = block_sum_256(s_obj, red), c2 = block_sum_256(s_cls, red);
@@ -171,9 +196,28 @@ extern "C" int tscd_loss_dense_f16(const void* raw, const void* outputs, const u
   TSCD_CHECK_ARG(workspace_bytes >= tscd_loss_workspace_bytes(B, A, 0), "loss_dense: workspace too small");
   const int nb = loss_blocks((long)B * A, 256);
   hipLaunchKernelGGL(loss_dense_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f16*)raw, (const f16*)outputs, fg_mask,
-                     matched_gt, pred_iou, labels, B, A, NC, Lmax, (float*)workspace, (f16*)d_logit);
+                     matched_gt, pred_iou, labels, B, A, NC, Lmax, (float*)workspace, (f16*)d_logit, (f16*)nullptr, 0, 0, 0.f, 0.f, 0.f);
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(192), 0, (hipStream_t)stream, (const float*)workspace, nb, sums);
   TSCD_CHECK_LAUNCH("loss_dense");
+  return TSCD_OK;
+}
+
+// The same with the gradient of the IoU-loss sum w.r.t. the raw box logits (d_reg [B][A][4] fp16): base-detector training
+// (yolo_head.py:267-434, row N4), where the box branch trains.  hw / stride: the three pyramid levels' anchor counts and strides.
+extern "C" int tscd_loss_dense_reg_f16(const void* raw, const void* outputs, const unsigned char* fg_mask, const int* matched_gt,
+                                       const float* pred_iou, const float* labels, int B, int A, int NC, int Lmax, const int* hw,
+                                       const int* stride, void* workspace, long workspace_bytes, float* sums, void* d_logit, void* d_reg,
+                                       void* stream) {
+  TSCD_CHECK_ARG(raw && outputs && fg_mask && matched_gt && pred_iou && labels && workspace && sums && hw && stride && d_reg,
+                 "loss_dense_reg: null pointer");
+  TSCD_CHECK_ARG(B > 0 && A > 0 && NC > 0 && Lmax > 0 && hw[0] + hw[1] + hw[2] == A, "loss_dense_reg: bad sizes");
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_loss_workspace_bytes(B, A, 0), "loss_dense_reg: workspace too small");
+  const int nb = loss_blocks((long)B * A, 256);
+  hipLaunchKernelGGL(loss_dense_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f16*)raw, (const f16*)outputs, fg_mask,
+                     matched_gt, pred_iou, labels, B, A, NC, Lmax, (float*)workspace, (f16*)d_logit, (f16*)d_reg, hw[0], hw[1],
+                     (float)stride[0], (float)stride[1], (float)stride[2]);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(192), 0, (hipStream_t)stream, (const float*)workspace, nb, sums);
+  TSCD_CHECK_LAUNCH("loss_dense_reg");
   return TSCD_OK;
 }
 

@@ -27,6 +27,7 @@ struct SimotaParams {
   float* iou;           // [B][G][A]   (-1 for anchors outside the candidate set)
   int* ngt;             // [B]
   int emu16;
+  float radius;         // centre-prior radius in strides: 4.5 (TSCD head, tscd_head.py:1470) or 2.5 (YOLOX base head, yolo_head.py:594)
 };
 
 __device__ __forceinline__ float r16(float x, int emu) { return emu ? (float)(f16)x : x; }
@@ -63,7 +64,7 @@ __global__ void simota_cost_kernel(SimotaParams p) {
     float gx = L[1], gy = L[2], gw = L[3], gh = L[4];
     float l = r16(gx - 0.5f * gw, emu), r = r16(gx + 0.5f * gw, emu), t = r16(gy - 0.5f * gh, emu), d = r16(gy + 0.5f * gh, emu);
     bool inb = fminf(fminf(r16(xc - l, emu), r16(yc - t, emu)), fminf(r16(r - xc, emu), r16(d - yc, emu))) > 0.f;
-    float rad = r16(4.5f * st, emu);
+    float rad = r16(p.radius * st, emu);
     float cl = r16(gx - rad, emu), cr = r16(gx + rad, emu), ct = r16(gy - rad, emu), cb = r16(gy + rad, emu);
     bool inc = fminf(fminf(r16(xc - cl, emu), r16(yc - ct, emu)), fminf(r16(cr - xc, emu), r16(cb - yc, emu))) > 0.f;
     any = any || inb || inc;
@@ -88,7 +89,7 @@ __global__ void simota_cost_kernel(SimotaParams p) {
     float gx = L[1], gy = L[2], gw = L[3], gh = L[4];
     float l = r16(gx - 0.5f * gw, emu), r = r16(gx + 0.5f * gw, emu), t = r16(gy - 0.5f * gh, emu), d = r16(gy + 0.5f * gh, emu);
     bool inb = fminf(fminf(r16(xc - l, emu), r16(yc - t, emu)), fminf(r16(r - xc, emu), r16(d - yc, emu))) > 0.f;
-    float rad = r16(4.5f * st, emu);
+    float rad = r16(p.radius * st, emu);
     float cl = r16(gx - rad, emu), cr = r16(gx + rad, emu), ct = r16(gy - rad, emu), cb = r16(gy + rad, emu);
     bool inc = fminf(fminf(r16(xc - cl, emu), r16(yc - ct, emu)), fminf(r16(cr - xc, emu), r16(cb - yc, emu))) > 0.f;
     // bboxes_iou(gt, pred, xyxy=False)
@@ -235,10 +236,22 @@ extern "C" long tscd_simota_workspace_bytes(int B, int A, int G, int topk) {
   return 2L * 4 * B * G * A + 4L * B * G * topk + 4L * B * G + 4L * B + 4096;
 }
 
+extern "C" int tscd_simota_assign_r(const void* outputs, const float* labels, int B, int A, int NC, int Lmax, int G,
+                                    const int* hw3, const int* w3, const int* stride3, int topk, int emu16, float center_radius,
+                                    void* workspace, long workspace_bytes, unsigned char* fg_mask, int* matched_gt, float* pred_iou,
+                                    int* num_fg, int* ngt, void* stream);
 extern "C" int tscd_simota_assign(const void* outputs, const float* labels, int B, int A, int NC, int Lmax, int G,
                                   const int* hw3, const int* w3, const int* stride3, int topk, int emu16, void* workspace,
                                   long workspace_bytes, unsigned char* fg_mask, int* matched_gt, float* pred_iou, int* num_fg,
                                   int* ngt, void* stream) {
+  return tscd_simota_assign_r(outputs, labels, B, A, NC, Lmax, G, hw3, w3, stride3, topk, emu16, 4.5f, workspace, workspace_bytes, fg_mask,
+                              matched_gt, pred_iou, num_fg, ngt, stream);
+}
+// The same with the centre-prior radius as an argument (in strides): the YOLOX base head uses 2.5 (yolo_head.py:594).
+extern "C" int tscd_simota_assign_r(const void* outputs, const float* labels, int B, int A, int NC, int Lmax, int G,
+                                    const int* hw3, const int* w3, const int* stride3, int topk, int emu16, float center_radius,
+                                    void* workspace, long workspace_bytes, unsigned char* fg_mask, int* matched_gt, float* pred_iou,
+                                    int* num_fg, int* ngt, void* stream) {
   TSCD_CHECK_ARG(outputs && labels && hw3 && w3 && stride3 && workspace && fg_mask && matched_gt && pred_iou && num_fg && ngt,
                  "simota_assign: null pointer");
   TSCD_CHECK_ARG(B > 0 && A > 0 && G > 0 && G <= Lmax && topk > 0 && topk <= 16, "simota_assign: bad sizes");
@@ -246,7 +259,7 @@ extern "C" int tscd_simota_assign(const void* outputs, const float* labels, int 
   hipStream_t st = (hipStream_t)stream;
   SimotaParams p;
   p.outputs = (const f16*)outputs; p.labels = labels;
-  p.B = B; p.A = A; p.NC = NC; p.Lmax = Lmax; p.G = G; p.emu16 = emu16;
+  p.B = B; p.A = A; p.NC = NC; p.Lmax = Lmax; p.G = G; p.emu16 = emu16; p.radius = center_radius;
   int acc = 0;
   for (int k = 0; k < 3; ++k) { p.hw[k] = hw3[k]; p.w[k] = w3[k]; p.stride[k] = stride3[k]; p.a0[k] = acc; acc += hw3[k]; }
   TSCD_CHECK_ARG(acc == A, "simota_assign: level sizes do not add up to A");

@@ -225,27 +225,35 @@ def haar_idwt_mul(hf, content):
 # ----------------------------------------------------------------------------------------------------
 class _DenseLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes):
+    def forward(ctx, raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes, geo):
         want = ctx.needs_input_grad[0]
-        sums, d = ops.loss_dense(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes, want_grad=want)
-        ctx.save_for_backward(d)
+        if geo is None:
+            sums, d = ops.loss_dense(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes, want_grad=want)
+            d_reg = None
+        else:
+            sums, d, d_reg = ops.loss_dense(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes, want_grad=want, geo=geo)
+        ctx.save_for_backward(d, d_reg)
         ctx.nc = num_classes
         return sums
 
     @staticmethod
     def backward(ctx, g):
-        (d,) = ctx.saved_tensors
+        d, d_reg = ctx.saved_tensors
         if d is None:
-            return (None,) * 7
+            return (None,) * 8
         nc = ctx.nc
-        # channel 0 (objectness) scales with d sums[1], channels 1.. (classes) with d sums[2]; the 4 box channels get no gradient
+        # channel 0 (objectness) scales with d sums[1], channels 1.. (classes) with d sums[2]; the 4 box channels get the IoU-loss
+        # gradient (d sums[0]) when the box branch trains (geo given), none otherwise
         gv = torch.cat((g[1:2], g[2:3].expand(nc))).to(torch.float16)
-        return torch.nn.functional.pad(d * gv, (4, 0)), None, None, None, None, None, None
+        if d_reg is None:
+            return torch.nn.functional.pad(d * gv, (4, 0)), None, None, None, None, None, None, None
+        return torch.cat((d_reg * g[0].to(torch.float16), d * gv), dim=-1), None, None, None, None, None, None, None
 
 
-def dense_loss(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes):
-    """-> fp32 [3]: IoU-loss sum (no gradient: the decoded boxes are detached), objectness BCE sum, class BCE sum."""
-    return _DenseLoss.apply(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes)
+def dense_loss(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes, geo=None):
+    """-> fp32 [3]: IoU-loss sum, objectness BCE sum, class BCE sum.  The IoU loss has a gradient (to the raw box logits, through the
+    decode) only when ``geo`` (ops.LevelGeometry) is given: the TSCD head's boxes are detached, the base detector's train (row N4)."""
+    return _DenseLoss.apply(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes, geo)
 
 
 class _RowLoss(torch.autograd.Function):

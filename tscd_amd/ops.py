@@ -832,7 +832,7 @@ def batched_nms(det, frame_off, L, num_classes, conf_thresh, iou_thresh, cap_m, 
     return out, idx, cnt, ovf
 
 
-def simota_assign(outputs, labels, geo, num_classes, max_gt, topk=10, emu16=True):
+def simota_assign(outputs, labels, geo, num_classes, max_gt, topk=10, emu16=True, center_radius=4.5):
     """outputs [B,A,5+NC] fp16, labels [B,Lmax,5] (any float dtype).  -> fg_mask u8 [B,A], matched_gt i32 [B,A],
     pred_iou f32 [B,A], num_fg i32 [B], ngt i32 [B]."""
     B, A, _ = outputs.shape
@@ -847,16 +847,16 @@ def simota_assign(outputs, labels, geo, num_classes, max_gt, topk=10, emu16=True
     nfg = torch.empty((B,), dtype=torch.int32, device=dev)
     ngt = torch.empty((B,), dtype=torch.int32, device=dev)
     assert outputs.is_contiguous() and outputs.dtype == torch.float16
-    call("tscd_simota_assign", outputs.data_ptr(), lab.data_ptr(), B, A, num_classes, lab.shape[1], G, geo.c_hw, geo.c_w,
-         geo.c_stride, topk, int(emu16), ws.data_ptr(), ws_bytes, fg.data_ptr(), mg.data_ptr(), pi.data_ptr(), nfg.data_ptr(),
-         ngt.data_ptr(), _stream())
+    call("tscd_simota_assign_r", outputs.data_ptr(), lab.data_ptr(), B, A, num_classes, lab.shape[1], G, geo.c_hw, geo.c_w,
+         geo.c_stride, topk, int(emu16), float(center_radius), ws.data_ptr(), ws_bytes, fg.data_ptr(), mg.data_ptr(), pi.data_ptr(),
+         nfg.data_ptr(), ngt.data_ptr(), _stream())
     return fg, mg, pi, nfg, ngt
 
 
 # ----------------------------------------------------------------------------------------------------
 # fused losses (loss.hip)
 # ----------------------------------------------------------------------------------------------------
-def loss_dense(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes, want_grad=True):
+def loss_dense(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes, want_grad=True, geo=None):
     """Base-detector losses over [B,A,5+NC]: -> (sums fp32 [3] = IoU-loss / objectness-BCE / class-BCE sums (un-normalised),
     d_logit fp16 [B,A,1+NC] = d(obj_sum + cls_sum) / d raw obj|cls logits, or None)."""
     B, A, nch = raw_all.shape
@@ -867,9 +867,15 @@ def loss_dense(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_clas
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     sums = torch.empty((3,), dtype=torch.float32, device=dev)
     d = torch.empty((B, A, 1 + num_classes), dtype=torch.float16, device=dev) if want_grad else None
+    if geo is not None and want_grad:      # base-detector training: also d(IoU-loss sum) / d raw box logits, [B,A,4]
+        d_reg = torch.empty((B, A, 4), dtype=torch.float16, device=dev)
+        call("tscd_loss_dense_reg_f16", raw_all.data_ptr(), outputs.data_ptr(), fg_mask.data_ptr(), matched_gt.data_ptr(), pred_iou.data_ptr(),
+             labels.data_ptr(), B, A, num_classes, labels.shape[1], geo.c_hw, geo.c_stride, ws.data_ptr(), ws_bytes, sums.data_ptr(), _ptr(d),
+             d_reg.data_ptr(), _stream())
+        return sums, d, d_reg
     call("tscd_loss_dense_f16", raw_all.data_ptr(), outputs.data_ptr(), fg_mask.data_ptr(), matched_gt.data_ptr(), pred_iou.data_ptr(),
          labels.data_ptr(), B, A, num_classes, labels.shape[1], ws.data_ptr(), ws_bytes, sums.data_ptr(), _ptr(d), _stream())
-    return sums, d
+    return (sums, d) if geo is None else (sums, d, None)
 
 
 def loss_rows(row_b, row_a, A, num_classes, fg_mask, matched_gt, pred_iou, labels, cls_logit=None, obj_logit=None, reg_delta=None,
