@@ -90,7 +90,11 @@ class YOLOXHead(nn.Module):
         loss = reg_weight * loss_iou + loss_obj + loss_cls + loss_l1
         return loss, reg_weight * loss_iou, loss_obj, loss_cls, loss_l1, num_fg / num_gts
 
-    simota_fp16 = True        # the assignment's IoU chain in fp16 op by op, as the reference evaluates it under autocast (tests: False)
+    # The assignment's IoU chain runs in fp32 here.  Under the reference's autocast the chain is evaluated in fp16, where the area of a
+    # box above 65504 px^2 (256 x 256) is inf and the IoU of two such boxes NaN -- at 640^2 with a randomly initialised box branch that
+    # poisons the class targets from the first step (measured: cls_loss NaN with the fp16 emulation, finite with fp32).  True selects
+    # the op-by-op fp16 emulation (ops.simota_assign emu16) for comparisons with a reference run.
+    simota_fp16 = False
 
     def forward(self, xin, labels=None, imgs=None):
         feats = [x.permute(0, 2, 3, 1) for x in xin]                 # channels-last maps -> NHWC views
