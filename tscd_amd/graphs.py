@@ -82,7 +82,9 @@ def _capture(module, x, key):
     saved, nb._DEFERRED_TICKS = nb._DEFERRED_TICKS, []           # the recorded pass executes nothing: its ticks are not real
     try:
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g, stream=side):
+        # thread_local: other threads keep making HIP calls while this one records (the assignment worker waits on its copy event, the
+        # process group's watchdog polls its events) -- only this thread's calls are checked against the capture
+        with torch.no_grad(), torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
             outs = module(ent.static_x)
     finally:
         nb._DEFERRED_TICKS = saved
