@@ -53,7 +53,33 @@ def test_graph_replay_matches_eager_pass(training):
     with torch.no_grad():
         next(bb.parameters()).mul_(1.0)
     graphs.frozen_pass(bb, clips[0])
-    assert graphs._GRAPHS[key[0]].versions == sum(p._version for p in bb.parameters())
+    assert graphs._GRAPHS[key[0]].versions == graphs._state_versions(bb, bb.training)
+    graphs.clear()
+
+
+def test_evaluation_after_training_passes_sees_the_new_running_statistics():
+    """Training-mode passes (eager or replayed) move the BatchNorm running statistics through raw pointers; the folded scale / shift
+    of the evaluation path and a recorded evaluation pass must both notice."""
+    from tscd_amd import graphs
+    graphs.clear()
+    bb = _backbone()
+    ref = copy.deepcopy(bb)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    clips = [(torch.rand(2, 3, 96, 128, device="cuda", generator=g) * 255).half() for _ in range(5)]
+    for rounds in range(2):
+        bb.eval(); ref.eval()
+        for x in clips[:2]:                                  # eval: first call eager + recorded, second replayed
+            with torch.no_grad():
+                want = ref(x)
+            got = graphs.frozen_pass(bb, x)
+            assert all(torch.equal(a, b) for a, b in zip(got, want)), rounds
+        bb.train(); ref.train()
+        for x in clips[2:]:                                  # three training passes: eager + recorded, replayed, replayed
+            with torch.no_grad():
+                ref(x)
+            graphs.frozen_pass(bb, x)
+    sd, sr = bb.state_dict(), ref.state_dict()
+    assert all(torch.equal(sd[k], sr[k]) for k in sd)
     graphs.clear()
 
 

@@ -21,11 +21,26 @@ MAX_GRAPHS = 8
 
 
 class _Entry:
-    __slots__ = ("graph", "static_x", "outs", "ticks", "versions", "module_ref")
+    __slots__ = ("graph", "static_x", "outs", "ticks", "stats", "versions", "module_ref")
 
 
-def _param_versions(module):
-    return sum(p._version for p in module.parameters())
+def _state_versions(module, training):
+    """What a recorded pass depends on besides its input.  Training-mode passes read-modify-write the BatchNorm buffers inside the
+    graph (always current), so only parameter writes invalidate them; an evaluation pass bakes the folded BatchNorm scale / shift in,
+    so buffer writes (training passes, EMA updates, load_state_dict) invalidate it too."""
+    v = sum(p._version for p in module.parameters())
+    if not training:
+        v += sum(b._version for b in module.buffers())
+    return v
+
+
+def _running_stats(module):
+    from yolox.models.network_blocks import BaseConv
+    out = []
+    for m in module.modules():
+        if isinstance(m, BaseConv) and m.training and m.bn.training and m.bn.track_running_stats:
+            out += [m.bn.running_mean, m.bn.running_var]
+    return out
 
 
 def _tick_buffers(module):
@@ -50,7 +65,7 @@ def frozen_pass(module, x):
         return module(x)
     key = (id(module), tuple(x.shape), x.dtype, x.stride(), module.training)
     ent = _GRAPHS.get(key)
-    if ent is not None and (ent.module_ref() is not module or ent.versions != _param_versions(module)):
+    if ent is not None and (ent.module_ref() is not module or ent.versions != _state_versions(module, module.training)):
         del _GRAPHS[key]
         ent = None
     if ent is None:
@@ -63,6 +78,8 @@ def frozen_pass(module, x):
     ent.static_x.copy_(x, non_blocking=True)
     ent.graph.replay()
     _apply_ticks(ent.ticks)
+    if ent.stats:                         # the replayed kernels wrote the running statistics: same version bump as the eager pass
+        torch.autograd.graph.increment_version(ent.stats)
     outs = tuple(o.clone() for o in ent.outs)
     for o in outs:
         o.record_stream(cur)
@@ -75,6 +92,7 @@ def _capture(module, x, key):
     ent = _Entry()
     ent.static_x = x.clone()
     ent.ticks = _tick_buffers(module)
+    ent.stats = _running_stats(module)
     ent.module_ref = weakref.ref(module)
     cur = torch.cuda.current_stream()
     side = torch.cuda.Stream(device=x.device)
@@ -91,7 +109,7 @@ def _capture(module, x, key):
     cur.wait_stream(side)
     ent.graph = g
     ent.outs = tuple(outs) if isinstance(outs, (tuple, list)) else (outs,)
-    ent.versions = _param_versions(module)
+    ent.versions = _state_versions(module, module.training)
     _GRAPHS[key] = ent
 
 

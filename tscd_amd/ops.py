@@ -236,6 +236,8 @@ def bn_finalize(partial, count, gamma, beta, running_mean, running_var, eps=BN_E
     call("tscd_bn_finalize", partial.data_ptr(), partial.shape[2], partial.shape[1], C, int(count), gamma.data_ptr(),
          beta.data_ptr(), eps, momentum, _ptr(running_mean), _ptr(running_var), ss.data_ptr(), mean.data_ptr(),
          invstd.data_ptr(), _stream())
+    if running_mean is not None:
+        torch.autograd.graph.increment_version((running_mean, running_var))
     return ss, mean, invstd
 
 
@@ -262,6 +264,10 @@ def conv_bn_act_train(x, wpk, cout, ksize, stride, gamma, beta, running_mean, ru
          B, H, W, Cin, cout, ksize, stride, nhwc_ld(x), gamma.data_ptr(), beta.data_ptr(), eps, momentum, _ptr(running_mean),
          _ptr(running_var), small.data_ptr(), out.data_ptr(), nhwc_ld(out), _ptr(residual),
          nhwc_ld(residual) if residual is not None else 0, act, _stream())
+    if running_mean is not None:
+        # the kernel wrote the running statistics through raw pointers: bump their version counters so that what is keyed on them
+        # (the folded evaluation scale / shift of BaseConv, evaluation graphs) notices the next time the module runs in eval mode
+        torch.autograd.graph.increment_version((running_mean, running_var))
     return out, raw, small[:2], small[2], small[3]
 
 
