@@ -243,6 +243,21 @@ def _ddp_worker(rank, world, port, q):
                 worst = (cos, k)
             assert cos > 0.99 and abs(ratio - 1) < 0.05, (k, cos, ratio)
         res = (len(acc), worst)
+    # two optimizer steps on the wrapped model: FusedSGD on the bucket-view gradients, the next clip's backbone pass prefetched in the
+    # assignment window (second step: hipGraph replay) -- the ranks' parameters must stay identical bit for bit
+    from tscd_amd.optim import FusedSGD
+    opt = FusedSGD([p for p in model.parameters() if p.requires_grad], lr=1e-3, momentum=0.9, nesterov=True)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        o2 = ddp(clips[rank], labels, temb, next_x=clips[rank], **kw)
+        (o2["total_loss"] * scale).backward()
+        opt.grad_scale, opt.found_inf = scale, torch.zeros((), device="cuda")
+        opt.step()
+    torch.cuda.synchronize()
+    chk = [float(p.double().sum()) for p in model.parameters() if p.requires_grad]
+    both = [None, None]
+    dist.all_gather_object(both, chk)
+    assert both[0] == both[1] and all(np.isfinite(c) for c in chk), "ranks diverged after the fused optimizer step"
     q.put((rank, res, float(out["total_loss"])))
     dist.barrier()
     dist.destroy_process_group()
