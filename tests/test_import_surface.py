@@ -160,3 +160,61 @@ def test_letterbox_and_transforms():
     assert tl.shape == (7, 5) and tl[0, 0] == 1
     # flipped horizontally: cx' = (W - cx) * r
     assert abs(tl[0, 1] - (40 - 9.0) * 1.6) < 1e-4 and abs(tl[0, 3] - 10 * 1.6) < 1e-4 and abs(tl[0, 4] - 20 * 1.6) < 1e-4
+
+
+def test_vid_dataset_xml_annotations_and_clip_rules(tmp_path):
+    """VIDDataset on an ImageNet-VID-shaped tree written by the test (reference vid.py:48-342): XML boxes clipped, mapped to the class
+    index of their WordNet id and scaled by the letterbox ratio; clip rules of photo_to_sequence; the json annotation cache."""
+    import random
+
+    from PIL import Image
+    from yolox.data import TrainTransform
+    from yolox.data.datasets import vid
+    from yolox.data.datasets.vid_classes import VID_classes, VID_wnids
+    assert len(VID_wnids) == 30 and VID_wnids[VID_classes.index("car")] == "n02958343"
+    rng = np.random.default_rng(0)
+    videos = []
+    for v, nframes in enumerate((9, 5, 3)):
+        frames = []
+        for f in range(nframes):
+            rel = f"Data/VID/train/vid{v}/{f:06d}.JPEG"
+            os.makedirs(tmp_path / os.path.dirname(rel), exist_ok=True)
+            Image.fromarray(rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)).save(tmp_path / rel, format="JPEG")
+            xml = tmp_path / rel.replace("Data", "Annotations").replace("JPEG", "xml")
+            os.makedirs(os.path.dirname(xml), exist_ok=True)
+            objs = "" if (v == 1 and f < 4) else (
+                f"<object><name>{VID_wnids[6]}</name><bndbox><xmax>{90 if f == 0 else 50}</xmax><xmin>10</xmin><ymax>40</ymax><ymin>-3</ymin></bndbox></object>"
+                f"<object><name>{VID_wnids[29]}</name><bndbox><xmax>70</xmax><xmin>60</xmin><ymax>55</ymax><ymin>45</ymin></bndbox></object>")
+            xml.write_text(f"<annotation><size><width>80</width><height>60</height></size>{objs}</annotation>")
+            frames.append(rel)
+        videos.append(frames)
+    with open(tmp_path / "seq.json", "w") as fh:
+        json.dump(videos, fh)
+    random.seed(0)
+    kw = dict(file_path=str(tmp_path / "seq.json"), img_size=(64, 64), dataset_pth=str(tmp_path), cache_file=str(tmp_path / "cache" / "ann.json"))
+    ds = vid.VIDDataset(preproc=TrainTransform(max_labels=50), lframe=2, gframe=2, mode="random", training=True, **kw)
+    r = min(64 / 60, 64 / 80)
+    a = ds.annotations[videos[0][0]]
+    assert a.shape == (2, 5) and np.allclose(a[0], [10 * r, 0, 80 * r, 40 * r, 6]) and a[1, 4] == 29        # clipped to the image
+    assert len(ds.annotations[videos[1][0]]) == 0
+    assert os.path.isfile(tmp_path / "cache" / "ann.json")
+    # video 0: four runs of two consecutive frames; video 1: runs (0,1), (2,3) carry no label and are skipped in training; video 2 too short
+    by_video = {}
+    for clip in ds.res:
+        assert len(clip) == 4 and len({os.path.dirname(c) for c in clip}) == 1
+        i0, i1 = (int(os.path.basename(c)[:6]) for c in clip[:2])
+        assert i1 == i0 + 1 and i0 % 2 == 0
+        assert not {clip[0], clip[1]} & set(clip[2:])                                                  # global frames come from the rest
+        by_video.setdefault(os.path.dirname(clip[0]), []).append(i0)
+    assert sorted(by_video["Data/VID/train/vid0"]) == [0, 2, 4, 6] and "Data/VID/train/vid1" not in by_video and len(by_video) == 1
+    img, target, info, path = ds[ds.res[0][0]]
+    assert img.shape == (3, 64, 64) and target.shape == (50, 5) and info == (60, 80)
+    imgs, targets, infos, raw, paths, temb = next(iter(vid.ovis_get_trans_loader(batch_size=4, data_num_workers=0, dataset=ds, rank=0, world_size=1)))
+    assert imgs.shape == (4, 3, 64, 64) and targets.shape == (4, 100, 5) and temb.shape == (4, 256)
+    assert torch.allclose(temb, vid.get_timing_signal_1d(torch.tensor([int(os.path.basename(p)[:6]) for p in paths]), 256))
+    # evaluation: every run, the json cache is read back, tnum caps the list
+    dv = vid.VIDDataset(preproc=None, lframe=2, gframe=2, mode="random", val=True, tnum=-1, **kw)
+    assert len(dv.res) == 4 + 2 and np.array_equal(dv.annotations[videos[0][0]], a)
+    assert len(vid.VIDDataset(preproc=None, lframe=2, gframe=2, mode="random", val=True, tnum=3, **kw).res) == 3
+    du = vid.VIDDataset(preproc=None, lframe=0, gframe=4, mode="uniform", val=True, tnum=-1, **kw)
+    assert du.res[0] == videos[0][0:8:2] and du.res[1] == videos[0][1:8:2]

@@ -175,33 +175,160 @@ class OVIS(torchDataset):
         per-frame record.  A frame whose letterbox needs the second resample of the host pipeline (pull_item resizes to (nh, nw),
         preproc then maps that onto int(nh * r'), int(nw * r') with r' = min(H / nh, W / nw) -- the identity except when a float
         truncation left nw one short of W) is transformed on the host and handed over as a finished H x W frame."""
-        from ..data_augment import TrainTransform, val_meta
         annos, _, _, img_path = self.annotations[self._pos[self.name_id_dic[path]]]
-        img = imread_bgr(os.path.join(self.data_dir, self.name, img_path))
-        h, w = img.shape[:2]
-        H, W = self.input_dim
-        r = min(self.img_size[0] / h, self.img_size[1] / w)
-        nh, nw = int(h * r), int(w * r)
-        r2 = min(H / nh, W / nw)
-        if (int(nh * r2), int(nw * r2)) != (nh, nw):
-            host = TrainTransform(self.preproc.max_labels, self.preproc.flip_prob, self.preproc.hsv_prob)
-            from ..data_augment import resize_bilinear
-            chw, target = host(resize_bilinear(img, nh, nw), annos.copy(), self.input_dim)
-            done = np.ascontiguousarray(chw.transpose(1, 2, 0).astype(np.uint8))
-            return done, target, (h, w), img_path, val_meta((H, W), (H, W))
-        meta, target = self.preproc((h, w), (nh, nw), annos.copy(), self.input_dim)
-        return img, target, (h, w), img_path, meta
+        return _pull_raw(self, os.path.join(self.data_dir, self.name, img_path), annos, img_path)
+
+
+def _pull_raw(ds, file, annos, ret_path):
+    """Shared by the datasets: decoded frame + host half of the device-side transform (see OVIS.pull_raw)."""
+    from ..data_augment import TrainTransform, resize_bilinear, val_meta
+    img = imread_bgr(file)
+    h, w = img.shape[:2]
+    H, W = ds.input_dim
+    r = min(ds.img_size[0] / h, ds.img_size[1] / w)
+    nh, nw = int(h * r), int(w * r)
+    r2 = min(H / nh, W / nw)
+    if (int(nh * r2), int(nw * r2)) != (nh, nw):
+        host = TrainTransform(ds.preproc.max_labels, ds.preproc.flip_prob, ds.preproc.hsv_prob)
+        chw, target = host(resize_bilinear(img, nh, nw), annos.copy(), ds.input_dim)
+        done = np.ascontiguousarray(chw.transpose(1, 2, 0).astype(np.uint8))
+        return done, target, (h, w), ret_path, val_meta((H, W), (H, W))
+    meta, target = ds.preproc((h, w), (nh, nw), annos.copy(), ds.input_dim)
+    return img, target, (h, w), ret_path, meta
 
 
 class VIDDataset(torchDataset):
-    """ImageNet-VID sequences (reference: vid.py:60-342, ``.npy`` lists of frame paths + XML annotations).  The constructor
-    contract is kept for the exp files; reading the XML annotations is not built."""
+    """ImageNet-VID sequences (reference: vid.py:48-342).  ``file_path``: a list of videos, each a list of frame paths relative to
+    ``dataset_pth`` (``Data/VID/.../000000.JPEG``) -- the reference's ``.npy`` object array (loaded with ``allow_pickle``: only ever a
+    file the user made with the reference's own tooling) or the same list as ``.json``.  Annotations are the dataset's XML files
+    (path with ``Data`` -> ``Annotations`` and ``JPEG`` -> ``xml``): boxes clipped to the image, class = index of the WordNet id, scaled by
+    the letterbox ratio like the reference; parsed once and kept in ``cache_file`` (json).  ``self.res`` = the clips of
+    ``photo_to_sequence``; ``dataset[frame path]`` -> (img, target, (h, w), path) after ``preproc``, or the undecorated frame + kernel
+    record for a ``TrainTransformGPU``."""
 
-    def __init__(self, file_path="train_seq.npy", img_size=(576, 576), preproc=None, lframe=0, gframe=16, val=False, mode="random",
-                 dataset_pth="", tnum=-1, formal=False, traj_linking=False, local_stride=1):
+    def __init__(self, file_path="train_seq.npy", img_size=(416, 416), preproc=None, lframe=18, gframe=6, val=False, mode="random",
+                 dataset_pth="", tnum=1000, formal=False, traj_linking=False, local_stride=1, training=False, cache_file=""):
         super().__init__()
-        raise NotImplementedError("ImageNet-VID (npy sequence lists + XML annotations) is not built; OVIS-style COCO json is "
-                                  "(yolox.data.datasets.vid.OVIS)")
+        self.tnum, self.traj_linking, self.input_dim, self.img_size = tnum, traj_linking, img_size, img_size
+        self.file_path, self.mode, self.preproc, self.val, self.formal = file_path, mode, preproc, val, formal
+        self.local_stride, self.training, self.dataset_pth, self.cache_file = local_stride, training, dataset_pth, cache_file
+        if file_path.endswith(".json"):
+            with open(file_path) as fh:
+                videos = json.load(fh)
+        else:
+            videos = np.load(file_path, allow_pickle=True).tolist()
+        videos = [list(v) for v in videos]
+        self.annotations = self._load_annotations(videos)
+        self.res = self.photo_to_sequence(videos, lframe, gframe)
+
+    def __len__(self):
+        return len(self.res)
+
+    # ---- annotations
+    def _load_annotations(self, videos):
+        if self.cache_file and os.path.isfile(self.cache_file):
+            with open(self.cache_file) as fh:
+                return {k: np.asarray(v, dtype=np.float64).reshape(-1, 5) for k, v in json.load(fh).items()}
+        ann = {frame: self.get_annotation(os.path.join(self.dataset_pth, frame), self.img_size) for video in videos for frame in video}
+        if self.cache_file:
+            os.makedirs(os.path.dirname(os.path.abspath(self.cache_file)), exist_ok=True)
+            with open(self.cache_file, "w") as fh:
+                json.dump({k: v.tolist() for k, v in ann.items()}, fh)
+        return ann
+
+    @staticmethod
+    def get_annotation(image_path, test_size):
+        """[n,5] (x1, y1, x2, y2, class) of one frame, scaled by r = min(H / height, W / width) (vid.py:243-285)."""
+        import xml.etree.ElementTree as ET
+        from .vid_classes import VID_wnids
+        root = ET.parse(image_path.replace("Data", "Annotations").replace("JPEG", "xml")).getroot()
+        width, height = int(root.find("size/width").text), int(root.find("size/height").text)
+        rows = []
+        for obj in root.iter("object"):
+            bb = obj.find("bndbox")
+            x1, y1 = max(0, int(bb.find("xmin").text)), max(0, int(bb.find("ymin").text))
+            x2, y2 = min(width, int(bb.find("xmax").text)), min(height, int(bb.find("ymax").text))
+            if x2 >= x1 and y2 >= y1:
+                rows.append((x1, y1, x2, y2, VID_wnids.index(obj.find("name").text)))
+        res = np.zeros((len(rows), 5))
+        if rows:
+            res[:] = rows
+        res[:, :4] *= min(test_size[0] / height, test_size[1] / width)
+        return res
+
+    # ---- clips
+    def photo_to_sequence(self, videos, lframe, gframe):
+        """vid.py:133-241.  Videos shorter than a clip are skipped (``formal``: kept, padded by sampling with replacement); 'random' with
+        local frames: consecutive runs of ``lframe`` frames (in training at most 15 per video, evenly spaced, and only runs that carry a
+        label) completed by ``gframe`` frames drawn from the rest of the video; ``local_stride`` > 1 interleaves; 'uniform': every
+        split-th frame.  Training keeps at most 15000 shuffled clips, evaluation the first ``tnum`` (-1: all)."""
+        res = []
+        for element in videos:
+            n = len(element)
+            if n < lframe + gframe:
+                if not self.formal:
+                    continue
+                if lframe == 0:
+                    res.append(element)
+                else:
+                    for i in np.arange(n // lframe) * lframe:
+                        res.append(element[i:i + lframe] + random.choices(element[:i] + element[i + lframe:], k=gframe))
+                continue
+            if self.mode == "uniform":
+                split = n // gframe
+                uni = element[:split * gframe]
+                res += [uni[i::split] for i in range(split)]
+                continue
+            if self.mode != "random":
+                raise ValueError(f"unsupported clip sampling mode {self.mode!r}")
+            if lframe == 0:
+                split = n // gframe
+                random.shuffle(element)
+                res += [element[i * gframe:(i + 1) * gframe] for i in range(split)]
+                if self.formal and element[split * gframe:]:
+                    res.append(element[split * gframe:])
+            elif self.local_stride == 1:
+                split = n // lframe
+                local_all = element[:split * lframe]
+                if self.training and split > 15:
+                    starts = np.arange(15) * (len(local_all) // 15)
+                else:
+                    starts = np.arange(split) * lframe
+                for i in starts:
+                    if self.traj_linking and i != 0:
+                        l_frame = local_all[i - 1:i + lframe]
+                    else:
+                        l_frame = local_all[i:i + lframe]
+                        if self.training and not any(len(self.annotations[f]) for f in l_frame):
+                            continue
+                    res.append(l_frame + random.sample(element[:i] + element[i + lframe:], gframe))
+                if self.formal and element[split * lframe:]:
+                    res.append(element[split * lframe - 1:] if self.traj_linking else element[split * lframe:])
+            else:
+                span = lframe * self.local_stride
+                for i in range(n // span):
+                    res += [element[span * i:span * (i + 1)][j::self.local_stride] for j in range(self.local_stride)]
+        if self.val:
+            return res if self.tnum == -1 else res[:self.tnum]
+        random.shuffle(res)
+        return res[:15000]
+
+    # ---- frames
+    def pull_item(self, path):
+        from ..data_augment import resize_bilinear
+        img = imread_bgr(os.path.join(self.dataset_pth, path))
+        h, w = img.shape[:2]
+        r = min(self.img_size[0] / h, self.img_size[1] / w)
+        return resize_bilinear(img, int(h * r), int(w * r)), self.annotations[path].copy(), (h, w), os.path.join(self.dataset_pth, path)
+
+    def __getitem__(self, path):
+        from ..data_augment import TrainTransformGPU
+        if isinstance(self.preproc, TrainTransformGPU):
+            return _pull_raw(self, os.path.join(self.dataset_pth, path), self.annotations[path], os.path.join(self.dataset_pth, path))
+        img, target, img_info, path = self.pull_item(path)
+        if self.preproc is not None:
+            img, target = self.preproc(img, target, self.input_dim)
+        return img, target, img_info, path
 
 
 class TrainSampler(Sampler):
