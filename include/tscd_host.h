@@ -50,6 +50,8 @@ int64_t tscd_lap_chain_spec_hits(int reset);
 
 /* Diagnostics: relaxation passes executed by the fixed-point solver since the last reset. */
 int64_t tscd_lap_debug_steps(int reset);
+/* Diagnostics: solves answered on the int16 (which = 0) / int32 (which = 1) fixed-point matrix so far. */
+int64_t tscd_lap_debug_width(int which, int reset);
 
 /* COCO bounding-box evaluation (replaces the reference's pybind11 extension
  * yolox/layers/cocoeval/cocoeval.cpp:59-199,370-502 and its pycocotools fallback, ovis_evaluator_v2.py:397-402).

@@ -49,6 +49,7 @@ M.AwarePositionRegMatcher.finish = finish
 from tscd_amd import _host
 _host._lib.tscd_lap_chain_set_parallel(MODE)
 print('chain mode', MODE, flush=True)
+_host._lib.tscd_lap_debug_steps(1)
 M.lap_chain_f16 = chain
 
 
@@ -76,4 +77,4 @@ for blk in range(10):
         fi.append(marks["finish"])
     torch.cuda.synchronize()
     print(f"steps {10 + blk * 25:4d}-{10 + blk * 25 + 24:4d}: step {(time.perf_counter() - t) / 25 * 1e3:6.2f} ms | assignment chain on the worker {np.mean(ch) * 1e3:5.2f} ms "
-          f"| main thread inside matcher.finish {np.mean(fi) * 1e3:5.2f} ms | loss {float(out['total_loss']):8.1f} | side-by-side answers so far {_host._lib.tscd_lap_chain_spec_hits(0)}", flush=True)
+          f"| main thread inside matcher.finish {np.mean(fi) * 1e3:5.2f} ms | loss {float(out['total_loss'].detach()):8.1f} | solves on the int16 / int32 matrix {_host._lib.tscd_lap_debug_width(0, 1)} / {_host._lib.tscd_lap_debug_width(1, 1)} | relaxation passes per step {_host._lib.tscd_lap_debug_steps(1) // 25}", flush=True)

@@ -52,6 +52,10 @@ _lib.tscd_lap_chain_set_parallel.argtypes = [C.c_int]
 _lib.tscd_lap_chain_set_parallel.restype = C.c_int
 _lib.tscd_lap_chain_spec_hits.argtypes = [C.c_int]
 _lib.tscd_lap_chain_spec_hits.restype = C.c_int64
+_lib.tscd_lap_debug_width.argtypes = [C.c_int, C.c_int]
+_lib.tscd_lap_debug_width.restype = C.c_int64
+_lib.tscd_lap_debug_steps.argtypes = [C.c_int]
+_lib.tscd_lap_debug_steps.restype = C.c_int64
 if os.environ.get("TSCD_LAP_PARALLEL", "1") == "0":       # diagnostics / A-B runs: strictly in-order chain
     _lib.tscd_lap_chain_set_parallel(0)
 KIND_SELF, KIND_STATE, KIND_PREV = 0, 1, 2

@@ -368,13 +368,18 @@ static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, 
 
 // cost: fp16 bits, [nr][ncp] with ncp % 32 == 0 (padding columns are never live), nr <= nc.  0 ok, 2 infeasible, 3 overflow.
 // The integer matrix is int16 (0.5 MB for 500x500: stays in the core's L2) when the entries' exponents span <= 4 binades --
-// CAFM's costs 1 - cos live in [0.5, 1.2] -- and int32 otherwise (e.g. the self-match, whose diagonal is ~0).
+// a randomly initialised CAFM's costs 1 - cos live in [0.5, 1.2] -- and int32 (unit 2^-24) otherwise: the self-match, whose diagonal is
+// ~0, and a CAFM that has started to separate its features (near-duplicate proposals give 1 - cos ~ 1e-3 next to ~1).  On the
+// MI355X host (EPYC 9575F) the two widths cost the same per relaxation pass (55 vs 57 ns solo on real 500x500 matrices); a third form
+// that kept the fp16 bits and converted them inside the pass was 12 % slower than int32 and is not kept.
+static std::atomic<int64_t> g_q16_solves{0}, g_q32_solves{0};      // which fixed-point width the solves took (diagnostics)
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
 static int solve_q(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, int32_t* col4row_out, int* unique_out = nullptr) {
   int emin, emax;
   exponent_span(cost, nr * ncp, emin, emax);
   if (emax < emin) { emin = emax = 1; }                      // all zeros
-  if (emax - emin <= 4) return solve_q_t<int16_t>(nr, nc, ncp, cost, emin, col4row_out, unique_out);
+  if (emax - emin <= 4) { ++g_q16_solves; return solve_q_t<int16_t>(nr, nc, ncp, cost, emin, col4row_out, unique_out); }
+  ++g_q32_solves;
   return solve_q_t<int32_t>(nr, nc, ncp, cost, 1, col4row_out, unique_out);   // unit 2^-24
 }
 
@@ -738,6 +743,17 @@ int tscd_lap_chain_f16(int K, const uint16_t* const* cost, const int64_t* nr, co
     o_perm += Cn;
   }
   return 0;
+}
+// solves answered on the int16 (which = 0) / int32 (which = 1) fixed-point matrix so far
+int64_t tscd_lap_debug_width(int which, int reset) {
+#if defined(__x86_64__)
+  std::atomic<int64_t>& c = which ? g_q32_solves : g_q16_solves;
+  int64_t v = c;
+  if (reset) c = 0;
+  return v;
+#else
+  return 0;
+#endif
 }
 int64_t tscd_lap_debug_steps(int reset) {
 #if defined(__x86_64__)
