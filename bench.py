@@ -400,6 +400,16 @@ def main():
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo" if rehearsal else "nccl")
+    force_ddp = world == 1 and bool(os.environ.get("TSCD_BENCH_FORCE_DDP"))
+    if force_ddp:
+        # A/B hook: one rank, but wrapped in DistributedDataParallel over a 1-rank RCCL group -- what the DDP schedule (reducer hooks,
+        # bucket copies, gradient-producing kernels on one stream) costs on its own, without a second GPU
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["TSCD_ONE_GRAD_STREAM"] = "1"
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=0, world_size=1)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -414,7 +424,7 @@ def main():
     scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
     ema = FusedEMA(model, optimizer=opt)
     net = model
-    if world > 1:
+    if world > 1 or force_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
                                                         gradient_as_bucket_view=True)
     imgs, targets0, temb = synth_clip(args.frames, args.size, device, seed=rank)
@@ -547,7 +557,7 @@ def main():
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         torch.distributed.destroy_process_group()
 
 
