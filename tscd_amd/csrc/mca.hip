@@ -195,14 +195,22 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p) {
   }
   int qrow = t.row0 + (lane & 31);
   if (qrow >= t.row0 + t.nrows) qrow = t.row0;
-  f16x8 qc[KS], qr[KS], vlc[KS], vlr[KS];
+  // DP >= 64: the local-row v^ fragments are re-read (L1-hot, 2 KB per head) in every key block instead of living in registers --
+  // 128 accumulator + 64 fragment + 32 score registers do not fit the 256 of an occupancy-2 wave
+  // (DP >= 96, both branches: 192 accumulator registers -- the q fragments are re-read as well)
+  constexpr bool VL_RELOAD = NEED_REG ? DP >= 64 : DP >= 96, Q_RELOAD = DP >= 96 && NEED_REG;
+  f16x8 qc[Q_RELOAD ? 1 : KS], qr[Q_RELOAD ? 1 : KS], vlc[VL_RELOAD ? 1 : KS], vlr[VL_RELOAD ? 1 : KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     long o = (long)qrow * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
-    qc[ks] = *(const f16x8*)(p.qn_c + o);
-    qr[ks] = *(const f16x8*)(p.qn_r + o);
-    vlc[ks] = *(const f16x8*)(p.vn_c + o);   // local rows of v^ are rows [0, N_L) of vn
-    vlr[ks] = *(const f16x8*)(p.vn_r + o);
+    if constexpr (!Q_RELOAD) {
+      qc[ks] = *(const f16x8*)(p.qn_c + o);
+      qr[ks] = *(const f16x8*)(p.qn_r + o);
+    }
+    if constexpr (!VL_RELOAD) {
+      vlc[ks] = *(const f16x8*)(p.vn_c + o);   // local rows of v^ are rows [0, N_L) of vn
+      vlr[ks] = *(const f16x8*)(p.vn_r + o);
+    }
   }
   f32x16 oc[NT], orr[NT], sfc[NT], sfr[NT];
 #pragma unroll
@@ -215,34 +223,63 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p) {
     int key0, lo, hi;
     block_range(t, p.N_L, p.N, j, key0, lo, hi, n_local);
     const int key = key0 + (lane & 31);
-    f32x16 sc, sr, rc, rr;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) sc[e] = sr[e] = rc[e] = rr[e] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      long o = (long)key * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
-      f16x8 kc = *(const f16x8*)(p.kn_c + o);
-      f16x8 kr = *(const f16x8*)(p.kn_r + o);
-      f16x8 vc = *(const f16x8*)(p.vn_c + o);
-      f16x8 vr = *(const f16x8*)(p.vn_r + o);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qc[ks], kc, sc, 0, 0, 0);
-      sr = __builtin_amdgcn_mfma_f32_32x32x16_f16(qr[ks], kr, sr, 0, 0, 0);
-      rc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlc[ks], vc, rc, 0, 0, 0);
-      rr = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlr[ks], vr, rr, 0, 0, 0);
-    }
     const bool valid = key >= lo && key < hi;
     const float kscore = valid ? (float)p.score[key] : 0.f;
     const int col = lane & 31;
+    // two passes (scores, then raw similarities) so that only two 32x32 accumulators are live at a time: with all four the
+    // DP = 64 instantiation spilled its q / v fragments to scratch and re-read them inside this loop
+    {
+      f32x16 sc, sr;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-      float pc = valid ? __expf(p.scale * kscore * sc[e] - p.scale) * invl[h][0][row] : 0.f;
-      float pr = valid ? __expf(p.scale * sr[e] - p.scale) * invl[h][1][row] : 0.f;
-      float pp = 0.5f * (pc + pr);
-      Pf[h][row][col] = pp;
-      Ph[h][row][col] = (f16)pp;
-      Rc[h][row][col] = valid ? rc[e] : -2.f;   // invalid keys can never pass the similarity masks
-      Rr[h][row][col] = valid ? rr[e] : -2.f;
+      for (int e = 0; e < 16; ++e) sc[e] = sr[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        long o = (long)key * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
+        f16x8 kc = *(const f16x8*)(p.kn_c + o);
+        f16x8 kr = *(const f16x8*)(p.kn_r + o);
+        if constexpr (Q_RELOAD) {
+          const long oq = (long)qrow * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.qn_c + oq), kc, sc, 0, 0, 0);
+          sr = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.qn_r + oq), kr, sr, 0, 0, 0);
+        } else {
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qc[ks], kc, sc, 0, 0, 0);
+          sr = __builtin_amdgcn_mfma_f32_32x32x16_f16(qr[ks], kr, sr, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        float pc = valid ? __expf(p.scale * kscore * sc[e] - p.scale) * invl[h][0][row] : 0.f;
+        float pr = valid ? __expf(p.scale * sr[e] - p.scale) * invl[h][1][row] : 0.f;
+        float pp = 0.5f * (pc + pr);
+        Pf[h][row][col] = pp;
+        Ph[h][row][col] = (f16)pp;
+      }
+    }
+    {
+      f32x16 rc, rr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) rc[e] = rr[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        long o = (long)key * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
+        f16x8 vc = *(const f16x8*)(p.vn_c + o);
+        f16x8 vr = *(const f16x8*)(p.vn_r + o);
+        if constexpr (VL_RELOAD) {
+          const long ol = (long)qrow * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
+          rc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.vn_c + ol), vc, rc, 0, 0, 0);
+          rr = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.vn_r + ol), vr, rr, 0, 0, 0);
+        } else {
+          rc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlc[ks], vc, rc, 0, 0, 0);
+          rr = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlr[ks], vr, rr, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        Rc[h][row][col] = valid ? rc[e] : -2.f;   // invalid keys can never pass the similarity masks
+        Rr[h][row][col] = valid ? rr[e] : -2.f;
+      }
     }
     __syncthreads();
     {
