@@ -40,7 +40,7 @@ else:
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
 cnt = collections.Counter()
@@ -54,9 +54,9 @@ for e in prof.events():
         n = k.name
         if any(t in n for t in ("Memcpy", "Memset", "copyBuffer", "fillBuffer", "elementwise", "CatArray", "gather", "index")):
             frames = tuple(s.split("/repo/")[-1] for s in (e.stack or []) if "/repo/" in s and "tools/find_copies" not in s)[:2]
-            key = (e.name, n[:36], frames[:1])
+            key = (e.name, n[:36], frames[:1], str(e.input_shapes)[:90])
             cnt[key] += 1
             stacks.setdefault(key, frames)
 print("device activities in the step:", total)
-for (name, kn, _), c in cnt.most_common(45):
-    print(f"{c:5d}  {name:28s} {kn:36s} {stacks[(name, kn, _)]}")
+for key, c in cnt.most_common(70):
+    print(f"{c:5d}  {key[0]:24s} {key[1]:36s} {key[3]} {stacks[key]}")
