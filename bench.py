@@ -391,6 +391,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    force_ddp = world == 1 and bool(os.environ.get("TSCD_BENCH_FORCE_DDP"))
+    json_fd = None
+    if world > 1 or force_ddp:
+        # RCCL prints its version banner on stdout when the communicator comes up: keep stdout for the ONE JSON line (file
+        # descriptor 1 points at stderr from here on, the line goes out through the saved descriptor)
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
     if world > 1:
         import torch.distributed as dist
         # rehearsal hook: TSCD_BENCH_REHEARSAL=1 runs every rank on GPU 0 over gloo (a one-GPU box cannot host two RCCL
@@ -400,14 +408,12 @@ def main():
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo" if rehearsal else "nccl")
-    force_ddp = world == 1 and bool(os.environ.get("TSCD_BENCH_FORCE_DDP"))
     if force_ddp:
-        # A/B hook: one rank, but wrapped in DistributedDataParallel over a 1-rank RCCL group -- what the DDP schedule (reducer hooks,
-        # bucket copies, gradient-producing kernels on one stream) costs on its own, without a second GPU
+        # A/B hook: one rank, but wrapped in DistributedDataParallel over a 1-rank RCCL group -- what the DDP machinery (reducer
+        # hooks, bucket bookkeeping) costs on its own, without a second GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ["TSCD_ONE_GRAD_STREAM"] = "1"
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=0, world_size=1)
     device = torch.device("cuda", local_rank)
@@ -425,8 +431,8 @@ def main():
     ema = FusedEMA(model, optimizer=opt)
     net = model
     if world > 1 or force_ddp:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
-                                                        gradient_as_bucket_view=True)
+        from tscd_amd import ddp as tscd_ddp
+        net = tscd_ddp.wrap(model, device_ids=[local_rank])
     imgs, targets0, temb = synth_clip(args.frames, args.size, device, seed=rank)
     gframe = args.frames - args.lframe
     one = torch.ones((), dtype=torch.float32, device=device)
@@ -556,7 +562,11 @@ def main():
                                    "(MCA, CAFM, loss kernels) on the product's own intermediates at this size"}
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(line), flush=True)
+        if json_fd is None:
+            print(json.dumps(line), flush=True)
+        else:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1 or force_ddp:
         torch.distributed.destroy_process_group()
 

@@ -31,7 +31,8 @@ def _worker(rank, world, port, ref_names, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     model = bench.build_model(0.33, 0.125, "500")
     trainable = {k for k, p in model.named_parameters() if p.requires_grad}
-    ddp = torch.nn.parallel.DistributedDataParallel(model, broadcast_buffers=False)
+    from tscd_amd import ddp as tscd_ddp
+    ddp = tscd_ddp.wrap(model)                             # the product's DDP wiring (bucket views, averaging hook: gloo = divide + sum)
     # surrogate "step": every trainable parameter contributes, scaled by (rank + 1)
     loss = sum(p.sum() for p in model.parameters() if p.requires_grad) * float(rank + 1)
     ddp.reducer.prepare_for_backward([])   # forward of the wrapped module is bypassed on CPU

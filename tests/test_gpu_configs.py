@@ -213,7 +213,8 @@ def _ddp_worker(rank, world, port, q):
     kw = dict(lframe=int(meta["lframe"]), gframe=int(meta["gframe"]), resume=False)
     scale = torch.full((), 64.0, device="cuda")
     model = fresh()
-    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True)
+    from tscd_amd import ddp as tscd_ddp
+    ddp = tscd_ddp.wrap(model, device_ids=[0])               # the product's DDP wiring (bucket views, averaging hook)
     model.head.loss_scale = scale
     out = ddp(clips[rank], labels, temb, **kw)               # eager class branch + level streams on (defaults)
     (out["total_loss"] * scale).backward()

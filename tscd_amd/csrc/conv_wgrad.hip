@@ -126,17 +126,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     __syncthreads();
     buf ^= 1;
   }
+  // partial tile -> part[s][row][col]: one base pointer per lane, row offsets as multiples of the (wave-uniform) row pitch; tiles that
+  // lie inside the matrix (all but the last row / column of tiles) skip the per-element bounds tests
+  {
+    const int row_w = c0 + wm * 64 + 4 * (lane >> 5), col_w = n0 + wn * 64 + (lane & 31);
+    float* const base = p.part + ((long)s * p.Cout + row_w) * p.Ncols + col_w;
+    const long pitch = p.Ncols;
+    const bool inside = c0 + 128 <= p.Cout && n0 + 128 <= p.Ncols;          // wave-uniform (the workgroup's tile)
+    if (inside) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = c0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (row < p.Cout && col < p.Ncols) p.part[((long)s * p.Cout + row) * p.Ncols + col] = acc[i][j][e];
-      }
+          for (int e = 0; e < 16; ++e) base[(i * 32 + (e & 3) + 8 * (e >> 2)) * pitch + j * 32] = acc[i][j][e];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int ro = i * 32 + (e & 3) + 8 * (e >> 2);
+            if (row_w + ro < p.Cout && col_w + j * 32 < p.Ncols) base[ro * pitch + j * 32] = acc[i][j][e];
+          }
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -329,17 +344,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(WgradParams p) 
       mfmas(std::integral_constant<int, 0>{});
     }
   }
+  // partial tile -> part[s][row][col]: one base pointer per lane, row offsets as multiples of the (wave-uniform) row pitch; tiles that
+  // lie inside the matrix (all but the last row / column of tiles) skip the per-element bounds tests
+  {
+    const int row_w = c0 + wm * 64 + 4 * (lane >> 5), col_w = n0 + wn * 64 + (lane & 31);
+    float* const base = p.part + ((long)s * p.Cout + row_w) * p.Ncols + col_w;
+    const long pitch = p.Ncols;
+    const bool inside = c0 + 128 <= p.Cout && n0 + 128 <= p.Ncols;          // wave-uniform (the workgroup's tile)
+    if (inside) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = c0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (row < p.Cout && col < p.Ncols) p.part[((long)s * p.Cout + row) * p.Ncols + col] = acc[i][j][e];
-      }
+          for (int e = 0; e < 16; ++e) base[(i * 32 + (e & 3) + 8 * (e >> 2)) * pitch + j * 32] = acc[i][j][e];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int ro = i * 32 + (e & 3) + 8 * (e >> 2);
+            if (row_w + ro < p.Cout && col_w + j * 32 < p.Ncols) base[ro * pitch + j * 32] = acc[i][j][e];
+          }
     }
+  }
 }
 
 // dW[cout][cin][kh][kw] (fp32, torch layout) = sum_s part[s][cout][(kh*KW+kw)*Cin + cin].  Threads walk the slabs in SLAB

@@ -11,6 +11,8 @@ import time
 import torch
 from torch.nn.parallel import DistributedDataParallel as DDP
 
+from tscd_amd import ddp as tscd_ddp
+
 from yolox.utils import checkpoint
 from yolox.utils import ModelEMA, all_reduce_norm, get_local_rank, get_rank, get_world_size, is_parallel, synchronize
 
@@ -51,7 +53,7 @@ class Trainer:
         self.max_iter = len(self.train_loader)
         self.lr_scheduler = self.exp.get_lr_scheduler(self.exp.basic_lr_per_img * self.args.batch_size, self.max_iter)
         if self.is_distributed:
-            model = DDP(model, device_ids=[self.local_rank], broadcast_buffers=False)
+            model = tscd_ddp.wrap(model, device_ids=[self.local_rank])        # DDP(model, device_ids=[local_rank], broadcast_buffers=False) + bucket views and an averaging hook
         if self.use_model_ema:
             self.ema_model = ModelEMA(model, 0.9998)
             self.ema_model.updates = self.max_iter * self.start_epoch

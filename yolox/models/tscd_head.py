@@ -190,13 +190,14 @@ class TSCDHead(nn.Module):
             cls_maps[k], reg_maps[k] = vid_feat, vid_feat_reg
 
         # The three pyramid levels are independent chains of 14 convs each; the 36x36 and 18x18 levels launch only 80-330
-        # workgroups per conv, so they run on side streams underneath the 72x72 level instead of after it.  Under
-        # DistributedDataParallel only their no-grad half does: the reducer syncs its all-reduce with the ONE stream that is
-        # current when a bucket's last gradient arrives, so gradient-producing kernels must all live on one stream.
+        # workgroups per conv, so they run on side streams underneath the 72x72 level instead of after it.  Also under
+        # DistributedDataParallel: the reducer keeps every parameter's AccumulateGrad node alive from its construction (on the
+        # main stream), autograd orders a gradient produced on a side stream in front of that node with an event wait (the
+        # "AccumulateGrad node's stream does not match" notice), and the reducer syncs a bucket's all-reduce with the stream its
+        # hook runs on -- the main one (same-box A/B of a 1-rank DDP step: 17.3 ms with the gradient-producing half of the side
+        # levels moved to the main stream, 16.8 without; TSCD_ONE_GRAD_STREAM=1 restores that schedule).
         if LEVEL_STREAMS and len(feats) > 1 and dev.type == "cuda":
-            import torch.distributed as dist
-            one_grad_stream = grad and ((dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-                                        or os.environ.get("TSCD_ONE_GRAD_STREAM") == "1")      # env: single-GPU rehearsal of the DDP schedule
+            one_grad_stream = grad and os.environ.get("TSCD_ONE_GRAD_STREAM") == "1"
             main = torch.cuda.current_stream()
             side = _side_streams(dev, len(feats) - 1)
             fork = torch.cuda.Event()
