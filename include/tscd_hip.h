@@ -91,6 +91,11 @@ int tscd_bias_relu_bwd_f16(const void* g, int ldg, const void* y, int ldy, void*
 long tscd_linear_bwd_workspace_bytes(int n, int in_f, int outp);
 int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, int lddy, const void* w, int w_is_f32, int n, int in_f, int out_f,
                         int outp, void* dx, float* dw, float* db, void* workspace, long workspace_bytes, void* stream);
+/* The same with W already packed in data-gradient order by the caller (tscd_pack_conv_weight mode 1 of the [out_f][in_f][1][1] view,
+ * cached per parameter version and refreshed by tscd_pack_conv_weights_batched): no pack launch inside the call.  NULL = pack here. */
+int tscd_linear_bwd_packed_f16(const void* x, int ldx, const void* dy, int lddy, const void* w, int w_is_f32,
+                               const void* w_dgrad_packed, int n, int in_f, int out_f, int outp, void* dx, float* dw, float* db,
+                               void* workspace, long workspace_bytes, void* stream);
 int tscd_bn_silu_bwd_f16(const void* dy, const void* raw, const float* scale_shift, const float* mean,
                          const float* invstd, const float* gamma, long M, int C, void* draw, float* sums_out,
                          void* workspace, long workspace_bytes, void* stream);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "tscd_bn_silu_bwd_f16": [P, P, P, P, P, P, L, I, P, P, P, L, P],
     "tscd_bias_relu_bwd_f16": [P, I, P, I, P, I, L, I, P, P, L, P],
     "tscd_linear_bwd_f16": [P, I, P, I, P, I, I, I, I, I, P, P, P, P, L, P],
+    "tscd_linear_bwd_packed_f16": [P, I, P, I, P, I, P, I, I, I, I, P, P, P, P, L, P],
     "tscd_simota_assign": [P, P, I, I, I, I, I, P, P, P, I, I, P, L, P, P, P, P, P, P],
     "tscd_simota_assign_r": [P, P, I, I, I, I, I, P, P, P, I, I, F, P, L, P, P, P, P, P, P],
     "tscd_loss_dense_f16": [P, P, P, P, P, P, I, I, I, I, P, L, P, P, P],

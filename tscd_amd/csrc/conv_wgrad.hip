@@ -679,9 +679,20 @@ extern "C" long tscd_linear_bwd_workspace_bytes(int n, int in_f, int outp) {
 }
 // x [n][in_f] (row stride ldx), dY [n][outp] fp16 with row stride lddy (outp % 8 == 0; columns >= out_f zero), w [out_f][in_f]
 // fp32 or fp16.  Outputs (each may be NULL): dx [n][in_f] fp16 contiguous, dw [outp][in_f] fp32, db [outp] fp32.
+extern "C" int tscd_linear_bwd_packed_f16(const void* x, int ldx, const void* dy, int lddy, const void* w, int w_is_f32,
+                                          const void* w_dgrad_packed, int n, int in_f, int out_f, int outp, void* dx, float* dw, float* db,
+                                          void* workspace, long workspace_bytes, void* stream);
 extern "C" int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, int lddy, const void* w, int w_is_f32, int n, int in_f,
                                    int out_f, int outp, void* dx, float* dw, float* db, void* workspace, long workspace_bytes,
                                    void* stream) {
+  return tscd_linear_bwd_packed_f16(x, ldx, dy, lddy, w, w_is_f32, nullptr, n, in_f, out_f, outp, dx, dw, db, workspace, workspace_bytes,
+                                    stream);
+}
+// w_dgrad_packed (optional): W already in data-gradient order (tscd_pack_conv_weight mode 1 of the [out_f][in_f][1][1] view, the copy
+// the caller caches per parameter version) -- the call then launches no pack kernel.
+extern "C" int tscd_linear_bwd_packed_f16(const void* x, int ldx, const void* dy, int lddy, const void* w, int w_is_f32,
+                                          const void* w_dgrad_packed, int n, int in_f, int out_f, int outp, void* dx, float* dw, float* db,
+                                          void* workspace, long workspace_bytes, void* stream) {
   TSCD_CHECK_ARG(x && dy && w && workspace && n > 0, "linear_bwd: bad args");
   TSCD_CHECK_ARG(outp % 8 == 0 && outp >= out_f && in_f % 8 == 0 && lddy % 8 == 0 && lddy >= outp,
                  "linear_bwd: in_f / padded out_f / lddy must be multiples of 8");
@@ -692,8 +703,10 @@ extern "C" int tscd_linear_bwd_f16(const void* x, int ldx, const void* dy, int l
     const int bn = tscd_conv_tile_n(in_f);
     const int rows_pad = cdiv(in_f, bn) * bn, kpad = cdiv(outp, 32) * 32;
     // data-gradient packing of a 1x1 "conv": rows = in_f, k = out channel (CinPad carries the padded out count)
-    if ((st = tscd_pack_conv_weight(w, w_is_f32, workspace, out_f, in_f, outp, 1, 1, rows_pad, kpad, 1, stream)) != TSCD_OK) return st;
-    if ((st = tscd_conv2d_nhwc_f16(dy, workspace, dx, nullptr, nullptr, nullptr, nullptr, 1, 1, n, outp, in_f, 1, 1, lddy, in_f, 0,
+    if (!w_dgrad_packed &&
+        (st = tscd_pack_conv_weight(w, w_is_f32, workspace, out_f, in_f, outp, 1, 1, rows_pad, kpad, 1, stream)) != TSCD_OK)
+      return st;
+    if ((st = tscd_conv2d_nhwc_f16(dy, w_dgrad_packed ? w_dgrad_packed : workspace, dx, nullptr, nullptr, nullptr, nullptr, 1, 1, n, outp, in_f, 1, 1, lddy, in_f, 0,
                                    stream)) != TSCD_OK)
       return st;
   }

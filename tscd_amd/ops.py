@@ -633,8 +633,10 @@ def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False):
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
-    call("tscd_linear_bwd_f16", x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), w.data_ptr(), int(w.dtype == torch.float32), n,
-         in_f, out_f, outp, _ptr(dx), _ptr(dw), _ptr(db), ws.data_ptr(), ws_bytes, _stream())
+    # the data-gradient copy of a PARAMETER is cached per version (and refreshed in the optimizer's batched re-pack): no pack launch here
+    wdg = LINEAR_WEIGHTS.get(weight, mode=1) if need_dx and isinstance(weight, torch.nn.Parameter) and weight.is_contiguous() else None
+    call("tscd_linear_bwd_packed_f16", x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), w.data_ptr(), int(w.dtype == torch.float32),
+         _ptr(wdg), n, in_f, out_f, outp, _ptr(dx), _ptr(dw), _ptr(db), ws.data_ptr(), ws_bytes, _stream())
     return dx, (None if dw is None else dw[:out_f]), (None if db is None else db[:out_f])
 
 
