@@ -58,8 +58,10 @@ int tscd_conv_tile_n(int cout);
 int tscd_pack_conv_weight(const void* w, int src_is_f32, void* out, int Cout, int Cin, int CinPad, int KH, int KW,
                           int rows_pad, int Kpad, int mode, void* stream);
 /* The same packing for many weights in one launch (after an optimizer step).  jobs: device array of 56-byte records {const void* w;
- * f16* out; int Cout, Cin, CinPad, KH, KW, rows_pad, Kpad, mode, src_is_f32, pad}; blockmap: one {int job, int block_in_job} per
- * workgroup, each covering tscd_pack_block_elems() consecutive outputs of its job. */
+ * f16* out; int Cout, Cin, CinPad, KH, KW, rows_pad, Kpad, mode, src_is_f32, pad}; blockmap: one {int job, int tile} per
+ * workgroup; tile t of a job is the (cout, cin) sub-block [T (t / nI), T (t / nI) + T) x [T (t % nI), T (t % nI) + T) of the weight with
+ * T = tscd_pack_block_elems() and nI = ceil(Cin / T); a job has ceil(Cout / T) * nI tiles.  Padding rows / columns of `out` are not
+ * written: `out` must come from tscd_pack_conv_weight (which zero-fills them). */
 int tscd_pack_block_elems(void);
 int tscd_pack_conv_weights_batched(const void* jobs, const void* blockmap, long nblocks, void* stream);
 int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* bias, const float* scale,

@@ -127,13 +127,17 @@ def test_packed_weight_copies_are_refreshed_in_place_by_the_step():
     conv_w = torch.nn.Parameter(torch.randn(40, 24, 3, 3, device="cuda"))
     lin_w = torch.nn.Parameter(torch.randn(25, 64, device="cuda"))
     frozen = torch.nn.Parameter(torch.randn(16, 16, 1, 1, device="cuda"), requires_grad=False)
+    conv5_w = torch.nn.Parameter(torch.randn(33, 72, 5, 5, device="cuda"))      # 25 taps: three staging passes per (cout, cin) tile, 3 cin tiles
+    copies5 = {"f": ops.WEIGHTS.get(conv5_w), "d": ops.WEIGHTS.get(conv5_w, None, 1)}
     copies = {"conv_f": ops.WEIGHTS.get(conv_w), "conv_d": ops.WEIGHTS.get(conv_w, None, 1), "lin_f": ops.LINEAR_WEIGHTS.get(lin_w),
               "lin_d": ops.LINEAR_WEIGHTS.get(lin_w, mode=1), "frozen": ops.WEIGHTS.get(frozen)}
     before = {k: v.clone() for k, v in copies.items()}
-    opt = FusedSGD([conv_w, lin_w], lr=0.5, momentum=0.9, nesterov=True)
-    conv_w.grad, lin_w.grad = torch.randn_like(conv_w), torch.randn_like(lin_w)
+    opt = FusedSGD([conv_w, lin_w, conv5_w], lr=0.5, momentum=0.9, nesterov=True)
+    conv_w.grad, lin_w.grad, conv5_w.grad = torch.randn_like(conv_w), torch.randn_like(lin_w), torch.randn_like(conv5_w)
     opt.step()
     torch.cuda.synchronize()
+    assert ops.WEIGHTS.get(conv5_w) is copies5["f"] and torch.equal(copies5["f"], ops.pack_conv_weight(conv5_w))
+    assert ops.WEIGHTS.get(conv5_w, None, 1) is copies5["d"] and torch.equal(copies5["d"], ops.pack_conv_weight(conv5_w, None, 1))
     fresh = {"conv_f": ops.pack_conv_weight(conv_w), "conv_d": ops.pack_conv_weight(conv_w, None, 1), "lin_f": ops.pack_linear_weight(lin_w),
              "lin_d": ops.pack_conv_weight(lin_w.detach().reshape(25, 64, 1, 1), mode=1)}
     again = {"conv_f": ops.WEIGHTS.get(conv_w), "conv_d": ops.WEIGHTS.get(conv_w, None, 1), "lin_f": ops.LINEAR_WEIGHTS.get(lin_w),
@@ -144,7 +148,7 @@ def test_packed_weight_copies_are_refreshed_in_place_by_the_step():
         assert not torch.equal(again[k], before[k]), k
     assert again["frozen"] is copies["frozen"] and torch.equal(again["frozen"], before["frozen"])
     # second step: table reused
-    conv_w.grad, lin_w.grad = torch.randn_like(conv_w), torch.randn_like(lin_w)
+    conv_w.grad, lin_w.grad, conv5_w.grad = torch.randn_like(conv_w), torch.randn_like(lin_w), torch.randn_like(conv5_w)
     opt.step()
     torch.cuda.synchronize()
     assert torch.equal(ops.WEIGHTS.get(conv_w), ops.pack_conv_weight(conv_w)) and ops.WEIGHTS.get(conv_w) is copies["conv_f"]

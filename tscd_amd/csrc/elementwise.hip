@@ -69,29 +69,55 @@ extern "C" int tscd_pack_conv_weight(const void* w, int src_is_f32, void* out, i
 
 // All trainable weights re-packed in ONE launch after the optimizer step (the per-weight launches above cost ~90 launches and
 // 0.4 ms per TSCD-L step: forward and data-gradient packing of ~45 convs / linears).  jobs: device array of PackJob; blockmap:
-// one {job, block-in-job} pair per workgroup, PACK_BLOCK_ELEMS outputs each.
-#define PACK_BLOCK_ELEMS 2048
+// one {job, tile} pair per workgroup.  A workgroup moves the PACK_TILE x PACK_TILE (cout, cin) sub-block of its weight through LDS:
+// the source rows w[cout][ci0 .. ci0+32)[KH][KW] are contiguous runs (coalesced fp32 reads), the packed rows leave as 64-byte
+// segments of consecutive cin (forward order) or consecutive cout (data-gradient order, taps flipped).  Element-wise gathering with
+// run-time divisions took 200 us for the 79 MB of TSCD-L's trainable weights (9216-byte stride between the lanes of the
+// data-gradient order).  Padding rows / columns of the packed copies are zero from the first (full) pack and are not rewritten.
+#define PACK_TILE 32
+#define PACK_TAPS 9          // taps staged per pass (3x3); larger filters take several passes
 struct PackJob { const void* w; f16* out; int Cout, Cin, CinPad, KH, KW, rows_pad, Kpad, mode, src_f32, pad_; };
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, const int2* __restrict__ blockmap) {
+  __shared__ f16 tile[PACK_TILE][PACK_TILE * PACK_TAPS + 2];            // [cout][cin * taps + tap], pitch 145 dwords (odd)
   const int2 bm = blockmap[blockIdx.x];
   const PackJob j = jobs[bm.x];
-  const long total = (long)j.rows_pad * j.Kpad;
-  const long lo = (long)bm.y * PACK_BLOCK_ELEMS, hi = lo + PACK_BLOCK_ELEMS < total ? lo + PACK_BLOCK_ELEMS : total;
-  for (long idx = lo + threadIdx.x; idx < hi; idx += 256) {
-    const int row = idx / j.Kpad, k = idx % j.Kpad;
-    const int tap = k / j.CinPad, c = k % j.CinPad;
-    long src = -1;
-    if (j.mode == 0) {
-      if (row < j.Cout && tap < j.KH * j.KW && c < j.Cin) src = (((long)row * j.Cin + c) * j.KH + tap / j.KW) * j.KW + tap % j.KW;
-    } else if (row < j.Cin && tap < j.KH * j.KW && c < j.Cout) {
-      src = (((long)c * j.Cin + row) * j.KH + (j.KH - 1 - tap / j.KW)) * j.KW + (j.KW - 1 - tap % j.KW);
+  const int tiles_i = (j.Cin + PACK_TILE - 1) / PACK_TILE;
+  const int co0 = (bm.y / tiles_i) * PACK_TILE, ci0 = (bm.y % tiles_i) * PACK_TILE;
+  const int nco = min(PACK_TILE, j.Cout - co0), nci = min(PACK_TILE, j.Cin - ci0);
+  const int KHW = j.KH * j.KW;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                // 8 rows of 32 lanes
+  for (int t0 = 0; t0 < KHW; t0 += PACK_TAPS) {
+    const int nt = min(PACK_TAPS, KHW - t0);
+    if (t0) __syncthreads();
+    // load: row r = source run w[co0 + r][ci0 .. ci0 + nci)[t0 .. t0 + nt): contiguous when the pass covers all taps
+    for (int r = ty; r < nco; r += 8) {
+      const long base = ((long)(co0 + r) * j.Cin + ci0) * KHW;
+      if (nt == KHW) {
+        for (int q = tx; q < nci * KHW; q += 32)
+          tile[r][q] = j.src_f32 ? (f16)((const float*)j.w)[base + q] : ((const f16*)j.w)[base + q];
+      } else {
+        for (int q = tx; q < nci * nt; q += 32) {
+          const int c = q / nt, t = q - c * nt;
+          const long src = base + (long)c * KHW + t0 + t;
+          tile[r][c * nt + t] = j.src_f32 ? (f16)((const float*)j.w)[src] : ((const f16*)j.w)[src];
+        }
+      }
     }
-    float v = 0.f;
-    if (src >= 0) v = j.src_f32 ? ((const float*)j.w)[src] : (float)((const f16*)j.w)[src];
-    j.out[idx] = (f16)v;
+    __syncthreads();
+    if (j.mode == 0) {
+      // out[cout][tap * CinPad + cin]: lanes along cin
+      for (int r = ty; r < nco; r += 8)
+        for (int t = 0; t < nt; ++t)
+          if (tx < nci) j.out[(long)(co0 + r) * j.Kpad + (t0 + t) * j.CinPad + ci0 + tx] = tile[r][tx * nt + t];
+    } else {
+      // out[cin][(KHW - 1 - tap) * CoutPad + cout]  (CinPad carries the padded cout count): lanes along cout
+      for (int c = ty; c < nci; c += 8)
+        for (int t = 0; t < nt; ++t)
+          if (tx < nco) j.out[(long)(ci0 + c) * j.Kpad + (KHW - 1 - (t0 + t)) * j.CinPad + co0 + tx] = tile[tx][c * nt + t];
+    }
   }
 }
-extern "C" int tscd_pack_block_elems(void) { return PACK_BLOCK_ELEMS; }
+extern "C" int tscd_pack_block_elems(void) { return PACK_TILE; }
 extern "C" int tscd_pack_conv_weights_batched(const void* jobs, const void* blockmap, long nblocks, void* stream) {
   TSCD_CHECK_ARG((jobs && blockmap) || nblocks == 0, "pack_conv_weights_batched: null table");
   if (nblocks == 0) return TSCD_OK;

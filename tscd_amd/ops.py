@@ -131,7 +131,7 @@ def refresh_packed_weights(params):
             assert tuple(packed.shape) == (rows_pad, kpad)
             jobs.append((w.data_ptr(), packed.data_ptr(), Cout | (Cin << 32), inner | (KH << 32), KW | (rows_pad << 32), kpad | (mode << 32),
                          int(w.dtype == torch.float32)))
-            nb = (rows_pad * kpad + be - 1) // be
+            nb = ((Cout + be - 1) // be) * ((Cin + be - 1) // be)      # (cout, cin) tiles of edge `be`
             bmap.extend((ji, b) for b in range(nb))
             sig.append((w.data_ptr(), packed.data_ptr()))
         dev = params[0].device
