@@ -113,6 +113,6 @@ rep("static int g_halo_auto = 1;", "static int g_abl = 0;\nextern \"C\" void tsc
 src = src.replace("  ConvParams p;", "  ConvParams p; p.abl = g_abl;")
 open(os.path.join(out, "conv_abl.hip"), "w").write(head + src)
 import subprocess
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-I",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wl,-Bsymbolic", "-Wno-unused-result", "-I",
                        os.path.join(root, "tscd_amd", "csrc"), "-shared", os.path.join(out, "conv_abl.hip"), "-o", os.path.join(out, "libabl.so")])
 print(os.path.join(out, "libabl.so"))

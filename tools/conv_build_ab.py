@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Same-process A/B of two builds of conv_igemm.hip (shared libraries under tools/_ablate/, e.g. one built from `git show
-HEAD:tscd_amd/csrc/conv_igemm.hip` and one from the working tree) on the bench clip's conv shapes, interleaved rounds."""
+HEAD:tscd_amd/csrc/conv_igemm.hip` and one from the working tree) on the bench clip's conv shapes, interleaved rounds.  Build them with -Wl,-Bsymbolic: the kernels' host
+stubs carry the same names in every build and in the product library (loaded RTLD_GLOBAL here), and an interposed stub launches the
+OTHER build's kernel.  The last column is the largest output difference between the first and each other build."""
 import ctypes as C, os, sys
 here = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(here))
@@ -39,4 +41,13 @@ for (B, H, W, Cin, Cout, k) in SHAPES:
             for _ in range(20): launch()
             e1.record(); torch.cuda.synchronize()
             res[li].append(e0.elapsed_time(e1) / 20 * 1e3)
-    print((B, H, W, Cin, Cout, k), "  ".join(f"{n}: {min(r):6.1f} us ({fl / min(r) / 1e6:5.0f} TF/s)" for n, r in zip(names, res)), flush=True)
+    outs = []
+    for l in libs:
+        mt = l.tscd_conv_stat_tiles(B * H * W, W, Cin, Cout, k, 1)
+        part = torch.empty((2, wpk.shape[0], mt), dtype=torch.float32, device=dev)
+        y.zero_()
+        assert l.tscd_conv2d_nhwc_f16(x.data_ptr(), wpk.data_ptr(), y.data_ptr(), None, None, None, part.data_ptr(), B, H, W, Cin, Cout, k, 1, Cin, Cout, 0, st) == 0
+        torch.cuda.synchronize()
+        outs.append(y.float().clone())
+    diffs = " ".join(f"{(o - outs[0]).abs().max().item():.2e}/{float((o != outs[0]).float().mean()):.3f}" for o in outs[1:])
+    print((B, H, W, Cin, Cout, k), "  ".join(f"{n}: {min(r):6.1f} us ({fl / min(r) / 1e6:5.0f} TF/s)" for n, r in zip(names, res)), " | max diff / fraction differing:", diffs, flush=True)

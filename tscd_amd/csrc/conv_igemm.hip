@@ -41,10 +41,14 @@ enum { EPI_RAW = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BN_SILU = 3, EPI_BN = 4
 // The finished fp16 tile is staged in LDS (row pitch BN+8 halves: the two half-waves of a ds_write land on disjoint bank
 // quarters, the 16-B read-back of a row is conflict-free) and leaves as 16-byte stores, 16 lanes per 256-B row segment,
 // instead of 64 two-byte stores per lane; the per-channel BatchNorm sums stay in the MFMA layout (in-lane over 16 rows).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SPLIT_STATS = false>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], f16* smem, int m0, int n0, int mt, int tid,
+// MF = 32: f32x16 accumulators of v_mfma_f32_32x32x16_f16 (layout above); MF = 16: f32x4 accumulators of v_mfma_f32_16x16x32_f16
+// (col = lane&15, row = 4*(lane>>4) + reg) -- TM / TN count MF x MF tiles.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SPLIT_STATS = false, int MF = 32, typename ACC = f32x16>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, ACC (&acc)[TM][TN], f16* smem, int m0, int n0, int mt, int tid,
                                               int lane, int wm, int wn) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, CP = BN + 8, NT = 64 * WAVES_M * WAVES_N;
+  constexpr int NE = MF == 32 ? 16 : 4;            // accumulator registers per tile
+  static_assert(WM == TM * MF && WN == TN * MF, "wave tile");
   f16* ctile = smem;                               // [BM][CP]
   float* red = (float*)(smem + BM * CP);           // [WAVES_M][BN][2]
   __syncthreads();                                 // every wave is done with the staging buffers of the main loop
@@ -57,7 +61,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     constexpr int EPI = decltype(epic)::value;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int cl = wn * WN + j * 32 + (lane & 31);
+      const int cl = wn * WN + j * MF + (lane & (MF - 1));
       const int n = n0 + cl;
       const bool nok = n < p.Cout;
       float bias = 0.f, sc = 1.f, sh = 0.f;
@@ -68,8 +72,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        for (int e = 0; e < NE; ++e) {
+          const int row = MF == 32 ? wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : wm * WM + i * 16 + 4 * (lane >> 4) + e;
           float v = acc[i][j][e];
           f16 o;
           if constexpr (EPI == EPI_RAW) {
@@ -109,8 +113,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     for (int j = 0; j < TN; ++j) {
       float a = s1[j] + __shfl_xor(s1[j], 32, 64);
       float b = s2[j] + __shfl_xor(s2[j], 32, 64);
-      if (lane < 32) {
-        int col = wn * WN + j * 32 + lane;
+      if constexpr (MF == 16) {
+        a += __shfl_xor(a, 16, 64);
+        b += __shfl_xor(b, 16, 64);
+      }
+      if (lane < MF) {
+        int col = wn * WN + j * MF + lane;
         red[(wm * BN + col) * 2 + 0] = a;
         red[(wm * BN + col) * 2 + 1] = b;
       }
@@ -858,7 +866,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_v5() {
 template <int TM>
 __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, int HRP) {
   constexpr int MAXP = 4;                                // A pieces per wave: halo of <= 512 rows
-  constexpr int BM = 64 * TM, BN = 256, NS = 6, WAVES_M = 2, WAVES_N = 4, TN = 2, WM = 32 * TM, WN = 64;
+  constexpr int BM = 64 * TM, BN = 256, NS = 6, WAVES_M = 2, WAVES_N = 4, WM = 32 * TM, WN = 64;
+  constexpr int TM16 = 2 * TM, TN16 = 4;                 // 16 x 16 tiles per wave: v_mfma_f32_16x16x32_f16, one MFMA per (tile, 32-channel step)
   constexpr int B_BYTES = BN * 64;                       // 16 KB per k-step
   constexpr int SMEM_BYTES = 2 * (1024 + 480 * 64) + NS * B_BYTES;         // HRP <= 480; also >= the epilogue's staging tile
   __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
@@ -924,24 +933,29 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
     }
   };
 
-  f32x16 acc[TM][TN];
+  f32x4 acc[TM16][TN16];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM16; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < TN16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- fragment addressing.  row-tile i of this wave: output pixel mloc = wm*WM + 32 i + (lane & 31); tap (kh, kw) reads halo
+  // ---- fragment addressing (16 x 16 x 32 MFMA: lane l holds row / column l & 15 and k = 8 (l >> 4) .. + 7, i.e. 16-byte chunk l >> 4:
+  // a 16-row piece of the LDS image IS one fragment).  Same-box A/B against v_mfma_f32_32x32x16_f16 with the same tile, reads and
+  // DMA: 110.9 -> 107.0 us on the dominant shape (tools/conv_build_ab.py); outputs bit-identical (the matrix core sums k in the same
+  // order either way), so the equality with the register-staged loop still holds bit for bit.
+  // row-tile i of this wave: output pixel mloc = wm*WM + 16 i + (lane & 15); tap (kh, kw) reads halo
   // row mloc + kh W + kw; byte offset of (halo row hr, chunk c) = (hr >> 4) * 1024 + c * 256 + (hr & 15) * 16
   //                                                            = 16 hr + 3 * ((16 hr) & ~255) + c * 256
-  const int frow = lane & 31, fk = lane >> 5;
+  const int frow = lane & 15, fk = lane >> 4;
   // a_pre[tap][i]: byte offset inside an A buffer of this lane's fragment for row-tile i at tap `tap` -- the halo row, or the
   // zero block when the tap falls outside the image for this lane's output pixel (9 x TM registers, computed once)
-  int a_pre[9][TM];
+  // (TM = 4, 256-pixel tiles: two 16-bit offsets per register -- 72 offsets next to 128 accumulator registers would spill)
+  constexpr bool PACKED = TM >= 4;
+  constexpr int NTAB = PACKED ? TM16 / 2 : TM16;
+  int a_pre[9][NTAB];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int mloc = wm * WM + i * 32 + frow;
+  for (int i = 0; i < TM16; ++i) {
+    const int mloc = wm * WM + i * 16 + frow;
     const int m = m0 + mloc;
     const bool live = m < p.M;
     const int rem = live ? m % HW : 0;
@@ -952,15 +966,24 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
       for (int kw = 0; kw < 3; ++kw) {
         const bool ok = live && (unsigned)(h + kh - 1) < (unsigned)p.H && (unsigned)(w + kw - 1) < (unsigned)W;
         const int t16 = (mloc + kh * W + kw) * 16;
-        a_pre[kh * 3 + kw][i] = ok ? 1024 + t16 + 3 * (t16 & ~255) + fk * 256 : (lane & 15) * 16;
+        const int off = ok ? 1024 + t16 + 3 * (t16 & ~255) + fk * 256 : (lane & 15) * 16;      // < 32 KB
+        if constexpr (!PACKED) a_pre[kh * 3 + kw][i] = off;
+        else if (i & 1) a_pre[kh * 3 + kw][i >> 1] |= off << 16;
+        else a_pre[kh * 3 + kw][i >> 1] = off;
       }
   }
-  int b_off[TN];
+  auto a_offset = [&](auto tapc, int i) __attribute__((always_inline)) {
+    constexpr int TAP = decltype(tapc)::value;
+    if constexpr (!PACKED) return a_pre[TAP][i];
+    else {
+      int v = a_pre[TAP][i >> 1];
+      asm volatile("" : "+v"(v));                      // unpack at the read (hoisted out of the loop, the halves are 72 registers again)
+      return (i & 1) ? (int)((unsigned)v >> 16) : (v & 0xffff);
+    }
+  };
+  int b_off[TN16];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int row = wn * WN + j * 32 + frow;
-    b_off[j] = (row >> 4) * 1024 + fk * 256 + (row & 15) * 16;
-  }
+  for (int j = 0; j < TN16; ++j) b_off[j] = (wn * (WN / 16) + j) * 1024 + lane * 16;
 
   // ---- prologue ----
   issue_a(0);
@@ -981,7 +1004,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();                        // stagger
 
-  f16x8 fa[2][TM], fb[2][TN];
+  f16x8 fa[TM16], fb[TN16];
   int rd_soff = 0;
   // one k-step = one (chunk, tap).  STEADY: not in the last chunk -- the DMA distance is full and a next chunk exists.
   auto step = [&](auto tapc, auto steadyc, int chunk_idx, int u) __attribute__((always_inline)) {
@@ -993,16 +1016,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
       const char* sa = smem + (chunk_idx & 1) * A_BYTES;
       const char* sb = b_ring + rd_soff;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const char* ptr = sa + a_pre[TAP][i];
-        fa[0][i] = *(const f16x8*)(ptr);
-        fa[1][i] = *(const f16x8*)(ptr + 512);
-      }
+      for (int i = 0; i < TM16; ++i) fa[i] = *(const f16x8*)(sa + a_offset(tapc, i));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        fb[0][j] = *(const f16x8*)(sb + b_off[j]);
-        fb[1][j] = *(const f16x8*)(sb + b_off[j] + 512);
-      }
+      for (int j = 0; j < TN16; ++j) fb[j] = *(const f16x8*)(sb + b_off[j]);
       rd_soff += B_BYTES;
       if (rd_soff == NS * B_BYTES) rd_soff = 0;
     }
@@ -1018,11 +1034,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int i = 0; i < TM16; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN16; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (STEADY) {
@@ -1051,7 +1065,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
   { HALO_CHUNK(std::false_type, ci) }
 #undef HALO_CHUNK
   if (grp == 0) __builtin_amdgcn_s_barrier();
-  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
+  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM16, TN16, false, 16, f32x4>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
 }
 
 // Tile choice: BN follows Cout (128 / 64 / 32); BM = 128.  Packed weights and BatchNorm partials are padded to a multiple of
