@@ -384,6 +384,13 @@ def attention_mca_g2l(sd, p, x_cls, x_reg, cls_score, n1, cfg, reconf=True, aux=
     raw_r = v_rn[:, :n1] @ v_rn.transpose(-2, -1)
     attn_c = (q_c @ k_c.transpose(-2, -1)) * cfg.mca_scale * cls_score.view(1, 1, -1)
     attn_r = (q_r @ k_r.transpose(-2, -1)) * cfg.mca_scale
+    if getattr(cfg, "mca_fp16_logits", False):
+        # the evaluator's model.half() / the trainer's autocast round q k^T, * scale and * cls_score to fp16 one after the other
+        # (post_trans.py:640-650) before the softmax; the HIP kernels keep the logits in fp32 -- this switch
+        # restates the reference's rounding so that tests/test_deviation_bounds.py can put a number on the difference
+        r16 = lambda t: t.half().float()
+        attn_c = r16(r16(r16(q_c @ k_c.transpose(-2, -1)) * cfg.mca_scale) * r16(cls_score).view(1, 1, -1))
+        attn_r = r16(r16(q_r @ k_r.transpose(-2, -1)) * cfg.mca_scale)
     attn = (attn_r.softmax(dim=-1) + attn_c.softmax(dim=-1)) / 2
     flat = lambda t: t.permute(1, 0, 2).reshape(t.shape[1], C)
     x_c = torch.cat([flat(attn @ v_c), flat(v_c[:, :n1])], dim=-1)
