@@ -31,6 +31,11 @@ struct McaParams {
   const f16 *kn_c, *kn_r;   // [Npad][WP]
   const f16 *vn_c, *vn_r;   // [Npad][WP]
   const f16 *vt_c, *vt_r;   // [WP][Npad]
+  // fragment-major copies for this file's kernels: the 64 x 16 bytes one wave loads for one MFMA B-operand are 1 KB contiguous
+  // (a row-major operand costs 32 cache lines per wave load: 16 bytes of 32 rows).  kF / vF: fragment (key block jb, head h, ks) at
+  // (((jb HEADS + h) KS + ks) 64 + lane) x 16 B, lane = (key & 31) | ((dim >> 3 & 1) << 5); vtF: fragment (jb, h, 32-dim tile nt, 16-key
+  // half ks) at ((((jb HEADS + h) NT + nt) 2 + ks) 64 + lane) x 16 B, lane = (dim & 31) | ((key >> 3 & 1) << 5).
+  const f16 *kF_c, *kF_r, *vF_c, *vF_r, *vtF_c, *vtF_r;
   const f16* score;         // [N]
   const McaTile* tiles;
   float* lsum;              // [S][HEADS][2][N_L]
@@ -45,7 +50,7 @@ struct McaParams {
 __global__ void mca_prep_kernel(const f16* __restrict__ q_c, const f16* __restrict__ kv_c, const f16* __restrict__ q_r,
                                 const f16* __restrict__ kv_r, int N, int N_L, int Npad, int W, int d, int DP, f16* qn_c,
                                 f16* kn_c, f16* vn_c, f16* vt_c, f16* qn_r, f16* kn_r, f16* vn_r, f16* vt_r, f16* xcat_c,
-                                f16* xcat_r) {
+                                f16* xcat_r, f16* kF_c, f16* kF_r, f16* vF_c, f16* vF_r, f16* vtF_c, f16* vtF_r) {
   int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   int n = wave >> 1, br = wave & 1;
   if (n >= Npad) return;
@@ -57,6 +62,10 @@ __global__ void mca_prep_kernel(const f16* __restrict__ q_c, const f16* __restri
   f16* vn = br ? vn_r : vn_c;
   f16* vt = br ? vt_r : vt_c;
   f16* xcat = br ? xcat_r : xcat_c;
+  f16* kF = br ? kF_r : kF_c;          // fragment-major copies (nullptr: the caller, the backward, does not use them)
+  f16* vF = br ? vF_r : vF_c;
+  f16* vtF = br ? vtF_r : vtF_c;
+  const int KSn = DP >> 4, NTn = DP >> 5, jb = n >> 5;
   for (int h = 0; h < MCA_HEADS; ++h) {
     float qv[2] = {0.f, 0.f}, kvv[2] = {0.f, 0.f}, vv[2] = {0.f, 0.f};
     float sq = 0.f, sk = 0.f, sv = 0.f;
@@ -84,6 +93,13 @@ __global__ void mca_prep_kernel(const f16* __restrict__ q_c, const f16* __restri
         kn[o] = real ? (f16)(kvv[rnd] * ik) : (f16)0.f;
         vn[o] = real ? (f16)(vv[rnd] * iv) : (f16)0.f;
         vt[(long)(h * DP + j) * Npad + n] = real ? (f16)vv[rnd] : (f16)0.f;
+        if (kF) {
+          const long of = ((((long)jb * MCA_HEADS + h) * KSn + (j >> 4)) * 64 + ((n & 31) | (((j >> 3) & 1) << 5))) * 8 + (j & 7);
+          kF[of] = real ? (f16)(kvv[rnd] * ik) : (f16)0.f;
+          vF[of] = real ? (f16)(vv[rnd] * iv) : (f16)0.f;
+          const long ot = (((((long)jb * MCA_HEADS + h) * NTn + (j >> 5)) * 2 + ((n >> 4) & 1)) * 64 + ((j & 31) | (((n >> 3) & 1) << 5))) * 8 + (n & 7);
+          vtF[ot] = real ? (f16)vv[rnd] : (f16)0.f;
+        }
         if (n < N_L) {
           qn[o] = real ? (f16)(qv[rnd] * iq) : (f16)0.f;
           if (j < d && xcat) xcat[(long)n * 2 * W + W + h * d + j] = (f16)vv[rnd];   // x_ori = own value rows
@@ -126,9 +142,9 @@ __global__ __launch_bounds__(256) void mca_stats_kernel(McaParams p) {
     for (int e = 0; e < 16; ++e) sc[e] = sr[e] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      long o = (long)key * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
-      f16x8 kc = *(const f16x8*)(p.kn_c + o);
-      f16x8 kr = *(const f16x8*)(p.kn_r + o);
+      const long of = ((((long)(key0 >> 5) * MCA_HEADS + h) * KS + ks) * 64 + lane) * 8;
+      f16x8 kc = *(const f16x8*)(p.kF_c + of);
+      f16x8 kr = *(const f16x8*)(p.kF_r + of);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qc[ks], kc, sc, 0, 0, 0);
       sr = __builtin_amdgcn_mfma_f32_32x32x16_f16(qr[ks], kr, sr, 0, 0, 0);
     }
@@ -234,9 +250,9 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p) {
       for (int e = 0; e < 16; ++e) sc[e] = sr[e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        long o = (long)key * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
-        f16x8 kc = *(const f16x8*)(p.kn_c + o);
-        f16x8 kr = *(const f16x8*)(p.kn_r + o);
+        const long of = ((((long)(key0 >> 5) * MCA_HEADS + h) * KS + ks) * 64 + lane) * 8;
+        f16x8 kc = *(const f16x8*)(p.kF_c + of);
+        f16x8 kr = *(const f16x8*)(p.kF_r + of);
         if constexpr (Q_RELOAD) {
           const long oq = (long)qrow * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
           sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.qn_c + oq), kc, sc, 0, 0, 0);
@@ -262,9 +278,9 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p) {
       for (int e = 0; e < 16; ++e) rc[e] = rr[e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        long o = (long)key * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
-        f16x8 vc = *(const f16x8*)(p.vn_c + o);
-        f16x8 vr = *(const f16x8*)(p.vn_r + o);
+        const long of = ((((long)(key0 >> 5) * MCA_HEADS + h) * KS + ks) * 64 + lane) * 8;
+        f16x8 vc = *(const f16x8*)(p.vF_c + of);
+        f16x8 vr = *(const f16x8*)(p.vF_r + of);
         if constexpr (VL_RELOAD) {
           const long ol = (long)qrow * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
           rc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.vn_c + ol), vc, rc, 0, 0, 0);
@@ -320,12 +336,12 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p) {
       f16x8 awr = *(const f16x8*)(&Wr[lane & 31][ko]);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        long o = (long)(h * DP + n * 32 + (lane & 31)) * p.Npad + key0 + ko;
-        f16x8 bvc = *(const f16x8*)(p.vt_c + o);
+        const long o = (((((long)(key0 >> 5) * MCA_HEADS + h) * NT + n) * 2 + ks) * 64 + lane) * 8;
+        f16x8 bvc = *(const f16x8*)(p.vtF_c + o);
         oc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap, bvc, oc[n], 0, 0, 0);
         sfc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(awc, bvc, sfc[n], 0, 0, 0);
         if (NEED_REG) {
-          f16x8 bvr = *(const f16x8*)(p.vt_r + o);
+          f16x8 bvr = *(const f16x8*)(p.vtF_r + o);
           orr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap, bvr, orr[n], 0, 0, 0);
           sfr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(awr, bvr, sfr[n], 0, 0, 0);
         }
@@ -407,9 +423,10 @@ __global__ void mca_finalize_kernel(const float* __restrict__ part_oc, const flo
 void mca_launch_prep(hipStream_t st, const f16* q_c, const f16* kv_c, const f16* q_r, const f16* kv_r, int N, int N_L, int Npad, int W,
                      int d, int DP, f16* qn_c, f16* kn_c, f16* vn_c, f16* vt_c, f16* qn_r, f16* kn_r, f16* vn_r, f16* vt_r, f16* xcat_c,
                      f16* xcat_r) {
+  // the backward keeps the row-major layouts only (its own layout kernel re-lays them)
   long waves = 2L * Npad;
   hipLaunchKernelGGL(mca_prep_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st, q_c, kv_c, q_r, kv_r, N, N_L, Npad,
-                     W, d, DP, qn_c, kn_c, vn_c, vt_c, qn_r, kn_r, vn_r, vt_r, xcat_c, xcat_r);
+                     W, d, DP, qn_c, kn_c, vn_c, vt_c, qn_r, kn_r, vn_r, vt_r, xcat_c, xcat_r, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------- C-ABI
@@ -419,9 +436,9 @@ extern "C" int tscd_mca_dp(int d) { return (d + 31) / 32 * 32; }
 extern "C" long tscd_mca_workspace_bytes(int N, int N_L, int W, int S) {
   int d = W / MCA_HEADS, DP = tscd_mca_dp(d), WP = MCA_HEADS * DP;
   long Npad = (N + 31) / 32 * 32 + 32;
-  long halves = 2L * N_L * WP + 4L * Npad * WP + 2L * WP * Npad;
+  long halves = 2L * N_L * WP + 4L * Npad * WP + 2L * WP * Npad + 6L * Npad * WP;      // + the fragment-major copies
   long floats = (long)S * MCA_HEADS * 2 * N_L + 4L * S * N_L * WP + 2L * S * N_L;
-  return halves * 2 + floats * 4 + 4096;
+  return halves * 2 + floats * 4 + 8192;
 }
 
 extern "C" int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
@@ -440,7 +457,7 @@ extern "C" int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q
 
   char* ws = (char*)workspace;
   auto take = [&](long bytes) { char* r = ws; ws += (bytes + 255) / 256 * 256; return r; };
-  // (the 256-B rounding is covered by the +4096 slack for <= 13 carve-outs)
+  // (the 256-B rounding is covered by the +8192 slack for <= 20 carve-outs)
   f16* qn_c = (f16*)take(2L * N_L * WP);
   f16* qn_r = (f16*)take(2L * N_L * WP);
   f16* kn_c = (f16*)take(2L * Npad * WP);
@@ -449,6 +466,12 @@ extern "C" int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q
   f16* vn_r = (f16*)take(2L * Npad * WP);
   f16* vt_c = (f16*)take(2L * WP * Npad);
   f16* vt_r = (f16*)take(2L * WP * Npad);
+  f16* kF_c = (f16*)take(2L * Npad * WP);
+  f16* kF_r = (f16*)take(2L * Npad * WP);
+  f16* vF_c = (f16*)take(2L * Npad * WP);
+  f16* vF_r = (f16*)take(2L * Npad * WP);
+  f16* vtF_c = (f16*)take(2L * Npad * WP);
+  f16* vtF_r = (f16*)take(2L * Npad * WP);
   float* lsum = (float*)take(4L * S * MCA_HEADS * 2 * N_L);
   float* part_oc = (float*)take(4L * S * N_L * WP);
   float* part_or = (float*)take(4L * S * N_L * WP);
@@ -461,11 +484,12 @@ extern "C" int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q
     long waves = 2L * Npad;
     hipLaunchKernelGGL(mca_prep_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st, (const f16*)q_c,
                        (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, N, N_L, Npad, W, d, DP, qn_c, kn_c, vn_c, vt_c,
-                       qn_r, kn_r, vn_r, vt_r, (f16*)xcat_c, (f16*)(need_reg ? xcat_r : nullptr));
+                       qn_r, kn_r, vn_r, vt_r, (f16*)xcat_c, (f16*)(need_reg ? xcat_r : nullptr), kF_c, kF_r, vF_c, vF_r, vtF_c, vtF_r);
     TSCD_CHECK_LAUNCH("mca_prep");
   }
   McaParams p;
   p.qn_c = qn_c; p.qn_r = qn_r; p.kn_c = kn_c; p.kn_r = kn_r; p.vn_c = vn_c; p.vn_r = vn_r; p.vt_c = vt_c; p.vt_r = vt_r;
+  p.kF_c = kF_c; p.kF_r = kF_r; p.vF_c = vF_c; p.vF_r = vF_r; p.vtF_c = vtF_c; p.vtF_r = vtF_r;
   p.score = (const f16*)score; p.tiles = (const McaTile*)tiles; p.lsum = lsum;
   p.part_oc = part_oc; p.part_or = part_or; p.part_sc = part_sc; p.part_sr = part_sr; p.part_den = part_den;
   p.N = N; p.N_L = N_L; p.Npad = Npad; p.WP = WP; p.S = S;
