@@ -146,6 +146,12 @@ int tscd_ema_update_f32(const void* table, long nchunks, float d, float one_minu
  * NULL; d, one_minus_d: EMA decay of this step. */
 int tscd_sgd_ema_step_f32(const void* table, long nchunks, const float* lr, const float* wd, int ngroups, float momentum, int nesterov,
                           const float* grad_scale, const float* found_inf, float d, float one_minus_d, void* stream);
+/* The same with the gradients addressed through a device array of per-parameter pointers (grad_base[i] = gradient of parameter i):
+ * chunk records then hold the byte offset of their slice in the `grad` field and `group | i << 8` in the group field.  The chunk
+ * table no longer depends on where this step's gradients were allocated. */
+int tscd_sgd_ema_step_indirect_f32(const void* table, long nchunks, const void* grad_base, const float* lr, const float* wd, int ngroups,
+                                   float momentum, int nesterov, const float* grad_scale, const float* found_inf, float d,
+                                   float one_minus_d, void* stream);
 int tscd_haar_idwt_mul_bwd_nhwc_f16(const void* d, const void* hf, const void* content, int ldc, void* dcontent, void* dhf,
                                     int B, int H, int W, int C, void* stream);
 

@@ -29,6 +29,7 @@ SIGNATURES = {
     "tscd_upsample2_bwd_nhwc_f16": [P, I, P, I, I, I, I, I, P],
     "tscd_clip_preproc_u8": [P, I, I, I, P, P, I, I, I, P],
     "tscd_sgd_ema_step_f32": [P, L, P, P, I, F, I, P, P, F, F, P],
+    "tscd_sgd_ema_step_indirect_f32": [P, L, P, P, P, I, F, I, P, P, F, F, P],
     "tscd_conv_bn_act_train_f16": [P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, P, F, F, P, P, P, P, I, P, I, I, P],
     "tscd_decode_score": [P, P, P, P, P, P, I, I, P, P, P, P],
     "tscd_select_proposals": [P, I, I, F, I, I, I, P, P, P],

@@ -28,10 +28,44 @@ def _state_versions(module, training):
     """What a recorded pass depends on besides its input.  Training-mode passes read-modify-write the BatchNorm buffers inside the
     graph (always current), so only parameter writes invalidate them; an evaluation pass bakes the folded BatchNorm scale / shift in,
     so buffer writes (training passes, EMA updates, load_state_dict) invalidate it too."""
-    v = sum(p._version for p in module.parameters())
+    ps, bs = _tensors_of(module)
+    v = sum(p._version for p in ps)
     if not training:
-        v += sum(b._version for b in module.buffers())
+        v += sum(b._version for b in bs)
     return v
+
+
+_TENSORS = {}     # id(module) -> (weakref, parameters, buffers, sentinel): module.parameters() walks the module tree (2 ms per call on CSPDarknet + PAFPN)
+
+
+def _sentinel(module):
+    """(owner, kind, name, tensor) of one floating-point buffer (or parameter): .half() / .to() / .cuda() REPLACE every such buffer
+    (Module._apply), so the cached lists are stale exactly when this one is no longer the tensor its owner holds."""
+    for owner in module.modules():
+        for name, b in owner._buffers.items():
+            if b is not None and b.is_floating_point():
+                return owner, "_buffers", name, b
+    for owner in module.modules():
+        for name, q in owner._parameters.items():
+            if q is not None:
+                return owner, "_parameters", name, q
+    return None
+
+
+def _tensors_of(module):
+    import weakref
+    hit = _TENSORS.get(id(module))
+    if hit is not None and hit[0]() is module:
+        sen = hit[3]
+        if sen is None or getattr(sen[0], sen[1]).get(sen[2]) is sen[3]:
+            return hit[1], hit[2]
+    hit = _TENSORS[id(module)] = (weakref.ref(module), tuple(module.parameters()), tuple(module.buffers()), _sentinel(module))
+    return hit[1], hit[2]
+
+
+def parameters_of(module):
+    """tuple(module.parameters()), cached (see _tensors_of)."""
+    return _tensors_of(module)[0]
 
 
 def _running_stats(module):
@@ -115,3 +149,4 @@ def _capture(module, x, key):
 
 def clear():
     _GRAPHS.clear()
+    _TENSORS.clear()

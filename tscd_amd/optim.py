@@ -48,10 +48,13 @@ class FusedSGD(torch.optim.SGD):
                 for t in (p, g, buf) + ((e,) if e is not None else ()):
                     if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()):
                         raise TypeError("FusedSGD: contiguous fp32 CUDA parameters, gradients and EMA copies only")
-                pp, pg, pb, pe, n = p.data_ptr(), g.data_ptr(), buf.data_ptr(), (e.data_ptr() if e is not None else 0), p.numel()
+                pp, pb, pe, n = p.data_ptr(), buf.data_ptr(), (e.data_ptr() if e is not None else 0), p.numel()
+                pi = len(params)
+                # gradient: byte offset + parameter index (tscd_sgd_ema_step_indirect_f32) -- the table does not depend on where
+                # this step's gradients were allocated
                 for o in range(0, n, ch):
-                    rec.append((pp + 4 * o, pg + 4 * o, pb + 4 * o, (pe + 4 * o) if pe else 0, min(ch, n - o), gi))
-                sig.append((pp, pg, pb, pe))
+                    rec.append((pp + 4 * o, 4 * o, pb + 4 * o, (pe + 4 * o) if pe else 0, min(ch, n - o), gi | (pi << 8)))
+                sig.append((pp, pb, pe))
                 params.append(p)
         dev = params[0].device if params else None
         table = torch.from_numpy(np.array(rec, dtype=np.int64).reshape(-1, 6)).to(dev) if rec else None
@@ -65,7 +68,7 @@ class FusedSGD(torch.optim.SGD):
                     continue
                 buf = self.state[p].get("momentum_buffer") if p in self.state else None
                 e = self._ema_of.get(id(p))
-                sig.append((p.data_ptr(), p.grad.data_ptr(), buf.data_ptr() if buf is not None else -1, e.data_ptr() if e is not None else 0))
+                sig.append((p.data_ptr(), buf.data_ptr() if buf is not None else -1, e.data_ptr() if e is not None else 0))
         return tuple(sig)
 
     @torch.no_grad()
@@ -76,8 +79,8 @@ class FusedSGD(torch.optim.SGD):
                 loss = closure()
         if len(self.param_groups) > 8:
             raise NotImplementedError("FusedSGD: at most 8 parameter groups")
-        # gradients are re-allocated by zero_grad(set_to_none=True) every step, usually at the same addresses (caching allocator):
-        # the table is rebuilt only when an address moved
+        # the chunk table names parameters, momentum buffers and EMA copies (stable addresses); gradients are re-allocated by
+        # zero_grad(set_to_none=True) every step and reach the kernel through a per-step array of ~150 pointers
         if self._table is None or self._table[0] != self._signature() or self._table[4] != len(self.param_groups):
             self._build()
         sig, table, n, params, _ = self._table
@@ -94,8 +97,13 @@ class FusedSGD(torch.optim.SGD):
         for t in (gs, fi):
             if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
                 raise TypeError("FusedSGD: grad_scale / found_inf must be fp32 device scalars")
-        call("tscd_sgd_ema_step_f32", table.data_ptr(), n, lr, wd, len(self.param_groups), float(g0["momentum"]), int(bool(g0["nesterov"])),
-             ops._ptr(gs), ops._ptr(fi), d, 1.0 - d, ops._stream())
+        for p in params:
+            g = p.grad
+            if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == p.numel()):
+                raise TypeError("FusedSGD: contiguous fp32 CUDA gradients only")
+        gbase = ops.h2d([p.grad.data_ptr() for p in params], torch.int64, params[0].device)
+        call("tscd_sgd_ema_step_indirect_f32", table.data_ptr(), n, gbase.data_ptr(), lr, wd, len(self.param_groups), float(g0["momentum"]),
+             int(bool(g0["nesterov"])), ops._ptr(gs), ops._ptr(fi), d, 1.0 - d, ops._stream())
         # raw-pointer writes: bump the version counters so caches keyed on them (packed weights, folded BN, graphs) notice
         torch.autograd.graph.increment_version(params)
         if self._ema_of:

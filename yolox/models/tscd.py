@@ -72,7 +72,7 @@ class TSCD(nn.Module):
         fpn_outs = self._pyramid(x)
         if self.training:
             assert targets is not None
-            frozen = not any(p.requires_grad for p in self.backbone.parameters())
+            frozen = not any(p.requires_grad for p in graphs.parameters_of(self.backbone))
             if PREFETCH_BACKBONE and next_x is not None and next_x.is_cuda and frozen:
                 self.head.window_hook = lambda: self._prefetch(next_x)
             try:
