@@ -254,6 +254,12 @@ int tscd_loss_rows_f16(const int* row_b, const int* row_a, int N, int A, int NC,
                        const void* obj_logit, const void* reg_delta, const void* base, int ndet, int part, void* workspace,
                        long workspace_bytes, float* sums, void* d_cls, void* d_obj, void* d_reg, void* stream);
 
+/* The scalar tail of get_matcher_refined_losses (tscd_head.py:1157-1203) in one launch: dense[3] / rows[3] loss sums, r_cls (device
+ * scalar), num_fg / ngt int[B] -> out[8] = {total, 3 iou, obj, cls, num_fg / max(num_gts, 1), r_cls, matched obj (clipped at 15),
+ * 6 matched iou} and weights[6] = d total / d {dense[0..2], rows[0..2]}. */
+int tscd_loss_combine_f32(const float* dense, const float* rows, const float* r_cls, const int* num_fg, const int* ngt, int B,
+                          int lframe, float* out, float* weights, void* stream);
+
 /* ---- SimOTA label assignment: get_fg_idx / get_assignments / get_in_boxes_info / dynamic_k_matching
  * (tscd_head.py:1712-1851,1330-1544), bboxes_iou (yolox/utils/boxes.py:131-154). */
 long tscd_simota_workspace_bytes(int B, int A, int G, int topk);

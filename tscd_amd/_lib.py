@@ -56,6 +56,7 @@ SIGNATURES = {
     "tscd_simota_assign": [P, P, I, I, I, I, I, P, P, P, I, I, P, L, P, P, P, P, P, P],
     "tscd_simota_assign_r": [P, P, I, I, I, I, I, P, P, P, I, I, F, P, L, P, P, P, P, P, P],
     "tscd_loss_dense_f16": [P, P, P, P, P, P, I, I, I, I, P, L, P, P, P],
+    "tscd_loss_combine_f32": [P, P, P, P, P, I, I, P, P, P],
     "tscd_loss_dense_reg_f16": [P, P, P, P, P, P, I, I, I, I, P, P, P, L, P, P, P, P],
     "tscd_loss_rows_f16": [P, P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, L, P, P, P, P, P],
 }

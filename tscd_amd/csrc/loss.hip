@@ -243,3 +243,48 @@ extern "C" int tscd_loss_rows_f16(const int* row_b, const int* row_a, int N, int
   TSCD_CHECK_LAUNCH("loss_rows");
   return TSCD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// The scalar tail of get_matcher_refined_losses (tscd_head.py:1157-1203) in one launch: normalisation of the loss sums by the
+// foreground counts, the clip of the matched-objectness loss at 15 (x / x.detach() * 15), the weighted total, the reported terms
+// and the factors the backward multiplies the incoming gradient with.  As ~25 zero-dimensional torch ops (and as many in backward)
+// this was 50 launches on the launch-bound stretch of the step.  Same fp32 operations in the same order (no contraction).
+//   dense[3] = IoU / objectness / class sums, rows[3] = refined class (unused here) / matched objectness / matched SmoothL1 sums,
+//   r_cls = the refined class loss (already normalised; produced by the eager class branch), num_fg / ngt int[B].
+//   out[8]  = total, 3 iou, obj, cls, num_fg / max(num_gts, 1), r_cls, m_obj, 6 m_iou
+//   w[6]    = d total / d dense[0..2], d total / d rows[0..2]
+// ------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ void loss_combine_kernel(const float* __restrict__ dense, const float* __restrict__ rows, const float* __restrict__ r_cls,
+                                    const int* __restrict__ num_fg_b, const int* __restrict__ ngt_b, int B, int lframe,
+                                    float* __restrict__ out, float* __restrict__ w) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long nfg = 0, nfl = 0, ngt = 0;
+  for (int b = 0; b < B; ++b) {
+    nfg += num_fg_b[b];
+    if (b < lframe) nfl += num_fg_b[b];
+    ngt += ngt_b[b];
+  }
+  const float num_fg = fmaxf((float)nfg, 1.f), num_fg_local = (float)nfl, num_gts = (float)ngt;
+  const float li = dense[0] / num_fg, lo = dense[1] / num_fg, lc = dense[2] / num_fg;
+  const float mo = rows[1] / num_fg_local, mi = rows[2] / num_fg_local;
+  const bool clip = mo > 15.f;
+  const float mo_c = clip ? mo / mo * 15.f : mo;
+  const float rc = *r_cls;
+  const float li3 = 3.0f * li, mi6 = 6.0f * mi;
+  float total = li3 + lo;
+  total = total + lc;
+  total = total + rc;
+  total = total + mo_c;
+  total = total + mi6;
+  out[0] = total; out[1] = li3; out[2] = lo; out[3] = lc; out[4] = num_fg / fmaxf(num_gts, 1.f); out[5] = rc; out[6] = mo_c; out[7] = mi6;
+  w[0] = 3.0f / num_fg; w[1] = 1.0f / num_fg; w[2] = 1.0f / num_fg;
+  w[3] = 0.f; w[4] = (clip ? 15.f / mo : 1.f) / num_fg_local; w[5] = 6.0f / num_fg_local;
+}
+extern "C" int tscd_loss_combine_f32(const float* dense, const float* rows, const float* r_cls, const int* num_fg, const int* ngt, int B,
+                                     int lframe, float* out, float* weights, void* stream) {
+  TSCD_CHECK_ARG(dense && rows && r_cls && num_fg && ngt && out && weights && B > 0 && lframe >= 0 && lframe <= B, "loss_combine: bad arguments");
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dense, rows, r_cls, num_fg, ngt, B, lframe, out, weights);
+  TSCD_CHECK_LAUNCH("loss_combine");
+  return TSCD_OK;
+}

@@ -280,3 +280,29 @@ def row_loss(row_b, row_a, A, num_classes, fg_mask, matched_gt, pred_iou, labels
     """-> fp32 [3]: refined class BCE sum (rows that are SimOTA foreground), matched-objectness BCE sum (all rows), SmoothL1 sum
     of the box deltas (foreground rows); a part whose logits are None is 0."""
     return _RowLoss.apply(cls_logit, obj_logit, reg_delta, base, row_b, row_a, A, num_classes, fg_mask, matched_gt, pred_iou, labels)
+
+
+class _CombineLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dense, rows, r_cls, num_fg_b, ngt_b, lframe):
+        dev = dense.device
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        w = torch.empty(6, dtype=torch.float32, device=dev)
+        rc = r_cls.detach().float().reshape(1)
+        ops.call("tscd_loss_combine_f32", dense.data_ptr(), rows.data_ptr(), rc.data_ptr(), num_fg_b.data_ptr(), ngt_b.data_ptr(),
+                 num_fg_b.numel(), int(lframe), out.data_ptr(), w.data_ptr(), ops._stream())
+        ctx.save_for_backward(w)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g, _g_stats):
+        (w,) = ctx.saved_tensors
+        d = g * w
+        return d[:3], d[3:], g, None, None, None
+
+
+def combine_losses(dense, rows, r_cls, num_fg_b, ngt_b, lframe):
+    """The scalar tail of get_matcher_refined_losses (tscd_head.py:1157-1203) -> (total loss (differentiable w.r.t. dense, rows, r_cls),
+    stats fp32 [8] = total, 3 iou, obj, cls, num_fg / num_gts, refined cls, matched obj (clipped), 6 matched iou)."""
+    return _CombineLosses.apply(dense.contiguous(), rows.contiguous(), r_cls, num_fg_b.contiguous(), ngt_b.contiguous(), lframe)

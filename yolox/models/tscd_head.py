@@ -288,10 +288,7 @@ class TSCDHead(nn.Module):
             # fused loss kernels (tscd_amd/csrc/loss.hip): sums + logit gradients in one pass each
             fg = fg_mask.bool()
             lab = labels.float().contiguous()
-            num_fg = num_fg_b.sum().float().clamp(min=1)
-            num_gts = ngt_b.sum().float()
             dense = TF.dense_loss(raw_all.contiguous(), outputs, fg_mask, matched_gt, pred_iou, lab, nc)   # IoU / obj / cls sums
-            loss_iou, loss_obj, loss_cls = dense[0] / num_fg, dense[1] / num_fg, dense[2] / num_fg
             # refined heads: local-frame proposals that SimOTA marked foreground
             row_b, row_a = b_idx32[:nl].contiguous(), a_idx32[:nl].contiguous()
             num_fg_local = num_fg_b[:lframe].sum().float()
@@ -340,9 +337,8 @@ class TSCDHead(nn.Module):
 
         # ---------------- refined-head losses (the rest was queued inside the assignment window) ----------------
         rows = TF.row_loss(*rowargs, obj_logit=m_obj.reshape(-1), reg_delta=m_reg, base=pred_rows[:nl])
-        loss_m_obj, loss_m_iou = rows[1] / num_fg_local, rows[2] / num_fg_local
-        loss_m_obj = torch.where(loss_m_obj > 15, loss_m_obj / loss_m_obj.detach() * 15, loss_m_obj)
-        loss = 3.0 * loss_iou + loss_obj + loss_cls + loss_r_cls + loss_m_obj + 6.0 * loss_m_iou
+        # normalisation by the foreground counts, the clip of the matched-objectness loss at 15 and the weighted total
+        # (tscd_head.py:1157-1203) in one launch: st = [total, 3 iou, obj, cls, num_fg / num_gts, refined cls, matched obj, 6 matched iou]
+        loss, st = TF.combine_losses(dense, rows, loss_r_cls, num_fg_b, ngt_b, lframe)
         self._dbg(fg_mask=fg_mask, matched_gt=matched_gt, pred_iou=pred_iou, num_fg=num_fg_b, refined_fg_rows=fg[b_idx[:nl], a_idx[:nl]].sum())
-        return (loss, 3.0 * loss_iou, loss_obj, loss_cls, 0.0, num_fg / num_gts.clamp(min=1), loss_r_cls, loss_m_obj,
-                6.0 * loss_m_iou)
+        return (loss, st[1], st[2], st[3], 0.0, st[4], loss_r_cls, st[6], st[7])
