@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Like tools/conv_ablate_gen.py, for conv_igemm_glds_kernel (the 128-channel-wide LDS-DMA variant): writes tools/_ablate/conv_abl_glds.hip
-with run-time switches (1 no LDS-DMA after the prologue, 4 no fragment reads, 8 no MFMAs, 64 no main loop, 128 no epilogue) and builds
+with run-time switches (1 no LDS-DMA after the prologue, 2 no weight (B) pieces after the prologue, 4 no fragment reads, 8 no MFMAs, 64 no main loop, 128 no epilogue) and builds
 tools/_ablate/libabl_glds.so.  Timing only -- the results are garbage.  The library is linked -Bsymbolic: its kernels' host stubs have the same names as the product library's (loaded RTLD_GLOBAL for tscd_set_error) and must not be interposed by them."""
 import os, subprocess
 here = os.path.dirname(os.path.abspath(__file__))
@@ -18,7 +18,7 @@ def rep(x, y, cnt=1):
 rep("  auto issue = [&](int stage) {\n    char* sbase = smem + stage * STAGE;", "  int n_issued = 0;\n  auto issue = [&](int stage) {\n    char* sbase = smem + stage * STAGE;\n    const bool dma = !(g_abl_dev & 1) || n_issued < NS; ++n_issued;")
 rep("      const f16* src = ((a_mask[i] >> ld_tap) & 1u) ? a_src[i] + ld_tapoff + ld_cin : g_zero_chunk;\n      __builtin_amdgcn_global_load_lds(",
     "      const f16* src = ((a_mask[i] >> ld_tap) & 1u) ? a_src[i] + ld_tapoff + ld_cin : g_zero_chunk;\n      if (dma) __builtin_amdgcn_global_load_lds(")
-rep("    for (int j = 0; j < B_LD; ++j) {\n      __builtin_amdgcn_global_load_lds(", "    for (int j = 0; j < B_LD; ++j) {\n      if (dma) __builtin_amdgcn_global_load_lds(")
+rep("    for (int j = 0; j < B_LD; ++j) {\n      __builtin_amdgcn_global_load_lds(", "    for (int j = 0; j < B_LD; ++j) {\n      if (dma && (!(g_abl_dev & 2) || n_issued <= NS)) __builtin_amdgcn_global_load_lds(")
 rep("    const char* sb = smem + (t % NS) * STAGE;\n", "    const char* sb = smem + (t % NS) * STAGE;\n    if ((g_abl_dev & 4) && t > 1) return;\n")
 rep("        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][i], fb[S][ks][j], acc[i][j], 0, 0, 0);\n  };",
     "        for (int j = 0; j < TN; ++j) { if (!(g_abl_dev & 8)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][i], fb[S][ks][j], acc[i][j], 0, 0, 0); else asm volatile(\"\" :: \"v\"(fa[S][ks][i]), \"v\"(fb[S][ks][j])); }\n  };")

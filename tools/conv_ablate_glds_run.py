@@ -16,7 +16,7 @@ abl.tscd_conv_set_halo_auto(0)
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cuda").manual_seed(0)
 st = torch.cuda.current_stream().cuda_stream
-NAMES = {0: "full kernel", 1: "no LDS-DMA after the prologue", 4: "no fragment reads", 8: "no MFMA", 13: "barriers + waits only", 64: "no main loop",
+NAMES = {0: "full kernel", 1: "no LDS-DMA after the prologue", 2: "no weight (B) pieces after the prologue", 4: "no fragment reads", 8: "no MFMA", 13: "barriers + waits only", 64: "no main loop",
          128: "no epilogue", 192: "launch + prologue only"}
 SHAPES = [(16, 72, 72, 256, 128, 1), (16, 36, 36, 512, 256, 1), (16, 36, 36, 256, 256, 3), (16, 72, 72, 128, 128, 3), (16, 144, 144, 64, 64, 3), (16, 18, 18, 512, 512, 3)]
 for (B, H, W, Cin, Cout, k) in SHAPES:
