@@ -100,3 +100,38 @@ def test_row_losses_match_oracle_expressions(B, A, NC, N):
     assert s1[1].item() == 0 and s1[2].item() == 0 and s2[0].item() == 0
     for got, ref in ((cd.grad, c32.grad), (od.grad, o32.grad), (gd.grad, g32.grad)):
         assert (got.float().cpu() - ref).abs().max().item() <= 2e-3 * max(ref.abs().max().item(), 1e-6)
+
+
+@pytest.mark.parametrize("clipped", [False, True])
+def test_loss_tail_matches_the_reference_expression(clipped):
+    """tscd_loss_combine_f32 vs the expression of get_matcher_refined_losses' tail (tscd_head.py:1157-1203), values bit for bit (same
+    fp32 operations in the same order) and gradients to fp32 rounding, with the matched-objectness clip at 15 off and on."""
+    from tscd_amd import functional as TF
+    g = torch.Generator().manual_seed(7 + int(clipped))
+    B, lframe = 16, 4
+    dense = (torch.rand(3, generator=g) * 900 + 20).cuda().requires_grad_()
+    rows = (torch.rand(3, generator=g) * (4000 if clipped else 60) + (2000 if clipped else 5)).cuda().requires_grad_()
+    r_cls = (torch.rand((), generator=g) * 9 + 0.5).cuda().requires_grad_()
+    num_fg_b = torch.randint(3, 12, (B,), generator=g).int().cuda()
+    ngt_b = torch.randint(2, 7, (B,), generator=g).int().cuda()
+    # reference expression (what the head computed with ~25 zero-dimensional torch ops)
+    d2, r2, c2 = dense.detach().clone().requires_grad_(), rows.detach().clone().requires_grad_(), r_cls.detach().clone().requires_grad_()
+    num_fg = num_fg_b.sum().float().clamp(min=1)
+    num_gts = ngt_b.sum().float()
+    num_fg_local = num_fg_b[:lframe].sum().float()
+    li, lo, lc = d2[0] / num_fg, d2[1] / num_fg, d2[2] / num_fg
+    mo, mi = r2[1] / num_fg_local, r2[2] / num_fg_local
+    mo = torch.where(mo > 15, mo / mo.detach() * 15, mo)
+    ref = 3.0 * li + lo + lc + c2 + mo + 6.0 * mi
+    assert bool((r2[1] / num_fg_local > 15)) == clipped
+    (ref * 1024.0).backward()
+    loss, st = TF.combine_losses(dense, rows, r_cls, num_fg_b, ngt_b, lframe)
+    (loss * 1024.0).backward()
+    torch.cuda.synchronize()
+    assert loss.item() == ref.item()
+    want = [ref, 3.0 * li, lo, lc, num_fg / num_gts.clamp(min=1), c2, mo, 6.0 * mi]
+    for i, w in enumerate(want):
+        assert st[i].item() == w.item(), (i, st[i].item(), w.item())
+    for got, exp in ((dense.grad, d2.grad), (rows.grad, r2.grad), (r_cls.grad, c2.grad)):
+        assert torch.allclose(got, exp, rtol=2e-6, atol=0), (got, exp)
+    assert rows.grad[0].item() == 0.0
