@@ -186,6 +186,14 @@ int tscd_mca_backward(const void* q_c, const void* kv_c, const void* q_r, const 
                       float conf_thresh, const float* stats, const void* dxcat_c, const void* dxcat_r, const void* dsoft_c,
                       const void* dsoft_r, int ld_dsoft, const void* soft_c, const void* soft_r, int ld_soft, void* workspace,
                       long workspace_bytes, void* dq_c, void* dkv_c, void* dq_r, void* dkv_r, float* dscore, void* stream);
+/* The same reading the normalised q / k / v rows from the (intact) workspace tscd_mca_forward ran in for the same inputs instead of
+ * re-deriving them (no prep launch); fwd_workspace NULL = tscd_mca_backward. */
+int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
+                          const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
+                          float sim_thresh, float conf_thresh, const float* stats, const void* dxcat_c,
+                          const void* dxcat_r, const void* dsoft_c, const void* dsoft_r, int ld_dsoft, const void* soft_c,
+                          const void* soft_r, int ld_soft, void* workspace, long workspace_bytes, void* dq_c, void* dkv_c,
+                          void* dq_r, void* dkv_r, float* dscore, const void* fwd_workspace, void* stream);
 
 /* ---- CAFM / TaskAligned pieces: PositionMHAttention / MHAttention (tscd_matching.py:31-60,140-181), SEModule
  * (:264-283), LayerNorm of forward_post (:566-589,:394-458), cosine normalisation of double_match_embds (:912-937).

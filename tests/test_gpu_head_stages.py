@@ -346,6 +346,30 @@ def test_mca_backward_is_deterministic(W, ppf, L):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def test_mca_backward_reads_the_forward_workspace_or_rederives_it_bit_for_bit():
+    """ops.mca_backward(fwd_ws=<the forward's workspace>) skips the prep launch and reads the normalised q / k / v rows the forward
+    left there; without it they are re-derived from the same inputs: identical gradients either way."""
+    from tscd_amd import ops
+    d = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    W, ppf, L = 256, [70, 33, 150, 97], 2
+    N, N_L = sum(ppf), sum(ppf[:L])
+    tiles = ops.mca_tiles(ppf, L, d)
+    mk = lambda n, c: torch.randn(n, c, generator=g).half().to(d).contiguous()
+    q_c, q_r, kv_c, kv_r = mk(N_L, W), mk(N_L, W), mk(N, 2 * W), mk(N, 2 * W)
+    score = torch.rand(N, generator=g).half().to(d)
+    for need_reg in (True, False):
+        xcat_c, cat3_c, xcat_r, cat3_r, stats, ws = ops.mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, 25.0, 0.75, 0.99,
+                                                                      want_stats=True, keep_workspace=True)
+        a = (mk(N_L, 2 * W), mk(N_L, 2 * W) if need_reg else None, mk(N_L, 3 * W), mk(N_L, 3 * W) if need_reg else None)
+        args = (q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, 25.0, 0.75, 0.99, stats, a[0], a[1], a[2], a[3], cat3_c, cat3_r)
+        r0 = ops.mca_backward(*args)
+        r1 = ops.mca_backward(*args, fwd_ws=ws)
+        torch.cuda.synchronize()
+        for x, y in zip(r0, r1):
+            assert torch.isfinite(x.float()).all() and torch.equal(x, y)
+
+
 def _cos(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))

@@ -37,6 +37,7 @@ SIGNATURES = {
     "tscd_gather_det": [P, I, I, P, I, P, I, I, P, P],
     "tscd_mca_forward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, L, P, P, P, P, P, P],
     "tscd_mca_backward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, P, P, P, P, I, P, P, I, P, L, P, P, P, P, P, P],
+    "tscd_mca_backward_fws": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, P, P, P, P, I, P, P, I, P, L, P, P, P, P, P, P, P],
     "tscd_cos_attn_f16": [P, P, P, I, I, P, I, P, P],
     "tscd_se_fuse_f16": [P, I, P, I, P, P, P, L, I, P, P],
     "tscd_add_layernorm_f16": [P, P, P, P, I, I, F, P, P],

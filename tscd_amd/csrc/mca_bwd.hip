@@ -860,12 +860,30 @@ void mca_launch_prep(hipStream_t st, const f16* q_c, const f16* kv_c, const f16*
 // dxcat_* : gradient w.r.t. the [N_L, 2W] concat (first W = attention output, second W = own value rows);
 // dsoft_* : gradient w.r.t. the first W columns of the [N_L, 3W] concat (row stride ld_dsoft); soft_* the forward values.
 // Outputs: dq_* [N_L, W], dkv_* [N, 2W] fp16; dscore [N] fp32.
+extern "C" int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
+                                     const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
+                                     float sim_thresh, float conf_thresh, const float* stats, const void* dxcat_c,
+                                     const void* dxcat_r, const void* dsoft_c, const void* dsoft_r, int ld_dsoft, const void* soft_c,
+                                     const void* soft_r, int ld_soft, void* workspace, long workspace_bytes, void* dq_c, void* dkv_c,
+                                     void* dq_r, void* dkv_r, float* dscore, const void* fwd_workspace, void* stream);
 extern "C" int tscd_mca_backward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
                                  const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
                                  float sim_thresh, float conf_thresh, const float* stats, const void* dxcat_c,
                                  const void* dxcat_r, const void* dsoft_c, const void* dsoft_r, int ld_dsoft, const void* soft_c,
                                  const void* soft_r, int ld_soft, void* workspace, long workspace_bytes, void* dq_c, void* dkv_c,
                                  void* dq_r, void* dkv_r, float* dscore, void* stream) {
+  return tscd_mca_backward_fws(q_c, kv_c, q_r, kv_r, score, tiles, ntiles, N, N_L, W, S, need_reg, scale, sim_thresh, conf_thresh, stats,
+                               dxcat_c, dxcat_r, dsoft_c, dsoft_r, ld_dsoft, soft_c, soft_r, ld_soft, workspace, workspace_bytes, dq_c,
+                               dkv_c, dq_r, dkv_r, dscore, nullptr, stream);
+}
+// fwd_workspace (optional): the workspace tscd_mca_forward ran in for the same inputs, still intact -- its normalised q / k / v rows are
+// read in place and the prep launch is skipped (the forward carves them first: qn_c, qn_r, kn_c, kn_r, vn_c, vn_r, 256-byte aligned).
+extern "C" int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
+                                     const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
+                                     float sim_thresh, float conf_thresh, const float* stats, const void* dxcat_c,
+                                     const void* dxcat_r, const void* dsoft_c, const void* dsoft_r, int ld_dsoft, const void* soft_c,
+                                     const void* soft_r, int ld_soft, void* workspace, long workspace_bytes, void* dq_c, void* dkv_c,
+                                     void* dq_r, void* dkv_r, float* dscore, const void* fwd_workspace, void* stream) {
   TSCD_CHECK_ARG(q_c && kv_c && q_r && kv_r && score && tiles && stats && dxcat_c && dsoft_c && soft_c && workspace && dq_c &&
                      dkv_c && dq_r && dkv_r && dscore, "mca_backward: null pointer");
   TSCD_CHECK_ARG(!need_reg || (dxcat_r && dsoft_r && soft_r), "mca_backward: reg gradients missing");
@@ -911,8 +929,16 @@ extern "C" int tscd_mca_backward(const void* q_c, const void* kv_c, const void* 
   p.dq_stride = dq_stride; p.dk_stride = dk_stride;
   p.scale = scale; p.sim_thresh = sim_thresh; p.conf_thresh = conf_thresh;
 
-  mca_launch_prep(st, (const f16*)q_c, (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, N, N_L, Npad, W, d, DP, qn_c, kn_c, vn_c,
-                  vt_c, qn_r, kn_r, vn_r, vt_r, nullptr, nullptr);
+  if (fwd_workspace) {
+    const char* fw = (const char*)fwd_workspace;
+    auto ftake = [&](long bytes) { const char* r = fw; fw += (bytes + 255) / 256 * 256; return (f16*)r; };
+    qn_c = ftake(2L * qN); qn_r = ftake(2L * qN);
+    kn_c = ftake(2L * kN); kn_r = ftake(2L * kN);
+    vn_c = ftake(2L * kN); vn_r = ftake(2L * kN);
+  } else {
+    mca_launch_prep(st, (const f16*)q_c, (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, N, N_L, Npad, W, d, DP, qn_c, kn_c, vn_c,
+                    vt_c, qn_r, kn_r, vn_r, vt_r, nullptr, nullptr);
+  }
   hipLaunchKernelGGL(mca_bwd_layout_kernel, dim3(Npad / 32, 8), dim3(256), 0, st, kn_c, kn_r, vn_c, vn_r, (const f16*)kv_c,
                      (const f16*)kv_r, N, Npad, W, d, DP, kF_c, kF_r, vnF_c, vnF_r, vrF_c, vrF_r, kT_c, kT_r, (const f16*)score, score_pad, scale);
   hipLaunchKernelGGL(mca_bwd_tiles_kernel, dim3(ntiles, 15), dim3(256), 0, st, (const McaTile*)tiles, qn_c, qn_r, vn_c, vn_r,

@@ -553,7 +553,7 @@ def mca_splits(ntiles):
 
 
 def mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale, sim_thresh, conf_thresh, splits=None,
-                  want_stats=False):
+                  want_stats=False, keep_workspace=False):
     """Fused global-to-local attention.  Returns (xcat_c [N_L,2W], cat3_c [N_L,3W], xcat_r, cat3_r, stats): first W columns
     of xcat = P@v, second W = own values; first W columns of cat3 = the sim_round2 aggregation (rest is filled by the
     caller's linear); stats (for backward) = softmax row sums [4,2,N_L] ++ sim_round2 denominators [2,N_L]."""
@@ -572,11 +572,13 @@ def mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale
     call("tscd_mca_forward", q_c.data_ptr(), kv_c.data_ptr(), q_r.data_ptr(), kv_r.data_ptr(), score.data_ptr(),
          tiles.data_ptr(), nt, N, N_L, W, splits, int(need_reg), float(scale), float(sim_thresh), float(conf_thresh),
          ws.data_ptr(), ws_bytes, xcat_c.data_ptr(), _ptr(xcat_r), cat3_c.data_ptr(), _ptr(cat3_r), _ptr(stats), _stream())
+    if keep_workspace:          # for mca_backward(fwd_ws=...): its normalised q / k / v rows are read in place (no second prep launch)
+        return xcat_c, cat3_c, xcat_r, cat3_r, stats, ws
     return xcat_c, cat3_c, xcat_r, cat3_r, stats
 
 
 def mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale, sim_thresh, conf_thresh, stats, dxcat_c, dxcat_r,
-                 dcat3_c, dcat3_r, cat3_c, cat3_r):
+                 dcat3_c, dcat3_r, cat3_c, cat3_r, fwd_ws=None):
     """Gradients of the fused attention w.r.t. the projected rows: -> (dq_c [N_L,W], dkv_c [N,2W], dq_r, dkv_r, dscore [N]).
     dxcat_* [N_L,2W] contiguous fp16; dcat3_* / cat3_* [N_L,3W] (only their first W columns are read)."""
     dev = q_c.device
@@ -591,10 +593,10 @@ def mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale,
     dscore = torch.empty((N,), dtype=torch.float32, device=dev)
     for t in (dxcat_c, dcat3_c, cat3_c) + ((dxcat_r, dcat3_r, cat3_r) if need_reg else ()):
         assert t.is_contiguous() and t.dtype == torch.float16
-    call("tscd_mca_backward", q_c.data_ptr(), kv_c.data_ptr(), q_r.data_ptr(), kv_r.data_ptr(), score.data_ptr(), tiles.data_ptr(), nt,
+    call("tscd_mca_backward_fws", q_c.data_ptr(), kv_c.data_ptr(), q_r.data_ptr(), kv_r.data_ptr(), score.data_ptr(), tiles.data_ptr(), nt,
          N, N_L, W, S, int(need_reg), float(scale), float(sim_thresh), float(conf_thresh), stats.data_ptr(), dxcat_c.data_ptr(),
          _ptr(dxcat_r), dcat3_c.data_ptr(), _ptr(dcat3_r), 3 * W, cat3_c.data_ptr(), _ptr(cat3_r), 3 * W, ws.data_ptr(), ws_bytes,
-         dq_c.data_ptr(), dkv_c.data_ptr(), dq_r.data_ptr(), dkv_r.data_ptr(), dscore.data_ptr(), _stream())
+         dq_c.data_ptr(), dkv_c.data_ptr(), dq_r.data_ptr(), dkv_r.data_ptr(), dscore.data_ptr(), _ptr(fwd_ws), _stream())
     return dq_c, dkv_c, dq_r, dkv_r, dscore
 
 

@@ -43,8 +43,12 @@ class _MCAFunction(torch.autograd.Function):
         q_r, kv_r = ops.linear(xr[:nl], wq_r), ops.linear(xr, wkv_r)
         tiles = ops.mca_tiles(ppf, lframe, xc.device)
         want = any(ctx.needs_input_grad)
-        xcat_c, cat3_c, xcat_r, cat3_r, stats = ops.mca_attention(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, scale, sim_thresh,
-                                                                  conf_thresh, want_stats=want)
+        # with a backward to come the forward's workspace stays alive: its normalised q / k / v rows are what the backward's first launch
+        # would re-derive
+        res = ops.mca_attention(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, scale, sim_thresh, conf_thresh, want_stats=want,
+                                keep_workspace=want)
+        xcat_c, cat3_c, xcat_r, cat3_r, stats = res[:5]
+        fwd_ws = res[5] if want else None
         ops.linear(xcat_c, w_lin, b_lin, out=cat3_c[:, W:])
         t_cls = ops.linear(cat3_c, w_out, b_out)
         t_obj = None
@@ -54,14 +58,14 @@ class _MCAFunction(torch.autograd.Function):
         if want:
             ctx.cfg = cfg
             ctx.save_for_backward(xc, xr, sc, q_c, kv_c, q_r, kv_r, tiles, stats, xcat_c, cat3_c, xcat_r, cat3_r, wq_c, wkv_c, wq_r, wkv_r,
-                                  w_lin, w_linr, w_out, w_obj)
+                                  w_lin, w_linr, w_out, w_obj, fwd_ws)
         return (t_cls, t_obj) if need_reg else t_cls
 
     @staticmethod
     def backward(ctx, g_cls, g_obj=None):
         ppf, lframe, scale, sim_thresh, conf_thresh, need_reg = ctx.cfg
         (xc, xr, sc, q_c, kv_c, q_r, kv_r, tiles, stats, xcat_c, cat3_c, xcat_r, cat3_r, wq_c, wkv_c, wq_r, wkv_r, w_lin, w_linr, w_out,
-         w_obj) = ctx.saved_tensors
+         w_obj, fwd_ws) = ctx.saved_tensors
         N, W = xc.shape
         nl = q_c.shape[0]
         z16 = lambda *shape: torch.zeros(shape, dtype=torch.float16, device=xc.device)
@@ -81,7 +85,7 @@ class _MCAFunction(torch.autograd.Function):
         else:
             dc3_r = dxc_r = dw_obj = db_obj = dw_linr = db_linr = None
         dq_c, dkv_c, dq_r, dkv_r, dscore = ops.mca_backward(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, scale, sim_thresh,
-                                                            conf_thresh, stats, dxc_c, dxc_r, dc3_c, dc3_r, cat3_c, cat3_r)
+                                                            conf_thresh, stats, dxc_c, dxc_r, dc3_c, dc3_r, cat3_c, cat3_r, fwd_ws=fwd_ws)
         dx_c, dw_kv_c, _ = ops.linear_bwd(xc, dkv_c, wkv_c)
         dxq_c, dw_q_c, _ = ops.linear_bwd(xc[:nl], dq_c, wq_c)
         dx_c[:nl] += dxq_c
