@@ -92,7 +92,7 @@ __global__ void mca_prep_kernel(const f16* __restrict__ q_c, const f16* __restri
         long o = (long)n * WP + h * DP + j;
         kn[o] = real ? (f16)(kvv[rnd] * ik) : (f16)0.f;
         vn[o] = real ? (f16)(vv[rnd] * iv) : (f16)0.f;
-        vt[(long)(h * DP + j) * Npad + n] = real ? (f16)vv[rnd] : (f16)0.f;
+        if (vt) vt[(long)(h * DP + j) * Npad + n] = real ? (f16)vv[rnd] : (f16)0.f;      // row-major V^T: no reader left (the aggregation reads vtF)
         if (kF) {
           const long of = ((((long)jb * MCA_HEADS + h) * KSn + (j >> 4)) * 64 + ((n & 31) | (((j >> 3) & 1) << 5))) * 8 + (j & 7);
           kF[of] = real ? (f16)(kvv[rnd] * ik) : (f16)0.f;
@@ -483,8 +483,8 @@ extern "C" int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q
   {
     long waves = 2L * Npad;
     hipLaunchKernelGGL(mca_prep_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st, (const f16*)q_c,
-                       (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, N, N_L, Npad, W, d, DP, qn_c, kn_c, vn_c, vt_c,
-                       qn_r, kn_r, vn_r, vt_r, (f16*)xcat_c, (f16*)(need_reg ? xcat_r : nullptr), kF_c, kF_r, vF_c, vF_r, vtF_c, vtF_r);
+                       (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, N, N_L, Npad, W, d, DP, qn_c, kn_c, vn_c, (f16*)nullptr,
+                       qn_r, kn_r, vn_r, (f16*)nullptr, (f16*)xcat_c, (f16*)(need_reg ? xcat_r : nullptr), kF_c, kF_r, vF_c, vF_r, vtF_c, vtF_r);
     TSCD_CHECK_LAUNCH("mca_prep");
   }
   McaParams p;

@@ -937,7 +937,7 @@ extern "C" int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const vo
     vn_c = ftake(2L * kN); vn_r = ftake(2L * kN);
   } else {
     mca_launch_prep(st, (const f16*)q_c, (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, N, N_L, Npad, W, d, DP, qn_c, kn_c, vn_c,
-                    vt_c, qn_r, kn_r, vn_r, vt_r, nullptr, nullptr);
+                    nullptr, qn_r, kn_r, vn_r, nullptr, nullptr, nullptr);
   }
   hipLaunchKernelGGL(mca_bwd_layout_kernel, dim3(Npad / 32, 8), dim3(256), 0, st, kn_c, kn_r, vn_c, vn_r, (const f16*)kv_c,
                      (const f16*)kv_r, N, Npad, W, d, DP, kF_c, kF_r, vnF_c, vnF_r, vrF_c, vrF_r, kT_c, kT_r, (const f16*)score, score_pad, scale);
