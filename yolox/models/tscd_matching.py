@@ -259,6 +259,20 @@ class ReferringCrossAttentionLayer(nn.Module):
         return add_layernorm(identity, t2, self.norm)
 
 
+class _PermuteRows(torch.autograd.Function):
+    """t[idx] for idx a permutation of all rows of t, idx_inv its inverse: backward = grad[idx_inv]."""
+
+    @staticmethod
+    def forward(ctx, t, idx, idx_inv):
+        ctx.save_for_backward(idx_inv)
+        return t.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx_inv,) = ctx.saved_tensors
+        return g.index_select(0, idx_inv), None, None
+
+
 class AwarePositionRegMatcher(nn.Module):
     def __init__(self, hidden_channel=512, feedforward_channel=2048, num_head=8, decoder_layer_num=6, act="silu"):
         super().__init__()
@@ -415,6 +429,9 @@ class AwarePositionRegMatcher(nn.Module):
         # row gathers by index_select: its backward is one index_add into zeros (the indices are distinct rows), where
         # advanced indexing would sort the indices first (8 small launches per gather on a launch-bound stretch)
         rows = lambda t, i: t.index_select(0, i)
+        # a gather by a PERMUTATION of all rows (the assignment order `c`, its inverse `inv`): the gradient is the gather by the inverse
+        # permutation -- one launch, where index_select's backward zero-fills a buffer and index_adds into it
+        prows = lambda t, i, i_inv: _PermuteRows.apply(t, i, i_inv)
         # per-frame views by ONE split (its backward is one cat) instead of a zero-filled [N, W] slice gradient per use
         n_loc = sum(preds_per_frame)
         f_loc = features[:n_loc].split(list(preds_per_frame))
@@ -449,12 +466,15 @@ class AwarePositionRegMatcher(nn.Module):
                     last_feat, last_edge = rows(self.last_outputs, r), rows(self.last_frame_edge_embeds, r)
                 else:
                     last_feat, last_edge = self.last_outputs, self.last_frame_edge_embeds
-                c = view(rec, "c")
-                self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = rows(cur_reg, c), rows(cur_cls, c), n
-                out = layer(rows(cur, c), last_feat, cur, t_i, self.last_frame_time_embedding, cur_edge, last_edge)
-                new_edge = rows(cur_edge, c)
+                c, c_inv = view(rec, "c"), view(rec, "inv")          # inv = argsort(perm): the inverse of c
+                self.last_frame_reg_embeds, self.last_frame_cls_embeds, self.last_frame_n = prows(cur_reg, c, c_inv), prows(cur_cls, c, c_inv), n
+                out = layer(prows(cur, c, c_inv), last_feat, cur, t_i, self.last_frame_time_embedding, cur_edge, last_edge)
+                new_edge = prows(cur_edge, c, c_inv)
             self.last_outputs, self.last_frame_time_embedding, self.last_frame_edge_embeds = out, t_i, new_edge
-            outs.append(rows(out, view(rec, "inv")))
+            if kind == "self":
+                outs.append(rows(out, view(rec, "inv")))
+            else:
+                outs.append(prows(out, view(rec, "inv"), view(rec, "c")))
         if not plan and len(preds_per_frame) and preds_per_frame[0] == 0 and resume is False:
             self._clear_state()
         if not outs:
