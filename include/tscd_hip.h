@@ -230,12 +230,17 @@ int tscd_add_layernorm_bwd_f16(const void* a, const void* b, const float* gamma,
 int tscd_row_normalize_f16(const void* x, int ldx, int n, int n_pad, int C, float eps, void* out, int ldo, void* stream);
 
 /* ---- eval tail: decode_reg_preds5 (tscd_head.py:914-949) + postprocess (post_process.py:9-85) +
- * torchvision.ops.batched_nms.  mode 0 = refined set, 1 = original detections. */
-long tscd_nms_workspace_bytes(int L, int capM);
+ * torchvision.ops.batched_nms.  mode 0 = refined set, 1 = original detections, 2 = original detections with class-agnostic
+ * suppression (utils/boxes.py:59-64).  No candidate or per-class capacity limits (the ImageNet-VID exp sets no upper proposal
+ * clamp, exps/TSCD_VID/vid_tscd_large.py:42): capM = what the caller sized the outputs for (rows x classes in mode 0), max_rows =
+ * the largest number of detection rows in one frame.  coord_trick = n > 0: frames with at most n candidates are suppressed with
+ * torchvision's fp16 coordinate-offset arithmetic (reference-faithful; torchvision's own GPU rule is n = 5000), 0 = exact
+ * per-class suppression in fp32 (the product's default). */
+long tscd_nms_workspace_bytes(int L, int capM, int NC, int max_rows);
 int tscd_batched_nms(const void* det, int ndet, const int* frame_off, int L, const void* cls_logit,
                      const void* obj_logit, const void* reg_delta, int NC, float conf_thresh, float iou_thresh, int capM,
-                     int mode, void* workspace, long workspace_bytes, void* out, int* out_idx, int* out_count,
-                     int* overflow_flag, void* stream);
+                     int max_rows, int mode, int coord_trick, void* workspace, long workspace_bytes, void* out, int* out_idx,
+                     int* out_count, void* stream);
 
 /* Fused losses (tscd_amd/csrc/loss.hip; reference: TSCDHead.get_matcher_refined_losses yolox/models/tscd_head.py:1008-1203,
  * IOUloss yolox/models/losses.py:9-53, encode_reg_preds tscd_head.py:951-974).  Sums are returned un-normalised (the caller
@@ -267,6 +272,11 @@ int tscd_loss_rows_f16(const int* row_b, const int* row_a, int N, int A, int NC,
  * 6 matched iou} and weights[6] = d total / d {dense[0..2], rows[0..2]}. */
 int tscd_loss_combine_f32(const float* dense, const float* rows, const float* r_cls, const int* num_fg, const int* ngt, int B,
                           int lframe, float* out, float* weights, void* stream);
+
+/* Backward of the fused losses: out[r][pad + c] = fp16(float(d[r][c]) * g[c < split ? i0 : i1]), columns [0, pad) zero.  g: fp32
+ * device scalars (loss scale x weight / num_fg): the product is formed in fp32 and rounded once, as the reference's autograd does
+ * (tscd_head.py:1157-1203). */
+int tscd_scale_grad_f16(const void* d, const float* g, int i0, int i1, int split, long rows, int C, int pad, void* out, void* stream);
 
 /* ---- SimOTA label assignment: get_fg_idx / get_assignments / get_in_boxes_info / dynamic_k_matching
  * (tscd_head.py:1712-1851,1330-1544), bboxes_iou (yolox/utils/boxes.py:131-154). */

@@ -43,9 +43,25 @@ def nms(boxes, scores, iou_threshold):
     return order[torch.tensor(keep, dtype=torch.int64)]
 
 
-def batched_nms(boxes, scores, idxs, iou_threshold):
+def batched_nms_vanilla(boxes, scores, idxs, iou_threshold):
+    """torchvision's ``_batched_nms_vanilla``: NMS per class without coordinate offsets, survivors in decreasing score order
+    (stable here: lower index first among equal scores)."""
+    keep_mask = torch.zeros_like(scores, dtype=torch.bool)
+    for class_id in torch.unique(idxs):
+        cur = torch.where(idxs == class_id)[0]
+        keep_mask[cur[nms(boxes[cur], scores[cur], iou_threshold)]] = True
+    keep = torch.where(keep_mask)[0]
+    return keep[torch.argsort(scores[keep].float(), descending=True, stable=True)]
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold, vanilla_above=None):
+    """``vanilla_above``: torchvision (0.10+) leaves the coordinate trick for per-class NMS when ``boxes.numel()`` exceeds a
+    threshold (4000 on the CPU, 20000 on a GPU in current releases); None = always the trick (the historical behaviour and what the
+    rest of this oracle uses)."""
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64)
+    if vanilla_above is not None and boxes.numel() > vanilla_above:
+        return batched_nms_vanilla(boxes, scores, idxs, iou_threshold)
     max_coordinate = boxes.max()
     offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
     return nms(boxes + offsets[:, None], scores, iou_threshold)

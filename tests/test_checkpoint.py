@@ -96,3 +96,25 @@ class _Short:
 
     def next(self):
         return self.src.next()
+
+
+@pytest.mark.gpu
+def test_failed_asynchronous_write_is_raised_on_the_training_thread(tmp_path):
+    """an exception in the writer thread (disk full, permission) used to be printed by the thread and lost -- training went
+    on reporting checkpoints that were never written.  wait() and the next save_checkpoint re-raise it; no .tmp file is left."""
+    from yolox.utils import checkpoint
+    d = tmp_path / "ck"
+    state = {"start_epoch": 1, "model": {"w": torch.ones(4, device="cuda")}, "optimizer": {}}
+    checkpoint.save_checkpoint(state, False, str(d), "latest")
+    checkpoint.wait()
+    # make the target unwritable in a way that also holds for root: the checkpoint's name is taken by a directory
+    os.remove(d / "latest_ckpt.pth")
+    os.makedirs(d / "latest_ckpt.pth" / "x")
+    checkpoint.save_checkpoint(state, True, str(d), "latest")
+    with pytest.raises(RuntimeError, match="asynchronous checkpoint write failed"):
+        checkpoint.wait()
+    assert not os.path.exists(d / "latest_ckpt.pth.tmp") and not os.path.exists(d / "best_ckpt.pth")
+    checkpoint.wait()                                       # raised once, then clear
+    checkpoint.save_checkpoint(state, False, str(d), "other")
+    checkpoint.wait()
+    assert os.path.isfile(d / "other_ckpt.pth")

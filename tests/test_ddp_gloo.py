@@ -66,3 +66,39 @@ def test_two_rank_gloo_gradient_allreduce(golden):
         # bn weights / decayed weights / biases / pg3: the reference's substring test "head.cls_convs" in k also matches
         # head.cls_convs2.* (ovis_tscd_large.py:177), so the trainable cls_convs2 weights train at lr * stem_lr_ratio
         assert ngroups == 4
+
+
+def _run_bench(args, env_extra):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus N` with no launcher must start N ranks itself (fresh interpreters, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*), and the one JSON line carries n_gpus = N and the world size the backend reports.  Dry run: gloo on the
+    CPU, no model (the GPU form of the same launch is tests/test_gpu_configs.py::test_bench_two_ranks_without_a_launcher)."""
+    r, line = _run_bench(["--gpus", "2"], {"TSCD_BENCH_DRYRUN": "1", "TSCD_BENCH_REHEARSAL": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["world_size_reported_by_backend"] == 2 and line["ranks_in_collective"] == 2
+    r, line = _run_bench(["--gpus", "3"], {"TSCD_BENCH_DRYRUN": "1", "TSCD_BENCH_REHEARSAL": "1"})
+    assert r.returncode == 0 and line["n_gpus"] == 3 and line["ranks_in_collective"] == 3
+    # a single rank needs no spawn and no process group
+    r, line = _run_bench([], {"TSCD_BENCH_DRYRUN": "1"})
+    assert r.returncode == 0 and line["n_gpus"] == 1
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """Without the rehearsal switch, --gpus N with fewer than N visible devices exits non-zero instead of printing a 1-GPU number
+    labelled as N (this container has no GPU: any N > 1 is too many)."""
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a host with fewer than 2 devices")
+    r, line = _run_bench(["--gpus", "2"], {"TSCD_BENCH_DRYRUN": "1"})
+    assert r.returncode != 0 and line is None and "device(s) visible" in r.stderr

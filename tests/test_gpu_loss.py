@@ -135,3 +135,47 @@ def test_loss_tail_matches_the_reference_expression(clipped):
     for got, exp in ((dense.grad, d2.grad), (rows.grad, r2.grad), (r_cls.grad, c2.grad)):
         assert torch.allclose(got, exp, rtol=2e-6, atol=0), (got, exp)
     assert rows.grad[0].item() == 0.0
+
+
+def test_loss_backward_forms_the_product_in_fp32_at_the_initial_loss_scale():
+    """the upstream scalar of the fused losses is loss_scale * weight / num_fg.  At GradScaler's initial scale
+    65536 with num_fg_local = 4 it is 6 * 65536 / 4 = 98304 > fp16 max: cast on its own it is inf, while the product with the stored
+    gradient (|d| <= 1 for BCE, <= 1 for SmoothL1) is representable.  The backward multiplies in fp32 and rounds once
+    (tscd_scale_grad_f16), like the reference's autograd (tscd_head.py:1157-1203): finite, equal to the fp32 expression."""
+    from tscd_amd import functional as TF
+    B, A, NC, N = 3, 336, 25, 96
+    raw, outputs, labels, fg, mg, pi = _scene(B, A, NC, 20, 11)
+    g = torch.Generator().manual_seed(5)
+    fgi = torch.nonzero(fg)
+    pick = fgi[torch.randint(0, len(fgi), (N // 2,), generator=g)]
+    rb = torch.cat((pick[:, 0], torch.randint(0, B, (N - N // 2,), generator=g)))
+    ra = torch.cat((pick[:, 1], torch.randint(0, A, (N - N // 2,), generator=g)))
+    cls = (torch.randn(N, NC, generator=g) * 2).half()
+    obj = (torch.randn(N, generator=g) * 2).half()
+    reg = (torch.randn(N, 4, generator=g) * 0.05).half()          # small deltas: SmoothL1 gradient = delta / beta, well inside fp16
+    base = torch.zeros(N, 7 + NC)
+    base[:, 0:2] = torch.rand(N, 2, generator=g) * 400
+    base[:, 2:4] = base[:, 0:2] + torch.rand(N, 2, generator=g) * 200 + 5
+    dev = lambda t: t.cuda()
+    args = (dev(rb.int()), dev(ra.int()), A, NC, dev(fg.to(torch.uint8)), dev(mg), dev(pi), dev(labels).contiguous())
+    cd, od, gd = dev(cls).requires_grad_(), dev(obj).requires_grad_(), dev(reg).requires_grad_()
+    rd = raw.cuda().requires_grad_()
+    scale, num_fg_local = 65536.0, 4.0
+    w = torch.tensor([scale * 1.0 / num_fg_local, scale * 1.0 / num_fg_local, scale * 6.0 / num_fg_local], device="cuda")
+    assert not torch.isfinite(w.half()).all()                      # the scalar alone does overflow fp16
+    s1 = TF.row_loss(*args, cls_logit=cd)
+    s2 = TF.row_loss(*args, obj_logit=od, reg_delta=gd, base=dev(base.half())[:N])
+    dense = TF.dense_loss(rd, outputs.cuda().contiguous(), fg.to(torch.uint8).cuda(), mg.cuda(), pi.cuda(), labels.cuda().contiguous(), NC)
+    (w[0] * s1[0] + w[1] * s2[1] + w[2] * s2[2] + w[1] * dense[1] + w[0] * dense[2]).backward()
+    torch.cuda.synchronize()
+    # the stored un-normalised gradients (fp16) times the fp32 scalar, rounded once
+    _, d_cls, d_obj, d_reg = __import__("tscd_amd.ops", fromlist=["x"]).loss_rows(*args, cls_logit=dev(cls), obj_logit=dev(obj), reg_delta=dev(reg),
+                                                                                  base=dev(base.half())[:N])
+    for got, d, s in ((cd.grad, d_cls, w[0]), (od.grad, d_obj, w[1]), (gd.grad, d_reg, w[2])):
+        want = (d.float() * s).half().reshape(got.shape)
+        assert torch.equal(got, want)
+        # finite wherever the fp32 product fits fp16 (|d| * 98304 < 65504 <=> |d| < 0.67: every BCE row here, most SmoothL1 rows);
+        # with the scalar cast first EVERY element of the box gradient would be inf or nan
+        assert torch.isfinite(got[(d.float() * s).abs().reshape(got.shape) < 65504]).all() and got.abs().max() > 0
+    assert torch.isfinite(cd.grad).all() and torch.isfinite(od.grad).all() and torch.isfinite(gd.grad).float().mean() > 0.3
+    assert torch.isfinite(rd.grad).all() and torch.all(rd.grad[..., :4] == 0) and rd.grad[..., 4:].abs().max() > 0

@@ -1,0 +1,130 @@
+"""The final NMS without capacity limits (VERDICT r02 missing #1).
+
+The reference's ``postprocess`` takes whatever the proposal selection hands it (yolox/models/post_process.py:9-85) and the
+ImageNet-VID exp sets no upper proposal clamp (exps/TSCD_VID/vid_tscd_large.py:42): all 6804 anchors x 30 classes can arrive.  Rounds
+1-2 raised above 65536 candidates per frame and above 2048 boxes of one class.  Here: 64-bit sort keys through global memory above
+65536 candidates, a tiled greedy pass above 2048 boxes per class -- kept candidate indices (INT) bit-exact against oracle/nms_ref.py
+(the restatement of torchvision.ops.batched_nms; torchvision is absent, so parity is pinned by that restatement only), in order.
+Also the reference-faithful switch: torchvision's fp16 coordinate-offset arithmetic (COORD_TRICK_MAX_BOXES)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tscd_oracle as O
+from oracle import nms_ref
+
+
+def _scene(ppf, NC, seed, pass_frac_bias=1.0, one_class_heavy=False, spread=480.0, size=(8.0, 98.0)):
+    g = torch.Generator().manual_seed(seed)
+    n = sum(ppf)
+    cxy = torch.rand(n, 2, generator=g) * spread + 40
+    wh = torch.rand(n, 2, generator=g) * (size[1] - size[0]) + size[0]
+    det = torch.zeros(n, 7 + NC)
+    det[:, 0:2], det[:, 2:4] = cxy - wh / 2, cxy + wh / 2
+    det[:, 4], det[:, 5] = torch.rand(n, generator=g), torch.rand(n, generator=g)
+    det[:, 6] = torch.randint(0, NC, (n,), generator=g).float()
+    cls = torch.randn(n, NC, generator=g) * 2.0 + pass_frac_bias
+    if one_class_heavy:
+        cls[:, 3] = 4.0 + torch.randn(n, generator=g)              # class 3 passes on every row: > 2048 boxes of one class
+    obj = torch.randn(n, generator=g) * 1.5 + 2.0
+    reg = 0.05 * torch.randn(n, 4, generator=g)
+    return det.half(), cls.half(), obj.half(), reg.half()
+
+
+def _oracle_keep(det, cls, obj, reg, ppf, NC, thr=0.001, iou=0.5, half_trick=False, vanilla_above=None):
+    """Candidate expansion as the reference's postprocess does it on fp16 tensors, then oracle/nms_ref.batched_nms; returns per frame
+    (keep indices into the expansion-ordered candidate list, number of candidates, per-class maximum)."""
+    q = lambda t: t.half().float()
+    reg_xyxy = O.decode_reg_preds5(reg, det[:, :4]).float()
+    out, s0 = [], 0
+    for c in ppf:
+        sc = q(torch.sigmoid(cls[s0:s0 + c].float()))
+        ob = q(torch.sigmoid(obj[s0:s0 + c].float()))
+        loc = torch.where(sc >= q(torch.tensor(thr)))
+        prod = q(ob[loc[0]] * sc[loc[0], loc[1]])
+        km = prod >= q(torch.tensor(thr))
+        boxes, scores, cids = reg_xyxy[s0:s0 + c][loc[0]][km], prod[km], loc[1][km]
+        if half_trick:
+            keep = nms_ref.batched_nms(boxes.half(), scores, cids.half(), iou, vanilla_above=vanilla_above)
+        else:
+            keep = nms_ref.batched_nms(boxes, scores, cids.float(), iou)
+        out.append((keep, len(scores), int(torch.bincount(cids, minlength=NC).max()) if len(cids) else 0))
+        s0 += c
+    return out
+
+
+def _check(ppf, NC, seed, want_min_cand, want_min_per_class, **scene):
+    from yolox.models.post_process import nms_frames
+    det, cls, obj, reg = _scene(ppf, NC, seed, **scene)
+    ref = _oracle_keep(det, cls, obj, reg, ppf, NC)
+    assert max(r[1] for r in ref) > want_min_cand and max(r[2] for r in ref) > want_min_per_class, [(r[1], r[2]) for r in ref]
+    out, ori, keep = nms_frames(det.cuda(), ppf, NC, cls.cuda(), obj.cuda(), reg.cuda(), 0.001, 0.5, return_idx=True)
+    torch.cuda.synchronize()
+    for i in range(len(ppf)):
+        k = keep[i].cpu().long()
+        assert torch.equal(k, ref[i][0]), (i, len(k), len(ref[i][0]), int((k[:min(len(k), len(ref[i][0]))] != ref[i][0][:min(len(k), len(ref[i][0]))]).sum()))
+        assert out[i].shape[0] == len(k)
+        sc = (out[i][:, 4].float() * out[i][:, 5].float()).half().float().cpu()
+        assert torch.all(sc[:-1] >= sc[1:])
+    return ref
+
+
+def test_more_than_65536_candidates_and_more_than_2048_boxes_of_one_class():
+    """3200 proposals x 30 classes in the large frame (VID regime past the old 2184-proposal limit): ~75 k candidates survive the
+    score filter (64-bit key sort over several workgroups) and class 3 holds 3200 boxes (two tiles of the greedy pass); next to it a
+    small frame (one LDS sort) and an empty one."""
+    _check([3200, 0, 260], 30, 5, 65536, 2048, pass_frac_bias=1.5, one_class_heavy=True, spread=260.0, size=(60.0, 220.0))
+
+
+def test_between_one_lds_chunk_and_65536_candidates_index_exact():
+    """The 32-bit-key path that sorts through global memory (16384 < candidates <= 65536), now compared index for index."""
+    _check([1500, 300], 30, 17, 16384, 1000, pass_frac_bias=-1.0)
+
+
+def test_class_agnostic_suppression_of_more_than_2048_boxes():
+    """yolox.utils.postprocess(class_agnostic=True) (tools/demo.py path, utils/boxes.py:59-64): every box of the image is one
+    class -- 8400 anchors of a 640^2 image used to raise above 2048."""
+    from yolox.utils import postprocess
+    g = torch.Generator().manual_seed(3)
+    A, NC = 8400, 80
+    cxy = torch.rand(1, A, 2, generator=g) * 560 + 40
+    wh = torch.rand(1, A, 2, generator=g) * 60 + 10
+    pred = torch.cat((cxy, wh, torch.rand(1, A, 1, generator=g) * 0.6 + 0.4, torch.rand(1, A, NC, generator=g)), -1).half()
+    p32 = pred.float().clone()
+    half = p32[..., 2:4] / 2
+    boxes = torch.cat((p32[..., :2] - half, p32[..., :2] + half), -1)[0].half().float()
+    conf, cid = torch.max(p32[0, :, 5:], -1)
+    score = (p32[0, :, 4].half() * conf.half()).float()
+    m = score >= torch.tensor(0.3).half().float()
+    assert int(m.sum()) > 2048
+    ref = nms_ref.nms(boxes[m], score[m], 0.45)
+    rows = postprocess(pred.cuda(), NC, 0.3, 0.45, class_agnostic=True)[0]
+    torch.cuda.synchronize()
+    assert rows.shape[0] == len(ref)
+    assert torch.allclose(rows[:, :4].float().cpu(), boxes[m][ref], atol=0.26)
+    assert torch.equal(rows[:, 6].float().cpu(), cid[m][ref].float())
+
+
+def test_reference_faithful_coordinate_trick_switch():
+    """COORD_TRICK_MAX_BOXES / nms_frames(coord_trick=n): torchvision.ops.batched_nms on the evaluator's fp16 tensors shifts every box
+    by fp16(class) * fp16(max + 1) and rounds to fp16 (post_process.py:58-63) -- frames with at most n candidates reproduce that
+    arithmetic (keep lists equal to oracle/nms_ref.batched_nms on HALF boxes), larger frames are suppressed per class without
+    offsets like torchvision's own rule above 5000 boxes.  The default (0) stays the exact per-class suppression."""
+    from yolox.models.post_process import nms_frames
+    NC, ppf = 25, [400, 90]
+    det, cls, obj, reg = _scene(ppf, NC, 23, pass_frac_bias=-0.5)
+    exact = _oracle_keep(det, cls, obj, reg, ppf, NC)
+    trick = _oracle_keep(det, cls, obj, reg, ppf, NC, half_trick=True)
+    assert exact[0][1] > 3000 and exact[1][1] < 3000
+    assert not torch.equal(exact[0][0], trick[0][0])                      # the quantisation does change the keep list
+    args = (det.cuda(), ppf, NC, cls.cuda(), obj.cuda(), reg.cuda(), 0.001, 0.5)
+    _, _, k_exact = nms_frames(*args, return_idx=True, coord_trick=0)
+    _, _, k_trick = nms_frames(*args, return_idx=True, coord_trick=2 ** 30)
+    _, _, k_rule = nms_frames(*args, return_idx=True, coord_trick=3000)   # frame 0 above the threshold, frame 1 below
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(k_exact[i].cpu().long(), exact[i][0]), i
+        assert torch.equal(k_trick[i].cpu().long(), trick[i][0]), i
+    assert torch.equal(k_rule[0].cpu().long(), exact[0][0]) and torch.equal(k_rule[1].cpu().long(), trick[1][0])

@@ -128,7 +128,9 @@ def test_train_sampler_is_rank_aware_and_eval_sharding_is_video_affine(tiny_ovis
     n = len(ds.res)
     a, b = vid.TrainSampler(ds, rank=0, world_size=2, seed=1), vid.TrainSampler(ds, rank=1, world_size=2, seed=1)
     ca, cb = [tuple(c) for c in a], [tuple(c) for c in b]
-    assert len(ca) + len(cb) == n and not (set(ca) & set(cb))                   # disjoint cover of the epoch's clips
+    assert len(ca) == len(cb) == len(a) == len(b) == (n + 1) // 2                # every rank runs the same number of steps per epoch
+    assert set(ca) | set(cb) == {tuple(c) for c in ds.res}                      # the epoch's clips are covered ...
+    assert len(set(ca) & set(cb)) == 2 * len(ca) - n                            # ... with only the wrap-around padding shared
     ca2 = [tuple(c) for c in a]
     assert ca2 != ca or n < 3                                                   # reshuffled in the next epoch
     # evaluation: clips of one video never leave their rank (CAFM state flows clip -> clip inside a video)
@@ -138,6 +140,28 @@ def test_train_sampler_is_rank_aware_and_eval_sharding_is_video_affine(tiny_ovis
     assert not (v0 & v1) and len(list(e0)) + len(list(e1)) == n
     order = [c[0] for c in e0]
     assert order == [c[0] for c in ds.res if c[0].split("/")[0] in v0]           # dataset order kept inside the shard
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("n", [1, 7, 10, 17])
+def test_train_sampler_gives_every_rank_the_same_epoch_length(world, n):
+    """ranks with different epoch lengths run different numbers of DDP steps and lr schedules -> mismatched
+    collectives.  Like torch's DistributedSampler the permutation is padded by wrapping around to a multiple of the world size."""
+    from yolox.data.datasets import vid
+
+    class _DS:
+        res = [[f"v{i}/f.jpg"] for i in range(n)]
+
+    samplers = [vid.TrainSampler(_DS(), rank=r, world_size=world, seed=3) for r in range(world)]
+    want = -(-n // world)
+    got = [[c[0] for c in s] for s in samplers]
+    assert all(len(s) == want for s in samplers) and all(len(g) == want for g in got)
+    flat = [c for g in got for c in g]
+    assert set(flat) == {c[0] for c in _DS.res}                                  # nothing dropped
+    assert len(flat) == want * world
+    # the same epoch on every rank: interleaving the shards gives ONE permutation (plus its wrapped head)
+    inter = [got[i % world][i // world] for i in range(want * world)]
+    assert len(set(inter[:n])) == n and inter[n:] == (inter[:n] * world)[:want * world - n]
 
 
 def test_letterbox_and_transforms():
@@ -218,3 +242,21 @@ def test_vid_dataset_xml_annotations_and_clip_rules(tmp_path):
     assert len(vid.VIDDataset(preproc=None, lframe=2, gframe=2, mode="random", val=True, tnum=3, **kw).res) == 3
     du = vid.VIDDataset(preproc=None, lframe=0, gframe=4, mode="uniform", val=True, tnum=-1, **kw)
     assert du.res[0] == videos[0][0:8:2] and du.res[1] == videos[0][1:8:2]
+    # a cache written for another letterbox size is stale: re-parsed (and re-written), never read as it is
+    d2 = vid.VIDDataset(preproc=None, lframe=2, gframe=2, mode="random", val=True, tnum=-1, **dict(kw, img_size=(128, 128)))
+    assert np.allclose(d2.annotations[videos[0][0]][0, :4], a[0, :4] * 2)
+    with open(tmp_path / "cache" / "ann.json") as fh:
+        assert json.load(fh)["img_size"] == [128, 128]
+    # the reference's object-array .npy list needs unpickling: refused unless asked for; a .json next to it is picked up instead
+    arr = np.empty(len(videos), dtype=object)
+    for i, v in enumerate(videos):
+        arr[i] = v
+    os.makedirs(tmp_path / "ref", exist_ok=True)
+    np.save(tmp_path / "ref" / "seq.npy", arr, allow_pickle=True)
+    kw_npy = dict(kw, file_path=str(tmp_path / "ref" / "seq.npy"), cache_file="")
+    with pytest.raises(ValueError, match="allow_pickle"):
+        vid.VIDDataset(preproc=None, lframe=2, gframe=2, val=True, tnum=-1, **kw_npy)
+    assert len(vid.VIDDataset(preproc=None, lframe=2, gframe=2, val=True, tnum=-1, allow_pickle=True, **kw_npy).res) == 6
+    with open(tmp_path / "ref" / "seq.json", "w") as fh:
+        json.dump(videos, fh)
+    assert len(vid.VIDDataset(preproc=None, lframe=2, gframe=2, val=True, tnum=-1, **kw_npy).res) == 6

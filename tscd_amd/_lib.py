@@ -48,7 +48,7 @@ SIGNATURES = {
     "tscd_se_fuse_bwd_f16": [P, I, P, I, P, P, P, L, I, P, P, P, P, P, P],
     "tscd_add_layernorm_bwd_f16": [P, P, P, P, I, I, F, P, P, P, P],
     "tscd_row_normalize_f16": [P, I, I, I, I, F, P, I, P],
-    "tscd_batched_nms": [P, I, P, I, P, P, P, I, F, F, I, I, P, L, P, P, P, P, P],
+    "tscd_batched_nms": [P, I, P, I, P, P, P, I, F, F, I, I, I, I, P, L, P, P, P, P],
     "tscd_conv_wgrad_nhwc_f16": [P, P, P, I, I, I, I, I, I, I, I, P, L, P],
     "tscd_bn_silu_bwd_f16": [P, P, P, P, P, P, L, I, P, P, P, L, P],
     "tscd_bias_relu_bwd_f16": [P, I, P, I, P, I, L, I, P, P, L, P],
@@ -58,6 +58,7 @@ SIGNATURES = {
     "tscd_simota_assign_r": [P, P, I, I, I, I, I, P, P, P, I, I, F, P, L, P, P, P, P, P, P],
     "tscd_loss_dense_f16": [P, P, P, P, P, P, I, I, I, I, P, L, P, P, P],
     "tscd_loss_combine_f32": [P, P, P, P, P, I, I, P, P, P],
+    "tscd_scale_grad_f16": [P, P, I, I, I, L, I, I, P, P],
     "tscd_loss_dense_reg_f16": [P, P, P, P, P, P, I, I, I, I, P, P, P, L, P, P, P, P],
     "tscd_loss_rows_f16": [P, P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, L, P, P, P, P, P],
 }
@@ -65,7 +66,7 @@ PLAIN = {"tscd_ema_chunk_elems": ([], I), "tscd_pack_block_elems": ([], I), "tsc
          "tscd_bn_silu_bwd_workspace_bytes": ([L, I], L), "tscd_linear_bwd_workspace_bytes": ([I, I, I], L),
          "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
          "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),
-         "tscd_nms_workspace_bytes": ([I, I], L), "tscd_simota_workspace_bytes": ([I, I, I, I], L), "tscd_loss_workspace_bytes": ([L, L, L], L),
+         "tscd_nms_workspace_bytes": ([I, I, I, I], L), "tscd_simota_workspace_bytes": ([I, I, I, I], L), "tscd_loss_workspace_bytes": ([L, L, L], L),
          "tscd_conv_set_variant": ([I], None), "tscd_conv_set_korder": ([I], None), "tscd_conv_set_halo_auto": ([I], None), "tscd_conv_set_tile_m": ([I], I), "tscd_conv_stat_tiles": ([L, I, I, I, I, I], I), "tscd_conv_wgrad_set_variant": ([I], I), "tscd_conv_set_debug": ([I], None), "tscd_cos_attn_mfma_supported": ([I], I), "tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
          "tscd_last_error": ([], C.c_char_p)}
 

@@ -288,3 +288,31 @@ extern "C" int tscd_loss_combine_f32(const float* dense, const float* rows, cons
   TSCD_CHECK_LAUNCH("loss_combine");
   return TSCD_OK;
 }
+
+// Backward of the fused losses: out[r][pad + c] = fp16( float(d[r][c]) * g[c < split ? i0 : i1] ), columns [0, pad) zero.
+// The upstream scalars g (fp32, on the device) are loss_scale * weight / num_fg: the PRODUCT is formed in fp32 and rounded once,
+// as the reference's autograd does -- casting g to fp16 first overflows at GradScaler's initial 65536 once num_fg <= 6
+// (tscd_head.py:1157-1203 normalises by the foreground counts).  One launch instead of cat / cast / multiply / pad.
+__global__ __launch_bounds__(256) void scale_grad_kernel(const f16* __restrict__ d, const float* __restrict__ g, int i0, int i1, int split,
+                                                        long rows, int C, int pad, f16* __restrict__ out) {
+  const int CO = C + pad;
+  const long total = rows * CO;
+  const float g0 = g[i0], g1 = g[i1];
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long r = idx / CO;
+    const int c = (int)(idx - r * CO) - pad;
+    out[idx] = c < 0 ? (f16)0.f : (f16)((float)d[r * C + c] * (c < split ? g0 : g1));
+  }
+}
+
+extern "C" int tscd_scale_grad_f16(const void* d, const float* g, int i0, int i1, int split, long rows, int C, int pad, void* out,
+                                   void* stream) {
+  TSCD_CHECK_ARG(d && g && out && rows >= 0 && C > 0 && pad >= 0 && i0 >= 0 && i1 >= 0, "scale_grad: bad arguments");
+  if (rows == 0) return TSCD_OK;
+  const long total = rows * (C + pad);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(scale_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)d, g, i0, i1, split, rows, C, pad,
+                     (f16*)out);
+  TSCD_CHECK_LAUNCH("scale_grad");
+  return TSCD_OK;
+}

@@ -5,18 +5,29 @@
 //                sig(refined cls); every (proposal, class) with score >= thr and obj*score >= thr becomes a
 //                candidate (row-major order, as torch.where).  Mode 1 builds the "original detections" set instead
 //                (one candidate per proposal: class = argmax id, score = obj * cls_conf).
-//   nms_sort     one workgroup per frame: bitonic sort by (score desc, candidate index asc) -- torchvision visits boxes in
-//                decreasing score order; <= 16384 candidates entirely in LDS, up to 65536 with global-memory cross-chunk steps.
+//   nms_sort     bitonic sort by (score desc, candidate index asc) -- torchvision visits boxes in decreasing score order.  Up to
+//                65536 candidates per frame: one workgroup per frame, 32-bit keys, <= 16384 entirely in LDS, beyond that with
+//                global-memory cross-chunk steps.  More (the ImageNet-VID exp sets no upper proposal clamp: up to A anchors x 30
+//                classes = 204 120 candidates at 576^2, post_process.py:9-85 takes whatever arrives): 64-bit keys in global memory,
+//                the same network spread over many workgroups -- chunk-local stages in LDS, cross-chunk strides one launch each.
 //   nms_greedy   one workgroup per (frame, class): class-aware NMS == independent greedy NMS per class (what the
-//                coordinate-offset trick of batched_nms implements); <= 2048 boxes of the class are pulled from the
-//                sorted list into LDS and suppressed greedily with IoU > thr (fp32 arithmetic).
+//                coordinate-offset trick of batched_nms implements).  The class's boxes are pulled from the sorted list into an
+//                LDS tile of 2048 and suppressed greedily with IoU > thr (fp32 arithmetic); a class with more boxes runs tile by
+//                tile (blocked greedy NMS: a tile is first suppressed by the boxes kept in earlier tiles -- a global list of at
+//                most max_rows boxes per (frame, class), since a proposal gives a class at most one candidate -- then within
+//                itself): the same keep set as the one-tile pass, no capacity limit.
+//                coord_trick = n > 0: the reference-faithful arithmetic of torchvision.ops.batched_nms on fp16 boxes for frames
+//                with at most n candidates -- every box is shifted by fp16(class id) * fp16(max coordinate + 1) and rounded to
+//                fp16 before the IoUs (boxes of the high class ids quantise to 4-8 px; tests/test_deviation_bounds.py) --
+//                instead of exact per-class suppression (torchvision itself switches to per-class NMS without offsets above
+//                5000 boxes on a GPU: n = 5000 reproduces that rule, 0 = never, INT_MAX = always).
 //   nms_compact  ordered compaction of the survivors -> [k,7] rows (x1,y1,x2,y2,obj,cls_score,cls_id) in decreasing
 //                score order, plus the kept candidate indices (INT output) and the count.
 // torchvision is absent from the reference tree, so NMS parity is pinned by oracle/nms_ref.py's restatement only.
 #include "common.h"
 
-#define NMS_MAXC 65536    // candidates per frame (16-bit index field of the sort key)
-#define NMS_MAXPC 2048    // boxes per (frame, class)
+#define NMS_MAXC32 65536  // candidates per frame the 32-bit sort key can index (16-bit index field); more: 64-bit keys
+#define NMS_MAXPC 2048    // boxes per (frame, class) in one LDS tile of the greedy pass
 
 // ---- candidate record arrays, all [L][capM] -------------------------------------------------------------
 struct Cand {
@@ -25,6 +36,7 @@ struct Cand {
   f16* aux;        // [L][capM][3]: obj, cls_score, cls_id  (fp16 values of the output row)
   int* cls;        // class id
   int* count;      // [L]
+  float* maxc;     // [L] largest coordinate among the frame's candidates (the coordinate trick's offset unit)
 };
 
 __device__ __forceinline__ f16 hs(f16 x) { return (f16)(1.0f / (1.0f + expf(-(float)x))); }
@@ -42,6 +54,7 @@ __global__ __launch_bounds__(256) void nms_expand_kernel(const f16* __restrict__
   const f16 thr16 = (f16)thr;
   if (tid == 0) base = 0;
   __syncthreads();
+  float cmax = -INFINITY;
   const int per_row = mode == 0 ? NC : 1;          // modes 1 / 2: one candidate per row (class = arg-max id)
   const long total = (long)n * per_row;
   for (long i0 = 0; i0 < total; i0 += 256) {
@@ -94,6 +107,7 @@ __global__ __launch_bounds__(256) void nms_expand_kernel(const f16* __restrict__
         long o = (long)f * capM + pos;
         c.box[o * 4 + 0] = bx[0]; c.box[o * 4 + 1] = bx[1]; c.box[o * 4 + 2] = bx[2]; c.box[o * 4 + 3] = bx[3];
         c.score[o] = sc;
+        cmax = fmaxf(cmax, fmaxf(fmaxf(bx[0], bx[1]), fmaxf(bx[2], bx[3])));
         c.aux[o * 3 + 0] = a_obj; c.aux[o * 3 + 1] = a_cs; c.aux[o * 3 + 2] = (f16)(float)cid;
         c.cls[o] = mode == 2 ? 0 : cid;            // mode 2: class-agnostic suppression (utils/boxes.py:59-64), the row keeps its class
       }
@@ -102,7 +116,14 @@ __global__ __launch_bounds__(256) void nms_expand_kernel(const f16* __restrict__
     if (tid == 0) base += tot;
     __syncthreads();
   }
-  if (tid == 0) c.count[f] = base < capM ? base : capM;
+  cmax = wave_max(cmax);
+  __syncthreads();
+  if (lane == 0) wsum[wv] = __float_as_int(cmax);
+  __syncthreads();
+  if (tid == 0) {
+    c.count[f] = base < capM ? base : capM;
+    c.maxc[f] = fmaxf(fmaxf(__int_as_float(wsum[0]), __int_as_float(wsum[1])), fmaxf(__int_as_float(wsum[2]), __int_as_float(wsum[3])));
+  }
 }
 
 // Bitonic sort of (score desc, index asc) keys.  Scores are fp16-representable and non-negative, so their fp16 bit pattern
@@ -110,8 +131,8 @@ __global__ __launch_bounds__(256) void nms_expand_kernel(const f16* __restrict__
 // sorted entirely in LDS (64 KiB).  Frames with more (the ImageNet-VID exp has no upper proposal clamp: 2000 proposals x 30
 // classes = 60000 candidates) keep their keys in a global workspace: compare-exchange steps whose stride reaches across
 // 16384-key chunks run on global memory (L2-resident, <= 256 KiB per frame), every run of smaller strides is done chunk by
-// chunk in LDS.  Same network, same keys => the same order as the single-chunk sort.  Limit: 65536 candidates per frame (the
-// index field of the key).
+// chunk in LDS.  Same network, same keys => the same order as the single-chunk sort.  This 32-bit form indexes 65536 candidates per
+// frame (the index field of the key); larger frames take the 64-bit form below.
 #define NMS_CHUNK 16384
 __device__ __forceinline__ void bitonic_lds_steps(unsigned int* keys, int base, int n, int size, int first_stride, int tid) {
   // strides first_stride .. 1 of the merge of width `size`, for the n keys (n a power of two <= NMS_CHUNK) at global offset `base`
@@ -175,21 +196,168 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
   for (int i = tid; i < M; i += 1024) order[(long)f * capM + i] = (int)(0xFFFFu - (gk[i] & 0xFFFFu));
 }
 
-// Greedy NMS for one (frame, class).  keep[f][sorted position] = 1 for survivors.
+// ---- 64-bit-key sort for frames with more than 65536 candidates: key = fp16 score bits << 32 | (0xFFFFFFFF - index), larger first.
+// Keys live in global memory [L][P] (P = capM rounded up to a power of two); frame f only sorts its first Pf = pow2(count[f]) keys
+// (stages of a width above Pf are skipped for it), so the work follows the survivors of the score filter, not the capacity.
+#define NMS_CH64 8192       // keys per LDS chunk (64 KiB)
+__device__ __forceinline__ int nms_pow2_dev(int m) {
+  int P = 1;
+  while (P < m) P <<= 1;
+  return P;
+}
+__device__ __forceinline__ void bitonic64_lds_steps(unsigned long long* keys, int base, int size, int first_stride, int tid) {
+  for (int stride = first_stride; stride > 0; stride >>= 1) {
+    for (int i = tid; i < (NMS_CH64 >> 1); i += 1024) {
+      int lo = (i / stride) * (stride << 1) + (i % stride), hi = lo + stride;
+      bool desc = (((base + lo) & size) == 0);
+      unsigned long long a = keys[lo], b = keys[hi];
+      if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+    }
+    __syncthreads();
+  }
+}
+// stage 0: build the keys of one chunk and run every merge that stays inside it (widths 2 .. NMS_CH64)
+__global__ __launch_bounds__(1024) void nms_sort64_local_kernel(const float* __restrict__ score, const int* __restrict__ count, int capM,
+                                                               unsigned long long* __restrict__ gkeys, int P) {
+  extern __shared__ unsigned long long keys64[];
+  const int f = blockIdx.y, c0 = blockIdx.x * NMS_CH64, tid = threadIdx.x;
+  const int M = count[f];
+  if (c0 >= nms_pow2_dev(M) && c0 > 0) return;
+  for (int i = tid; i < NMS_CH64; i += 1024) {
+    const int g = c0 + i;
+    unsigned long long k = 0ull;
+    if (g < M) {
+      f16 h = (f16)score[(long)f * capM + g];
+      k = ((unsigned long long)__builtin_bit_cast(unsigned short, h) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)g);
+    }
+    keys64[i] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= NMS_CH64; size <<= 1) bitonic64_lds_steps(keys64, c0, size, size >> 1, tid);
+  unsigned long long* gk = gkeys + (long)f * P;
+  for (int i = tid; i < NMS_CH64; i += 1024) gk[c0 + i] = keys64[i];
+}
+// one cross-chunk compare-exchange stride of the merge of width `size`
+__global__ __launch_bounds__(256) void nms_sort64_global_kernel(const int* __restrict__ count, unsigned long long* __restrict__ gkeys, int P,
+                                                               int size, int stride) {
+  const int f = blockIdx.y;
+  const int Pf = nms_pow2_dev(count[f]);
+  if (size > Pf) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (Pf >> 1)) return;
+  unsigned long long* gk = gkeys + (long)f * P;
+  const int lo = (i / stride) * (stride << 1) + (i % stride), hi = lo + stride;
+  const bool desc = ((lo & size) == 0);
+  unsigned long long a = gk[lo], b = gk[hi];
+  if ((a < b) == desc) { gk[lo] = b; gk[hi] = a; }
+}
+// the strides below a chunk of the merge of width `size`, chunk by chunk in LDS
+__global__ __launch_bounds__(1024) void nms_sort64_merge_kernel(const int* __restrict__ count, unsigned long long* __restrict__ gkeys, int P,
+                                                               int size) {
+  extern __shared__ unsigned long long keys64[];
+  const int f = blockIdx.y, c0 = blockIdx.x * NMS_CH64, tid = threadIdx.x;
+  const int Pf = nms_pow2_dev(count[f]);
+  if (size > Pf || c0 >= Pf) return;
+  unsigned long long* gk = gkeys + (long)f * P;
+  for (int i = tid; i < NMS_CH64; i += 1024) keys64[i] = gk[c0 + i];
+  __syncthreads();
+  bitonic64_lds_steps(keys64, c0, size, NMS_CH64 >> 1, tid);
+  for (int i = tid; i < NMS_CH64; i += 1024) gk[c0 + i] = keys64[i];
+}
+__global__ __launch_bounds__(256) void nms_sort64_order_kernel(const int* __restrict__ count, const unsigned long long* __restrict__ gkeys,
+                                                              int P, int capM, int* __restrict__ order) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i < count[f]) order[(long)f * capM + i] = (int)(0xFFFFFFFFu - (unsigned)(gkeys[(long)f * P + i] & 0xFFFFFFFFull));
+}
+
+// Greedy NMS for one (frame, class), tile by tile.  keep[f][sorted position] = 1 for survivors.
+// kept_box [L][NCg][max_rows][4]: the boxes this (frame, class) has kept so far (only touched when the class overflows one tile).
 __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict__ box, const int* __restrict__ cls,
                                                         const int* __restrict__ order, const int* __restrict__ count, int capM,
-                                                        float iou_thr, unsigned char* __restrict__ keep, int* __restrict__ overflow) {
+                                                        float iou_thr, unsigned char* __restrict__ keep, float* __restrict__ kept_box,
+                                                        int max_rows, const float* __restrict__ maxc, int coord_trick) {
   __shared__ float bx[NMS_MAXPC][4];
   __shared__ int pos[NMS_MAXPC];
   __shared__ unsigned char dead[NMS_MAXPC];
   __shared__ int wsum[4];
-  __shared__ int base;
+  __shared__ int base, nkept_s;
   const int f = blockIdx.x, cid = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = count[f];
-  if (tid == 0) base = 0;
+  float* kb = kept_box ? kept_box + ((long)f * gridDim.y + cid) * max_rows * 4 : nullptr;
+  // coordinate trick (torchvision.ops.batched_nms on the evaluator's fp16 tensors): offset = fp16(class id) * fp16(max + 1)
+  const bool trick = coord_trick > 0 && M <= coord_trick;
+  float off_c = 0.f;
+  if (trick) off_c = (float)(f16)((float)(f16)(float)cid * (float)(f16)((float)(f16)maxc[f] + 1.0f));
+  if (tid == 0) { base = 0; nkept_s = 0; }
   __syncthreads();
-  // pull this class' boxes out of the score-sorted list, preserving order
+  // one tile: suppress by the boxes kept in earlier tiles, greedy inside the tile, publish the survivors
+  auto process_tile = [&](int n, bool more) {
+    const int nk = nkept_s;
+    if (nk > 0) {
+      for (int j = tid; j < n; j += 256) {
+        const float x1 = bx[j][0], y1 = bx[j][1], x2 = bx[j][2], y2 = bx[j][3];
+        const float aj = (x2 - x1) * (y2 - y1);
+        bool d = false;
+        for (int k = 0; k < nk && !d; ++k) {
+          const float kx1 = kb[k * 4 + 0], ky1 = kb[k * 4 + 1], kx2 = kb[k * 4 + 2], ky2 = kb[k * 4 + 3];
+          float iw = fmaxf(fminf(kx2, x2) - fmaxf(kx1, x1), 0.f);
+          float ih = fmaxf(fminf(ky2, y2) - fmaxf(ky1, y1), 0.f);
+          float inter = iw * ih;
+          float ai = (kx2 - kx1) * (ky2 - ky1);
+          float iou = inter / (ai + aj - inter);
+          d = iou > iou_thr;
+        }
+        if (d) dead[j] = 1;
+      }
+      __syncthreads();
+    }
+    for (int i = 0; i < n; ++i) {
+      if (dead[i]) continue;   // uniform: read after the barrier of the previous iteration
+      const float x1 = bx[i][0], y1 = bx[i][1], x2 = bx[i][2], y2 = bx[i][3];
+      const float ai = (x2 - x1) * (y2 - y1);
+      for (int j = i + 1 + tid; j < n; j += 256) {
+        if (dead[j]) continue;
+        float iw = fmaxf(fminf(x2, bx[j][2]) - fmaxf(x1, bx[j][0]), 0.f);
+        float ih = fmaxf(fminf(y2, bx[j][3]) - fmaxf(y1, bx[j][1]), 0.f);
+        float inter = iw * ih;
+        float aj = (bx[j][2] - bx[j][0]) * (bx[j][3] - bx[j][1]);
+        float iou = inter / (ai + aj - inter);
+        if (iou > iou_thr) dead[j] = 1;
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) keep[(long)f * capM + pos[i]] = dead[i] ? 0 : 1;
+    if (more && kb) {
+      // append the tile's survivors to the kept list (their order does not matter to later tiles: any kept box suppresses)
+      for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const bool k = i < n && !dead[i];
+        unsigned long long m = __ballot(k);
+        int before = __popcll(m & ((1ull << lane) - 1));
+        if (lane == 0) wsum[wv] = __popcll(m);
+        __syncthreads();
+        int off = nkept_s;
+        for (int w = 0; w < wv; ++w) off += wsum[w];
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (k && off + before < max_rows) {
+          float* d = kb + (long)(off + before) * 4;
+          d[0] = bx[i][0]; d[1] = bx[i][1]; d[2] = bx[i][2]; d[3] = bx[i][3];
+        }
+        __syncthreads();
+        if (tid == 0) nkept_s += tot;
+        __syncthreads();
+      }
+      __threadfence_block();
+    }
+    __syncthreads();
+  };
+  // pull this class' boxes out of the score-sorted list, preserving order; a full tile is processed before the pull goes on
   for (int i0 = 0; i0 < M; i0 += 256) {
+    if (base > NMS_MAXPC - 256) {            // uniform (shared): the next 256 candidates might not fit
+      process_tile(base, true);
+      if (tid == 0) base = 0;
+      __syncthreads();
+    }
     int i = i0 + tid;
     int src = i < M ? order[(long)f * capM + i] : 0;
     bool mine = i < M && cls[(long)f * capM + src] == cid;
@@ -200,10 +368,15 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
     int off = base;
     for (int w = 0; w < wv; ++w) off += wsum[w];
     int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (mine && off + before < NMS_MAXPC) {
+    if (mine) {
       int p = off + before;
       const float* b = box + ((long)f * capM + src) * 4;
-      bx[p][0] = b[0]; bx[p][1] = b[1]; bx[p][2] = b[2]; bx[p][3] = b[3];
+      if (trick) {
+        bx[p][0] = (float)(f16)(b[0] + off_c); bx[p][1] = (float)(f16)(b[1] + off_c);
+        bx[p][2] = (float)(f16)(b[2] + off_c); bx[p][3] = (float)(f16)(b[3] + off_c);
+      } else {
+        bx[p][0] = b[0]; bx[p][1] = b[1]; bx[p][2] = b[2]; bx[p][3] = b[3];
+      }
       pos[p] = i;
       dead[p] = 0;
     }
@@ -211,27 +384,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
     if (tid == 0) base += tot;
     __syncthreads();
   }
-  int n = base;
-  if (n > NMS_MAXPC) {
-    if (tid == 0) atomicAdd(overflow, 1);
-    n = NMS_MAXPC;
-  }
-  for (int i = 0; i < n; ++i) {
-    if (dead[i]) continue;   // uniform: read after the barrier of the previous iteration
-    const float x1 = bx[i][0], y1 = bx[i][1], x2 = bx[i][2], y2 = bx[i][3];
-    const float ai = (x2 - x1) * (y2 - y1);
-    for (int j = i + 1 + tid; j < n; j += 256) {
-      if (dead[j]) continue;
-      float iw = fmaxf(fminf(x2, bx[j][2]) - fmaxf(x1, bx[j][0]), 0.f);
-      float ih = fmaxf(fminf(y2, bx[j][3]) - fmaxf(y1, bx[j][1]), 0.f);
-      float inter = iw * ih;
-      float aj = (bx[j][2] - bx[j][0]) * (bx[j][3] - bx[j][1]);
-      float iou = inter / (ai + aj - inter);
-      if (iou > iou_thr) dead[j] = 1;
-    }
-    __syncthreads();
-  }
-  for (int i = tid; i < n; i += 256) keep[(long)f * capM + pos[i]] = dead[i] ? 0 : 1;
+  process_tile(base, false);
 }
 
 __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restrict__ box, const f16* __restrict__ aux,
@@ -274,26 +427,36 @@ static int nms_pow2(int capM) {
   while (P < capM) P <<= 1;
   return P;
 }
+static int nms_pow2_64(int capM) {
+  int P = nms_pow2(capM);
+  return P < NMS_CH64 ? NMS_CH64 : P;
+}
 
-extern "C" long tscd_nms_workspace_bytes(int L, int capM) {
-  long per = (long)capM * (16 + 4 + 6 + 4 + 4 + 1) + 64 + 7 * 256;
-  if (capM > NMS_CHUNK) per += 4L * nms_pow2(capM);        // global sort keys of frames with more than one LDS chunk
-  return (long)L * per + 4096;
+// max_rows: the largest number of detection rows (proposals) in one frame -- a class of a frame has at most that many boxes; the
+// kept-box lists of the tiled greedy pass are only reserved when it exceeds one tile.
+extern "C" long tscd_nms_workspace_bytes(int L, int capM, int NC, int max_rows) {
+  long per = (long)capM * (16 + 4 + 6 + 4 + 4 + 1) + 64 + 8 * 256;
+  if (capM > NMS_MAXC32) per += 8L * nms_pow2_64(capM) + 256;   // 64-bit sort keys
+  else if (capM > NMS_CHUNK) per += 4L * nms_pow2(capM) + 256;  // global 32-bit sort keys of frames with more than one LDS chunk
+  if (max_rows > NMS_MAXPC) per += 16L * (NC > 0 ? NC : 1) * max_rows + 256;
+  return (long)L * per + 8192;
 }
 
 // det [N,ndet] rows of the local frames (pred_result), frame_off [L+1] row offsets.
 // mode 0: refined set (needs cls_logit [N,NC], obj_logit [N], reg_delta [N,4]); mode 1: original detections (one candidate per
 // row, class-aware); mode 2: the same with class-agnostic suppression (YOLOX demo postprocess).
+// coord_trick = n > 0: frames with at most n candidates are suppressed on boxes shifted by fp16(class) * fp16(max + 1) and rounded
+// to fp16 (torchvision.ops.batched_nms on the evaluator's fp16 tensors, post_process.py:58-63) instead of exactly per class.
 // out [L][capM][7] fp16, out_idx [L][capM] (kept candidate index = row*NC + class in mode 0, row in mode 1),
-// out_count [L].  Returns TSCD_ERR_ARG if a frame exceeds the LDS sort capacity.
+// out_count [L].  No capacity limits: capM is whatever the caller sized the outputs for (rows x classes in mode 0).
 extern "C" int tscd_batched_nms(const void* det, int ndet, const int* frame_off, int L, const void* cls_logit,
                                 const void* obj_logit, const void* reg_delta, int NC, float conf_thresh, float iou_thresh,
-                                int capM, int mode, void* workspace, long workspace_bytes, void* out, int* out_idx,
-                                int* out_count, int* overflow_flag, void* stream) {
-  TSCD_CHECK_ARG(det && frame_off && workspace && out && out_idx && out_count && overflow_flag, "batched_nms: null pointer");
+                                int capM, int max_rows, int mode, int coord_trick, void* workspace, long workspace_bytes, void* out,
+                                int* out_idx, int* out_count, void* stream) {
+  TSCD_CHECK_ARG(det && frame_off && workspace && out && out_idx && out_count, "batched_nms: null pointer");
   TSCD_CHECK_ARG(mode == 1 || mode == 2 || (cls_logit && obj_logit && reg_delta), "batched_nms: mode 0 needs refined predictions");
-  TSCD_CHECK_ARG(capM > 0 && capM <= NMS_MAXC, "batched_nms: capM=%d exceeds the %d candidates per frame the sort key can index", capM, NMS_MAXC);
-  TSCD_CHECK_ARG(workspace_bytes >= tscd_nms_workspace_bytes(L, capM), "batched_nms: workspace too small");
+  TSCD_CHECK_ARG(capM > 0 && max_rows > 0 && NC > 0, "batched_nms: capM=%d max_rows=%d NC=%d", capM, max_rows, NC);
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_nms_workspace_bytes(L, capM, NC, max_rows), "batched_nms: workspace too small");
   if (L == 0) return TSCD_OK;
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
@@ -304,19 +467,42 @@ extern "C" int tscd_batched_nms(const void* det, int ndet, const int* frame_off,
   c.aux = (f16*)take(6L * L * capM);
   c.cls = (int*)take(4L * L * capM);
   c.count = (int*)take(4L * L);
+  c.maxc = (float*)take(4L * L);
   int* order = (int*)take(4L * L * capM);
   unsigned char* keep = (unsigned char*)take((long)L * capM);
   (void)hipMemsetAsync(keep, 0, (long)L * capM, st);
   hipLaunchKernelGGL(nms_expand_kernel, dim3(L), dim3(256), 0, st, (const f16*)det, ndet, frame_off, (const f16*)cls_logit,
                      (const f16*)obj_logit, (const f16*)reg_delta, NC, conf_thresh, capM, mode, logf(736.0f / 32.0f), c);
   TSCD_CHECK_LAUNCH("nms_expand");
-  const int P = nms_pow2(capM);
-  unsigned int* gkeys = capM > NMS_CHUNK ? (unsigned int*)take(4L * L * P) : nullptr;
-  hipLaunchKernelGGL(nms_sort_kernel, dim3(L), dim3(1024), (size_t)(P < NMS_CHUNK ? P : NMS_CHUNK) * 4, st, c.score, c.count, capM,
-                     gkeys, P, order);
-  TSCD_CHECK_LAUNCH("nms_sort");
-  hipLaunchKernelGGL(nms_greedy_kernel, dim3(L, mode == 2 ? 1 : NC), dim3(256), 0, st, c.box, c.cls, order, c.count, capM, iou_thresh, keep,
-                     overflow_flag);
+  if (capM <= NMS_MAXC32) {
+    const int P = nms_pow2(capM);
+    unsigned int* gkeys = capM > NMS_CHUNK ? (unsigned int*)take(4L * L * P) : nullptr;
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(L), dim3(1024), (size_t)(P < NMS_CHUNK ? P : NMS_CHUNK) * 4, st, c.score, c.count, capM,
+                       gkeys, P, order);
+    TSCD_CHECK_LAUNCH("nms_sort");
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {       // 64 KiB of dynamic LDS per workgroup
+      (void)hipFuncSetAttribute((const void*)nms_sort64_local_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_CH64 * 8);
+      (void)hipFuncSetAttribute((const void*)nms_sort64_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_CH64 * 8);
+      attr_set = true;
+    }
+    const int P = nms_pow2_64(capM);
+    unsigned long long* gkeys = (unsigned long long*)take(8L * L * P);
+    const int nch = P / NMS_CH64;
+    hipLaunchKernelGGL(nms_sort64_local_kernel, dim3(nch, L), dim3(1024), (size_t)NMS_CH64 * 8, st, c.score, c.count, capM, gkeys, P);
+    for (int size = 2 * NMS_CH64; size <= P; size <<= 1) {
+      for (int stride = size >> 1; stride >= NMS_CH64; stride >>= 1)
+        hipLaunchKernelGGL(nms_sort64_global_kernel, dim3(P / 2 / 256, L), dim3(256), 0, st, c.count, gkeys, P, size, stride);
+      hipLaunchKernelGGL(nms_sort64_merge_kernel, dim3(nch, L), dim3(1024), (size_t)NMS_CH64 * 8, st, c.count, gkeys, P, size);
+    }
+    hipLaunchKernelGGL(nms_sort64_order_kernel, dim3(cdiv(capM, 256), L), dim3(256), 0, st, c.count, gkeys, P, capM, order);
+    TSCD_CHECK_LAUNCH("nms_sort64");
+  }
+  const int ncg = mode == 2 ? 1 : NC;
+  float* kept_box = max_rows > NMS_MAXPC ? (float*)take(16L * L * ncg * max_rows) : nullptr;
+  hipLaunchKernelGGL(nms_greedy_kernel, dim3(L, ncg), dim3(256), 0, st, c.box, c.cls, order, c.count, capM, iou_thresh, keep, kept_box,
+                     max_rows, c.maxc, coord_trick);
   TSCD_CHECK_LAUNCH("nms_greedy");
   hipLaunchKernelGGL(nms_compact_kernel, dim3(L), dim3(256), 0, st, c.box, c.aux, order, keep, c.count, capM, (f16*)out,
                      out_idx, out_count);

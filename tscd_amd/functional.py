@@ -244,10 +244,12 @@ class _DenseLoss(torch.autograd.Function):
         nc = ctx.nc
         # channel 0 (objectness) scales with d sums[1], channels 1.. (classes) with d sums[2]; the 4 box channels get the IoU-loss
         # gradient (d sums[0]) when the box branch trains (geo given), none otherwise
-        gv = torch.cat((g[1:2], g[2:3].expand(nc))).to(torch.float16)
+        # (the products are formed in fp32 and rounded once -- ops.scale_grad: g = loss scale x weight / num_fg overflows fp16 by itself
+        # at GradScaler's initial 65536 with a handful of foreground anchors, the product does not)
+        g = g.float().contiguous()
         if d_reg is None:
-            return torch.nn.functional.pad(d * gv, (4, 0)), None, None, None, None, None, None, None
-        return torch.cat((d_reg * g[0].to(torch.float16), d * gv), dim=-1), None, None, None, None, None, None, None
+            return ops.scale_grad(d, g, 1, 2, split=1, pad=4), None, None, None, None, None, None, None
+        return torch.cat((ops.scale_grad(d_reg, g, 0), ops.scale_grad(d, g, 1, 2, split=1)), dim=-1), None, None, None, None, None, None, None
 
 
 def dense_loss(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_classes, geo=None):
@@ -271,8 +273,8 @@ class _RowLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         d_cls, d_obj, d_reg = ctx.saved_tensors
-        gh = g.to(torch.float16)
-        out = [None if d is None else (d * gh[i]).reshape(shp) for i, (d, shp) in enumerate(zip((d_cls, d_obj, d_reg), ctx.shapes))]
+        g = g.float().contiguous()          # product in fp32, rounded once (see _DenseLoss.backward)
+        out = [None if d is None else ops.scale_grad(d, g, i).reshape(shp) for i, (d, shp) in enumerate(zip((d_cls, d_obj, d_reg), ctx.shapes))]
         return (out[0], out[1], out[2]) + (None,) * 9
 
 

@@ -827,19 +827,20 @@ def match_cost(ref_reg, cur_reg, ref_cls, cur_cls):
 # NMS / SimOTA
 # ----------------------------------------------------------------------------------------------------
 def batched_nms(det, frame_off, L, num_classes, conf_thresh, iou_thresh, cap_m, mode, cls_logit=None, obj_logit=None,
-                reg_delta=None):
-    """-> (rows [L,capM,7] fp16, keep_idx [L,capM] int32, count [L] int32, overflow [1] int32)."""
+                reg_delta=None, max_rows=None, coord_trick=0):
+    """-> (rows [L,capM,7] fp16, keep_idx [L,capM] int32, count [L] int32).  ``max_rows``: the largest number of det rows of one
+    frame (default: all of them); ``coord_trick`` = n: torchvision's fp16 coordinate-offset arithmetic for frames with <= n candidates."""
     dev = det.device
-    ws_bytes = lib.tscd_nms_workspace_bytes(L, cap_m)
+    max_rows = int(max_rows) if max_rows else max(int(det.shape[0]), 1)
+    ws_bytes = lib.tscd_nms_workspace_bytes(L, cap_m, num_classes, max_rows)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     out = torch.empty((L, cap_m, 7), dtype=torch.float16, device=dev)
     idx = torch.empty((L, cap_m), dtype=torch.int32, device=dev)
     cnt = torch.zeros((L,), dtype=torch.int32, device=dev)
-    ovf = torch.zeros((1,), dtype=torch.int32, device=dev)
     call("tscd_batched_nms", det.data_ptr(), det.shape[1], frame_off.data_ptr(), L, _ptr(cls_logit), _ptr(obj_logit),
-         _ptr(reg_delta), num_classes, float(conf_thresh), float(iou_thresh), cap_m, mode, ws.data_ptr(), ws_bytes,
-         out.data_ptr(), idx.data_ptr(), cnt.data_ptr(), ovf.data_ptr(), _stream())
-    return out, idx, cnt, ovf
+         _ptr(reg_delta), num_classes, float(conf_thresh), float(iou_thresh), cap_m, max_rows, mode, int(coord_trick), ws.data_ptr(),
+         ws_bytes, out.data_ptr(), idx.data_ptr(), cnt.data_ptr(), _stream())
+    return out, idx, cnt
 
 
 def simota_assign(outputs, labels, geo, num_classes, max_gt, topk=10, emu16=True, center_radius=4.5):
@@ -911,6 +912,19 @@ def loss_rows(row_b, row_a, A, num_classes, fg_mask, matched_gt, pred_iou, label
          matched_gt.data_ptr(), pred_iou.data_ptr(), labels.data_ptr(), _ptr(cls_logit), _ptr(obj_logit), _ptr(reg_delta), _ptr(base), ndet,
          part, ws.data_ptr(), ws_bytes, sums.data_ptr(), _ptr(d_cls), _ptr(d_obj), _ptr(d_reg), _stream())
     return sums, d_cls, d_obj, d_reg
+
+
+def scale_grad(d, g, i0, i1=None, split=0, pad=0):
+    """Backward of a fused loss: fp16(d.float() * g[i]) in ONE launch (product in fp32, rounded once: g = loss scale x weight / num_fg
+    overflows fp16 on its own at GradScaler's initial scale).  d fp16 [..., C] contiguous; g fp32 device vector; columns < split take
+    g[i0], the others g[i1]; ``pad`` zero columns are put in front."""
+    assert d.is_contiguous() and d.dtype == torch.float16 and g.dtype == torch.float32 and g.is_contiguous()
+    C = d.shape[-1] if d.dim() > 1 else 1
+    rows = d.numel() // C
+    out = torch.empty(d.shape[:-1] + (C + pad,) if d.dim() > 1 else d.shape, dtype=torch.float16, device=d.device)
+    i1 = i0 if i1 is None else i1
+    call("tscd_scale_grad_f16", d.data_ptr(), g.data_ptr(), i0, i1, split if i1 != i0 else C, rows, C, pad, out.data_ptr(), _stream())
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@ multiscale ``exp.preprocess``, forward, ``GradScaler``-scaled backward, SGD step
 model computes in fp16 inside the HIP kernels, so no autocast context is needed.  DDP: gradients all-reduced over
 RCCL, the parameters that never get a gradient are frozen so the bucket set is static, buffers are not
 broadcast (BN statistics stay per rank until ``all_reduce_norm`` before evaluation, as in the reference)."""
+import collections
 import os
 import time
 
@@ -21,6 +22,8 @@ DEAD_PARAMS = ("transformer_self_attention_layers", "transformer_ffn_layers", "e
 
 
 class Trainer:
+    HISTORY_LEN = 2048
+
     def __init__(self, exp, args, val_loader=None, val=False):
         self.exp, self.args, self.val_loader, self.val = exp, args, val_loader, val
         self.max_epoch = exp.max_epoch
@@ -34,7 +37,9 @@ class Trainer:
         self.best_ap = 0
         self.file_name = os.path.join(exp.output_dir, getattr(args, "experiment_name", None) or exp.exp_name)
         self.lframe, self.gframe = exp.lframe, exp.gframe
-        self.history = []
+        # the last HISTORY_LEN iterations (print / eval intervals read a window of it): bounded, a run of 10^6 iterations keeps
+        # 10^6 dicts of device tensors alive otherwise
+        self.history = collections.deque(maxlen=self.HISTORY_LEN)
         if self.rank == 0:
             os.makedirs(self.file_name, exist_ok=True)
 
@@ -165,7 +170,7 @@ class Trainer:
 
     def history_floats(self, last=None):
         """The recorded iterations (or the last ``last`` of them) with every loss term as a Python float (synchronises)."""
-        rows = self.history if last is None else self.history[-last:]
+        rows = list(self.history) if last is None else list(self.history)[-last:]
         return [{k: (float(v) if torch.is_tensor(v) else v) for k, v in r.items()} for r in rows]
 
     # ------------------------------------------------------------------ eval / checkpoints

@@ -199,23 +199,32 @@ def _pull_raw(ds, file, annos, ret_path):
 
 class VIDDataset(torchDataset):
     """ImageNet-VID sequences (reference: vid.py:48-342).  ``file_path``: a list of videos, each a list of frame paths relative to
-    ``dataset_pth`` (``Data/VID/.../000000.JPEG``) -- the reference's ``.npy`` object array (loaded with ``allow_pickle``: only ever a
-    file the user made with the reference's own tooling) or the same list as ``.json``.  Annotations are the dataset's XML files
+    ``dataset_pth`` (``Data/VID/.../000000.JPEG``) -- the same list as ``.json`` (the documented format; a ``.json`` next to a ``.npy``
+    path is picked up by itself) or the reference's ``.npy`` object array, which can only be read by unpickling and therefore needs
+    ``allow_pickle=True`` (or a one-off ``tools/convert_seq_npy.py``).  Annotations are the dataset's XML files
     (path with ``Data`` -> ``Annotations`` and ``JPEG`` -> ``xml``): boxes clipped to the image, class = index of the WordNet id, scaled by
     the letterbox ratio like the reference; parsed once and kept in ``cache_file`` (json).  ``self.res`` = the clips of
     ``photo_to_sequence``; ``dataset[frame path]`` -> (img, target, (h, w), path) after ``preproc``, or the undecorated frame + kernel
     record for a ``TrainTransformGPU``."""
 
     def __init__(self, file_path="train_seq.npy", img_size=(416, 416), preproc=None, lframe=18, gframe=6, val=False, mode="random",
-                 dataset_pth="", tnum=1000, formal=False, traj_linking=False, local_stride=1, training=False, cache_file=""):
+                 dataset_pth="", tnum=1000, formal=False, traj_linking=False, local_stride=1, training=False, cache_file="",
+                 allow_pickle=False):
         super().__init__()
         self.tnum, self.traj_linking, self.input_dim, self.img_size = tnum, traj_linking, img_size, img_size
         self.file_path, self.mode, self.preproc, self.val, self.formal = file_path, mode, preproc, val, formal
         self.local_stride, self.training, self.dataset_pth, self.cache_file = local_stride, training, dataset_pth, cache_file
+        if not file_path.endswith(".json") and os.path.isfile(os.path.splitext(file_path)[0] + ".json"):
+            file_path = os.path.splitext(file_path)[0] + ".json"          # the converted list next to the reference's .npy wins
         if file_path.endswith(".json"):
             with open(file_path) as fh:
                 videos = json.load(fh)
         else:
+            # the reference's object-array .npy can only be read by unpickling, which executes what the file says: opt-in only
+            # (tools/convert_seq_npy.py turns such a file into .json once)
+            if not allow_pickle:
+                raise ValueError(f"{file_path}: an object-array .npy sequence list needs unpickling; convert it to .json "
+                                 "(tools/convert_seq_npy.py) or pass allow_pickle=True for a file you trust")
             videos = np.load(file_path, allow_pickle=True).tolist()
         videos = [list(v) for v in videos]
         self.annotations = self._load_annotations(videos)
@@ -226,14 +235,28 @@ class VIDDataset(torchDataset):
 
     # ---- annotations
     def _load_annotations(self, videos):
+        """Parsed annotations, cached as json keyed by the letterbox size they were scaled for (a cache written for another
+        ``img_size`` is stale and ignored).  Only rank 0 writes the cache, through a temporary file + ``os.replace``."""
+        size = [int(self.img_size[0]), int(self.img_size[1])]
         if self.cache_file and os.path.isfile(self.cache_file):
             with open(self.cache_file) as fh:
-                return {k: np.asarray(v, dtype=np.float64).reshape(-1, 5) for k, v in json.load(fh).items()}
+                blob = json.load(fh)
+            if isinstance(blob, dict) and blob.get("img_size") == size and isinstance(blob.get("annotations"), dict):
+                return {k: np.asarray(v, dtype=np.float64).reshape(-1, 5) for k, v in blob["annotations"].items()}
         ann = {frame: self.get_annotation(os.path.join(self.dataset_pth, frame), self.img_size) for video in videos for frame in video}
-        if self.cache_file:
+        rank = 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank()
+        except Exception:
+            pass
+        if self.cache_file and rank == 0:
             os.makedirs(os.path.dirname(os.path.abspath(self.cache_file)), exist_ok=True)
-            with open(self.cache_file, "w") as fh:
-                json.dump({k: v.tolist() for k, v in ann.items()}, fh)
+            tmp = f"{self.cache_file}.tmp.{os.getpid()}"
+            with open(tmp, "w") as fh:
+                json.dump({"img_size": size, "annotations": {k: v.tolist() for k, v in ann.items()}}, fh)
+            os.replace(tmp, self.cache_file)
         return ann
 
     @staticmethod
@@ -332,8 +355,10 @@ class VIDDataset(torchDataset):
 
 
 class TrainSampler(Sampler):
-    """Yields clips (lists of file names).  Rank-aware: all ranks draw the same permutation from (seed, epoch) and keep every
-    world-th clip starting at their rank; call ``set_epoch`` once per epoch."""
+    """Yields clips (lists of file names).  Rank-aware: all ranks draw the same permutation from (seed, epoch), pad it by wrapping
+    around to a multiple of the world size (as torch's DistributedSampler does) and keep every world-th clip starting at their rank --
+    every rank therefore sees the SAME number of clips per epoch (equal DDP step counts, equal lr schedules, matched collectives);
+    call ``set_epoch`` once per epoch."""
 
     def __init__(self, data_source, rank=None, world_size=None, seed=0):
         self.data_source = data_source
@@ -347,16 +372,22 @@ class TrainSampler(Sampler):
         self.epoch = epoch
 
     def _mine(self):
+        n = len(self.data_source.res)
+        if n == 0:
+            return []
         g = torch.Generator().manual_seed(self.seed * 1000003 + self.epoch)
-        order = torch.randperm(len(self.data_source.res), generator=g).tolist()
-        return [self.data_source.res[i] for i in order[self.rank::self.world]]
+        order = torch.randperm(n, generator=g).tolist()
+        total = len(self) * self.world
+        while len(order) < total:                       # wrap around (also covers n < world)
+            order += order[:total - len(order)]
+        return [self.data_source.res[i] for i in order[self.rank:total:self.world]]
 
     def __iter__(self):
         self.epoch += 1
         return iter(self._mine())
 
     def __len__(self):
-        return (len(self.data_source.res) - self.rank + self.world - 1) // self.world
+        return (len(self.data_source.res) + self.world - 1) // self.world
 
 
 class TestSampler(SequentialSampler):

@@ -26,10 +26,8 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agn
     conf, cid = torch.max(prediction[..., 5:5 + num_classes], -1, keepdim=True)
     det = torch.cat((prediction[..., :5], conf, cid.to(prediction.dtype)), -1).to(torch.float16).reshape(B * A, 7).contiguous()
     frame_off = ops.h2d([i * A for i in range(B + 1)], torch.int32, prediction.device)
-    rows, idx, cnt, ovf = ops.batched_nms(det, frame_off, B, num_classes, conf_thre, nms_thre, A, 2 if class_agnostic else 1)
-    counts = torch.cat((cnt, ovf)).cpu().tolist()
-    if counts[B]:
-        raise RuntimeError("NMS per-class capacity (2048 boxes of one class in one image) exceeded")
+    rows, idx, cnt = ops.batched_nms(det, frame_off, B, num_classes, conf_thre, nms_thre, A, 2 if class_agnostic else 1, max_rows=A)
+    counts = cnt.cpu().tolist()
     return [rows[i, :counts[i]].to(prediction.dtype) if counts[i] > 0 else None for i in range(B)]
 
 

@@ -13,6 +13,7 @@ import threading
 import torch
 
 _writer = None          # at most one checkpoint in flight
+_failure = None         # exception of the last writer thread that failed, re-raised on the training thread by wait()
 _pinned = {}            # (key path, shape, dtype) -> pinned buffer, reused from one checkpoint to the next
 
 
@@ -42,10 +43,15 @@ def _snapshot(obj, path=""):
 
 
 def wait():
-    global _writer
+    """Joins the writer in flight and re-raises, on the calling (training) thread, whatever made it fail -- a full disk or an
+    unwritable directory must stop the run, not be reported as a checkpoint that was never written."""
+    global _writer, _failure
     if _writer is not None:
         _writer.join()
         _writer = None
+    if _failure is not None:
+        err, _failure = _failure, None
+        raise RuntimeError(f"asynchronous checkpoint write failed: {err!r}") from err
 
 
 def save_checkpoint(state, is_best, save_dir, model_name="", non_blocking=True):
@@ -67,13 +73,21 @@ def save_checkpoint(state, is_best, save_dir, model_name="", non_blocking=True):
     dev = torch.cuda.current_device()
 
     def write():
-        torch.cuda.set_device(dev)
-        done.synchronize()
+        global _failure
         tmp = filename + ".tmp"
-        torch.save(host, tmp)
-        os.replace(tmp, filename)                 # a reader never sees a half-written file
-        if is_best:
-            shutil.copyfile(filename, os.path.join(save_dir, "best_ckpt.pth"))
+        try:
+            torch.cuda.set_device(dev)
+            done.synchronize()
+            torch.save(host, tmp)
+            os.replace(tmp, filename)                 # a reader never sees a half-written file
+            if is_best:
+                shutil.copyfile(filename, os.path.join(save_dir, "best_ckpt.pth"))
+        except BaseException as ex:                   # surfaced by wait() / the next save_checkpoint
+            _failure = ex
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
 
     _writer = threading.Thread(target=write, name="tscd-ckpt-writer", daemon=False)
     _writer.start()
