@@ -31,29 +31,10 @@ const char* tscd_last_error(void);
  * 2 +bias,ReLU, 3 folded BN + SiLU (eval), 4 folded BN, 5 Hungarian cost 1 - v/2 with NaN->0
  * (tscd_matching.py:926-930). */
 int tscd_conv_tile_m(void);
-/* Main-loop selection of tscd_conv2d_nhwc_f16: -1 automatic (LDS-DMA ring when Cin % 32 == 0 and Cout > 32 -- as 128 x 256
- * tiles with BK = 64 when Cin % 64 == 0, Cout is a multiple of 256 and the launch still has >= 512 workgroups -- register
- * staging otherwise), 0 force register staging, 1 LDS-DMA with 128-wide tiles only, 3 the 128 x 256 variant wherever its
- * shape constraints hold, 4 the same tile with BK = 32 and the two wave groups of a workgroup staggered by one barrier
- * interval, 5 the halo-staged 256 x 256 tile for 3x3 / stride-1 convs (input pixels fetched once per 32-channel chunk and
- * shared by the 9 taps).  Variants 0-4 accumulate in the same order: outputs and BatchNorm partial sums are bit-identical;
- * variant 5 walks k as (channel chunk, tap) and equals variant 0 bit for bit once that takes the same order
- * (tscd_conv_set_korder(1)) -- tests/test_gpu_conv.py. */
-void tscd_conv_set_variant(int variant);
-/* k order of the register-staged loop (variant 0): 0 = (tap, channel) as packed, 1 = (32-channel chunk, tap); test hook. */
-void tscd_conv_set_korder(int order);
-/* 1: launches that qualify (3x3, stride 1, Cin % 32 == 0, Cout % 256 == 0, at least one tile per CU) take the halo-staged
- * variant automatically (variant -1); 6 forces its 192-pixel tile, 5 its 256-pixel tile. */
-void tscd_conv_set_halo_auto(int on);
 /* Per-channel BatchNorm partial-sum entries a raw-epilogue launch of this shape writes (= its number of M-tiles, which
- * depends on the main-loop variant it takes): the `mtiles` argument of tscd_bn_finalize.  M = B*Ho*Wo, W = output width. */
+ * depends on the main loop it takes): the `mtiles` argument of tscd_bn_finalize.  M = B*Ho*Wo, W = output width. */
 int tscd_conv_stat_tiles(long M, int W, int Cin, int Cout, int ksize, int stride);
-/* Tile height of the 128-channel-wide LDS-DMA variant: 0 = automatic (64 / 128 / 192 rows by how the grid fills 256 CUs),
- * 64 / 128 / 192 = forced (tests, A/B timing).  Returns the previous setting. */
-int tscd_conv_set_tile_m(int rows);
-/* Measurement hook (scratch experiments, never set by the product path): bit0 makes the LDS-DMA loop's A gather read a
- * zero block, bit1 makes every B row read row 0 -- isolates how much of a launch is memory stall.  Results are wrong. */
-void tscd_conv_set_debug(int bits);
+int tscd_conv_stat_tiles_ex(long M, int W, int Cin, int Cout, int ksize, int stride, int groups, int variant, int tile_m);
 int tscd_conv_tile_n(int cout);
 int tscd_pack_conv_weight(const void* w, int src_is_f32, void* out, int Cout, int Cin, int CinPad, int KH, int KW,
                           int rows_pad, int Kpad, int mode, void* stream);
@@ -67,6 +48,21 @@ int tscd_pack_conv_weights_batched(const void* jobs, const void* blockmap, long 
 int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* bias, const float* scale,
                          const float* shift, float* bn_partial, int B, int H, int W, int Cin, int Cout, int ksize,
                          int stride, int ldx, int ldy, int epilogue, void* stream);
+/* The general form.  groups > 1: `groups` convolutions of Cin -> Cout channels each in ONE launch (the four towers of
+ * TSCDHead.forward, tscd_head.py:315-324): group g reads channels [g*Cin, (g+1)*Cin) of x, the g-th packed matrix of wpk (each
+ * padded to a multiple of tscd_conv_tile_n(Cout) rows) and writes channels [g*Cout, (g+1)*Cout) of y; bias / scale / shift run
+ * over the groups*Cout concatenated channels, bn_partial is [2][groups * rows_pad][tscd_conv_stat_tiles_ex(...)].
+ * Main-loop plan, per call (there is no process-global switch): variant -1 automatic -- LDS-DMA ring (global_load_lds, 4 stages)
+ * when Cin % 32 == 0 and Cout > 32, its halo-staged form (input pixels fetched once per 32-channel chunk and shared by the 9 taps,
+ * 192- or 256-pixel x 256-channel tiles) for 3x3 / stride-1 convs with Cout % 256 == 0 and at least ~one tile per CU, register
+ * staging otherwise; 0 register staging, 1 LDS-DMA 128-wide tiles only, 5 / 6 the halo form with 256- / 192-pixel tiles wherever
+ * its shape allows (tests, A/B timing).  korder 1: the register-staged loop walks k as (32-channel chunk, tap) like the halo form
+ * -- the two are then bit-identical (tests/test_gpu_conv.py); the other forms accumulate in (tap, channel) order and are
+ * bit-identical among themselves.  tile_m 64 / 128 / 192: tile height of the 128-wide LDS-DMA form (0 automatic). */
+int tscd_conv2d_nhwc_f16_ex(const void* x, const void* wpk, void* y, const float* bias, const float* scale,
+                            const float* shift, float* bn_partial, int B, int H, int W, int Cin, int Cout, int ksize,
+                            int stride, int ldx, int ldy, int epilogue, int groups, int variant, int korder, int tile_m,
+                            void* stream);
 
 /* ---- backward of the trainable head convs (autograd of network_blocks.py:36-61 / surrounding_extraction.py:223-232
  * under tscd_trainer.py:171-176).  Weight gradient of a stride-1 "same" conv as a pixel-axis GEMM with
@@ -77,11 +73,20 @@ int tscd_conv_wgrad_splits(long M, int Cout, int Cin, int ksize);
 long tscd_conv_wgrad_workspace_bytes(long M, int Cout, int Cin, int ksize);
 int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
                              int ldx, int lddy, void* workspace, long workspace_bytes, void* stream);
-/* Which main loop tscd_conv_wgrad_nhwc_f16 runs: 1 (default) the LDS-DMA ring (global_load_lds, swizzled lane-linear
- * tiles), 0 the register-staged loop kept as the cross-check; same tiles, splits and accumulation order, so dw is
- * bit-identical (tests/test_gpu_conv.py).  Returns the previous setting. */
-int tscd_conv_wgrad_set_variant(int variant);
+/* groups > 1: `groups` weight gradients in one launch (group g from channels [g*Cin, ...) of x and [g*Cout, ...) of dy into
+ * dw[g][Cout][Cin][k][k]; Cin / Cout per group).  variant (tests): 1 the LDS-DMA ring (global_load_lds, swizzled lane-linear tiles),
+ * 0 the register-staged loop kept as the cross-check -- same tiles, splits and accumulation order, dw bit-identical. */
+long tscd_conv_wgrad_workspace_bytes_ex(long M, int Cout, int Cin, int ksize, int groups);
+int tscd_conv_wgrad_nhwc_f16_ex(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
+                                int ldx, int lddy, int groups, int variant, void* workspace, long workspace_bytes, void* stream);
 long tscd_bn_silu_bwd_workspace_bytes(long M, int C);
+/* dY in up to two channel segments ([0, cseg) from dy0, [cseg, C) from dy1, each with its own row stride), gamma in up to two
+ * vectors ([0, gseg) / [gseg, C)), raw / draw as channel slices: the two trainable towers of TSCDHead share one conv launch, their
+ * BatchNorms stay separate modules. */
+int tscd_bn_silu_bwd_f16_ex(const void* dy0, long lddy0, const void* dy1, long lddy1, int cseg, const void* raw, long ldraw,
+                            const float* scale_shift, const float* mean, const float* invstd, const float* gamma0,
+                            const float* gamma1, int gseg, long M, int C, void* draw, long lddraw, float* sums_out, void* workspace,
+                            long workspace_bytes, void* stream);
 /* Backward of an nn.Linear (y = x W^T + b) in one host call: dx = dY W (MFMA GEMM on W packed in data-gradient order),
  * dw = dY^T x (pixel-axis wgrad GEMM), db = column sums.  dY [n][outp] is fp16 with row stride lddy and outp = out_f rounded up to 8
  * (extra columns zero); dx [n][in_f] fp16, dw [outp][in_f] fp32, db [outp] fp32; any output may be NULL.
@@ -114,6 +119,15 @@ int tscd_conv_bn_act_train_f16(const void* x, const void* wpk, void* raw, int ld
                                int Cin, int Cout, int ksize, int stride, int ldx, const float* gamma, const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var, float* small, void* out, int ldo,
                                const void* residual, int ldr, int act, void* stream);
+/* The same for SEVERAL BaseConvs in one conv launch (the four towers of TSCDHead.forward, tscd_head.py:315-324): groups == 1 -- convs
+ * that share their INPUT run as one dense conv over the nseg * seg_c concatenated output channels (the stem output is staged once for
+ * all of them); groups == nseg -- convs with their own input / output channel slices run as one grouped launch.  gamma / beta /
+ * running_mean / running_var: (host) arrays of nseg device pointers, one BatchNorm each; small [4][nseg*seg_c]; partial
+ * [2][rows][tscd_conv_stat_tiles_ex(...)] with rows = groups * (per-group output channels padded to tscd_conv_tile_n). */
+int tscd_conv_bn_act_train_multi_f16(const void* x, const void* wpk, void* raw, int ldraw, float* partial, int B, int H, int W, int Cin,
+                                     int seg_c, int nseg, int groups, int ksize, int ldx, const void* const* gamma,
+                                     const void* const* beta, float eps, float momentum, void* const* running_mean,
+                                     void* const* running_var, float* small, void* out, int ldo, int act, void* stream);
 int tscd_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                  float* scale_shift, void* stream);
 int tscd_bn_act_nhwc_f16(const void* x, int ldx, void* y, int ldy, const float* scale_shift, const void* residual,
@@ -162,8 +176,9 @@ int tscd_decode_score(const void* raw0, const void* raw1, const void* raw2, cons
                       const int* stride3, int B, int NC, void* outputs, void* det, void* score, void* stream);
 int tscd_select_proposals(const void* score, int B, int A, float conf_thresh, int min_keep, int max_keep, int cap,
                           int* out_idx, int* out_count, void* stream);
+/* map_ld: pixel stride (elements) of every map -- W for contiguous maps, wider when the maps are channel slices of one buffer. */
 int tscd_gather_rows(const void* const* maps, const int* hw3, const int* sel_idx, int cap, const int* frame_off, int B,
-                     int N, int W, int nmaps, void* out0, void* out1, void* out2, int scatter, void* stream);
+                     int N, int W, int map_ld, int nmaps, void* out0, void* out1, void* out2, int scatter, void* stream);
 int tscd_gather_det(const void* det, int A, int ndet, const int* sel_idx, int cap, const int* frame_off, int B, int N,
                     void* out, void* stream);
 

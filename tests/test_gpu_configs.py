@@ -185,9 +185,21 @@ def test_c4_vid_eval_without_an_upper_proposal_clamp():
     import bench
     from oracle import nms_ref
     from oracle import tscd_oracle as O
-    model = _tscd(1.0, 1.0, 30, 0).cuda().eval().half()
+    model = _tscd(1.0, 1.0, 30, 0).cuda()
     assert model.head.kwargs["maximal_limit"] == 0
-    imgs, _, temb = bench.synth_clip(4, 576, "cuda")
+    imgs, t0, temb = bench.synth_clip(4, 576, "cuda")
+    # A randomly initialised network evaluated with FRESH running statistics (mean 0, var 1) shrinks its activations layer by layer
+    # until whole feature rows flush to zero in fp16 -- and the reference's x / ||x|| (post_trans.py:623-628, no epsilon) turns a zero
+    # row into NaN for every query that sees it.  One training-mode pass with momentum 1 gives the BatchNorms the batch statistics
+    # a trained checkpoint would carry.
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for m in bns:
+        m.momentum = 1.0
+    with torch.no_grad():
+        model.train()(imgs, t0, temb, lframe=1, gframe=3, resume=False)
+    for m in bns:
+        m.momentum = 0.03
+    model = model.eval().half()
     model.head.debug = {}
     with torch.no_grad():
         res, ori = model(imgs, time_embedding=temb, lframe=1, gframe=3, resume=False)

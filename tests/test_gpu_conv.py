@@ -202,18 +202,12 @@ def test_conv_wgrad_lds_dma_matches_register_loop(case):
     the register-staged loop on the same operands: same tiles, splits and k order, so dw must be bit-identical -- images
     smaller than a k-tile, ragged pixel counts, Cin of 8 (a tile spans 16 taps/chunks), splits with a short tail."""
     from tscd_amd import ops
-    from tscd_amd._lib import lib
     B, H, W, Ci, Co, k = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(B, H, W, Ci, generator=g).half().to(dev())
     dy = torch.randn(B, H, W, Co, generator=g).half().to(dev())
-    prev = lib.tscd_conv_wgrad_set_variant(0)
-    try:
-        ref = ops.conv_wgrad(x, dy, Ci, Co, k).clone()
-        lib.tscd_conv_wgrad_set_variant(1)
-        out = ops.conv_wgrad(x, dy, Ci, Co, k).clone()
-    finally:
-        lib.tscd_conv_wgrad_set_variant(prev)
+    ref = ops.conv_wgrad(x, dy, Ci, Co, k, variant=0).clone()       # per-call plan argument: no process-global switch
+    out = ops.conv_wgrad(x, dy, Ci, Co, k).clone()
     torch.cuda.synchronize()
     assert torch.equal(out, ref), float((out - ref).abs().max())
 
@@ -250,26 +244,14 @@ def test_conv_lds_dma_variant_bit_identical_to_register_staging(case):
     xg = x.to(dev()).permute(0, 2, 3, 1).contiguous()
     wpk = ops.pack_conv_weight(w.to(dev()))
     tall = {}
-    try:
-        lib.tscd_conv_set_tile_m(128)
-        lib.tscd_conv_set_variant(0)
-        y0, st0 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
-        lib.tscd_conv_set_variant(1)              # 128-wide LDS-DMA tiles only
-        y1, st1 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
-        lib.tscd_conv_set_variant(3)              # the 128 x 256 / BK=64 variant wherever the shape allows it
-        y2, st2 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
-        lib.tscd_conv_set_variant(4)              # 128 x 256 / BK=32, staggered wave groups, wherever the shape allows it
-        y3, st3 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
-        lib.tscd_conv_set_variant(1)
-        for bm in (64, 192):                      # the other tile heights of the 128-wide LDS-DMA variant
-            lib.tscd_conv_set_tile_m(bm)
-            tall[bm] = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True)
-    finally:
-        lib.tscd_conv_set_variant(-1)
-        lib.tscd_conv_set_tile_m(0)
+    # the main-loop plan is a per-call argument (tscd_conv2d_nhwc_f16_ex): nothing process-global is switched
+    y0, st0 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True, variant=0, tile_m=128)
+    y1, st1 = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True, variant=1, tile_m=128)       # 128-wide LDS-DMA tiles only
+    for bm in (64, 192):                      # the other tile heights of the 128-wide LDS-DMA variant
+        tall[bm] = ops.conv2d(xg, wpk, Cout, k, s, want_stats=True, variant=1, tile_m=bm)
     torch.cuda.synchronize()
-    assert torch.equal(y0, y1) and torch.equal(y0, y2) and torch.equal(y0, y3)
-    assert torch.equal(st0, st1) and torch.equal(st0, st2) and torch.equal(st0, st3)
+    assert torch.equal(y0, y1)
+    assert torch.equal(st0, st1)
     for bm, (yb, stb) in tall.items():            # same MFMA sequence per output; the statistics are grouped by other row blocks
         assert torch.equal(y0, yb), bm
         M = B * yb.shape[1] * yb.shape[2]
@@ -334,20 +316,11 @@ def test_conv_halo_variant_matches_chunk_major_register_loop_bit_for_bit(case):
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half()
     xg = x.to(dev()).permute(0, 2, 3, 1).contiguous()
     wpk = ops.pack_conv_weight(w.to(dev()))
-    try:
-        lib.tscd_conv_set_variant(0)
-        y_def, st_def = ops.conv2d(xg, wpk, Cout, 3, 1, want_stats=True)
-        lib.tscd_conv_set_korder(1)
-        y0, st0 = ops.conv2d(xg, wpk, Cout, 3, 1, want_stats=True)
-        lib.tscd_conv_set_korder(0)
-        lib.tscd_conv_set_variant(5)                # 256-pixel tiles
-        y5, st5 = ops.conv2d(xg, wpk, Cout, 3, 1, want_stats=True)
-        yb = ops.conv2d(xg, wpk, Cout, 3, 1, epilogue=ops.EPI_BIAS_RELU, bias=torch.linspace(-1, 1, Cout, device=dev()))[0]
-        lib.tscd_conv_set_variant(6)                # 192-pixel tiles
-        y6, st6 = ops.conv2d(xg, wpk, Cout, 3, 1, want_stats=True)
-    finally:
-        lib.tscd_conv_set_korder(0)
-        lib.tscd_conv_set_variant(-1)
+    y_def, st_def = ops.conv2d(xg, wpk, Cout, 3, 1, want_stats=True, variant=0)
+    y0, st0 = ops.conv2d(xg, wpk, Cout, 3, 1, want_stats=True, variant=0, korder=1)
+    y5, st5 = ops.conv2d(xg, wpk, Cout, 3, 1, want_stats=True, variant=5)                # 256-pixel tiles
+    yb = ops.conv2d(xg, wpk, Cout, 3, 1, epilogue=ops.EPI_BIAS_RELU, bias=torch.linspace(-1, 1, Cout, device=dev()), variant=5)[0]
+    y6, st6 = ops.conv2d(xg, wpk, Cout, 3, 1, want_stats=True, variant=6)                # 192-pixel tiles
     torch.cuda.synchronize()
     assert torch.equal(y0, y5) and torch.equal(y0, y6)
     # per-channel sums of the same fp16 outputs, tiles of another height: compare the totals over the M-tiles
@@ -358,3 +331,119 @@ def test_conv_halo_variant_matches_chunk_major_register_loop_bit_for_bit(case):
     assert_close(y5.permute(0, 3, 1, 2), ref)
     refb = torch.relu(ref + torch.linspace(-1, 1, Cout).view(1, -1, 1, 1))
     assert_close(yb.permute(0, 3, 1, 2), refb)
+
+
+GROUP_CASES = [
+    # B, H, W, Cin (per group), Cout (per group), k, groups
+    (2, 36, 36, 256, 256, 3, 2),     # the trainable towers' second convs on the 36x36 level: halo-staged form, 2 groups
+    (2, 18, 18, 256, 256, 3, 4),     # all four towers' second convs, 64-row LDS-DMA tiles
+    (1, 9, 11, 64, 128, 3, 2),       # small ragged image, LDS-DMA 128-wide tiles
+    (2, 7, 5, 32, 320, 1, 2),        # per-group Cout padded to 384 rows (TSCD-X head width)
+    (1, 6, 6, 24, 40, 3, 3),         # Cin % 32 != 0: register-staged loop, BN = 64 tiles
+    (3, 72, 72, 128, 128, 3, 2),     # TSCD-S head width on the 72x72 level
+]
+
+
+@pytest.mark.parametrize("case", GROUP_CASES)
+def test_grouped_conv_equals_the_separate_launches_bit_for_bit(case):
+    """groups convs in ONE launch (tscd_conv2d_nhwc_f16_ex: the towers' second convs, reference tscd_head.py:315-324) == the same convs
+    launched one by one on the channel slices: outputs bit-identical (the same MFMA sequence per output as the separate launch of the
+    same main-loop form), BatchNorm partial sums equal to fp32 rounding of a different tile height, bias epilogue included."""
+    from tscd_amd import ops
+    B, H, W, Cin, Cout, k, G = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, G * Cin, generator=g).half().to(dev())
+    ws = [(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).half().to(dev()) for _ in range(G)]
+    wpk = torch.cat([ops.pack_conv_weight(w) for w in ws], 0).contiguous()
+    yg, stg = ops.conv2d(x, wpk, Cout, k, 1, want_stats=True, groups=G)
+    bias = torch.linspace(-1, 1, G * Cout, device=dev())
+    yb = ops.conv2d(x, wpk, Cout, k, 1, epilogue=ops.EPI_BIAS_RELU, bias=bias, groups=G)[0]
+    torch.cuda.synchronize()
+    rows = wpk.shape[0] // G
+    for i, w in enumerate(ws):
+        xi = x[..., i * Cin:(i + 1) * Cin]
+        ref = F.conv2d(xi.permute(0, 3, 1, 2).float().cpu(), w.float().cpu(), None, 1, (k - 1) // 2)
+        assert_close(yg[..., i * Cout:(i + 1) * Cout].permute(0, 3, 1, 2), ref)
+        # the separate launch, forced onto the same main-loop form where the automatic choice would differ with fewer tiles
+        outs = [ops.conv2d(xi, ops.pack_conv_weight(w), Cout, k, 1, want_stats=True, variant=v) for v in (-1, 0, 1, 5, 6)]
+        torch.cuda.synchronize()
+        same = [torch.equal(o[0], yg[..., i * Cout:(i + 1) * Cout]) for o in outs]
+        assert any(same), (i, same)
+        y1, st1 = outs[same.index(True)]
+        assert torch.allclose(stg[:, i * rows:i * rows + Cout].double().sum(-1), st1[:, :Cout].double().sum(-1), rtol=1e-6, atol=1e-5)
+        refb = torch.relu(ref + bias[i * Cout:(i + 1) * Cout].cpu().view(1, -1, 1, 1))
+        assert_close(yb[..., i * Cout:(i + 1) * Cout].permute(0, 3, 1, 2), refb)
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 36, 36, 256), (3, 18, 18, 128), (2, 10, 14, 64)])
+def test_several_baseconvs_in_one_launch_match_the_single_calls(groups, shape):
+    """conv_bn_act_train_multi (tscd_conv_bn_act_train_multi_f16): the towers' first convs as ONE dense conv over the concatenated
+    output channels (groups=1: shared input) and their second convs as ONE grouped launch (groups=2), each BatchNorm with its own
+    gamma / beta / running statistics, one statistics and one apply launch for all -- against conv_bn_act_train called per conv:
+    activations bit-identical, batch statistics and running statistics equal to fp32 rounding (tile heights differ)."""
+    from tscd_amd import ops
+    B, H, W, C = shape
+    nseg = 2
+    g = torch.Generator().manual_seed(sum(shape) + groups)
+    x = torch.randn(B, H, W, C * (groups if groups > 1 else 1), generator=g).half().to(dev())
+    ws = [(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).half().to(dev()) for _ in range(nseg)]
+    mk = lambda: [((torch.rand(C, generator=g) + 0.5).to(dev()), (torch.randn(C, generator=g) * 0.1).to(dev()),
+                   torch.zeros(C, device=dev()), torch.ones(C, device=dev())) for _ in range(nseg)]
+    bns = mk()
+    bns_ref = [tuple(t.clone() for t in b) for b in bns]
+    if groups == 1:
+        wpk = ops.pack_conv_weight(torch.cat(ws, 0))
+    else:
+        wpk = torch.cat([ops.pack_conv_weight(w) for w in ws], 0).contiguous()
+    out, raw, ss, mean, invstd = ops.conv_bn_act_train_multi(x, wpk, C, bns, 3, groups, keep_raw=True)
+    torch.cuda.synchronize()
+    for i, w in enumerate(ws):
+        xi = x if groups == 1 else x[..., i * C:(i + 1) * C]
+        gm, bt, rm, rv = bns_ref[i]
+        o1, r1, ss1, m1, iv1 = ops.conv_bn_act_train(xi, ops.pack_conv_weight(w), C, 3, 1, gm, bt, rm, rv, keep_raw=True)
+        torch.cuda.synchronize()
+        sl = slice(i * C, (i + 1) * C)
+        assert torch.equal(raw[..., sl], r1) or (raw[..., sl].float() - r1.float()).abs().max() <= 2e-3 * r1.float().abs().max()
+        assert torch.allclose(mean[sl], m1, rtol=1e-5, atol=1e-6) and torch.allclose(invstd[sl], iv1, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(ss[:, sl], ss1, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bns[i][2], rm, rtol=1e-5, atol=1e-7) and torch.allclose(bns[i][3], rv, rtol=1e-5, atol=1e-7)
+        assert (out[..., sl].float() - o1.float()).abs().max() <= 4e-3 * o1.float().abs().max()
+
+
+@pytest.mark.parametrize("case", [(2, 36, 36, 256, 256, 3, 2), (1, 9, 7, 64, 96, 3, 2), (2, 18, 18, 128, 128, 1, 3)])
+def test_grouped_wgrad_and_two_segment_bn_backward(case):
+    """tscd_conv_wgrad_nhwc_f16_ex with groups == the per-group calls on the channel slices (bit-identical when the split count is
+    the same, fp32-sum tolerance otherwise); bn_silu_bwd_multi over two gradient tensors and a strided raw slice == the plain
+    kernel on the concatenated contiguous tensors, bit for bit."""
+    from tscd_amd import ops
+    B, H, W, Ci, Co, k, G = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, G * Ci, generator=g).half().to(dev())
+    dy = torch.randn(B, H, W, G * Co, generator=g).half().to(dev())
+    dw = ops.conv_wgrad(x, dy, Ci, Co, k, groups=G)
+    torch.cuda.synchronize()
+    assert dw.shape == (G * Co, Ci, k, k)
+    for i in range(G):
+        ref = ops.conv_wgrad(x[..., i * Ci:(i + 1) * Ci], dy[..., i * Co:(i + 1) * Co], Ci, Co, k)
+        torch.cuda.synchronize()
+        got = dw[i * Co:(i + 1) * Co]
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-3 * float(ref.abs().max())), (i, float((got - ref).abs().max()))
+    # BatchNorm + SiLU backward over two segments
+    C = 2 * Co
+    big = torch.randn(B, H, W, C + 16, generator=g).half().to(dev())
+    raw = big[..., 8:8 + C]                                      # a channel slice (pixel stride C + 16)
+    d0 = torch.randn(B, H, W, Co, generator=g).half().to(dev())
+    d1big = torch.randn(B, H, W, Co + 8, generator=g).half().to(dev())
+    d1 = d1big[..., :Co]
+    gam = [(torch.rand(Co, generator=g) + 0.5).to(dev()) for _ in range(2)]
+    ss = torch.stack((torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1)).to(dev())
+    mean, invstd = torch.randn(C, generator=g).to(dev()) * 0.1, (torch.rand(C, generator=g) + 0.5).to(dev())
+    draw, dg, db = ops.bn_silu_bwd_multi([d0, d1], raw, ss, mean, invstd, gam)
+    draw_r, dg_r, db_r = ops.bn_silu_bwd(torch.cat((d0, d1), -1).contiguous(), raw.contiguous(), ss, mean, invstd, torch.cat(gam))
+    torch.cuda.synchronize()
+    assert torch.equal(draw, draw_r) and torch.equal(dg, dg_r) and torch.equal(db, db_r)
+    # one gradient tensor spanning both BatchNorms (the fused first convs' backward): the gamma split is independent of the dY split
+    draw2, dg2, db2 = ops.bn_silu_bwd_multi([torch.cat((d0, d1), -1).contiguous()], raw, ss, mean, invstd, gam)
+    torch.cuda.synchronize()
+    assert torch.equal(draw2, draw_r) and torch.equal(dg2, dg_r) and torch.equal(db2, db_r)

@@ -2,9 +2,10 @@
 """A/B of the implicit-GEMM conv main-loop variants on one device, in one process, interleaved rounds
 (cdna_hip_programming.md rule 24): bit-identity against variant 1, then min / median launch time per variant.
 
-    python tools/conv_ab.py [--variants 1,3,4] [--rounds 5] [--iters 20]
+    python tools/conv_ab.py [--variants 1,6,-1] [--rounds 5] [--iters 20]
 
-variant 1 = 128x128 LDS-DMA tiles, 3 = 128x256 / BK=64 lockstep, 4 = 128x256 / BK=32 staggered wave groups."""
+variant 1 = 128-wide LDS-DMA tiles, 5 / 6 = halo-staged 256- / 192-pixel tiles, 0 = register staging, -1 = automatic (a per-call
+argument of tscd_conv2d_nhwc_f16_ex)."""
 import argparse
 import os
 import statistics
@@ -22,22 +23,20 @@ SHAPES = ((16, 72, 72, 256, 256, 3), (16, 36, 36, 256, 256, 3), (16, 18, 18, 256
 
 
 def run(x, wpk, cout, k, variant, iters):
-    lib.tscd_conv_set_variant(variant)
     for _ in range(2):
-        ops.conv2d(x, wpk, cout, k, 1, want_stats=True)
+        ops.conv2d(x, wpk, cout, k, 1, want_stats=True, variant=variant)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.conv2d(x, wpk, cout, k, 1, want_stats=True)
+        ops.conv2d(x, wpk, cout, k, 1, want_stats=True, variant=variant)
     e1.record()
     torch.cuda.synchronize()
-    lib.tscd_conv_set_variant(-1)
     return e0.elapsed_time(e1) / iters * 1e3      # us
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="3,6,-1")
+    ap.add_argument("--variants", default="1,6,-1")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
@@ -52,14 +51,12 @@ def main():
         ref = None
         same = {}
         for v in variants:
-            lib.tscd_conv_set_variant(v)
-            y, st = ops.conv2d(x, wpk, Cout, k, 1, want_stats=True)
+            y, st = ops.conv2d(x, wpk, Cout, k, 1, want_stats=True, variant=v)
             torch.cuda.synchronize()
             if ref is None:
                 ref = (y.clone(), st.clone())
             same[v] = "==" if bool(torch.equal(y, ref[0]) and torch.equal(st, ref[1])) else (
                 "~=" if (y.float() - ref[0].float()).abs().max().item() <= 2e-3 * ref[0].float().abs().max().item() else "DIFF")
-        lib.tscd_conv_set_variant(-1)
         ts = {v: [] for v in variants}
         for _ in range(args.rounds):
             for v in variants:

@@ -18,23 +18,22 @@ SHAPES = ((16, 36, 36, 256, 256, 3), (16, 18, 18, 256, 256, 3), (16, 18, 18, 512
 
 
 def run(x, wpk, cout, k, bm, iters):
-    lib.tscd_conv_set_tile_m(bm)
+    # the 128-wide LDS-DMA form on every shape (variant 1: the halo form would take the 72x72 3x3 otherwise); bm = 0: automatic height
+    kw = dict(variant=1, tile_m=bm)
     for _ in range(2):
-        ops.conv2d(x, wpk, cout, k, 1, want_stats=True)
+        ops.conv2d(x, wpk, cout, k, 1, want_stats=True, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.conv2d(x, wpk, cout, k, 1, want_stats=True)
+        ops.conv2d(x, wpk, cout, k, 1, want_stats=True, **kw)
     e1.record()
     torch.cuda.synchronize()
-    lib.tscd_conv_set_tile_m(0)
     return e0.elapsed_time(e1) / iters * 1e3      # us
 
 
 def main():
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cuda").manual_seed(0)
-    lib.tscd_conv_set_halo_auto(0)                 # the 128-wide variant on every shape (the halo variant takes the 72x72 3x3 otherwise)
     for (B, H, W, Cin, Cout, k) in SHAPES:
         x = torch.randn(B, H, W, Cin, device=dev, generator=g).half()
         w = (torch.randn(Cout, Cin, k, k, device=dev, generator=g) / (Cin * k * k) ** 0.5).half()
@@ -44,10 +43,9 @@ def main():
         for _ in range(4):
             for bm in times:
                 times[bm].append(run(x, wpk, Cout, k, bm, 20))
-        auto = lib.tscd_conv_stat_tiles(B * H * W, W, Cin, Cout, k, 1)
+        auto = lib.tscd_conv_stat_tiles_ex(B * H * W, W, Cin, Cout, k, 1, 1, 1, 0)
         txt = "  ".join(f"{('auto' if bm == 0 else bm)}: {min(t):6.1f}/{statistics.median(t):6.1f} us ({fl / min(t) / 1e6:5.0f} TF/s)" for bm, t in times.items())
         print(f"{(B, H, W, Cin, Cout, k)}: {txt}   [auto tiles {auto}]", flush=True)
-    lib.tscd_conv_set_halo_auto(1)
 
 
 main()

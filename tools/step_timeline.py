@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Steady-state timeline of a train step (500-proposal regime, after an 80-step pre-roll): host marks AND device-event marks of the
+points that bound the step's critical path  forward up to the cost matrices -> host assignment chain -> rest of forward + backward.
+Device marks are events recorded on the main stream where the host passes; all times in ms from the step's start (host clock for host
+marks; device marks = elapsed from the step-start event).  Usage: python tools/step_timeline.py [preroll]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bench
+import yolox.models.tscd_matching as M
+from tscd_amd import ops
+
+PREROLL = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+sys.argv = ["bench.py"]
+args = bench.parse()
+dev = torch.device("cuda", 0)
+model = bench.build_model(args.depth, args.width, args.props).to(dev).train()
+opt = bench.make_optimizer(model, lr=args.lr)
+scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
+ema = bench.FusedEMA(model, optimizer=opt)
+imgs, t0_, temb = bench.synth_clip(args.frames, args.size, dev, seed=0)
+targets = bench.targets_on_top_proposals(model, imgs, t0_, temb, args.lframe, args.frames - args.lframe)
+one = torch.ones((), device=dev)
+H, D = {}, {}          # host marks (perf_counter), device marks (events)
+
+
+def mark(name):
+    H[name] = time.perf_counter()
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    D[name] = e
+
+
+def wrap(obj, attr, before=None, after=None):
+    f = getattr(obj, attr)
+
+    def g(*a, **k):
+        if before:
+            mark(before)
+        r = f(*a, **k)
+        if after:
+            mark(after)
+        return r
+    setattr(obj, attr, g)
+
+
+wrap(ops, "gather_det", before="counts_on_host")                                   # first call behind the D2H of the proposal counts
+wrap(M.AwarePositionRegMatcher, "prepare", before="prepare_in", after="costs_queued")
+wrap(M.AwarePositionRegMatcher, "finish", before="finish_in", after="finish_out")
+orig_chain = M.lap_chain_f16
+
+
+def chain(base_ptr, shapes, kinds, before=None):
+    if before is not None:
+        before()
+    H["chain_start"] = time.perf_counter()
+    r = orig_chain(base_ptr, shapes, kinds, None)
+    H["chain_end"] = time.perf_counter()
+    return r
+
+
+M.lap_chain_f16 = chain
+
+
+def step(rec=None):
+    mark("start")
+    model.head.loss_scale = scaler.scale(one)
+    out = model(imgs, targets, temb, lframe=args.lframe, gframe=args.frames - args.lframe, resume=False, next_x=imgs)
+    mark("forward_out")
+    opt.zero_grad(set_to_none=True)
+    scaler.scale(out["total_loss"]).backward()
+    mark("backward_out")
+    scaler.step(opt)
+    scaler.update()
+    model.join_prefetch()
+    ema.update()
+    mark("step_out")
+    if rec is not None:
+        rec.append((dict(H), dict(D)))
+
+
+for _ in range(PREROLL):
+    step()
+torch.cuda.synchronize()
+rec = []
+t = time.perf_counter()
+N = 30
+for _ in range(N):
+    step(rec)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t) / N * 1e3
+names = ["counts_on_host", "prepare_in", "costs_queued", "chain_start", "finish_in", "chain_end", "finish_out", "forward_out", "backward_out", "step_out"]
+print(f"steady state after {PREROLL} steps: {ms:.2f} ms per step (no drains)")
+print("host clock, ms from the step's start (median of %d steps):" % N)
+for n in names:
+    print(f"  {n:16s} {np.median([(h[n] - h['start']) * 1e3 for h, _ in rec]):7.2f}")
+print("device clock, ms from the step-start event reaching the main stream (median):")
+for n in [x for x in names if x not in ("chain_start", "chain_end")]:
+    print(f"  {n:16s} {np.median([d['start'].elapsed_time(d[n]) for _, d in rec]):7.2f}")
+lag = [(h["start"] - rec[0][0]["start"]) * 1e3 - rec[0][1]["start"].elapsed_time(d["start"]) for h, d in rec]
+print(f"host start minus device start of the same step (how far the host runs ahead), ms: median {np.median(lag):.2f}  min {min(lag):.2f}  max {max(lag):.2f}")
+print(f"chain duration {np.median([(h['chain_end'] - h['chain_start']) * 1e3 for h, _ in rec]):.2f} ms")

@@ -12,6 +12,10 @@ P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 # name -> argtypes (every entry point returns int status, 0 = ok)
 SIGNATURES = {
     "tscd_conv2d_nhwc_f16": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "tscd_conv2d_nhwc_f16_ex": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "tscd_conv_bn_act_train_multi_f16": [P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, P, F, F, P, P, P, P, I, I, P],
+    "tscd_conv_wgrad_nhwc_f16_ex": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
+    "tscd_bn_silu_bwd_f16_ex": [P, L, P, L, I, P, L, P, P, P, P, P, I, L, I, P, L, P, P, L, P],
     "tscd_pack_conv_weight": [P, I, P, I, I, I, I, I, I, I, I, P],
     "tscd_pack_conv_weights_batched": [P, P, L, P],
     "tscd_bn_finalize": [P, I, I, I, L, P, P, F, F, P, P, P, P, P, P],
@@ -33,7 +37,7 @@ SIGNATURES = {
     "tscd_conv_bn_act_train_f16": [P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, P, F, F, P, P, P, P, I, P, I, I, P],
     "tscd_decode_score": [P, P, P, P, P, P, I, I, P, P, P, P],
     "tscd_select_proposals": [P, I, I, F, I, I, I, P, P, P],
-    "tscd_gather_rows": [P, P, P, I, P, I, I, I, I, P, P, P, I, P],
+    "tscd_gather_rows": [P, P, P, I, P, I, I, I, I, I, P, P, P, I, P],
     "tscd_gather_det": [P, I, I, P, I, P, I, I, P, P],
     "tscd_mca_forward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, L, P, P, P, P, P, P],
     "tscd_mca_backward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, P, P, P, P, I, P, P, I, P, L, P, P, P, P, P, P],
@@ -67,7 +71,8 @@ PLAIN = {"tscd_ema_chunk_elems": ([], I), "tscd_pack_block_elems": ([], I), "tsc
          "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
          "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),
          "tscd_nms_workspace_bytes": ([I, I, I, I], L), "tscd_simota_workspace_bytes": ([I, I, I, I], L), "tscd_loss_workspace_bytes": ([L, L, L], L),
-         "tscd_conv_set_variant": ([I], None), "tscd_conv_set_korder": ([I], None), "tscd_conv_set_halo_auto": ([I], None), "tscd_conv_set_tile_m": ([I], I), "tscd_conv_stat_tiles": ([L, I, I, I, I, I], I), "tscd_conv_wgrad_set_variant": ([I], I), "tscd_conv_set_debug": ([I], None), "tscd_cos_attn_mfma_supported": ([I], I), "tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
+         "tscd_conv_stat_tiles": ([L, I, I, I, I, I], I), "tscd_conv_stat_tiles_ex": ([L, I, I, I, I, I, I, I, I], I),
+         "tscd_conv_wgrad_workspace_bytes_ex": ([L, I, I, I, I], L), "tscd_cos_attn_mfma_supported": ([I], I), "tscd_conv_tile_n": ([I], I), "tscd_conv_tile_m": ([], I), "tscd_abi_version": ([], I),
          "tscd_last_error": ([], C.c_char_p)}
 
 

@@ -30,10 +30,31 @@ struct ConvParams {
   int K, Kpad, M;
   int epilogue;
   int mtiles, ntiles, cstride;
-  int mtiles_stat;   // BatchNorm partials are kept per 128 output pixels whatever the tile height (bn_finalize's layout)
   int korder;        // 0: k runs (tap, cin) as packed; 1: (32-channel chunk, tap) -- variant 5's order (Cin % 32 == 0 only)
-  int debug;   // experiments only: bit0 = A gather reads the zero chunk, bit1 = B rows all read row 0
+  // Grouped launch (G > 1: the second convs of the head's towers, which read different channel slices of one activation buffer and
+  // write different slices of one output buffer): Cin / Cout / cstride are PER GROUP, ntiles = G * ntiles_g N-tiles in all.  Group g
+  // reads channels [g*Cin, (g+1)*Cin) of x, the packed weight block g (wrows_g rows of Kpad), and writes channels [g*Cout, ...) of y;
+  // bias / scale / shift are indexed by the concatenated channel g*Cout + n, BatchNorm partial rows by g*cstride + n.
+  int G, ntiles_g, wrows_g;
 };
+
+// what a workgroup needs to know about its group: pointer bases and channel bases
+struct GroupView {
+  const f16* x;
+  const f16* w;
+  int cbase;     // first output channel of the group in y / bias / scale / shift
+  int sbase;     // first row of the group in the BatchNorm partial table
+};
+__device__ __forceinline__ GroupView group_view(const ConvParams& p, int nta, int& nt) {
+  const int g = p.G > 1 ? nta / p.ntiles_g : 0;
+  nt = nta - g * p.ntiles_g;
+  GroupView v;
+  v.x = p.x + g * p.Cin;
+  v.w = p.w + (long)g * p.wrows_g * p.Kpad;
+  v.cbase = g * p.Cout;
+  v.sbase = g * p.cstride;
+  return v;
+}
 
 enum { EPI_RAW = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BN_SILU = 3, EPI_BN = 4, EPI_COST = 5 };
 
@@ -43,9 +64,9 @@ enum { EPI_RAW = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_BN_SILU = 3, EPI_BN = 4
 // instead of 64 two-byte stores per lane; the per-channel BatchNorm sums stay in the MFMA layout (in-lane over 16 rows).
 // MF = 32: f32x16 accumulators of v_mfma_f32_32x32x16_f16 (layout above); MF = 16: f32x4 accumulators of v_mfma_f32_16x16x32_f16
 // (col = lane&15, row = 4*(lane>>4) + reg) -- TM / TN count MF x MF tiles.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SPLIT_STATS = false, int MF = 32, typename ACC = f32x16>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int TM, int TN, int MF = 32, typename ACC = f32x16>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, ACC (&acc)[TM][TN], f16* smem, int m0, int n0, int mt, int tid,
-                                              int lane, int wm, int wn) {
+                                              int lane, int wm, int wn, int cbase = 0, int sbase = 0) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, CP = BN + 8, NT = 64 * WAVES_M * WAVES_N;
   constexpr int NE = MF == 32 ? 16 : 4;            // accumulator registers per tile
   static_assert(WM == TM * MF && WN == TN * MF, "wave tile");
@@ -66,8 +87,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, ACC (&acc)[TM
       const bool nok = n < p.Cout;
       float bias = 0.f, sc = 1.f, sh = 0.f;
       if (nok) {
-        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) bias = p.bias[n];
-        if constexpr (EPI == EPI_BN_SILU || EPI == EPI_BN) { sc = p.scale[n]; sh = p.shift[n]; }
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) bias = p.bias[cbase + n];
+        if constexpr (EPI == EPI_BN_SILU || EPI == EPI_BN) { sc = p.scale[cbase + n]; sh = p.shift[cbase + n]; }
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -125,7 +146,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, ACC (&acc)[TM
     }
   }
   __syncthreads();
-  const bool vec_ok = (p.Cout & 7) == 0 && (p.ldy & 7) == 0 && ((uintptr_t)p.y & 15) == 0;
+  f16* const yg = p.y + cbase;
+  const bool vec_ok = (p.Cout & 7) == 0 && (p.ldy & 7) == 0 && ((uintptr_t)yg & 15) == 0;
   if (vec_ok) {
     constexpr int CPR = BN / 8;                    // 16-byte chunks per tile row
 #pragma unroll
@@ -133,37 +155,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, ACC (&acc)[TM
       const int idx = tid + it * NT;
       const int row = idx / CPR, ch = idx % CPR;
       const int m = m0 + row, n = n0 + ch * 8;
-      if (m < p.M && n < p.Cout) *(f16x8*)(p.y + (long)m * p.ldy + n) = *(const f16x8*)(ctile + row * CP + ch * 8);
+      if (m < p.M && n < p.Cout) *(f16x8*)(yg + (long)m * p.ldy + n) = *(const f16x8*)(ctile + row * CP + ch * 8);
     }
   } else {                                         // ragged Cout (prediction heads: 1 / 4 / NC channels, cost matrices)
     for (int idx = tid; idx < BM * BN; idx += NT) {
       const int row = idx / BN, cl = idx % BN;
       const int m = m0 + row, n = n0 + cl;
-      if (m < p.M && n < p.Cout) p.y[(long)m * p.ldy + n] = ctile[row * CP + cl];
+      if (m < p.M && n < p.Cout) yg[(long)m * p.ldy + n] = ctile[row * CP + cl];
     }
   }
   if (stats && tid < BN) {
-    if constexpr (SPLIT_STATS) {
-      // 256-row tile, each wave row-group = 128 rows = one entry of the per-128-pixel partial table
+    float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES_M; ++w) {
-        const int ms = mt * WAVES_M + w;
-        if (ms < p.mtiles_stat) {
-          p.bn_partial[(long)(n0 + tid) * p.mtiles_stat + ms] = red[(w * BN + tid) * 2 + 0];
-          p.bn_partial[((long)p.cstride + n0 + tid) * p.mtiles_stat + ms] = red[(w * BN + tid) * 2 + 1];
-        }
-      }
-    } else {
-      float a = 0.f, b = 0.f;
-#pragma unroll
-      for (int w = 0; w < WAVES_M; ++w) {
-        a += red[(w * BN + tid) * 2 + 0];
-        b += red[(w * BN + tid) * 2 + 1];
-      }
-      // channel-major [2][cstride][mtiles]: bn_finalize's wave-per-channel reduction then reads contiguous floats
-      p.bn_partial[(long)(n0 + tid) * p.mtiles + mt] = a;
-      p.bn_partial[((long)p.cstride + n0 + tid) * p.mtiles + mt] = b;
+    for (int w = 0; w < WAVES_M; ++w) {
+      a += red[(w * BN + tid) * 2 + 0];
+      b += red[(w * BN + tid) * 2 + 1];
     }
+    // channel-major [2][G * cstride][mtiles]: the reduction over M-tiles then reads contiguous floats
+    p.bn_partial[(long)(sbase + n0 + tid) * p.mtiles + mt] = a;
+    p.bn_partial[((long)p.G * p.cstride + sbase + n0 + tid) * p.mtiles + mt] = b;
   }
 }
 
@@ -185,7 +195,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+  const int nta = lid % p.ntiles, mt = lid / p.ntiles;
+  int nt;
+  const GroupView gv = group_view(p, nta, nt);
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-thread gather state for the A (im2col) tile: A_CH rows, one 8-half chunk each ----
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     int ho = rem / p.Wo, wo = rem - ho * p.Wo;
     a_hi0[i] = ho * p.stride - p.pad;
     a_wi0[i] = wo * p.stride - p.pad;
-    a_base[i] = p.x + (long)b * p.H * p.W * p.ldx;
+    a_base[i] = gv.x + (long)b * p.H * p.W * p.ldx;
   }
   int cin = a_chunk * 8, kh = 0, kw = 0;
   while (cin >= p.Cin) {
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
     for (int j = 0; j < B_CH; ++j) {
       int idx = tid + j * 256;
-      if (idx < BN * 4) b_reg[j] = *(const f16x8*)(p.w + (long)(n0 + (idx >> 2)) * p.Kpad + kcol + (idx & 3) * 8);
+      if (idx < BN * 4) b_reg[j] = *(const f16x8*)(gv.w + (long)(n0 + (idx >> 2)) * p.Kpad + kcol + (idx & 3) * 8);
     }
     if (chunk_major) {
       if (++cm_tap == ntaps) { cm_tap = 0; ++cm_chunk; }
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     buf ^= 1;
   }
 
-  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, smem, m0, n0, mt, tid, lane, wm, wn);
+  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, smem, m0, n0, mt, tid, lane, wm, wn, gv.cbase, gv.sbase);
 }
 
 // ====================================================================================================================
@@ -345,7 +357,9 @@ __global__ __launch_bounds__(128 * WAVES_N, (BM == 64 ? 3 : 2)) void conv_igemm_
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+  const int nta = lid % p.ntiles, mt = lid / p.ntiles;
+  int nt;
+  const GroupView gv = group_view(p, nta, nt);
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-lane source state: slot s = lane&3 of row (lane>>2) in each 16-row piece; chunk = s ^ ((row>>2)&3) ----
@@ -361,17 +375,17 @@ __global__ __launch_bounds__(128 * WAVES_N, (BM == 64 ? 3 : 2)) void conv_igemm_
     const int rem = mm - b * (p.Ho * p.Wo);
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
     const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-    a_src[i] = p.x + ((long)(b * p.H + hi0) * p.W + wi0) * p.ldx + chunk * 8;
+    a_src[i] = gv.x + ((long)(b * p.H + hi0) * p.W + wi0) * p.ldx + chunk * 8;
     unsigned mask = 0;
     for (int kh = 0; kh < p.KH; ++kh)
       for (int kw = 0; kw < p.KW; ++kw)
         if (ok && (unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W) mask |= 1u << (kh * p.KW + kw);
-    a_mask[i] = (p.debug & 1) ? 0u : mask;
+    a_mask[i] = mask;
   }
   const f16* b_src[B_LD];
 #pragma unroll
   for (int j = 0; j < B_LD; ++j)
-    b_src[j] = p.w + ((p.debug & 2) ? 0L : (long)(n0 + wave * (16 * B_LD) + j * 16 + (lane >> 2)) * p.Kpad) + chunk * 8;
+    b_src[j] = gv.w + (long)(n0 + wave * (16 * B_LD) + j * 16 + (lane >> 2)) * p.Kpad + chunk * 8;
 
   const int nk = p.Kpad >> 5;
   int ld_tap = 0, ld_cin = 0, ld_kw = 0;     // wave-uniform position of the NEXT k-tile to issue
@@ -480,350 +494,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (BM == 64 ? 3 : 2)) void conv_igemm_
   } else {
     mfmas(std::integral_constant<int, 0>{});
   }
-  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
-}
-
-// ====================================================================================================================
-// Main-loop variant 3 (Cin % 64 == 0, Cout > 128): 128 x 256 tile, 8 waves, BK = 64.
-// Per-launch counters of variant 2 on the dominant shape (rocprofv3 SQ_*: waves 33 % issuing, 27 % parked on
-// s_waitcnt / s_barrier, 41 % waiting for the MFMA pipe; ~95 instructions per 8 MFMAs) say the 128^2 / BK=32 loop spends its
-// time on everything but the MFMAs.  This variant halves the per-MFMA overhead: one barrier and one set of waits per 16
-// MFMAs, 128-byte rows (one gather address per 64 channels, full cache lines per request), a ring of 3 x 48 KB stages whose
-// index is a compile-time constant in every phase (fragment reads and LDS-DMA destinations are immediates), and the A
-// gather fetched once for all 256 output channels.  K order is unchanged, so results stay bit-identical to variants 1 / 2.
-// ====================================================================================================================
-template <int N> __device__ __forceinline__ void wait_vmcnt6() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-}
-
-__global__ __launch_bounds__(512, 1) void conv_igemm_v3_kernel(ConvParams p) {
-  constexpr int BM = 128, BN = 256, NS = 3, WAVES_M = 2, WAVES_N = 4, TM = 2, TN = 2, WM = 64, WN = 64;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 16 KB + 32 KB
-  constexpr int A_LD = 2, B_LD = 4, LD = A_LD + B_LD;                                 // glds (8 rows x 128 B) per wave and k-tile
-  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int nt = lid % p.ntiles, mt = lid / p.ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  // LDS image: row r (128 B = 8 slots of 16 B), slot s holds k-chunk s ^ ((r >> 1) & 7).  The lane that fills slot lane&7 of
-  // row (piece base + lane>>3) therefore fetches chunk (lane&7) ^ (4*(piece&1) + (lane>>4)).
-  const int ch0 = (lane & 7) ^ (lane >> 4), ch1 = (lane & 7) ^ (4 + (lane >> 4));
-  const f16* a_src[A_LD];
-  unsigned a_mask[A_LD];
-#pragma unroll
-  for (int i = 0; i < A_LD; ++i) {
-    const int m = m0 + wave * 16 + i * 8 + (lane >> 3);
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    const int b = mm / (p.Ho * p.Wo);
-    const int rem = mm - b * (p.Ho * p.Wo);
-    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-    a_src[i] = p.x + ((long)(b * p.H + hi0) * p.W + wi0) * p.ldx + (i ? ch1 : ch0) * 8;
-    unsigned mask = 0;
-    for (int kh = 0; kh < p.KH; ++kh)
-      for (int kw = 0; kw < p.KW; ++kw)
-        if (ok && (unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W) mask |= 1u << (kh * p.KW + kw);
-    a_mask[i] = mask;
-  }
-  const f16* b_src[B_LD];
-#pragma unroll
-  for (int j = 0; j < B_LD; ++j)
-    b_src[j] = p.w + (long)(n0 + wave * 32 + j * 8 + (lane >> 3)) * p.Kpad + ((j & 1) ? ch1 : ch0) * 8;
-
-  const int nk = p.Kpad >> 6;
-  int ld_tap = 0, ld_cin = 0, ld_kw = 0;
-  long ld_tapoff = 0;
-  auto issue = [&](auto stagec) __attribute__((always_inline)) {
-    constexpr int ST = decltype(stagec)::value;
-    char* sbase = smem + ST * STAGE;
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      const f16* src = ((a_mask[i] >> ld_tap) & 1u) ? a_src[i] + ld_tapoff + ld_cin : g_zero_chunk;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sbase + (wave * 16 + i * 8) * 128), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < B_LD; ++j) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[j],
-                                       (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wave * 32 + j * 8) * 128), 16, 0, 0);
-      b_src[j] += 64;
-    }
-    ld_cin += 64;
-    if (ld_cin == p.Cin) {
-      ld_cin = 0;
-      ++ld_tap;
-      if (++ld_kw == p.KW) { ld_kw = 0; ld_tapoff += (long)(p.W - p.KW + 1) * p.ldx; } else ld_tapoff += p.ldx;
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // fragment read offsets inside a stage: row r, chunk c = 2 ks + (lane >> 5)  ->  r*128 + ((c ^ ((r>>1)&7)) * 16)
-  const int frow = lane & 31, fsw = (frow >> 1) & 7, fk = lane >> 5;
-  int a_off[TM], b_off[TN];           // chunk-0 offsets; the chunk term is XORed in per k-step
-#pragma unroll
-  for (int i = 0; i < TM; ++i) a_off[i] = (wm * WM + i * 32 + frow) * 128;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) b_off[j] = A_BYTES + (wn * WN + j * 32 + frow) * 128;
-  int cslot[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) cslot[ks] = ((2 * ks + fk) ^ fsw) * 16;
-
-  // Two half-tile fragment sets (k-steps {0,1} and {2,3}, 32 VGPRs each).  Per tile: read the second half under the first
-  // half's 8 MFMAs; then wait + ONE barrier (every wave now holds all of tile t in registers), refill tile t's stage, read
-  // the next tile's first half under the second half's 8 MFMAs.  Stage indices are compile-time constants.
-  f16x8 fa[2][2][TM], fb[2][2][TN];     // [half][ks within half][tile]
-  auto read_half = [&](auto halfc, auto stagec) __attribute__((always_inline)) {
-    constexpr int HF = decltype(halfc)::value, ST = decltype(stagec)::value;
-    const char* sb = smem + ST * STAGE;
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[HF][k2][i] = *(const f16x8*)(sb + a_off[i] + cslot[2 * HF + k2]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[HF][k2][j] = *(const f16x8*)(sb + b_off[j] + cslot[2 * HF + k2]);
-    }
-  };
-  auto mfma_half = [&](auto halfc) __attribute__((always_inline)) {
-    constexpr int HF = decltype(halfc)::value;
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[HF][k2][i], fb[HF][k2][j], acc[i][j], 0, 0, 0);
-  };
-  using C0 = std::integral_constant<int, 0>;
-  using C1 = std::integral_constant<int, 1>;
-  using C2 = std::integral_constant<int, 2>;
-  // tile kt lives in stage ST and has a successor
-  auto phase = [&](auto stagec, auto steadyc, int kt) __attribute__((always_inline)) {
-    constexpr int ST = decltype(stagec)::value;
-    constexpr bool STEADY = decltype(steadyc)::value;
-    read_half(C1{}, stagec);
-    mfma_half(C0{});
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): all of tile kt is in this wave's registers
-    if (STEADY || kt + 2 < nk) wait_vmcnt6<6>(); else wait_vmcnt6<0>();   // tile kt+1 landed; tile kt+2 may stay in flight
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (STEADY || kt + NS < nk) issue(stagec);               // tile kt+3 -> the stage tile kt just left
-    read_half(C0{}, std::integral_constant<int, (ST + 1) % NS>{});
-    mfma_half(C1{});
-  };
-  auto last = [&](auto stagec) __attribute__((always_inline)) {
-    read_half(C1{}, stagec);
-    mfma_half(C0{});
-    mfma_half(C1{});
-  };
-
-  issue(C0{});
-  if (nk > 1) issue(C1{});
-  if (nk > 1) wait_vmcnt6<6>(); else wait_vmcnt6<0>();      // tile 0 landed (tile 1 may still be in flight)
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  if (nk > 2) issue(C2{});
-  read_half(C0{}, C0{});
-  int kt = 0;
-  for (; kt + 2 + NS < nk; kt += 3) {
-    phase(C0{}, std::true_type{}, kt);
-    phase(C1{}, std::true_type{}, kt + 1);
-    phase(C2{}, std::true_type{}, kt + 2);
-  }
-  // tail (at most 2 + NS tiles left): same stage sequence, each step checked
-  bool done = false;
-#define V3_TAIL(STC)                                                         \
-  if (!done) {                                                               \
-    if (kt + 1 < nk) { phase(STC{}, std::false_type{}, kt); ++kt; }          \
-    else { last(STC{}); done = true; }                                       \
-  }
-  V3_TAIL(C0) V3_TAIL(C1) V3_TAIL(C2) V3_TAIL(C0) V3_TAIL(C1) V3_TAIL(C2)
-#undef V3_TAIL
-  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
-}
-
-// ====================================================================================================================
-// Main-loop variant 4 (Cin % 32 == 0, Cout > 128): 128 x 256 tile, 8 waves, BK = 32 stages in a 6-deep LDS-DMA ring, the two
-// wave groups of a workgroup STAGGERED by one barrier interval.
-//
-// Why: variants 2 / 3 run their two co-resident waves per SIMD in lockstep -- both fetch fragments, then both queue on the
-// SIMD's one matrix pipe, then both wait -- and measure 650-700 TFLOP/s on the dominant shape (760-840 with every operand
-// L1-hot: the loop structure, not memory, is the first limit).  Here waves 0-3 (group 0) and waves 4-7 (group 1: the waves
-// that share SIMDs with 0-3) alternate roles every barrier interval:
-//
-//   interval      2u          2u+1        2u+2        2u+3
-//   group 0     L(u)        M(u)        L(u+1)      M(u+1)         L(t) = 8 ds_read_b128 of k-tile t's fragments + this wave's
-//   group 1     M(u-1)      L(u)        M(u)        L(u+1)                3 LDS-DMA pieces of a later tile;  M(t) = 8 MFMAs
-//
-// so in every interval one wave of each SIMD feeds the matrix pipe (256 cycles of v_mfma_f32_32x32x16_f16) while its partner
-// fetches fragments and issues DMA -- matrix beside memory (MI355X_MICROARCH.md, "Two waves per SIMD").  Synchronisation by
-// construction (one raw s_barrier per interval, counted vmcnt, no __syncthreads in the loop):
-//   RAW  k-tile t is read by group 0 in interval 2t and by group 1 in 2t+1.  Every wave retires ITS OWN pieces of tile t with a
-//        counted s_waitcnt vmcnt at the end of an M segment that lies before barrier 2t: group 0 waits for tile u+1 at the end of
-//        M(u) (interval 2u+1), group 1 for tile u+2 at the end of M(u) (interval 2u+2).
-//   WAR  the fragment reads of tile t are retired (lgkmcnt(0) right behind the barrier that opens the M segment) by barrier 2t+2
-//        at the latest; the stage is refilled -- tile t+6 -- by group 1 in L(t+1) (interval 2t+3) and by group 0 in L(t+2)
-//        (interval 2t+4), i.e. at least one full barrier after the last reader has its data in registers.
-//   Each wave keeps 3 tiles (9 pieces) of its own DMA in flight across the barriers; the ring holds 6 x 24 KB = 144 KB.
-// K order and MFMA shape are those of variants 0-3, so outputs (and the BatchNorm partial sums) are bit-identical.
-// ====================================================================================================================
-template <int N> __device__ __forceinline__ void wait_vmcnt9() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-}
-
-__global__ __launch_bounds__(512, 1) void conv_igemm_v4_kernel(ConvParams p) {
-  constexpr int BM = 128, BN = 256, NS = 6, WAVES_M = 2, WAVES_N = 4, TM = 2, TN = 2, WM = 64, WN = 64;
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;      // 8 KB + 16 KB per k-tile of 32
-  constexpr int B_LD = 2;                                                              // pieces (16 rows x 64 B) per wave: 1 A + 2 B
-  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;                          // 0: waves 0-3, 1: waves 4-7 (SIMD partners of 0-3)
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int nt = lid % p.ntiles, mt = lid / p.ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  // ---- per-lane DMA source state (as variant 2): slot s = lane&3 of row lane>>2 in a 16-row piece holds chunk s ^ ((row>>2)&3)
-  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
-  const f16* a_src;
-  unsigned a_mask;
-  {
-    const int m = m0 + wave * 16 + (lane >> 2);
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    const int b = mm / (p.Ho * p.Wo);
-    const int rem = mm - b * (p.Ho * p.Wo);
-    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-    a_src = p.x + ((long)(b * p.H + hi0) * p.W + wi0) * p.ldx + chunk * 8;
-    unsigned mask = 0;
-    for (int kh = 0; kh < p.KH; ++kh)
-      for (int kw = 0; kw < p.KW; ++kw)
-        if (ok && (unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W) mask |= 1u << (kh * p.KW + kw);
-    a_mask = mask;
-  }
-  const f16* b_src[B_LD];
-#pragma unroll
-  for (int j = 0; j < B_LD; ++j) b_src[j] = p.w + (long)(n0 + wave * 32 + j * 16 + (lane >> 2)) * p.Kpad + chunk * 8;
-
-  const int nk = p.Kpad >> 5;
-  int ld_tile = 0, ld_tap = 0, ld_cin = 0, ld_kw = 0, ld_soff = 0;     // wave-uniform position of the NEXT k-tile this wave issues
-  long ld_tapoff = 0;
-  auto issue = [&]() __attribute__((always_inline)) {
-    char* sbase = smem + ld_soff;
-    const f16* src = ((a_mask >> ld_tap) & 1u) ? a_src + ld_tapoff + ld_cin : g_zero_chunk;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(sbase + wave * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < B_LD; ++j) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[j],
-                                       (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wave * 2 + j) * 1024), 16, 0, 0);
-      b_src[j] += 32;
-    }
-    ++ld_tile;
-    ld_soff += STAGE;
-    if (ld_soff == NS * STAGE) ld_soff = 0;
-    ld_cin += 32;
-    if (ld_cin == p.Cin) {
-      ld_cin = 0;
-      ++ld_tap;
-      if (++ld_kw == p.KW) { ld_kw = 0; ld_tapoff += (long)(p.W - p.KW + 1) * p.ldx; } else ld_tapoff += p.ldx;
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // fragment read offsets inside a stage: row r, chunk c -> r*64 + ((c ^ ((r>>2)&3)) * 16)
-  const int frow = lane & 31, fsw = (frow >> 2) & 3, fk = lane >> 5;
-  int a_off[TM][2], b_off[TN][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) a_off[i][ks] = (wm * WM + i * 32 + frow) * 64 + (((ks * 2 + fk) ^ fsw) * 16);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b_off[j][ks] = A_BYTES + (wn * WN + j * 32 + frow) * 64 + (((ks * 2 + fk) ^ fsw) * 16);
-  }
-
-  // prologue: group 0 starts 4 tiles, group 1 5 tiles (their steady-state issue distances: L(u) issues tile u+4 / u+5)
-  const int ahead = 4 + grp;
-  for (int t = 0; t < ahead; ++t)
-    if (ld_tile < nk) issue();
-  // retire this wave's pieces of tile 0 (and tile 1 for group 1, which never gets another chance before tile 1 is read)
-  auto wait_own = [&](int t) __attribute__((always_inline)) {      // this wave's pieces of tiles <= t have landed
-    if (t >= nk) t = nk - 1;
-    const int younger = ld_tile - 1 - t;                            // tiles of this wave still allowed in flight
-    if (younger >= 3) wait_vmcnt9<9>();
-    else if (younger == 2) wait_vmcnt9<6>();
-    else if (younger == 1) wait_vmcnt9<3>();
-    else wait_vmcnt9<0>();
-  };
-  wait_own(grp);
-  __builtin_amdgcn_s_barrier();                                     // barrier 0
-  if (grp == 1) __builtin_amdgcn_s_barrier();                       // the stagger: group 1 runs one interval behind
-
-  f16x8 fa[2][TM], fb[2][TN];
-  int rd_soff = 0;
-  for (int u = 0; u < nk; ++u) {
-    // ---------------- L(u): fragments of k-tile u, DMA of a later tile ----------------
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const char* sb = smem + rd_soff;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[ks][i] = *(const f16x8*)(sb + a_off[i][ks]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[ks][j] = *(const f16x8*)(sb + b_off[j][ks]);
-      }
-      rd_soff += STAGE;
-      if (rd_soff == NS * STAGE) rd_soff = 0;
-    }
-    if (ld_tile < nk) issue();             // group 0: tile u+4 (stage of tile u-2), group 1: tile u+5 (stage of tile u-1)
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // ---------------- M(u) ----------------
-    __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): the fragments are in registers (retires this wave's reads of tile u)
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    wait_own(u + 1 + grp);                 // group 0: tile u+1, group 1: tile u+2 (both precede the barrier their readers need)
-    __builtin_amdgcn_s_barrier();
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();                       // even out the barrier count of the two groups
-  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
+  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn, gv.cbase, gv.sbase);
 }
 
 // ====================================================================================================================
@@ -882,7 +553,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+  const int nta = lid % p.ntiles, mt = lid / p.ntiles;
+  int nt;
+  const GroupView gv = group_view(p, nta, nt);
   const int m0 = mt * BM, n0 = nt * BN;
   const int W = p.W, HW = p.H * p.W;
 
@@ -898,14 +571,14 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
     const int pc = wave + 8 * i;
     const long pix = (long)m0 - W - 1 + pc * 16 + (lane & 15);
     a_ok[i] = pc < NP && pix >= 0 && pix < p.M;
-    a_src[i] = p.x + (a_ok[i] ? pix : 0) * p.ldx + (lane >> 4) * 8;
+    a_src[i] = gv.x + (a_ok[i] ? pix : 0) * p.ldx + (lane >> 4) * 8;
     na_wave += pc < NP ? 1 : 0;
   }
   const bool burst_big = na_wave >= 3;
   // B: piece = 16 weight rows; wave w fills rows 32 w .. 32 w + 31 (2 pieces); lane: row lane & 15, chunk lane >> 4
   const f16* b_src[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) b_src[j] = p.w + (long)(n0 + wave * 32 + j * 16 + (lane & 15)) * p.Kpad + (lane >> 4) * 8;
+  for (int j = 0; j < 2; ++j) b_src[j] = gv.w + (long)(n0 + wave * 32 + j * 16 + (lane & 15)) * p.Kpad + (lane >> 4) * 8;
 
   const int nchunks = p.Cin >> 5, nk = nchunks * 9;
   int ld_tile = 0, ld_tap = 0, ld_cin = 0, ld_soff = 0;      // next B k-step this wave issues: (chunk ld_cin/32, tap ld_tap)
@@ -1065,7 +738,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
   { HALO_CHUNK(std::false_type, ci) }
 #undef HALO_CHUNK
   if (grp == 0) __builtin_amdgcn_s_barrier();
-  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM16, TN16, false, 16, f32x4>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn);
+  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM16, TN16, 16, f32x4>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn, gv.cbase, gv.sbase);
 }
 
 // Tile choice: BN follows Cout (128 / 64 / 32); BM = 128.  Packed weights and BatchNorm partials are padded to a multiple of
@@ -1076,24 +749,24 @@ static int pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 extern "C" int tscd_conv_tile_n(int cout) { return pick_bn(cout); }
 extern "C" int tscd_conv_tile_m(void) { return 128; }
 
-static int g_conv_debug = 0;
-static int g_conv_korder = 0;     // tests: 1 = chunk-major k order in the register-staged loop (variant 5's order)
-static int g_conv_variant = -1;   // -1 auto, 0 register staging, 1 LDS-DMA 128-wide tiles only, 3 / 4: 128x256 variants wherever their shape allows, 5 / 6: halo variant with 256- / 192-pixel tiles wherever its shape allows (tests / A-B timing)
+// Per-call plan overrides (tests and A/B timing only; the product passes the automatic values): there is no process-global state.
+//   variant  -1 automatic; 0 register-staged loop; 1 LDS-DMA 128-wide tiles only; 5 / 6 halo-staged 256- / 192-pixel tiles wherever
+//            their shape allows
+//   korder   1 = chunk-major k order in the register-staged loop (the halo variant's order; Cin % 32 == 0)
+//   tile_m   64 / 128 / 192: tile height of the LDS-DMA 128-wide variant; 0 automatic
+struct ConvPlan { int variant, korder, tile_m; };
 
 // Tile height (output pixels) of the halo-staged variant for this launch, 0 = the launch does not take it.
-// Shape: 3x3, stride 1, Cin % 32 == 0, Cout a multiple of 256, halo (tile + 2W + 2 pixels) <= 480 rows.  Automatic selection:
-// only when the launch has enough tiles to give every CU one (its 1-workgroup-per-CU tiles cannot share a CU with anything),
-// and then the height (192 / 256) whose last round leaves fewer CUs idle.
-static int g_halo_auto = 1;      // automatic selection of the halo variant (tscd_conv_set_halo_auto)
-extern "C" void tscd_conv_set_halo_auto(int v) { g_halo_auto = v; }
-static int halo_tile_m(long M, int W, int Cin, int Cout, int ksize, int stride) {
-  if (g_conv_variant != -1 && g_conv_variant != 5 && g_conv_variant != 6) return 0;
-  if (g_conv_variant == -1 && !g_halo_auto) return 0;
+// Shape: 3x3, stride 1, Cin % 32 == 0, Cout (per group) a multiple of 256, halo (tile + 2W + 2 pixels) <= 480 rows.  Automatic
+// selection: only when the launch has enough tiles to give every CU one (its 1-workgroup-per-CU tiles cannot share a CU with
+// anything), and then the height (192 / 256) whose last round leaves fewer CUs idle.
+static int halo_tile_m(const ConvPlan& pl, long M, int W, int Cin, int Cout, int ksize, int stride, int G) {
+  if (pl.variant != -1 && pl.variant != 5 && pl.variant != 6) return 0;
   if (ksize != 3 || stride != 1 || Cin % 32 != 0 || Cout % 256 != 0) return 0;
   auto fits = [&](int bm) { return (bm + 2 * W + 2 + 15) / 16 * 16 <= 480; };
-  if (g_conv_variant == 5) return fits(256) ? 256 : 0;
-  if (g_conv_variant == 6) return fits(192) ? 192 : 0;
-  const long nt = Cout / 256;
+  if (pl.variant == 5) return fits(256) ? 256 : 0;
+  if (pl.variant == 6) return fits(192) ? 192 : 0;
+  const long nt = (long)(Cout / 256) * G;
   int best = 0;
   double best_cost = 1e30;
   for (int bm : {192, 256}) {
@@ -1106,19 +779,6 @@ static int halo_tile_m(long M, int W, int Cin, int Cout, int ksize, int stride) 
   return best;
 }
 
-// 128 x 256 tiles: 3 = the BK=64 variant, 4 = the staggered one, 0 = neither (shared by the launch and tscd_conv_stat_tiles).
-// Variant 3 pays off (+7 %) only when its half-as-many, twice-as-large workgroups still cover the chip at least twice
-// (measured: 72x72 level x1.07, 36x36 x1.01, 18x18 x0.77); tscd_conv_set_variant(3 / 4) forces one (tests).
-static int wide_variant(long M, int Cin, int Cout) {
-  const int BNP = pick_bn(Cout);
-  const bool dma_ok = Cin % 32 == 0 && BNP >= 64 && g_conv_variant != 0;
-  const int cout_pad = cdiv(Cout, BNP) * BNP;
-  if (!dma_ok || Cout <= 128 || cout_pad % 256 != 0) return 0;
-  if (g_conv_variant == 4) return 4;
-  if (Cin % 64 == 0 && g_conv_variant != 1 && (g_conv_variant == 3 || (long)cdiv(M, 128) * cdiv(Cout, 256) >= 512)) return 3;
-  return 0;
-}
-
 // Tile height of the LDS-DMA 128-channel-wide variant for this launch, from same-box A/B timing of the bench clip's shapes
 // (tools/conv_tile_ab.py, profiles/r02_conv_tile_ab.txt; t128 = workgroups with 128-row tiles, 2 of which share a CU):
 //   * t128 <= 200 (18x18 level: 82 / 164 workgroups): 64-row tiles, 3 per CU -- 31.4 -> 22.5 us (256 ch 3x3), 54 -> 48 us (512 ch);
@@ -1127,13 +787,10 @@ static int wide_variant(long M, int Cin, int Cout) {
 //   * long K loops whose 128-row grid needs a second, partly filled round while 192-row tiles fit 2 per CU in one
 //     (72x72 128 -> 128 3x3: 648 -> 432 workgroups): 192-row tiles -- 49.4 -> 42.7 us;
 //   * otherwise 128 (36x36 256 ch 3x3: 45 us with 128, 46 with 192, 52 with 64).
-// tscd_conv_set_tile_m(64 / 128 / 192) forces a height (tests, A/B).
-static int g_conv_tile_m = 0;
-extern "C" int tscd_conv_set_tile_m(int v) { int o = g_conv_tile_m; g_conv_tile_m = v; return o; }
-static int pick_bm(long M, int Cin, int Cout, int ksize) {
-  if (Cin % 32 != 0 || pick_bn(Cout) != 128 || g_conv_variant == 0) return 128;      // only the <*, 128, 2> instantiations vary BM
-  if (g_conv_tile_m == 64 || g_conv_tile_m == 128 || g_conv_tile_m == 192) return g_conv_tile_m;
-  const long nt = cdiv(Cout, 128), nk = (long)ksize * ksize * Cin / 32;
+static int pick_bm(const ConvPlan& pl, long M, int Cin, int Cout, int ksize, int G) {
+  if (Cin % 32 != 0 || pick_bn(Cout) != 128 || pl.variant == 0) return 128;      // only the <*, 128, 2> instantiations vary BM
+  if (pl.tile_m == 64 || pl.tile_m == 128 || pl.tile_m == 192) return pl.tile_m;
+  const long nt = (long)cdiv(Cout, 128) * G, nk = (long)ksize * ksize * Cin / 32;
   const long t128 = cdiv(M, 128) * nt, t192 = cdiv(M, 192) * nt;
   if (t128 <= 200) return 64;
   if (nk <= 32 && t128 <= 700) return 64;
@@ -1141,31 +798,35 @@ static int pick_bm(long M, int Cin, int Cout, int ksize) {
   return 128;
 }
 
-// Number of per-channel partial-sum entries a raw-epilogue launch writes (one per M-tile of the variant it takes):
-// bn_finalize must be told this count.
-extern "C" int tscd_conv_stat_tiles(long M, int W, int Cin, int Cout, int ksize, int stride) {
-  const int bm = halo_tile_m(M, W, Cin, Cout, ksize, stride);
+static int stat_tiles(const ConvPlan& pl, long M, int W, int Cin, int Cout, int ksize, int stride, int G) {
+  const int bm = halo_tile_m(pl, M, W, Cin, Cout, ksize, stride, G);
   if (bm > 0) return cdiv(M, bm);
-  if (wide_variant(M, Cin, Cout) != 0) return cdiv(M, 128);      // the 128 x 256 variants keep 128-row tiles
-  return cdiv(M, pick_bm(M, Cin, Cout, ksize));
+  return cdiv(M, pick_bm(pl, M, Cin, Cout, ksize, G));
 }
 
-extern "C" void tscd_conv_set_debug(int v) { g_conv_debug = v; }
-extern "C" void tscd_conv_set_korder(int v) { g_conv_korder = v; }
-extern "C" void tscd_conv_set_variant(int v) { g_conv_variant = v; }
+// Number of per-channel partial-sum entries a raw-epilogue launch writes (one per M-tile of the variant it takes): the BatchNorm
+// reduction must be told this count.  Cout / Cin per group.
+extern "C" int tscd_conv_stat_tiles(long M, int W, int Cin, int Cout, int ksize, int stride) {
+  return stat_tiles(ConvPlan{-1, 0, 0}, M, W, Cin, Cout, ksize, stride, 1);
+}
+extern "C" int tscd_conv_stat_tiles_ex(long M, int W, int Cin, int Cout, int ksize, int stride, int groups, int variant, int tile_m) {
+  return stat_tiles(ConvPlan{variant, 0, tile_m}, M, W, Cin, Cout, ksize, stride, groups < 1 ? 1 : groups);
+}
 
-extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* bias, const float* scale,
-                                    const float* shift, float* bn_partial, int B, int H, int W, int Cin, int Cout,
-                                    int ksize, int stride, int ldx, int ldy, int epilogue, void* stream) {
+static int conv_launch(const void* x, const void* wpk, void* y, const float* bias, const float* scale, const float* shift,
+                       float* bn_partial, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int ldx, int ldy,
+                       int epilogue, int G, const ConvPlan& pl, void* stream) {
   TSCD_CHECK_ARG(x && wpk && y, "conv2d: null pointer");
-  TSCD_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv2d: bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, H,
-                 W, Cin, Cout);
-  TSCD_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && ldx >= Cin, "conv2d: Cin=%d / ldx=%d must be multiples of 8", Cin, ldx);
-  TSCD_CHECK_ARG(ldy >= Cout, "conv2d: ldy=%d < Cout=%d", ldy, Cout);
+  TSCD_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && G >= 1, "conv2d: bad shape B=%d H=%d W=%d Cin=%d Cout=%d groups=%d", B, H,
+                 W, Cin, Cout, G);
+  TSCD_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && ldx >= G * Cin, "conv2d: Cin=%d / ldx=%d must be multiples of 8 (ldx >= groups * Cin)", Cin, ldx);
+  TSCD_CHECK_ARG(ldy >= G * Cout, "conv2d: ldy=%d < groups * Cout=%d", ldy, G * Cout);
+  TSCD_CHECK_ARG(G == 1 || Cout % 8 == 0, "conv2d: grouped launches need Cout %% 8 == 0 (Cout=%d)", Cout);
   TSCD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wpk & 15) == 0, "conv2d: x / w must be 16-byte aligned");
   TSCD_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d: ksize %d not supported", ksize);
   TSCD_CHECK_ARG(stride == 1 || stride == 2, "conv2d: stride %d not supported", stride);
   TSCD_CHECK_ARG(epilogue >= 0 && epilogue <= 5, "conv2d: bad epilogue %d", epilogue);
+  TSCD_CHECK_ARG(pl.variant == -1 || pl.variant == 0 || pl.variant == 1 || pl.variant == 5 || pl.variant == 6, "conv2d: variant %d", pl.variant);
   if (epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU) TSCD_CHECK_ARG(bias, "conv2d: bias epilogue without bias");
   if (epilogue == EPI_BN_SILU || epilogue == EPI_BN) TSCD_CHECK_ARG(scale && shift, "conv2d: BN epilogue without scale/shift");
   ConvParams p;
@@ -1182,41 +843,35 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
   TSCD_CHECK_ARG(M < (1L << 31), "conv2d: M too large");
   p.M = (int)M;
   p.epilogue = epilogue;
-  p.debug = g_conv_debug;
   const int BNP = pick_bn(Cout);
-  const bool dma_ok = Cin % 32 == 0 && BNP >= 64 && g_conv_variant != 0;
-  const int cout_pad = cdiv(Cout, BNP) * BNP;
-  const int wv = wide_variant(M, Cin, Cout);
-  const bool v3_ok = wv == 3, v4_ok = wv == 4;
+  const bool dma_ok = Cin % 32 == 0 && BNP >= 64 && pl.variant != 0;
   // variant 5 (input halo staged once per channel chunk, 192- or 256-pixel x 256-channel tiles): 3x3 stride-1 convs
-  const int v5_tm = halo_tile_m(M, W, Cin, Cout, ksize, stride);
+  const int v5_tm = halo_tile_m(pl, M, W, Cin, Cout, ksize, stride, G);
   const bool v5_ok = v5_tm > 0;
-  const int BN = (v3_ok || v4_ok || v5_ok) ? 256 : BNP;
-  const int BM = (v3_ok || v4_ok || !dma_ok) ? 128 : pick_bm(M, Cin, Cout, ksize);
-  p.korder = (g_conv_korder == 1 && Cin % 32 == 0) ? 1 : 0;
-  p.mtiles_stat = cdiv(M, 128);
+  const int BN = v5_ok ? 256 : BNP;
+  const int BM = !dma_ok ? 128 : pick_bm(pl, M, Cin, Cout, ksize, G);
+  p.korder = (pl.korder == 1 && Cin % 32 == 0) ? 1 : 0;
+  p.G = G;
+  p.cstride = cdiv(Cout, BNP) * BNP;
+  p.wrows_g = p.cstride;
+  hipStream_t s = (hipStream_t)stream;
   if (v5_ok) {
     const int hrp = (v5_tm + 2 * W + 2 + 15) / 16 * 16;
     p.mtiles = cdiv(M, v5_tm);
-    p.ntiles = cdiv(Cout, 256);
-    p.cstride = cdiv(Cout, BNP) * BNP;
+    p.ntiles_g = cdiv(Cout, 256);
+    p.ntiles = p.ntiles_g * G;
     if (v5_tm == 192)
-      hipLaunchKernelGGL((conv_igemm_halo_kernel<3>), dim3(p.mtiles * p.ntiles), dim3(512), 0, (hipStream_t)stream, p, hrp);
+      hipLaunchKernelGGL((conv_igemm_halo_kernel<3>), dim3(p.mtiles * p.ntiles), dim3(512), 0, s, p, hrp);
     else
-      hipLaunchKernelGGL((conv_igemm_halo_kernel<4>), dim3(p.mtiles * p.ntiles), dim3(512), 0, (hipStream_t)stream, p, hrp);
+      hipLaunchKernelGGL((conv_igemm_halo_kernel<4>), dim3(p.mtiles * p.ntiles), dim3(512), 0, s, p, hrp);
     TSCD_CHECK_LAUNCH("conv2d (halo)");
     return TSCD_OK;
   }
   p.mtiles = cdiv(M, BM);
-  p.ntiles = cdiv(Cout, BN);
-  p.cstride = cdiv(Cout, BNP) * BNP;
-  dim3 grid(p.mtiles * p.ntiles), block((v3_ok || v4_ok) ? 512 : 256);
-  hipStream_t s = (hipStream_t)stream;
-  if (v4_ok)
-    hipLaunchKernelGGL(conv_igemm_v4_kernel, grid, block, 0, s, p);
-  else if (v3_ok)
-    hipLaunchKernelGGL(conv_igemm_v3_kernel, grid, block, 0, s, p);
-  else if (dma_ok && BN == 128)
+  p.ntiles_g = cdiv(Cout, BN);
+  p.ntiles = p.ntiles_g * G;
+  dim3 grid(p.mtiles * p.ntiles), block(256);
+  if (dma_ok && BN == 128)
     if (BM == 64) hipLaunchKernelGGL((conv_igemm_glds_kernel<64, 128, 2>), grid, block, 0, s, p);
     else if (BM == 192) hipLaunchKernelGGL((conv_igemm_glds_kernel<192, 128, 2>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128, 2>), grid, block, 0, s, p);
@@ -1230,4 +885,23 @@ extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, con
     hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1>), grid, block, 0, s, p);
   TSCD_CHECK_LAUNCH("conv2d");
   return TSCD_OK;
+}
+
+extern "C" int tscd_conv2d_nhwc_f16(const void* x, const void* wpk, void* y, const float* bias, const float* scale,
+                                    const float* shift, float* bn_partial, int B, int H, int W, int Cin, int Cout,
+                                    int ksize, int stride, int ldx, int ldy, int epilogue, void* stream) {
+  return conv_launch(x, wpk, y, bias, scale, shift, bn_partial, B, H, W, Cin, Cout, ksize, stride, ldx, ldy, epilogue, 1,
+                     ConvPlan{-1, 0, 0}, stream);
+}
+
+// The general form: `groups` convolutions of Cin -> Cout channels each in one launch (group g reads channels [g*Cin, (g+1)*Cin) of
+// x and writes channels [g*Cout, (g+1)*Cout) of y; wpk = the groups' packed matrices one after the other, each padded to
+// tscd_conv_tile_n(Cout) rows; bias / scale / shift over the groups * Cout concatenated channels; bn_partial
+// [2][groups * rows_pad][tscd_conv_stat_tiles_ex]) and the per-call plan overrides (variant / korder / tile_m: tests and A/B timing).
+extern "C" int tscd_conv2d_nhwc_f16_ex(const void* x, const void* wpk, void* y, const float* bias, const float* scale,
+                                       const float* shift, float* bn_partial, int B, int H, int W, int Cin, int Cout, int ksize,
+                                       int stride, int ldx, int ldy, int epilogue, int groups, int variant, int korder, int tile_m,
+                                       void* stream) {
+  return conv_launch(x, wpk, y, bias, scale, shift, bn_partial, B, H, W, Cin, Cout, ksize, stride, ldx, ldy, epilogue, groups,
+                     ConvPlan{variant, korder, tile_m}, stream);
 }

@@ -26,7 +26,10 @@ struct WgradParams {
   float* part;   // [S][Cout][Ncols]
   int B, H, W, Cin, Cout, KH, KW, pad;
   int ldx, lddy;
-  int M, Ncols, S, ktiles_per_split, mtiles, ntiles, debug;
+  int M, Ncols, S, ktiles_per_split, mtiles, ntiles;
+  // grouped launch (the towers' second convs: separate channel slices of one x / dY buffer): Cin / Cout per group; group g reads
+  // channels [g*Cin, ...) of x and [g*Cout, ...) of dy and owns the slabs part[g][S][Cout][Ncols]
+  int G;
 };
 
 __device__ __forceinline__ f16x8 tr_frag(const f16* tile_row0_col0, int ldst, int lane) {
@@ -52,6 +55,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   const int mt = blockIdx.x / p.ntiles, nt = blockIdx.x % p.ntiles;
   const int c0 = mt * BM, n0 = nt * BN;
   const int s = blockIdx.y;
+  p.x += blockIdx.z * p.Cin;
+  p.dy += blockIdx.z * p.Cout;
+  p.part += (long)blockIdx.z * p.S * p.Cout * p.Ncols;
   const int kt0 = s * p.ktiles_per_split;
   int kt1 = kt0 + p.ktiles_per_split;
   const int ktotal = (p.M + BK - 1) / BK;
@@ -197,7 +203,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(WgradParams p) 
   const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tiles = p.mtiles * p.ntiles;
-  const int s = lid / tiles, tile = lid - s * tiles;
+  const int per_group = tiles * p.S;
+  const int grp = lid / per_group;
+  const int lid_g = lid - grp * per_group;
+  p.x += grp * p.Cin;
+  p.dy += grp * p.Cout;
+  p.part += (long)grp * p.S * p.Cout * p.Ncols;
+  const int s = lid_g / tiles, tile = lid_g - s * tiles;
   const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
   const int c0 = mt * BM, n0 = nt * BN;
   const int ktotal = (p.M + BK - 1) / BK;
@@ -234,14 +246,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(WgradParams p) 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool mok = m_row[i] < p.M;
-      const f16* ys = (mok && y_ok && !(p.debug & 1)) ? y_src[i] : g_wg_zero_chunk;
+      const f16* ys = (mok && y_ok) ? y_src[i] : g_wg_zero_chunk;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ys,
                                        (__attribute__((address_space(3))) void*)(sbase + (wave * 8 + i * 4) * 256), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool ok = m_row[i] < p.M && n_ok && (p.KH == 1 || ((unsigned)(ho[i] + dh) < (unsigned)p.H && (unsigned)(wo[i] + dw) < (unsigned)p.W));
-      const f16* xs = (ok && !(p.debug & 2)) ? x_src[i] : g_wg_zero_chunk;
+      const f16* xs = ok ? x_src[i] : g_wg_zero_chunk;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xs,
                                        (__attribute__((address_space(3))) void*)(sbase + T_BYTES + (wave * 8 + i * 4) * 256), 16, 0, 0);
       m_row[i] += BK;
@@ -375,25 +387,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(WgradParams p) 
 // dW[cout][cin][kh][kw] (fp32, torch layout) = sum_s part[s][cout][(kh*KW+kw)*Cin + cin].  Threads walk the slabs in SLAB
 // order (a wave reads 256 contiguous bytes of every slab; the S-times smaller dw stream takes the scattered side), four
 // wave-groups share the splits of 64 outputs and combine through LDS in a fixed order (deterministic, no atomics).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int S, int Cout, int Cin, int KH, int KW, float* __restrict__ dw) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int S, int Cout, int Cin, int KH, int KW, int G,
+                                                          float* __restrict__ dw) {
   __shared__ float red[4][64];
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int taps = KH * KW, Ncols = taps * Cin;
-  const long total = (long)Cout * Ncols;
+  const long total_g = (long)Cout * Ncols, total = total_g * G;
   for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
     const long src = base + o;
+    const long grp = src / total_g, r = src - grp * total_g;
     float a = 0.f;
     if (src < total) {
+      const float* pg = part + grp * S * total_g + r;
 #pragma unroll 4
-      for (int s = g; s < S; s += 4) a += part[(long)s * total + src];
+      for (int s = g; s < S; s += 4) a += pg[(long)s * total_g];
     }
     red[g][o] = a;
     __syncthreads();
     if (g == 0 && src < total) {
       a = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
-      const int co = (int)(src / Ncols), col = (int)(src - (long)co * Ncols);
+      const int co = (int)(r / Ncols), col = (int)(r - (long)co * Ncols);
       const int tap = col / Cin, ci = col - tap * Cin;
-      dw[((long)co * Cin + ci) * taps + tap] = a;
+      dw[grp * total_g + ((long)co * Cin + ci) * taps + tap] = a;
     }
     __syncthreads();
   }
@@ -401,9 +416,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // Split-K over the pixel axis: as many splits as keep tiles x splits within the 512 resident workgroups, at least 8 k-tiles
 // (256 pixels) per split so the fp32 slab traffic stays small next to the operand reads.
-extern "C" int tscd_conv_wgrad_splits(long M, int Cout, int Cin, int ksize) {
+static int wgrad_splits(long M, int Cout, int Cin, int ksize, int G) {
   long kt = (M + 31) / 32;
-  long tiles = (long)cdiv(Cout, 128) * cdiv((long)ksize * ksize * Cin, 128);
+  long tiles = (long)cdiv(Cout, 128) * cdiv((long)ksize * ksize * Cin, 128) * G;
   long s = 512 / tiles;                      // two workgroups per CU, never a second round (540 blocks take ~1.5x the time of 504)
   if (ksize == 1 && kt <= 24) return 1;      // proposal-stage linears (a few hundred rows): one pass, written straight into dw
   if (s > kt / 8) s = kt / 8;
@@ -411,17 +426,22 @@ extern "C" int tscd_conv_wgrad_splits(long M, int Cout, int Cin, int ksize) {
   if (s > 256) s = 256;
   return (int)s;
 }
+extern "C" int tscd_conv_wgrad_splits(long M, int Cout, int Cin, int ksize) { return wgrad_splits(M, Cout, Cin, ksize, 1); }
 extern "C" long tscd_conv_wgrad_workspace_bytes(long M, int Cout, int Cin, int ksize) {
-  return 4L * tscd_conv_wgrad_splits(M, Cout, Cin, ksize) * Cout * ksize * ksize * Cin + 256;
+  return 4L * wgrad_splits(M, Cout, Cin, ksize, 1) * Cout * ksize * ksize * Cin + 256;
+}
+extern "C" long tscd_conv_wgrad_workspace_bytes_ex(long M, int Cout, int Cin, int ksize, int groups) {
+  return 4L * groups * wgrad_splits(M, Cout, Cin, ksize, groups) * Cout * ksize * ksize * Cin + 256;
 }
 
-static int g_wgrad_variant = 1;      // 1: LDS-DMA kernel, 0: register-staged cross-check
-extern "C" int tscd_conv_wgrad_set_variant(int v) { int o = g_wgrad_variant; g_wgrad_variant = v; return o; }
-
-extern "C" int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
-                                        int ldx, int lddy, void* workspace, long workspace_bytes, void* stream) {
+// groups > 1: `groups` weight gradients in one launch -- group g from channels [g*Cin, ...) of x and [g*Cout, ...) of dy into
+// dw[g][Cout][Cin][k][k].  variant (tests only): 1 the LDS-DMA ring, 0 the register-staged loop kept as the cross-check (same tiles,
+// splits and accumulation order: dw bit-identical).
+static int wgrad_launch(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize, int ldx, int lddy,
+                        int G, int variant, void* workspace, long workspace_bytes, void* stream) {
   TSCD_CHECK_ARG(x && dy && dw && workspace, "conv_wgrad: null pointer");
   TSCD_CHECK_ARG(ksize == 1 || ksize == 3, "conv_wgrad: ksize %d", ksize);
+  TSCD_CHECK_ARG(G >= 1 && ldx >= G * Cin && lddy >= G * Cout, "conv_wgrad: groups=%d ldx=%d lddy=%d", G, ldx, lddy);
   TSCD_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, "conv_wgrad: channels / strides must be multiples of 8");
   TSCD_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv_wgrad: pointers must be 16-byte aligned");
   WgradParams p;
@@ -431,28 +451,36 @@ extern "C" int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw
   long M = (long)B * H * W;
   TSCD_CHECK_ARG(M < (1L << 31), "conv_wgrad: M too large");
   p.M = (int)M; p.Ncols = ksize * ksize * Cin;
-  p.S = tscd_conv_wgrad_splits(M, Cout, Cin, ksize);
-  TSCD_CHECK_ARG(workspace_bytes >= tscd_conv_wgrad_workspace_bytes(M, Cout, Cin, ksize), "conv_wgrad: workspace too small");
+  p.G = G;
+  p.S = wgrad_splits(M, Cout, Cin, ksize, G);
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_conv_wgrad_workspace_bytes_ex(M, Cout, Cin, ksize, G), "conv_wgrad: workspace too small");
   int ktotal = (p.M + 31) / 32;
   p.ktiles_per_split = (ktotal + p.S - 1) / p.S;
   p.mtiles = cdiv(Cout, 128); p.ntiles = cdiv(p.Ncols, 128);
   hipStream_t st = (hipStream_t)stream;
   const bool direct = p.S == 1 && ksize == 1;   // [Cout][Cin] slab == torch layout: no reduction pass
   if (direct) p.part = dw;
-  p.debug = g_wgrad_variant >> 4;
   // the LDS-DMA loop carries (ho, wo) incrementally with a single wrap per k-tile: images at least 32 / W + 1 rows high
   const bool dma_ok = ksize == 1 || 32 / W + 1 <= H;
-  if ((g_wgrad_variant & 15) == 0 || !dma_ok)
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.mtiles * p.ntiles, p.S), dim3(256), 0, st, p);
+  if (variant == 0 || !dma_ok)
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.mtiles * p.ntiles, p.S, G), dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL(conv_wgrad_glds_kernel, dim3(p.mtiles * p.ntiles * p.S), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(conv_wgrad_glds_kernel, dim3(p.mtiles * p.ntiles * p.S * G), dim3(256), 0, st, p);
   TSCD_CHECK_LAUNCH("conv_wgrad");
   if (direct) return TSCD_OK;
-  long total = (long)Cout * p.Ncols;
+  long total = (long)G * Cout * p.Ncols;
   long grid = (total + 63) / 64;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(grid > 8192 ? 8192 : grid)), dim3(256), 0, st, p.part, p.S, Cout, Cin, ksize, ksize, dw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(grid > 8192 ? 8192 : grid)), dim3(256), 0, st, p.part, p.S, Cout, Cin, ksize, ksize, G, dw);
   TSCD_CHECK_LAUNCH("wgrad_reduce");
   return TSCD_OK;
+}
+extern "C" int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
+                                        int ldx, int lddy, void* workspace, long workspace_bytes, void* stream) {
+  return wgrad_launch(x, dy, dw, B, H, W, Cin, Cout, ksize, ldx, lddy, 1, 1, workspace, workspace_bytes, stream);
+}
+extern "C" int tscd_conv_wgrad_nhwc_f16_ex(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
+                                           int ldx, int lddy, int groups, int variant, void* workspace, long workspace_bytes, void* stream) {
+  return wgrad_launch(x, dy, dw, B, H, W, Cin, Cout, ksize, ldx, lddy, groups, variant, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------- BN + SiLU backward
@@ -464,7 +492,20 @@ __device__ __forceinline__ float silu_grad_(float t) {
 }
 // partial [nblk][2][C]: sum dt, sum dt*xhat over the block's BNB_ROWS rows.  Block = (256/cv) row groups x cv chunk
 // threads; the row groups are combined through LDS in a fixed order.
-__global__ __launch_bounds__(256) void bn_silu_bwd_stats_kernel(const f16* __restrict__ dy, const f16* __restrict__ raw,
+// dY may come as two channel segments (the two trainable towers hand their gradients over as separate tensors): channels
+// [0, cseg) from dy0 (row stride ld0), [cseg, C) from dy1 (row stride ld1); raw / draw are channel slices with row strides of their own.
+struct BnBwdSrc {
+  const f16* dy0;
+  const f16* dy1;
+  const float* gamma0;
+  const float* gamma1;
+  long ld0, ld1, ldraw, lddraw;
+  int cseg, gseg;      // dY splits at channel cseg, gamma at channel gseg (independently: one dY tensor may span two BatchNorms)
+};
+__device__ __forceinline__ const f16* bnb_dy(const BnBwdSrc& q, long r, int c) {
+  return c < q.cseg ? q.dy0 + r * q.ld0 + c : q.dy1 + r * q.ld1 + (c - q.cseg);
+}
+__global__ __launch_bounds__(256) void bn_silu_bwd_stats_kernel(BnBwdSrc q, const f16* __restrict__ raw,
                                                                 const float* __restrict__ ss, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, long M, int C, int cv, int rg,
                                                                 float* __restrict__ partial) {
@@ -479,7 +520,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_stats_kernel(const f16* __res
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s1[e] = s2[e] = 0.f; sc[e] = ss[c + e]; sh[e] = ss[C + c + e]; mu[e] = mean[c + e]; iv[e] = invstd[c + e]; }
       for (long r = r0 + g; r < r0 + BNB_ROWS && r < M; r += rg) {
-        f16x8 gy = *(const f16x8*)(dy + r * C + c), x = *(const f16x8*)(raw + r * C + c);
+        f16x8 gy = *(const f16x8*)bnb_dy(q, r, c), x = *(const f16x8*)(raw + r * q.ldraw + c);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float xr = (float)x[e];
@@ -499,7 +540,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_stats_kernel(const f16* __res
   __syncthreads();
   for (int i = tid; i < 2 * C; i += blockDim.x) {
     float a = 0.f;
-    for (int q = 0; q < rg; ++q) a += red[q * 2 * C + i];
+    for (int k = 0; k < rg; ++k) a += red[k * 2 * C + i];
     partial[(long)blockIdx.x * 2 * C + i] = a;
   }
 }
@@ -522,36 +563,38 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
     out[c] = (float)r;
   }
 }
-__global__ void bn_silu_bwd_apply_kernel(const f16* __restrict__ dy, const f16* __restrict__ raw, const float* __restrict__ ss,
+__global__ void bn_silu_bwd_apply_kernel(BnBwdSrc q, const f16* __restrict__ raw, const float* __restrict__ ss,
                                          const float* __restrict__ mean, const float* __restrict__ invstd,
-                                         const float* __restrict__ gamma, const float* __restrict__ sums, long M, int C,
-                                         f16* __restrict__ draw) {
+                                         const float* __restrict__ sums, long M, int C, f16* __restrict__ draw) {
   const int cv = C >> 3;
   const long total = M * cv;
   const float invn = 1.0f / (float)M;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     long r = idx / cv;
     int c = (int)(idx - r * cv) << 3;
-    f16x8 g = *(const f16x8*)(dy + r * C + c), x = *(const f16x8*)(raw + r * C + c), o;
+    f16x8 g = *(const f16x8*)bnb_dy(q, r, c), x = *(const f16x8*)(raw + r * q.ldraw + c), o;
+    const float* gam = c < q.gseg ? q.gamma0 + c : q.gamma1 + (c - q.gseg);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float xr = (float)x[e];
       float t = (float)(f16)(xr * ss[c + e] + ss[C + c + e]);
       float dt = (float)g[e] * silu_grad_(t);
       float xh = (xr - mean[c + e]) * invstd[c + e];
-      o[e] = (f16)(gamma[c + e] * invstd[c + e] * (dt - sums[c + e] * invn - xh * sums[C + c + e] * invn));
+      o[e] = (f16)(gam[e] * invstd[c + e] * (dt - sums[c + e] * invn - xh * sums[C + c + e] * invn));
     }
-    *(f16x8*)(draw + r * C + c) = o;
+    *(f16x8*)(draw + r * q.lddraw + c) = o;
   }
 }
 
-// dy, raw, draw: contiguous [M, C] fp16.  sums_out [2][C] = (dbeta, dgamma).  workspace: floats [nblk][2][C].
+// dy, raw, draw: [M, C] fp16 (row strides C in the plain form).  sums_out [2][C] = (dbeta, dgamma).  workspace: floats [nblk][2][C].
 extern "C" long tscd_bn_silu_bwd_workspace_bytes(long M, int C) { return 4L * ((M + BNB_ROWS - 1) / BNB_ROWS) * 2 * C + 256; }
-extern "C" int tscd_bn_silu_bwd_f16(const void* dy, const void* raw, const float* scale_shift, const float* mean, const float* invstd,
-                                    const float* gamma, long M, int C, void* draw, float* sums_out, void* workspace,
-                                    long workspace_bytes, void* stream) {
-  TSCD_CHECK_ARG(dy && raw && scale_shift && mean && invstd && gamma && draw && sums_out && workspace, "bn_silu_bwd: null pointer");
-  TSCD_CHECK_ARG(C % 8 == 0 && M > 0, "bn_silu_bwd: C must be a multiple of 8");
+static int bn_silu_bwd_launch(const BnBwdSrc& q, const void* raw, const float* scale_shift, const float* mean, const float* invstd, long M,
+                              int C, void* draw, float* sums_out, void* workspace, long workspace_bytes, void* stream) {
+  TSCD_CHECK_ARG(q.dy0 && raw && scale_shift && mean && invstd && q.gamma0 && draw && sums_out && workspace, "bn_silu_bwd: null pointer");
+  TSCD_CHECK_ARG(C % 8 == 0 && M > 0 && q.cseg % 8 == 0 && q.cseg > 0 && q.cseg <= C, "bn_silu_bwd: C / segment must be multiples of 8");
+  TSCD_CHECK_ARG((q.cseg == C || q.dy1) && (q.gseg == C || q.gamma1) && q.gseg % 8 == 0 && q.gseg > 0 && q.gseg <= C,
+                 "bn_silu_bwd: second segment without pointers");
+  TSCD_CHECK_ARG(q.ld0 % 8 == 0 && q.ld1 % 8 == 0 && q.ldraw % 8 == 0 && q.lddraw % 8 == 0, "bn_silu_bwd: row strides must be multiples of 8");
   TSCD_CHECK_ARG(workspace_bytes >= tscd_bn_silu_bwd_workspace_bytes(M, C), "bn_silu_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   int nblk = (int)((M + BNB_ROWS - 1) / BNB_ROWS);
@@ -559,15 +602,35 @@ extern "C" int tscd_bn_silu_bwd_f16(const void* dy, const void* raw, const float
   if (cv > 256) cv = 256;
   int rg = 256 / cv;
   if (rg > BNB_ROWS) rg = BNB_ROWS;
-  hipLaunchKernelGGL(bn_silu_bwd_stats_kernel, dim3(nblk), dim3(256), (size_t)rg * 2 * C * sizeof(float), st, (const f16*)dy,
-                     (const f16*)raw, scale_shift, mean, invstd, M, C, cv, rg, (float*)workspace);
+  hipLaunchKernelGGL(bn_silu_bwd_stats_kernel, dim3(nblk), dim3(256), (size_t)rg * 2 * C * sizeof(float), st, q, (const f16*)raw, scale_shift,
+                     mean, invstd, M, C, cv, rg, (float*)workspace);
   hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, st, (const float*)workspace, nblk, 2 * C, sums_out);
   long total = M * (C / 8);
   int grid = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, st, (const f16*)dy, (const f16*)raw,
-                     scale_shift, mean, invstd, gamma, sums_out, M, C, (f16*)draw);
+  hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, st, q, (const f16*)raw, scale_shift, mean, invstd,
+                     sums_out, M, C, (f16*)draw);
   TSCD_CHECK_LAUNCH("bn_silu_bwd");
   return TSCD_OK;
+}
+extern "C" int tscd_bn_silu_bwd_f16(const void* dy, const void* raw, const float* scale_shift, const float* mean, const float* invstd,
+                                    const float* gamma, long M, int C, void* draw, float* sums_out, void* workspace,
+                                    long workspace_bytes, void* stream) {
+  BnBwdSrc q;
+  q.dy0 = (const f16*)dy; q.dy1 = nullptr; q.gamma0 = gamma; q.gamma1 = nullptr;
+  q.ld0 = C; q.ld1 = 0; q.ldraw = C; q.lddraw = C; q.cseg = C; q.gseg = C;
+  return bn_silu_bwd_launch(q, raw, scale_shift, mean, invstd, M, C, draw, sums_out, workspace, workspace_bytes, stream);
+}
+// The general form: dY in up to two channel segments ([0, cseg) from dy0, [cseg, C) from dy1, each with its own row stride and gamma
+// vector: the two trainable towers of TSCDHead share one fused conv launch, their BatchNorms stay separate modules), raw / draw as
+// channel slices (row strides ldraw / lddraw).
+extern "C" int tscd_bn_silu_bwd_f16_ex(const void* dy0, long lddy0, const void* dy1, long lddy1, int cseg, const void* raw, long ldraw,
+                                       const float* scale_shift, const float* mean, const float* invstd, const float* gamma0,
+                                       const float* gamma1, int gseg, long M, int C, void* draw, long lddraw, float* sums_out,
+                                       void* workspace, long workspace_bytes, void* stream) {
+  BnBwdSrc q;
+  q.dy0 = (const f16*)dy0; q.dy1 = (const f16*)dy1; q.gamma0 = gamma0; q.gamma1 = gamma1;
+  q.ld0 = lddy0; q.ld1 = lddy1; q.ldraw = ldraw; q.lddraw = lddraw; q.cseg = cseg; q.gseg = gseg;
+  return bn_silu_bwd_launch(q, raw, scale_shift, mean, invstd, M, C, draw, sums_out, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------- fused nn.Linear backward

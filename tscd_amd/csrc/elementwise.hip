@@ -135,21 +135,36 @@ extern "C" int tscd_pack_conv_weights_batched(const void* jobs, const void* bloc
 // running statistics exactly like torch (momentum, unbiased variance) -- reference: network_blocks.py:52-58 with
 // eps=1e-3, momentum=0.03 (exps/TSCD_OVIS/ovis_tscd_large.py:109-113).
 // ------------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int mtiles, int cstride, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* running_mean, float* running_var, float* scale_shift,
-                                   float* save_mean, float* save_invstd) {
+// One launch may cover several BatchNorm modules (the fused first convs / grouped second convs of the head's towers write Ctot =
+// nseg * seg_c channels): segment s = c / seg_c has its own gamma / beta / running statistics.  For a grouped conv launch the partial
+// table keeps group_cstride rows per group of group_c channels (rows padded per group); dense launches pass group_c = Ctot.
+struct BnSegs {
+  const float* gamma[4];
+  const float* beta[4];
+  float* rm[4];
+  float* rv[4];
+  int seg_c, group_c, group_cstride, rows;     // rows = row count of one half of the partial table
+};
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int mtiles, int C, double count, BnSegs sg, float eps,
+                                   float momentum, float* scale_shift, float* save_mean, float* save_invstd) {
   int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (c >= C) return;
+  const int seg = c / sg.seg_c, cc = c - seg * sg.seg_c;
+  const int grp = c / sg.group_c;
+  const long row = (long)grp * sg.group_cstride + (c - grp * sg.group_c);
   double s1 = 0.0, s2 = 0.0;
   // issued ahead of the reduction so their latency overlaps the partial loads (the kernel is one dependent chain otherwise)
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-  const float rm0 = running_mean ? running_mean[c] : 0.f, rv0 = running_mean ? running_var[c] : 0.f;
+  const float* gamma = sg.gamma[seg];
+  const float* beta = sg.beta[seg];
+  float* running_mean = sg.rm[seg];
+  float* running_var = sg.rv[seg];
+  const float g = gamma ? gamma[cc] : 1.f, b = beta ? beta[cc] : 0.f;
+  const float rm0 = running_mean ? running_mean[cc] : 0.f, rv0 = running_mean ? running_var[cc] : 0.f;
 #pragma unroll 8
   for (int t = lane; t < mtiles; t += 64) {
-    s1 += (double)partial[(long)c * mtiles + t];
-    s2 += (double)partial[((long)cstride + c) * mtiles + t];
+    s1 += (double)partial[row * mtiles + t];
+    s2 += (double)partial[((long)sg.rows + row) * mtiles + t];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -167,8 +182,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int mtiles
     if (save_invstd) save_invstd[c] = invstd;
     if (running_mean) {
       double unbiased = count > 1 ? var * count / (count - 1.0) : var;
-      running_mean[c] = (1.f - momentum) * rm0 + momentum * (float)mean;
-      running_var[c] = (1.f - momentum) * rv0 + momentum * (float)unbiased;
+      running_mean[cc] = (1.f - momentum) * rm0 + momentum * (float)mean;
+      running_var[cc] = (1.f - momentum) * rv0 + momentum * (float)unbiased;
     }
   }
 }
@@ -178,9 +193,12 @@ extern "C" int tscd_bn_finalize(const float* partial, int mtiles, int cstride, i
                                 float* scale_shift, float* save_mean, float* save_invstd, void* stream) {
   TSCD_CHECK_ARG(partial && scale_shift && C > 0 && mtiles > 0 && count > 0, "bn_finalize: bad args");
   TSCD_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partial, mtiles, cstride, C,
-                     (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale_shift, save_mean,
-                     save_invstd);
+  BnSegs sg;
+  memset(&sg, 0, sizeof(sg));
+  sg.gamma[0] = gamma; sg.beta[0] = beta; sg.rm[0] = running_mean; sg.rv[0] = running_var;
+  sg.seg_c = C; sg.group_c = C; sg.group_cstride = cstride; sg.rows = cstride;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partial, mtiles, C,
+                     (double)count, sg, eps, momentum, scale_shift, save_mean, save_invstd);
   TSCD_CHECK_LAUNCH("bn_finalize");
   return TSCD_OK;
 }
@@ -865,4 +883,50 @@ extern "C" int tscd_conv_bn_act_train_f16(const void* x, const void* wpk, void* 
                         small + 3 * (long)Cout, stream);
   if (st != TSCD_OK) return st;
   return tscd_bn_act_nhwc_f16(raw, ldraw, out, ldo, small, residual, ldr, M, Cout, act, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The same for SEVERAL BaseConvs in one conv launch (reference: the four towers of TSCDHead.forward, tscd_head.py:315-324, all read the
+// stem output):
+//   groups == 1: convs that share their INPUT run as one dense conv over the concatenated output channels (Ctot = nseg * seg_c rows
+//                of the packed matrix, the stem output staged once for all of them);
+//   groups == nseg > 1: convs with separate inputs (channel slices g * Cin of x) and outputs (slices g * seg_c of raw / out): one
+//                grouped launch (tscd_conv2d_nhwc_f16_ex).
+// Each of the nseg BatchNorms keeps its own gamma / beta / running statistics (arrays of nseg device pointers); small [4][Ctot] =
+// scale | shift | save_mean | save_invstd over the concatenated channels; ONE statistics launch and ONE apply launch cover them all.
+// ------------------------------------------------------------------------------------------------------
+extern "C" int tscd_conv2d_nhwc_f16_ex(const void* x, const void* wpk, void* y, const float* bias, const float* scale, const float* shift,
+                                       float* bn_partial, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int ldx, int ldy,
+                                       int epilogue, int groups, int variant, int korder, int tile_m, void* stream);
+extern "C" int tscd_conv_stat_tiles_ex(long M, int W, int Cin, int Cout, int ksize, int stride, int groups, int variant, int tile_m);
+extern "C" int tscd_conv_tile_n(int cout);
+extern "C" int tscd_conv_bn_act_train_multi_f16(const void* x, const void* wpk, void* raw, int ldraw, float* partial, int B, int H, int W,
+                                                int Cin, int seg_c, int nseg, int groups, int ksize, int ldx, const void* const* gamma,
+                                                const void* const* beta, float eps, float momentum, void* const* running_mean,
+                                                void* const* running_var, float* small, void* out, int ldo, int act, void* stream) {
+  TSCD_CHECK_ARG(x && wpk && raw && partial && small && out && gamma && beta, "conv_bn_act_train_multi: null pointer");
+  TSCD_CHECK_ARG(nseg >= 1 && nseg <= 4 && (groups == 1 || groups == nseg), "conv_bn_act_train_multi: nseg=%d groups=%d", nseg, groups);
+  const long M = (long)B * H * W;                     // stride 1, 'same' padding
+  const int Ctot = nseg * seg_c;
+  const int cout_launch = groups == 1 ? Ctot : seg_c; // output channels per group of the conv launch
+  int st = tscd_conv2d_nhwc_f16_ex(x, wpk, raw, nullptr, nullptr, nullptr, partial, B, H, W, Cin, cout_launch, ksize, 1, ldx, ldraw, 0, groups,
+                                   -1, 0, 0, stream);
+  if (st != TSCD_OK) return st;
+  const int mtiles = tscd_conv_stat_tiles_ex(M, W, Cin, cout_launch, ksize, 1, groups, -1, 0);
+  const int bn = tscd_conv_tile_n(cout_launch);
+  BnSegs sg;
+  memset(&sg, 0, sizeof(sg));
+  for (int i = 0; i < nseg; ++i) {
+    sg.gamma[i] = (const float*)gamma[i]; sg.beta[i] = (const float*)beta[i];
+    sg.rm[i] = running_mean ? (float*)running_mean[i] : nullptr; sg.rv[i] = running_var ? (float*)running_var[i] : nullptr;
+    TSCD_CHECK_ARG(sg.gamma[i] && sg.beta[i] && ((sg.rm[i] == nullptr) == (sg.rv[i] == nullptr)), "conv_bn_act_train_multi: segment %d", i);
+  }
+  sg.seg_c = seg_c;
+  sg.group_c = cout_launch;
+  sg.group_cstride = (cout_launch + bn - 1) / bn * bn;
+  sg.rows = groups * sg.group_cstride;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Ctot, 4)), dim3(256), 0, (hipStream_t)stream, partial, mtiles, Ctot, (double)M, sg, eps,
+                     momentum, small, small + 2 * (long)Ctot, small + 3 * (long)Ctot);
+  TSCD_CHECK_LAUNCH("bn_finalize (multi)");
+  return tscd_bn_act_nhwc_f16(raw, ldraw, out, ldo, small, nullptr, 0, M, Ctot, act, stream);
 }

@@ -270,12 +270,32 @@ __global__ __launch_bounds__(256) void nms_sort64_order_kernel(const int* __rest
   if (i < count[f]) order[(long)f * capM + i] = (int)(0xFFFFFFFFu - (unsigned)(gkeys[(long)f * P + i] & 0xFFFFFFFFull));
 }
 
+// IoU(a, b) > thr with a = the earlier (kept) box, every product and sum rounded on its own like the oracle's numpy float32
+// arithmetic: with fused multiply-adds (hipcc's default contraction) an IoU within an ulp of the threshold flips -- 2 of 96 000
+// candidates in tests/test_gpu_nms_unbounded.py, and differently in differently shaped loops.
+__device__ __forceinline__ bool nms_suppresses(float ax1, float ay1, float ax2, float ay2, float bx1, float by1, float bx2, float by2,
+                                               float thr) {
+#pragma clang fp contract(off)
+  const float iw = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f);
+  const float ih = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
+  const float inter = iw * ih;
+  const float aa = (ax2 - ax1) * (ay2 - ay1);
+  const float ab = (bx2 - bx1) * (by2 - by1);
+  const float iou = inter / (aa + ab - inter);
+  return iou > thr;
+}
+
 // Greedy NMS for one (frame, class), tile by tile.  keep[f][sorted position] = 1 for survivors.
+// agnostic != 0 (the coordinate-trick pass): ONE workgroup per frame takes every candidate, each shifted by its own class offset --
+// torchvision's batched_nms is a class-agnostic NMS on the shifted boxes, and in fp16 boxes of neighbouring classes do meet (offsets
+// are multiples of max + 1, boxes reach below 0 and the shifted coordinates round to 4-8 px).  Frames are split between the two
+// passes by their candidate count: coord_trick = n sends frames with <= n candidates to the agnostic pass, the others to the
+// per-class pass.
 // kept_box [L][NCg][max_rows][4]: the boxes this (frame, class) has kept so far (only touched when the class overflows one tile).
 __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict__ box, const int* __restrict__ cls,
                                                         const int* __restrict__ order, const int* __restrict__ count, int capM,
                                                         float iou_thr, unsigned char* __restrict__ keep, float* __restrict__ kept_box,
-                                                        int max_rows, const float* __restrict__ maxc, int coord_trick) {
+                                                        int max_rows, const float* __restrict__ maxc, int coord_trick, int agnostic) {
   __shared__ float bx[NMS_MAXPC][4];
   __shared__ int pos[NMS_MAXPC];
   __shared__ unsigned char dead[NMS_MAXPC];
@@ -283,11 +303,11 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
   __shared__ int base, nkept_s;
   const int f = blockIdx.x, cid = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = count[f];
+  const bool trick = coord_trick > 0 && M <= coord_trick;
+  if (trick != (agnostic != 0)) return;                  // this frame belongs to the other pass (uniform per workgroup)
   float* kb = kept_box ? kept_box + ((long)f * gridDim.y + cid) * max_rows * 4 : nullptr;
   // coordinate trick (torchvision.ops.batched_nms on the evaluator's fp16 tensors): offset = fp16(class id) * fp16(max + 1)
-  const bool trick = coord_trick > 0 && M <= coord_trick;
-  float off_c = 0.f;
-  if (trick) off_c = (float)(f16)((float)(f16)(float)cid * (float)(f16)((float)(f16)maxc[f] + 1.0f));
+  const float unit = trick ? (float)(f16)((float)(f16)maxc[f] + 1.0f) : 0.f;
   if (tid == 0) { base = 0; nkept_s = 0; }
   __syncthreads();
   // one tile: suppress by the boxes kept in earlier tiles, greedy inside the tile, publish the survivors
@@ -296,17 +316,9 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
     if (nk > 0) {
       for (int j = tid; j < n; j += 256) {
         const float x1 = bx[j][0], y1 = bx[j][1], x2 = bx[j][2], y2 = bx[j][3];
-        const float aj = (x2 - x1) * (y2 - y1);
         bool d = false;
-        for (int k = 0; k < nk && !d; ++k) {
-          const float kx1 = kb[k * 4 + 0], ky1 = kb[k * 4 + 1], kx2 = kb[k * 4 + 2], ky2 = kb[k * 4 + 3];
-          float iw = fmaxf(fminf(kx2, x2) - fmaxf(kx1, x1), 0.f);
-          float ih = fmaxf(fminf(ky2, y2) - fmaxf(ky1, y1), 0.f);
-          float inter = iw * ih;
-          float ai = (kx2 - kx1) * (ky2 - ky1);
-          float iou = inter / (ai + aj - inter);
-          d = iou > iou_thr;
-        }
+        for (int k = 0; k < nk && !d; ++k)
+          d = nms_suppresses(kb[k * 4 + 0], kb[k * 4 + 1], kb[k * 4 + 2], kb[k * 4 + 3], x1, y1, x2, y2, iou_thr);
         if (d) dead[j] = 1;
       }
       __syncthreads();
@@ -314,15 +326,9 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
     for (int i = 0; i < n; ++i) {
       if (dead[i]) continue;   // uniform: read after the barrier of the previous iteration
       const float x1 = bx[i][0], y1 = bx[i][1], x2 = bx[i][2], y2 = bx[i][3];
-      const float ai = (x2 - x1) * (y2 - y1);
       for (int j = i + 1 + tid; j < n; j += 256) {
         if (dead[j]) continue;
-        float iw = fmaxf(fminf(x2, bx[j][2]) - fmaxf(x1, bx[j][0]), 0.f);
-        float ih = fmaxf(fminf(y2, bx[j][3]) - fmaxf(y1, bx[j][1]), 0.f);
-        float inter = iw * ih;
-        float aj = (bx[j][2] - bx[j][0]) * (bx[j][3] - bx[j][1]);
-        float iou = inter / (ai + aj - inter);
-        if (iou > iou_thr) dead[j] = 1;
+        if (nms_suppresses(x1, y1, x2, y2, bx[j][0], bx[j][1], bx[j][2], bx[j][3], iou_thr)) dead[j] = 1;
       }
       __syncthreads();
     }
@@ -360,7 +366,8 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
     }
     int i = i0 + tid;
     int src = i < M ? order[(long)f * capM + i] : 0;
-    bool mine = i < M && cls[(long)f * capM + src] == cid;
+    const int ccls = i < M ? cls[(long)f * capM + src] : 0;
+    bool mine = i < M && (agnostic || ccls == cid);
     unsigned long long m = __ballot(mine);
     int before = __popcll(m & ((1ull << lane) - 1));
     if (lane == 0) wsum[wv] = __popcll(m);
@@ -372,6 +379,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
       int p = off + before;
       const float* b = box + ((long)f * capM + src) * 4;
       if (trick) {
+        const float off_c = (float)(f16)((float)(f16)(float)ccls * unit);
         bx[p][0] = (float)(f16)(b[0] + off_c); bx[p][1] = (float)(f16)(b[1] + off_c);
         bx[p][2] = (float)(f16)(b[2] + off_c); bx[p][3] = (float)(f16)(b[3] + off_c);
       } else {
@@ -436,6 +444,7 @@ static int nms_pow2_64(int capM) {
 // kept-box lists of the tiled greedy pass are only reserved when it exceeds one tile.
 extern "C" long tscd_nms_workspace_bytes(int L, int capM, int NC, int max_rows) {
   long per = (long)capM * (16 + 4 + 6 + 4 + 4 + 1) + 64 + 8 * 256;
+  per += 16L * capM + 256;                                      // kept boxes of the class-agnostic coordinate-trick pass (worst case)
   if (capM > NMS_MAXC32) per += 8L * nms_pow2_64(capM) + 256;   // 64-bit sort keys
   else if (capM > NMS_CHUNK) per += 4L * nms_pow2(capM) + 256;  // global 32-bit sort keys of frames with more than one LDS chunk
   if (max_rows > NMS_MAXPC) per += 16L * (NC > 0 ? NC : 1) * max_rows + 256;
@@ -502,8 +511,16 @@ extern "C" int tscd_batched_nms(const void* det, int ndet, const int* frame_off,
   const int ncg = mode == 2 ? 1 : NC;
   float* kept_box = max_rows > NMS_MAXPC ? (float*)take(16L * L * ncg * max_rows) : nullptr;
   hipLaunchKernelGGL(nms_greedy_kernel, dim3(L, ncg), dim3(256), 0, st, c.box, c.cls, order, c.count, capM, iou_thresh, keep, kept_box,
-                     max_rows, c.maxc, coord_trick);
+                     max_rows, c.maxc, coord_trick, 0);
   TSCD_CHECK_LAUNCH("nms_greedy");
+  if (coord_trick > 0) {
+    // the class-agnostic pass over the shifted boxes of the frames with at most coord_trick candidates
+    const int rows = coord_trick < capM ? coord_trick : capM;
+    float* kept_all = rows > NMS_MAXPC ? (float*)take(16L * L * rows) : nullptr;
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(L, 1), dim3(256), 0, st, c.box, c.cls, order, c.count, capM, iou_thresh, keep, kept_all,
+                       rows, c.maxc, coord_trick, 1);
+    TSCD_CHECK_LAUNCH("nms_greedy (coordinate trick)");
+  }
   hipLaunchKernelGGL(nms_compact_kernel, dim3(L), dim3(256), 0, st, c.box, c.aux, order, keep, c.count, capM, (f16*)out,
                      out_idx, out_count);
   TSCD_CHECK_LAUNCH("nms_compact");

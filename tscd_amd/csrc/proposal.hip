@@ -217,7 +217,7 @@ struct MapTable {
 };
 
 __global__ void gather_rows_kernel(MapTable t, const int* __restrict__ sel_idx, int cap, const int* __restrict__ frame_off,
-                                   int B, int N, int W, int nmaps, f16* __restrict__ out0, f16* __restrict__ out1,
+                                   int B, int N, int W, int ld, int nmaps, f16* __restrict__ out0, f16* __restrict__ out1,
                                    f16* __restrict__ out2) {
   int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   int n = wave / nmaps, f = wave % nmaps;
@@ -226,13 +226,13 @@ __global__ void gather_rows_kernel(MapTable t, const int* __restrict__ sel_idx, 
   while (b + 1 < B && frame_off[b + 1] <= n) ++b;
   int a = sel_idx[(long)b * cap + (n - frame_off[b])];
   int k = a >= t.a0[2] ? 2 : (a >= t.a0[1] ? 1 : 0);
-  const f16* src = t.map[f][k] + ((long)b * t.hw[k] + (a - t.a0[k])) * W;
+  const f16* src = t.map[f][k] + ((long)b * t.hw[k] + (a - t.a0[k])) * ld;
   f16* dst = (f == 0 ? out0 : (f == 1 ? out1 : out2)) + (long)n * W;
   for (int c = lane * 8; c < W; c += 512) *(f16x8*)(dst + c) = *(const f16x8*)(src + c);
 }
 
 __global__ void scatter_rows_kernel(MapTable t, const int* __restrict__ sel_idx, int cap, const int* __restrict__ frame_off,
-                                    int B, int N, int W, int nmaps, const f16* __restrict__ g0, const f16* __restrict__ g1,
+                                    int B, int N, int W, int ld, int nmaps, const f16* __restrict__ g0, const f16* __restrict__ g1,
                                     const f16* __restrict__ g2) {
   int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   int n = wave / nmaps, f = wave % nmaps;
@@ -241,16 +241,17 @@ __global__ void scatter_rows_kernel(MapTable t, const int* __restrict__ sel_idx,
   while (b + 1 < B && frame_off[b + 1] <= n) ++b;
   int a = sel_idx[(long)b * cap + (n - frame_off[b])];
   int k = a >= t.a0[2] ? 2 : (a >= t.a0[1] ? 1 : 0);
-  f16* dst = t.gmap[f][k] + ((long)b * t.hw[k] + (a - t.a0[k])) * W;
+  f16* dst = t.gmap[f][k] + ((long)b * t.hw[k] + (a - t.a0[k])) * ld;
   const f16* src = (f == 0 ? g0 : (f == 1 ? g1 : g2)) + (long)n * W;
   for (int c = lane * 8; c < W; c += 512) *(f16x8*)(dst + c) = *(const f16x8*)(src + c);
 }
 
-// maps: 9 pointers [feature 0..2][level 0..2]; features beyond nmaps may be null.
+// maps: 9 pointers [feature 0..2][level 0..2]; features beyond nmaps may be null.  map_ld: pixel stride of every map in elements (W
+// for contiguous maps; the towers' outputs are W-channel slices of a wider buffer).
 extern "C" int tscd_gather_rows(const void* const* maps, const int* hw3, const int* sel_idx, int cap, const int* frame_off,
-                                int B, int N, int W, int nmaps, void* out0, void* out1, void* out2, int scatter,
+                                int B, int N, int W, int map_ld, int nmaps, void* out0, void* out1, void* out2, int scatter,
                                 void* stream) {
-  TSCD_CHECK_ARG(maps && hw3 && sel_idx && frame_off && N >= 0 && W % 8 == 0 && nmaps >= 1 && nmaps <= 3,
+  TSCD_CHECK_ARG(maps && hw3 && sel_idx && frame_off && N >= 0 && W % 8 == 0 && map_ld % 8 == 0 && map_ld >= W && nmaps >= 1 && nmaps <= 3,
                  "gather_rows: bad args");
   if (N == 0) return TSCD_OK;
   MapTable t;
@@ -265,10 +266,10 @@ extern "C" int tscd_gather_rows(const void* const* maps, const int* hw3, const i
   long waves = (long)N * nmaps;
   dim3 grid((unsigned)((waves * 64 + 255) / 256)), block(256);
   if (!scatter)
-    hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, (hipStream_t)stream, t, sel_idx, cap, frame_off, B, N, W, nmaps,
+    hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, (hipStream_t)stream, t, sel_idx, cap, frame_off, B, N, W, map_ld, nmaps,
                        (f16*)out0, (f16*)out1, (f16*)out2);
   else
-    hipLaunchKernelGGL(scatter_rows_kernel, grid, block, 0, (hipStream_t)stream, t, sel_idx, cap, frame_off, B, N, W, nmaps,
+    hipLaunchKernelGGL(scatter_rows_kernel, grid, block, 0, (hipStream_t)stream, t, sel_idx, cap, frame_off, B, N, W, map_ld, nmaps,
                        (const f16*)out0, (const f16*)out1, (const f16*)out2);
   TSCD_CHECK_LAUNCH("gather_rows");
   return TSCD_OK;

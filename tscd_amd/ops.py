@@ -195,21 +195,31 @@ def conv_out_hw(H, W, ksize, stride):
     return (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
 
 
-def conv2d(x, wpk, cout, ksize, stride=1, epilogue=EPI_RAW, bias=None, scale_shift=None, out=None, want_stats=False):
-    """Implicit-GEMM conv.  x [B,H,W,Cin] fp16 NHWC(-slice).  Returns (y, bn_partial or None)."""
+def conv2d(x, wpk, cout, ksize, stride=1, epilogue=EPI_RAW, bias=None, scale_shift=None, out=None, want_stats=False, groups=1,
+           variant=-1, korder=0, tile_m=0):
+    """Implicit-GEMM conv.  x [B,H,W,groups*Cin] fp16 NHWC(-slice).  Returns (y [B,Ho,Wo,groups*cout], bn_partial or None).
+    ``groups`` > 1: that many convs of Cin -> cout channels in one launch, group g on channels [g*Cin, (g+1)*Cin) of x with the g-th
+    packed matrix of ``wpk`` ([groups * rows_pad, Kpad]) into channels [g*cout, (g+1)*cout) of y.  ``variant`` / ``korder`` / ``tile_m``:
+    per-call main-loop plan of tscd_conv2d_nhwc_f16_ex (tests and A/B timing; the product passes the automatic values)."""
     require_gpu(x, "conv input")
-    B, H, W, Cin = x.shape
+    B, H, W, Cx = x.shape
+    assert Cx % groups == 0
+    Cin = Cx // groups
     ldx = nhwc_ld(x)
     Ho, Wo = conv_out_hw(H, W, ksize, stride)
     if out is None:
-        out = empty_nhwc(B, Ho, Wo, cout, x.device)
-    assert tuple(out.shape) == (B, Ho, Wo, cout), (out.shape, (B, Ho, Wo, cout))
+        out = empty_nhwc(B, Ho, Wo, groups * cout, x.device)
+    assert tuple(out.shape) == (B, Ho, Wo, groups * cout), (out.shape, (B, Ho, Wo, groups * cout))
     ldy = nhwc_ld(out)
     kpad = (ksize * ksize * Cin + 31) // 32 * 32
-    assert wpk.shape[1] == kpad and wpk.shape[0] >= cout, (wpk.shape, kpad, cout)
+    rows_g = wpk.shape[0] // groups
+    assert wpk.shape[1] == kpad and rows_g >= cout and (groups == 1 or rows_g % lib.tscd_conv_tile_n(cout) == 0), (wpk.shape, kpad, cout, groups)
     partial = None
+    plain = groups == 1 and variant == -1 and korder == 0 and tile_m == 0
     if want_stats:
-        mt = lib.tscd_conv_stat_tiles(B * Ho * Wo, Wo, Cin, cout, ksize, stride)     # one partial-sum entry per M-tile of the variant taken
+        # one partial-sum entry per M-tile of the main loop the launch takes
+        mt = lib.tscd_conv_stat_tiles(B * Ho * Wo, Wo, Cin, cout, ksize, stride) if plain else \
+            lib.tscd_conv_stat_tiles_ex(B * Ho * Wo, Wo, Cin, cout, ksize, stride, groups, variant, tile_m)
         partial = torch.empty((2, wpk.shape[0], mt), dtype=torch.float32, device=x.device)
     scale = shift = None
     if scale_shift is not None:
@@ -218,12 +228,16 @@ def conv2d(x, wpk, cout, ksize, stride=1, epilogue=EPI_RAW, bias=None, scale_shi
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("tscd_conv2d_nhwc_f16", x.data_ptr(), wpk.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(scale), _ptr(shift),
-         _ptr(partial), B, H, W, Cin, cout, ksize, stride, ldx, ldy, epilogue, _stream())
+    if plain:
+        call("tscd_conv2d_nhwc_f16", x.data_ptr(), wpk.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(scale), _ptr(shift),
+             _ptr(partial), B, H, W, Cin, cout, ksize, stride, ldx, ldy, epilogue, _stream())
+    else:
+        call("tscd_conv2d_nhwc_f16_ex", x.data_ptr(), wpk.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(scale), _ptr(shift),
+             _ptr(partial), B, H, W, Cin, cout, ksize, stride, ldx, ldy, epilogue, groups, variant, korder, tile_m, _stream())
     if prof is not None:
         e1.record()
-        prof.append((lib.tscd_conv_tile_n(cout), Cin, 2.0 * B * Ho * Wo * cout * ksize * ksize * Cin, e0, e1,
-                     (B, H, W, Cin, cout, ksize, stride)))
+        prof.append((lib.tscd_conv_tile_n(cout), Cin, 2.0 * B * Ho * Wo * groups * cout * ksize * ksize * Cin, e0, e1,
+                     (B, H, W, Cin, cout, ksize, stride) + ((f"x{groups} groups",) if groups > 1 else ())))
     return out, partial
 
 
@@ -268,6 +282,51 @@ def conv_bn_act_train(x, wpk, cout, ksize, stride, gamma, beta, running_mean, ru
         # the kernel wrote the running statistics through raw pointers: bump their version counters so that what is keyed on them
         # (the folded evaluation scale / shift of BaseConv, evaluation graphs) notices the next time the module runs in eval mode
         torch.autograd.graph.increment_version((running_mean, running_var))
+    return out, raw, small[:2], small[2], small[3]
+
+
+def _ptr_array(tensors):
+    import ctypes as C
+    return (C.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
+
+
+def conv_bn_act_train_multi(x, wpk, seg_c, bns, ksize, groups, eps=BN_EPS, momentum=BN_MOMENTUM, act=ACT_SILU, keep_raw=False):
+    """Several BaseConvs (3x3 / 1x1, stride 1) in training mode through ONE conv launch + ONE statistics launch + ONE apply launch.
+    ``bns``: list of nseg (gamma, beta, running_mean, running_var) fp32 tuples, one BatchNorm of seg_c channels each.
+    groups == 1: the convs share their input x [B,H,W,Cin]; wpk = their packed matrices as one [nseg*seg_c (padded), Kpad] matrix.
+    groups == nseg: conv g reads channels [g*Cin, ...) of x; wpk = [groups * rows_pad, Kpad].
+    -> (out [B,H,W,nseg*seg_c], raw (== out unless keep_raw), scale_shift [2,Ctot], mean [Ctot], invstd [Ctot])."""
+    B, H, W, Cx = x.shape
+    nseg = len(bns)
+    assert groups in (1, nseg) and Cx % groups == 0
+    Cin = Cx // groups
+    Ctot = nseg * seg_c
+    dev = x.device
+    out = empty_nhwc(B, H, W, Ctot, dev)
+    raw = empty_nhwc(B, H, W, Ctot, dev) if keep_raw else out
+    cout_launch = Ctot if groups == 1 else seg_c
+    if CONV_PROFILE is not None:            # roofline instrumentation brackets the conv launch alone: separate calls
+        raw_, part = conv2d(x, wpk, cout_launch, ksize, 1, EPI_RAW, out=raw, want_stats=True, groups=groups)
+        sss = []
+        for i, (g, b, rm, rv) in enumerate(bns):      # per-module statistics from the module's rows of the partial table
+            rows_g = wpk.shape[0] // groups
+            r0 = i * seg_c if groups == 1 else i * rows_g
+            sub = torch.stack((part[0, r0:r0 + seg_c], part[1, r0:r0 + seg_c])).contiguous()
+            sss.append(bn_finalize(sub, B * H * W, g, b, rm, rv, eps, momentum))
+        ss = torch.cat([t[0] for t in sss], 1).contiguous()
+        mean, invstd = torch.cat([t[1] for t in sss]), torch.cat([t[2] for t in sss])
+        bn_act(raw, ss, act, out=out if keep_raw else None)
+        return out, raw, ss, mean, invstd
+    mt = lib.tscd_conv_stat_tiles_ex(B * H * W, W, Cin, cout_launch, ksize, 1, groups, -1, 0)
+    partial = torch.empty((2, wpk.shape[0], mt), dtype=torch.float32, device=dev)
+    small = torch.empty((4, Ctot), dtype=torch.float32, device=dev)
+    rms = [t[2] for t in bns]
+    call("tscd_conv_bn_act_train_multi_f16", x.data_ptr(), wpk.data_ptr(), raw.data_ptr(), nhwc_ld(raw), partial.data_ptr(), B, H, W, Cin,
+         seg_c, nseg, groups, ksize, nhwc_ld(x), _ptr_array([t[0] for t in bns]), _ptr_array([t[1] for t in bns]), eps, momentum,
+         _ptr_array(rms) if rms[0] is not None else None, _ptr_array([t[3] for t in bns]) if rms[0] is not None else None,
+         small.data_ptr(), out.data_ptr(), nhwc_ld(out), act, _stream())
+    if rms[0] is not None:
+        torch.autograd.graph.increment_version(tuple(rms) + tuple(t[3] for t in bns))
     return out, raw, small[:2], small[2], small[3]
 
 
@@ -502,17 +561,27 @@ def _map_table(maps_per_feature):
     return (C.c_void_p * 9)(*ptrs)
 
 
+def _maps_ld(maps_per_feature, W):
+    """Common pixel stride of the feature maps ([B,h,w,W] NHWC tensors or W-channel slices of wider buffers)."""
+    ld = None
+    for f in maps_per_feature:
+        for m in f:
+            l = nhwc_ld(m)
+            assert m.shape[-1] == W and (ld is None or l == ld), "feature maps of one gather must share their pixel stride"
+            ld = l
+    return ld
+
+
 def gather_rows(maps_per_feature, geo, sel_idx, frame_off, N, W):
-    """maps_per_feature: list (<=3) of per-level lists of contiguous [B,h,w,W] maps.  -> list of [N, W] tensors."""
+    """maps_per_feature: list (<=3) of per-level lists of [B,h,w,W] maps (NHWC or channel slices of one pixel stride).
+    -> list of [N, W] tensors."""
     nm = len(maps_per_feature)
     dev = sel_idx.device
     outs = [torch.empty((N, W), dtype=torch.float16, device=dev) for _ in range(nm)]
-    for f in maps_per_feature:
-        for m in f:
-            assert m.is_contiguous() and m.shape[-1] == W
+    ld = _maps_ld(maps_per_feature, W)
     B = maps_per_feature[0][0].shape[0]
     call("tscd_gather_rows", _map_table(maps_per_feature), geo.c_hw, sel_idx.data_ptr(), sel_idx.shape[1], frame_off.data_ptr(),
-         B, N, W, nm, _ptr(outs[0]), _ptr(outs[1] if nm > 1 else None), _ptr(outs[2] if nm > 2 else None), 0, _stream())
+         B, N, W, ld, nm, _ptr(outs[0]), _ptr(outs[1] if nm > 1 else None), _ptr(outs[2] if nm > 2 else None), 0, _stream())
     return outs
 
 
@@ -521,8 +590,9 @@ def scatter_rows(grads, grad_maps_per_feature, geo, sel_idx, frame_off, N, W):
     nm = len(grads)
     B = grad_maps_per_feature[0][0].shape[0]
     gs = [g.contiguous() for g in grads]
+    ld = _maps_ld(grad_maps_per_feature, W)
     call("tscd_gather_rows", _map_table(grad_maps_per_feature), geo.c_hw, sel_idx.data_ptr(), sel_idx.shape[1],
-         frame_off.data_ptr(), B, N, W, nm, _ptr(gs[0]), _ptr(gs[1] if nm > 1 else None), _ptr(gs[2] if nm > 2 else None), 1,
+         frame_off.data_ptr(), B, N, W, ld, nm, _ptr(gs[0]), _ptr(gs[1] if nm > 1 else None), _ptr(gs[2] if nm > 2 else None), 1,
          _stream())
 
 
@@ -930,15 +1000,23 @@ def scale_grad(d, g, i0, i1=None, split=0, pad=0):
 # ----------------------------------------------------------------------------------------------------
 # backward kernels of the trainable head convs
 # ----------------------------------------------------------------------------------------------------
-def conv_wgrad(x, dy, cin, cout, ksize):
-    """dW [cout,cin,k,k] fp32 of a stride-1 'same' conv; x [B,H,W,cin], dy [B,H,W,cout] fp16 NHWC(-slices)."""
+def conv_wgrad(x, dy, cin, cout, ksize, groups=1, variant=1):
+    """dW [groups*cout,cin,k,k] fp32 of stride-1 'same' convs; x [B,H,W,groups*cin], dy [B,H,W,groups*cout] fp16 NHWC(-slices).
+    ``groups`` > 1: group g's gradient from channels [g*cin, ...) of x and [g*cout, ...) of dy, stacked along dim 0.
+    ``variant`` (tests): 0 = the register-staged cross-check loop."""
     B, H, W, _ = x.shape
     M = B * H * W
-    ws_bytes = lib.tscd_conv_wgrad_workspace_bytes(M, cout, cin, ksize)
+    dw = torch.empty((groups * cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    if groups == 1 and variant == 1:
+        ws_bytes = lib.tscd_conv_wgrad_workspace_bytes(M, cout, cin, ksize)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+        call("tscd_conv_wgrad_nhwc_f16", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, cin, cout, ksize, nhwc_ld(x), nhwc_ld(dy),
+             ws.data_ptr(), ws_bytes, _stream())
+        return dw
+    ws_bytes = lib.tscd_conv_wgrad_workspace_bytes_ex(M, cout, cin, ksize, groups)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
-    call("tscd_conv_wgrad_nhwc_f16", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, cin, cout, ksize, nhwc_ld(x), nhwc_ld(dy),
-         ws.data_ptr(), ws_bytes, _stream())
+    call("tscd_conv_wgrad_nhwc_f16_ex", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, cin, cout, ksize, nhwc_ld(x), nhwc_ld(dy),
+         groups, variant, ws.data_ptr(), ws_bytes, _stream())
     return dw
 
 
@@ -962,6 +1040,26 @@ def bn_silu_bwd(dy, raw, scale_shift, mean, invstd, gamma):
     sums = torch.empty((2, C), dtype=torch.float32, device=raw.device)
     call("tscd_bn_silu_bwd_f16", dy.data_ptr(), raw.data_ptr(), scale_shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
          gamma.data_ptr(), M, C, draw.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+    return draw, sums[1], sums[0]
+
+
+def bn_silu_bwd_multi(dys, raw, scale_shift, mean, invstd, gammas):
+    """The same over the channels of SEVERAL BaseConvs that shared a conv launch: dys = 1 or 2 gradient tensors [B,H,W,c_i]
+    (NHWC(-slices), sum c_i = C), raw [B,H,W,C] a channel slice, gammas = 1 or 2 fp32 vectors covering the C channels.
+    -> (draw [B,H,W,C] contiguous fp16, dgamma [C], dbeta [C])."""
+    B, H, W, C = raw.shape
+    M = B * H * W
+    assert len(dys) in (1, 2) and sum(d.shape[-1] for d in dys) == C and all(d.dtype == torch.float16 for d in dys)
+    assert len(gammas) in (1, 2) and sum(g.shape[0] for g in gammas) == C and all(g.dtype == torch.float32 for g in gammas)
+    ws_bytes = lib.tscd_bn_silu_bwd_workspace_bytes(M, C)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=raw.device)
+    draw = empty_nhwc(B, H, W, C, raw.device)
+    sums = torch.empty((2, C), dtype=torch.float32, device=raw.device)
+    d1 = dys[1] if len(dys) == 2 else None
+    call("tscd_bn_silu_bwd_f16_ex", dys[0].data_ptr(), nhwc_ld(dys[0]), _ptr(d1), nhwc_ld(d1) if d1 is not None else 0, dys[0].shape[-1],
+         raw.data_ptr(), nhwc_ld(raw), scale_shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gammas[0].data_ptr(),
+         _ptr(gammas[1] if len(gammas) > 1 else None), gammas[0].shape[0], M, C, draw.data_ptr(), C, sums.data_ptr(), ws.data_ptr(),
+         ws_bytes, _stream())
     return draw, sums[1], sums[0]
 
 

@@ -7,12 +7,15 @@ import torch.nn as nn
 from tscd_amd import graphs
 
 from .network_blocks import defer_bn_ticks
+from .tscd_head import HeadPrefix
 
 # Cross-step overlap (training, frozen backbone): while the host solves the clip's assignments the device has ~3 ms with
 # nothing to do, and the launch-bound stretch after it leaves more holes.  `forward(..., next_x=<next clip>)` runs the NEXT
-# clip's frozen backbone pass inside that window on a low-priority side stream; the next call (same tensor object) picks the
-# pyramid up instead of recomputing it.  Frozen weights do not change at the optimizer step, so the features are exactly
-# those of an in-place pass.  TSCD_PREFETCH_BACKBONE=0 disables it.
+# clip's frozen FRONT -- the backbone pass and the head's frozen half (stems, base towers, box prediction convs:
+# ovis_tscd_large.py:141-149) -- inside that window on a low-priority side stream; the next call (same tensor object) picks the
+# result up instead of recomputing it.  Frozen weights do not change at the optimizer step, so the features are exactly
+# those of an in-place pass, and this clip's step no longer has them on its critical path (forward up to the cost matrices -> host
+# assignment chain -> rest).  TSCD_PREFETCH_BACKBONE=0 disables it.
 PREFETCH_BACKBONE = os.environ.get("TSCD_PREFETCH_BACKBONE", "1") != "0"
 _PREFETCHED = {}        # id(model) -> (clip tensor, pyramid, ready event); module-level: the model must stay deep-copyable
 _PREFETCH_STREAM = {}   # device -> low-priority stream
@@ -29,6 +32,24 @@ def _prefetch_stream(dev):
     return st
 
 
+class _FrozenFront(nn.Module):
+    """backbone + the head's frozen half (stems, base towers, box prediction convs) as ONE gradient-free pass: what
+    ``graphs.frozen_pass`` captures and replays.  The modules are the model's own (shared, not copied); this wrapper is never registered
+    in the model's module tree (state_dict untouched)."""
+
+    def __init__(self, backbone, head):
+        super().__init__()
+        self.backbone = backbone
+        self.prefix = nn.ModuleList(head.prefix_modules())
+        object.__setattr__(self, "_head", head)
+
+    def forward(self, x):
+        return self._head.frozen_prefix(self.backbone(x)).tensors()
+
+
+_FRONTS = {}            # id(model) -> (weakref(model), _FrozenFront)
+
+
 class TSCD(nn.Module):
     """backbone (YOLOPAFPN) + TSCDHead.  Training returns the reference's loss dict, eval (result, result_ori)."""
 
@@ -37,17 +58,37 @@ class TSCD(nn.Module):
         self.backbone = backbone
         self.head = head
 
+    def _front(self):
+        """The frozen front of this model (backbone + head prefix) when every parameter of it is frozen, else None."""
+        import weakref
+        if not hasattr(self.head, "prefix_modules"):
+            return None
+        hit = _FRONTS.get(id(self))
+        if hit is None or hit[0]() is not self or hit[1].backbone is not self.backbone or hit[1]._head is not self.head:
+            hit = _FRONTS[id(self)] = (weakref.ref(self), _FrozenFront(self.backbone, self.head))
+        front = hit[1]
+        if any(p.requires_grad for p in graphs.parameters_of(front)):
+            return None
+        front.training = self.training          # the graph key carries the mode; the children keep their own flags
+        return front
+
     def forward(self, x, targets=None, time_embedding=None, nms_thresh=0.5, lframe=0, gframe=32, resume=False, next_x=None):
         with defer_bn_ticks():
             return self._forward(x, targets, time_embedding, nms_thresh, lframe, gframe, resume, next_x)
 
     def _pyramid(self, x):
+        """What the head consumes: the prefetched / replayed frozen front (a HeadPrefix: stem outputs, base-tower features, box logits)
+        when backbone AND head prefix are frozen -- the TSCD exps -- else the pyramid itself."""
         hit = _PREFETCHED.pop(id(self), None)
         if hit is not None and hit[0] is x:
             torch.cuda.current_stream().wait_event(hit[2])
             for t in hit[1]:
                 t.record_stream(torch.cuda.current_stream())
-            return hit[1]
+            return HeadPrefix.from_tensors(hit[1])
+        front = self._front() if x.is_cuda else None
+        if front is not None:
+            with torch.no_grad():
+                return HeadPrefix.from_tensors(graphs.frozen_pass(front, x))
         if not torch.is_grad_enabled() or (not self.training and not any(p.requires_grad for p in self.backbone.parameters())):
             return graphs.frozen_pass(self.backbone, x)
         return self.backbone(x)
@@ -62,8 +103,9 @@ class TSCD(nn.Module):
     def _prefetch(self, next_x):
         side = _prefetch_stream(next_x.device)
         side.wait_stream(torch.cuda.current_stream())            # next_x and every buffer the pass recycles are settled
+        front = self._front()
         with torch.cuda.stream(side), torch.no_grad():
-            outs = graphs.frozen_pass(self.backbone, next_x)      # hipGraph replay after the first clip of a shape
+            outs = graphs.frozen_pass(front, next_x)               # hipGraph replay after the first clip of a shape
             ev = torch.cuda.Event()
             ev.record(side)
         _PREFETCHED[id(self)] = (next_x, outs, ev)
@@ -72,7 +114,7 @@ class TSCD(nn.Module):
         fpn_outs = self._pyramid(x)
         if self.training:
             assert targets is not None
-            frozen = not any(p.requires_grad for p in graphs.parameters_of(self.backbone))
+            frozen = self._front() is not None
             if PREFETCH_BACKBONE and next_x is not None and next_x.is_cuda and frozen:
                 self.head.window_hook = lambda: self._prefetch(next_x)
             try:

@@ -24,6 +24,7 @@ from tscd_amd import functional as TF
 from tscd_amd import ops
 from tscd_amd.autograd import eager_branch
 
+from . import tower_fusion as TW
 from .network_blocks import BaseConv
 from .post_process import nms_frames
 from .post_trans import MCA_tscd_g2l_reg
@@ -51,7 +52,27 @@ class _GatherRows(torch.autograd.Function):
         return (None,) * 6 + tuple(zeros)
 
 
+class HeadPrefix:
+    """The part of the head that depends on nothing the optimizer steps (reference: ovis_tscd_large.py:141-149 freezes ``stems``,
+    ``reg_convs``, ``cls_convs`` and ``reg_preds``): per pyramid level (x = stem output [B,h,w,W], fz = [reg_feat | cls_feat]
+    [B,h,w,2W], reg_o = box logits [B,h,w,4]), all NHWC fp16.  TSCD computes it together with the backbone pass -- for the NEXT clip
+    inside this clip's assignment window, as one hipGraph replay (yolox/models/tscd.py) -- and hands it to TSCDHead.forward in place of
+    the pyramid."""
+    __slots__ = ("levels",)
+
+    def __init__(self, levels):
+        self.levels = levels
+
+    def tensors(self):
+        return tuple(t for lvl in self.levels for t in lvl)
+
+    @staticmethod
+    def from_tensors(ts):
+        return HeadPrefix([tuple(ts[i:i + 3]) for i in range(0, len(ts), 3)])
+
+
 LEVEL_STREAMS = os.environ.get("TSCD_LEVEL_STREAMS", "1") != "0"
+FUSE_TOWERS = os.environ.get("TSCD_FUSE_TOWERS", "1") != "0"
 EAGER_CLASS_BRANCH = os.environ.get("TSCD_EAGER_CLASS_BRANCH", "1") != "0"
 
 
@@ -160,75 +181,112 @@ class TSCDHead(nn.Module):
         if self.debug is not None:
             self.debug.update(kw)
 
+    @torch.no_grad()
+    def frozen_prefix(self, xin):
+        """stems + the base towers (+ the box prediction convs when they are frozen too) of every level, without autograd -- the
+        reference's frozen half of tscd_head.py:315-373 (its BatchNorms still take batch statistics in training mode).  xin: the
+        pyramid as NCHW-logical maps.  The two base towers run as fused launches (tower_fusion.py)."""
+        W = self.width
+        levels = []
+        for k, xf in enumerate(xin):
+            f = xf.permute(0, 2, 3, 1)
+            f = f if f.dtype == torch.float16 else f.half()
+            x = self.stems[k](f)
+            firsts, seconds = [self.reg_convs[k][0], self.cls_convs[k][0]], [self.reg_convs[k][1], self.cls_convs[k][1]]
+            if FUSE_TOWERS and TW.fusable(firsts + seconds):
+                fz = TW.towers_nograd(x, firsts, seconds)                 # [reg_feat | cls_feat]
+            else:
+                fz = ops.empty_nhwc(x.shape[0], x.shape[1], x.shape[2], 2 * W, x.device)
+                self.reg_convs[k][1](self.reg_convs[k][0](x), out=fz[..., :W])
+                self.cls_convs[k][1](self.cls_convs[k][0](x), out=fz[..., W:])
+            rp = self.reg_preds[k]
+            reg_o = None if rp.weight.requires_grad else TF.conv_bias(fz[..., :W], rp.weight, rp.bias)
+            levels.append((x, fz, reg_o))
+        return HeadPrefix(levels)
+
+    def prefix_modules(self):
+        """The modules frozen_prefix runs (what a captured graph of it depends on)."""
+        return [self.stems, self.reg_convs, self.cls_convs, self.reg_preds]
+
     def forward(self, xin, labels=None, imgs=None, time_embedding=None, nms_thresh=0.5, lframe=0, gframe=32, resume=False):
         nc, W = self.num_classes, self.width
         nch = 5 + nc
-        feats = [x.permute(0, 2, 3, 1) for x in xin]                 # NCHW-logical (channels-last) -> NHWC views
-        feats = [f if f.dtype == torch.float16 else f.half() for f in feats]
-        B = feats[0].shape[0]
-        dev = feats[0].device
         training = self.training
         grad = torch.is_grad_enabled() and training
-        geo = ops.LevelGeometry([f.shape[1:3] for f in feats], self.strides)
+        pre = xin if isinstance(xin, HeadPrefix) else self.frozen_prefix(xin)
+        nlev = len(pre.levels)
+        x0 = pre.levels[0][0]
+        B, dev = x0.shape[0], x0.device
+        geo = ops.LevelGeometry([lvl[0].shape[1:3] for lvl in pre.levels], self.strides)
+        self.hw = [tuple(lvl[0].shape[1:3]) for lvl in pre.levels]
 
-        raw_levels, cls_maps, reg_maps = [None] * len(feats), [None] * len(feats), [None] * len(feats)
+        raw_levels, cls_maps, reg_maps = [None] * nlev, [None] * nlev, [None] * nlev
 
-        def frozen(k, x):
-            with torch.no_grad():                                    # frozen stem / base towers (ovis_tscd_large.py:141-149)
-                x = self.stems[k](x)
-                reg_feat = self.reg_convs[k][1](self.reg_convs[k][0](x))
-                cls_feat = self.cls_convs[k][1](self.cls_convs[k][0](x))
-            return x, reg_feat, cls_feat
+        def towers(k):
+            """The trained towers cls_convs2 / reg_convs2 of level k on the stem output (tscd_head.py:321-324)."""
+            x = pre.levels[k][0]
+            t0, t1 = self.cls_convs2[k], self.reg_convs2[k]
+            fus = FUSE_TOWERS and not x.requires_grad and TW.fusable([t0[0], t1[0], t0[1], t1[1]])
+            if fus and grad and all(p.requires_grad for p in list(t0.parameters()) + list(t1.parameters())):
+                cls_maps[k], reg_maps[k] = TW.tower_pair_train(x, t0, t1)
+            elif fus and not grad:
+                b2 = TW.towers_nograd(x, [t0[0], t1[0]], [t0[1], t1[1]])
+                cls_maps[k], reg_maps[k] = b2[..., :W], b2[..., W:]
+            else:
+                cls_maps[k], reg_maps[k] = t0[1](t0[0](x)), t1[1](t1[0](x))
 
-        def trainable(k, x, reg_feat, cls_feat):
-            vid_feat = self.cls_convs2[k][1](self.cls_convs2[k][0](x))
-            vid_feat_reg = self.reg_convs2[k][1](self.reg_convs2[k][0](x))
-            reg_o = TF.conv_bias(reg_feat, self.reg_preds[k].weight, self.reg_preds[k].bias)
+        def preds(k):
+            x, fz, reg_o = pre.levels[k]
+            reg_feat, cls_feat = fz[..., :W], fz[..., W:]
+            if reg_o is None:
+                reg_o = TF.conv_bias(reg_feat, self.reg_preds[k].weight, self.reg_preds[k].bias)
             obj_o = TF.conv_bias(reg_feat, self.obj_preds[k].weight, self.obj_preds[k].bias)
             cls_o = TF.conv_bias(cls_feat, self.cls_preds[k].weight, self.cls_preds[k].bias)
             raw_levels[k] = torch.cat([reg_o, obj_o, cls_o], -1)      # [B,h,w,5+NC]: tiny, autograd-tracked
-            cls_maps[k], reg_maps[k] = vid_feat, vid_feat_reg
 
-        # The three pyramid levels are independent chains of 14 convs each; the 36x36 and 18x18 levels launch only 80-330
-        # workgroups per conv, so they run on side streams underneath the 72x72 level instead of after it.  Also under
-        # DistributedDataParallel: the reducer keeps every parameter's AccumulateGrad node alive from its construction (on the
-        # main stream), autograd orders a gradient produced on a side stream in front of that node with an event wait (the
-        # "AccumulateGrad node's stream does not match" notice), and the reducer syncs a bucket's all-reduce with the stream its
-        # hook runs on -- the main one (same-box A/B of a 1-rank DDP step: 17.3 ms with the gradient-producing half of the side
-        # levels moved to the main stream, 16.8 without; TSCD_ONE_GRAD_STREAM=1 restores that schedule).
-        if LEVEL_STREAMS and len(feats) > 1 and dev.type == "cuda":
-            one_grad_stream = grad and os.environ.get("TSCD_ONE_GRAD_STREAM") == "1"
+        # Order of issue: what the proposal COUNTS depend on comes first (prediction convs on the frozen features, decode, selection,
+        # the asynchronous copy of the counts), the trained towers -- which the counts do not depend on -- are queued behind the copy and
+        # run while the host waits for it.  The 36x36 / 18x18 levels' towers run on side streams underneath the 72x72 level (their
+        # launches do not fill the chip).  Also under DistributedDataParallel: the reducer keeps every parameter's AccumulateGrad node
+        # alive from its construction (on the main stream), autograd orders a gradient produced on a side stream in front of that
+        # node with an event wait, and the reducer syncs a bucket's all-reduce with the stream its hook runs on -- the main one
+        # (TSCD_ONE_GRAD_STREAM=1 keeps every gradient-producing kernel on the main stream).
+        use_side = LEVEL_STREAMS and nlev > 1 and dev.type == "cuda" and not (grad and os.environ.get("TSCD_ONE_GRAD_STREAM") == "1")
+        joins = []
+        if use_side:
             main = torch.cuda.current_stream()
-            side = _side_streams(dev, len(feats) - 1)
+            side = _side_streams(dev, nlev - 1)
             fork = torch.cuda.Event()
             fork.record(main)
-            joins, held = [], {}
-            for k in range(1, len(feats)):
+            for k in range(1, nlev):
                 side[k - 1].wait_event(fork)
                 with torch.cuda.stream(side[k - 1]):
-                    held[k] = frozen(k, feats[k])
-                    if not one_grad_stream:
-                        trainable(k, *held[k])
+                    towers(k)
                     ev = torch.cuda.Event()
                     ev.record(side[k - 1])
                     joins.append(ev)
-            trainable(0, *frozen(0, feats[0]))
-            for k, ev in zip(range(1, len(feats)), joins):
-                main.wait_event(ev)
-                if one_grad_stream:
-                    trainable(k, *held[k])
-        else:
-            for k, x in enumerate(feats):
-                trainable(k, *frozen(k, x))
-        self.hw = [tuple(f.shape[1:3]) for f in feats]
-
+        for k in range(nlev):
+            preds(k)
         with torch.no_grad():
             outputs, det, score = ops.decode_score([r.detach().contiguous() for r in raw_levels], geo, nc, training)
             sel_idx, sel_cnt = ops.select_proposals(score, 0.001, self.kwargs.get("minimal_limit", 0),
                                                     self.kwargs.get("maximal_limit", 0))
-            if training:
-                fg_mask, matched_gt, pred_iou, num_fg_b, ngt_b = ops.simota_assign(outputs, labels, geo, nc, self.max_gt)
-        ppf = sel_cnt.cpu().tolist()                                   # sync #1: ragged sizes
+            counts_host = torch.empty((B,), dtype=torch.int32, pin_memory=True) if dev.type == "cuda" else None
+            if counts_host is not None:
+                counts_host.copy_(sel_cnt, non_blocking=True)
+                counts_ready = torch.cuda.Event()
+                counts_ready.record()
+        towers(0)
+        if not use_side:
+            for k in range(1, nlev):
+                towers(k)
+        for ev in joins:
+            main.wait_event(ev)
+        if counts_host is not None:
+            counts_ready.synchronize()                                 # sync #1: ragged sizes (the towers run meanwhile)
+            ppf = counts_host.tolist()
+        else:
+            ppf = sel_cnt.cpu().tolist()
         N, nl = sum(ppf), sum(ppf[:lframe])
         self._dbg(outputs=outputs, det=det, score=score, sel_idx=sel_idx, preds_per_frame=ppf)
         if N == 0 and training:
@@ -247,7 +305,7 @@ class TSCDHead(nn.Module):
         b_idx32 = b_idx.int()
 
         def gather(feature_maps):
-            maps = [m.contiguous() for m in feature_maps]
+            maps = list(feature_maps)               # [B,h,w,W] maps or W-channel slices of the towers' fused output buffers
             nf = len(maps) // 3
             if grad and any(m.requires_grad for m in maps):
                 return _GatherRows.apply(geo, sel_idx, frame_off, N, W, nf, *maps)
@@ -269,6 +327,10 @@ class TSCDHead(nn.Module):
         # block, its gather, the first MCA and the class predictions, none of which depend on the assignments -- runs on
         # the device while the host solves them.
         prep = self.local_reg_matcher.prepare(features_reg, features_cls, ppf[:lframe], resume=resume)
+        if training:
+            # the label assignment only feeds the losses: queued behind the cost matrices, it runs inside the assignment window
+            with torch.no_grad():
+                fg_mask, matched_gt, pred_iou, num_fg_b, ngt_b = ops.simota_assign(outputs, labels, geo, nc, self.max_gt)
         edge_maps = [self.edge_enhance_reg[k][0](reg_maps[k]) for k in range(len(reg_maps))]
         (f_edge,) = gather(edge_maps)
         if self.debug is not None:
