@@ -199,8 +199,9 @@ def test_train_losses_and_grads(golden, model):
 
 
 def test_backbone_prefetch_in_assignment_window_is_exact(golden, model):
-    """forward(..., next_x=clip) runs the next clip's frozen backbone pass inside the assignment window (side stream) and the
-    next call consumes it: the pyramid must be bit-identical to an in-place pass, the BatchNorm running statistics must
+    """forward(..., next_x=clip) runs the next clip's frozen front -- the backbone pass and the head's frozen half (stems, base
+    towers, box prediction convs: ovis_tscd_large.py:141-149) -- inside the assignment window (side stream) and the next call
+    consumes it: the prefix must be bit-identical to an in-place pass, the BatchNorm running statistics of backbone AND head must
     advance exactly once per clip, and a call with a different tensor must ignore the stash."""
     cfg, sd, vec, meta = golden
     import copy
@@ -213,8 +214,9 @@ def test_backbone_prefetch_in_assignment_window_is_exact(golden, model):
 
     def fresh():
         m = copy.deepcopy(model).train()
-        for p in m.backbone.parameters():
-            p.requires_grad = False
+        for mod in (m.backbone, m.head.stems, m.head.reg_convs, m.head.cls_convs, m.head.reg_preds):
+            for p in mod.parameters():
+                p.requires_grad = False
         return m
 
     a, b, c = fresh(), fresh(), fresh()
@@ -227,7 +229,8 @@ def test_backbone_prefetch_in_assignment_window_is_exact(golden, model):
     out_b1 = b(imgs, labels, temb, **kw)
     c(imgs, labels, temb, **kw)
     with torch.no_grad():
-        direct = c.backbone(imgs2)                           # what an in-place pass of clip 2 produces at this point
+        direct = c.head.frozen_prefix(c.backbone(imgs2)).tensors()     # what an in-place pass of clip 2 produces at this point
+    assert len(stash) == len(direct) == 9
     out_b2 = b(imgs2, labels, temb, **kw)
     torch.cuda.synchronize()
     for s_, d_ in zip(stash, direct):
@@ -235,7 +238,7 @@ def test_backbone_prefetch_in_assignment_window_is_exact(golden, model):
     for k in ("total_loss", "iou_loss", "conf_loss", "cls_loss"):
         assert float(out_a1[k]) == float(out_b1[k]), k
         assert float(out_a2[k]) == float(out_b2[k]), k
-    sa, sb = a.backbone.state_dict(), b.backbone.state_dict()
+    sa, sb = a.state_dict(), b.state_dict()
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k                  # running statistics / num_batches_tracked advanced identically
     # a next clip of another size (multiscale training): the stash is keyed on the tensor, not on the shape

@@ -508,6 +508,77 @@ def test_cafm_ragged_counts_and_carried_state_match_oracle(W, counts):
         close(out[-1], ref, 6e-2, 1.5e-2)
 
 
+@pytest.mark.parametrize("W,n,L", [(256, 96, 4), (64, 40, 3), (256, 500, 2)])
+def test_cafm_fused_chain_equals_the_per_op_path_and_the_oracle_autograd(W, n, L):
+    """_CafmChain (the clamped training regime: every local frame with the same number of proposals, the whole frame-to-frame chain as
+    ONE autograd node with batched k / v projections) against the per-op path on the same inputs: forward bit-identical (same kernels
+    on the same rows), every gradient -- features, edge features, and all 11 parameters incl. the time-embedding linear -- equal to
+    the per-op autograd within fp16 accumulation noise, and both within tolerance of the oracle's fp32 autograd."""
+    import yolox.models.tscd_matching as M
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(W + n + L)
+    mod = M.AwarePositionRegMatcher(hidden_channel=W, feedforward_channel=W, num_head=8, decoder_layer_num=1)
+    with torch.no_grad():
+        for name, prm in mod.named_parameters():
+            if prm.dim() == 1:
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.1 + (1.0 if name.endswith("norm.weight") else 0.0))
+    sd = {"m." + k: v.detach().clone().float() for k, v in mod.state_dict().items()}
+    mod = mod.to(dev).train()
+    ppf = [n] * L
+    nl = n * L
+    pool_reg = torch.nn.functional.normalize(torch.randn(n, 4 * W, generator=g), dim=1)
+    pool_cls = torch.nn.functional.normalize(torch.randn(n, 4 * W, generator=g), dim=1)
+    regs, clss = [], []
+    for _ in range(L):
+        order = torch.randperm(n, generator=g)
+        regs.append((pool_reg[order] + 0.01 * torch.randn(n, 4 * W, generator=g)).half())
+        clss.append((pool_cls[order] + 0.01 * torch.randn(n, 4 * W, generator=g)).half())
+    reg, cls = torch.cat(regs).to(dev), torch.cat(clss).to(dev)
+    feats0 = torch.randn(nl, W, generator=g).half()
+    edge0 = torch.randn(nl, W, generator=g).half()
+    temb = torch.randn(L, 256, generator=g).half().to(dev)
+    wgt = torch.randn(nl, W, generator=g).half().to(dev)
+    used = ("absolute_position_embedding", "transformer_aware_cross_attention_layers.0.CA", "multihead_attn.q_reg", "multihead_attn.k_reg",
+            "multihead_attn.v_reg", "transformer_aware_cross_attention_layers.0.norm", "decoder_norm")
+
+    def run(fused):
+        M.FUSED_CHAIN = fused
+        mod.zero_grad(set_to_none=True)
+        f = feats0.to(dev).requires_grad_()
+        e = edge0.to(dev).requires_grad_()
+        out = mod(f, reg, cls, e, ppf, temb, resume=False)[-1]
+        (out.float() * wgt.float()).sum().backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().float().cpu().clone() for k, p in mod.named_parameters() if p.grad is not None}
+        return out.detach().float().cpu(), f.grad.float().cpu(), e.grad.float().cpu(), grads, [np.asarray(h) for h in mod.last_hungarian]
+
+    try:
+        o1, df1, de1, g1, h1 = run(True)
+        o0, df0, de0, g0, h0 = run(False)
+    finally:
+        M.FUSED_CHAIN = True
+    assert all(np.array_equal(a, b) for a, b in zip(h0, h1))
+    assert torch.equal(o0, o1)
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+    assert cos(df0, df1) > 0.9995 and cos(de0, de1) > 0.9995, (cos(df0, df1), cos(de0, de1))
+    assert set(g0) == set(g1) and len(g1) == 11 and all(any(u in k for u in used) for k in g1), sorted(g1)
+    for k in g0:
+        c = cos(g0[k], g1[k])
+        r = (g1[k].norm() / g0[k].norm().clamp(min=1e-12)).item()
+        assert c > 0.999 and abs(r - 1) < 2e-2, (k, c, r)
+    # the oracle's fp32 autograd on the same inputs
+    sd_o = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    fo, eo = feats0.float().requires_grad_(), edge0.float().requires_grad_()
+    ref = O.aware_position_reg_matcher(sd_o, "m", fo, reg.float().cpu(), cls.float().cpu(), eo, ppf, temb.float().cpu(), False, O.MatcherState(),
+                                       O.TSCDConfig(), {})
+    (ref * wgt.float().cpu()).sum().backward()
+    close(o1, ref.detach(), 6e-2, 1.5e-2)
+    assert cos(df1, fo.grad) > 0.995 and cos(de1, eo.grad) > 0.995, (cos(df1, fo.grad), cos(de1, eo.grad))
+    for k, v in g1.items():
+        gr = sd_o["m." + k].grad
+        assert gr is not None and cos(v, gr) > 0.99, (k, cos(v, gr))
+
+
 def test_nms_more_candidates_than_one_lds_sort_chunk():
     """The ImageNet-VID regime (no upper proposal clamp, 30 classes): a frame with 1500 proposals has up to 45000
     (proposal, class) candidates -- more than the 16384 keys one LDS sort holds -- next to a small frame.  Kept candidate

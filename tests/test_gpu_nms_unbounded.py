@@ -16,7 +16,11 @@ from oracle import tscd_oracle as O
 from oracle import nms_ref
 
 
-def _scene(ppf, NC, seed, pass_frac_bias=1.0, one_class_heavy=False, spread=480.0, size=(8.0, 98.0)):
+def _scene(ppf, NC, seed, pass_frac_bias=1.0, one_class_heavy=False, spread=480.0, size=(8.0, 98.0), reg_scale=0.0):
+    """reg_scale 0: zero box deltas -- decode_reg_preds5 is then exact IEEE arithmetic on both sides (exp(0) = 1).  With non-zero
+    deltas the device's expf and libm's exp round a few refined coordinates to neighbouring fp16 values (0.25-0.5 px), and among
+    thousands of candidates some IoU sits close enough to the threshold to flip: an index-for-index comparison at this scale needs
+    inputs both sides decode identically (tests/test_gpu_head_stages.py::test_nms_bit_exact_keep_lists covers the decode itself)."""
     g = torch.Generator().manual_seed(seed)
     n = sum(ppf)
     cxy = torch.rand(n, 2, generator=g) * spread + 40
@@ -29,7 +33,7 @@ def _scene(ppf, NC, seed, pass_frac_bias=1.0, one_class_heavy=False, spread=480.
     if one_class_heavy:
         cls[:, 3] = 4.0 + torch.randn(n, generator=g)              # class 3 passes on every row: > 2048 boxes of one class
     obj = torch.randn(n, generator=g) * 1.5 + 2.0
-    reg = 0.05 * torch.randn(n, 4, generator=g)
+    reg = reg_scale * torch.randn(n, 4, generator=g)
     return det.half(), cls.half(), obj.half(), reg.half()
 
 
@@ -49,7 +53,10 @@ def _oracle_keep(det, cls, obj, reg, ppf, NC, thr=0.001, iou=0.5, half_trick=Fal
         if half_trick:
             keep = nms_ref.batched_nms(boxes.half(), scores, cids.half(), iou, vanilla_above=vanilla_above)
         else:
-            keep = nms_ref.batched_nms(boxes, scores, cids.float(), iou)
+            # exact suppression per class (torchvision's _batched_nms_vanilla).  The coordinate trick in fp32 is NOT the same thing once a
+            # box has a coordinate below 2 px: its fp16 spacing (2^-10) is finer than fp32's at offsets of 16384+ (2^-9), the shifted
+            # coordinate rounds, and an IoU within 1e-5 of the threshold flips (2 of 96 000 candidates in the large scene below)
+            keep = nms_ref.batched_nms_vanilla(boxes, scores, cids, iou)
         out.append((keep, len(scores), int(torch.bincount(cids, minlength=NC).max()) if len(cids) else 0))
         s0 += c
     return out
@@ -128,3 +135,34 @@ def test_reference_faithful_coordinate_trick_switch():
         assert torch.equal(k_exact[i].cpu().long(), exact[i][0]), i
         assert torch.equal(k_trick[i].cpu().long(), trick[i][0]), i
     assert torch.equal(k_rule[0].cpu().long(), exact[0][0]) and torch.equal(k_rule[1].cpu().long(), trick[1][0])
+
+
+@pytest.mark.parametrize("n,NC,trick,spread", [(3000, 1, False, 400.0), (9000, 2, False, 400.0), (70000, 30, False, 900.0),
+                                               (5000, 25, True, 400.0), (12000, 25, True, 700.0)])
+def test_original_detections_at_scale(n, NC, trick, spread):
+    """Mode 1 (the "original detections" set, post_process.py:73-78: one candidate per proposal, score = obj * class confidence taken
+    from the rows as they are) at sizes the proposal stage cannot produce but the kernels must survive: one class with 3000 boxes
+    (two tiles of the greedy pass), 4500 per class (three tiles), 70 000 candidates in one frame (64-bit keys), and the class-agnostic
+    coordinate-trick pass over 5000 / 12 000 shifted boxes -- keep lists index for index against oracle/nms_ref.py."""
+    from tscd_amd import ops
+    g = torch.Generator().manual_seed(n + NC)
+    cxy = torch.rand(n, 2, generator=g) * spread + 40
+    wh = torch.rand(n, 2, generator=g) * 120 + 20
+    det = torch.zeros(n, 7 + NC)
+    det[:, 0:2], det[:, 2:4] = cxy - wh / 2, cxy + wh / 2
+    det[:, 4], det[:, 5] = torch.rand(n, generator=g) * 0.9 + 0.1, torch.rand(n, generator=g) * 0.9 + 0.1
+    det[:, 6] = torch.randint(0, NC, (n,), generator=g).float()
+    det = det.half()
+    frame_off = ops.h2d([0, n], torch.int32, "cuda")
+    rows, idx, cnt = ops.batched_nms(det.cuda(), frame_off, 1, NC, 0.001, 0.5, n, 1, max_rows=n, coord_trick=(2 ** 30 if trick else 0))
+    torch.cuda.synchronize()
+    k = idx[0, :int(cnt[0])].cpu().long()
+    d = det.float()
+    score = (d[:, 4].half() * d[:, 5].half()).float()
+    assert bool((score >= 0.001).all())
+    if trick:
+        ref = nms_ref.batched_nms(d[:, :4].half(), score, d[:, 6].half(), 0.5)
+    else:
+        ref = nms_ref.batched_nms_vanilla(d[:, :4], score, d[:, 6].long(), 0.5)
+    assert torch.equal(k, ref), (len(k), len(ref))
+    assert torch.equal(rows[0, :len(k), :4].float().cpu(), d[ref, :4]) and torch.equal(rows[0, :len(k), 6].float().cpu(), d[ref, 6])

@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
   __shared__ float bx[NMS_MAXPC][4];
   __shared__ int pos[NMS_MAXPC];
   __shared__ unsigned char dead[NMS_MAXPC];
+  __shared__ float kst[256][4];              // staging of the kept list (cross-tile suppression)
   __shared__ int wsum[4];
   __shared__ int base, nkept_s;
   const int f = blockIdx.x, cid = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -313,12 +314,23 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
   // one tile: suppress by the boxes kept in earlier tiles, greedy inside the tile, publish the survivors
   auto process_tile = [&](int n, bool more) {
     const int nk = nkept_s;
-    if (nk > 0) {
+    // The kept list is written and re-read by this workgroup across tiles: it is read with agent-scope (sc1) loads, which are served by
+    // L2 -- a plain load may hit a line the CU's L1 / scalar cache fetched while an earlier tile read its neighbours, before this
+    // workgroup's own later appends to the same line (seen as 2-40 missed suppressions once a class needs three tiles) -- and staged
+    // through LDS 256 boxes at a time so every thread compares against them from there.
+    for (int k0 = 0; k0 < nk; k0 += 256) {
+      const int kn = nk - k0 < 256 ? nk - k0 : 256;
+      if (tid < kn) {
+        const float* src = kb + (long)(k0 + tid) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kst[tid][e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
       for (int j = tid; j < n; j += 256) {
+        if (dead[j]) continue;
         const float x1 = bx[j][0], y1 = bx[j][1], x2 = bx[j][2], y2 = bx[j][3];
         bool d = false;
-        for (int k = 0; k < nk && !d; ++k)
-          d = nms_suppresses(kb[k * 4 + 0], kb[k * 4 + 1], kb[k * 4 + 2], kb[k * 4 + 3], x1, y1, x2, y2, iou_thr);
+        for (int k = 0; k < kn && !d; ++k) d = nms_suppresses(kst[k][0], kst[k][1], kst[k][2], kst[k][3], x1, y1, x2, y2, iou_thr);
         if (d) dead[j] = 1;
       }
       __syncthreads();
@@ -347,13 +359,14 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
         const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         if (k && off + before < max_rows) {
           float* d = kb + (long)(off + before) * 4;
-          d[0] = bx[i][0]; d[1] = bx[i][1]; d[2] = bx[i][2]; d[3] = bx[i][3];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) __hip_atomic_store(d + e, bx[i][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (tid == 0) nkept_s += tot;
         __syncthreads();
       }
-      __threadfence_block();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's appends have left the CU before the barrier releases the readers
     }
     __syncthreads();
   };

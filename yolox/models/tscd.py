@@ -67,7 +67,9 @@ class TSCD(nn.Module):
         if hit is None or hit[0]() is not self or hit[1].backbone is not self.backbone or hit[1]._head is not self.head:
             hit = _FRONTS[id(self)] = (weakref.ref(self), _FrozenFront(self.backbone, self.head))
         front = hit[1]
-        if any(p.requires_grad for p in graphs.parameters_of(front)):
+        # frozen as the exps freeze them (ovis_tscd_large.py:116-117,141-149): the backbone, and the box prediction convs (whose output
+        # is part of the prefix); stems and base towers run without autograd whatever their flags say, exactly as TSCDHead always has
+        if any(p.requires_grad for p in graphs.parameters_of(self.backbone)) or any(p.requires_grad for p in self.head.reg_preds.parameters()):
             return None
         front.training = self.training          # the graph key carries the mode; the children keep their own flags
         return front

@@ -22,6 +22,9 @@ from tscd_amd import ops
 from tscd_amd._host import KIND_PREV, KIND_SELF, KIND_STATE, lap_chain_f16, lap_f16
 
 
+FUSED_CHAIN = __import__("os").environ.get("TSCD_FUSED_CAFM", "1") != "0"     # _CafmChain: the clamped training regime as one autograd node
+
+
 # the clip's chain of host assignments runs on this worker while the main thread keeps queueing device work
 _ASSIGN_WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="tscd-lap")
 
@@ -273,6 +276,164 @@ class _PermuteRows(torch.autograd.Function):
         return g.index_select(0, idx_inv), None, None
 
 
+class _CafmChain(torch.autograd.Function):
+    """The whole frame-to-frame chain of AwarePositionRegMatcher.forward (tscd_matching.py:761-888) for a clip whose local frames all
+    carry the same number of proposals (the clamped regime: every frame at ``maximal_limit``) as ONE autograd node: the per-frame
+    SE gates, q / k / v projections, cosine attention and residual LayerNorms are the same kernels the per-op path launches, but the
+    k / v projections of all frames run as one GEMM each (they do not depend on the recurrence), the row permutations are written
+    straight into their destinations, and the backward walks the chain in reverse without autograd's bookkeeping (its ~50 small
+    nodes per clip -- slices, cats, index gradients, dtype casts -- were host time on the critical path behind the assignments).
+
+    inputs: feat / edge [nl, W] fp16 (rows of the local frames, frame-major), temb [L, 256], index table (int64, device) with per
+    frame c (assignment order) and inv (its inverse), then the parameters.  ``meta`` = (n per frame, L, heads, offsets of c / inv in
+    the index table, eps of the two LayerNorms)."""
+
+    @staticmethod
+    def forward(ctx, meta, idx, feat, edge, temb, w_pos, b_pos, se_w0, se_w2, wq, wk, wv, ln_g, ln_b, dec_g, dec_b):
+        n, L, heads, slots, eps_ln, eps_dec = meta
+        W = feat.shape[1]
+        dev = feat.device
+        f32 = lambda t: t if t.dtype == torch.float32 else t.float()
+        w0f, w2f = f32(se_w0).contiguous(), f32(se_w2).contiguous()
+        g_ln, b_ln, g_dec, b_dec = f32(ln_g).contiguous(), f32(ln_b).contiguous(), f32(dec_g).contiguous(), f32(dec_b).contiguous()
+        feat, edge = feat.contiguous(), edge.contiguous()
+        nl = n * L
+        temb16 = temb.to(torch.float16).contiguous()
+        t_emb = ops.linear(temb16, w_pos, b_pos).float()                   # [L, W] fp32 rows (the SE gate takes fp32 position vectors)
+        # key side of every frame: k_in = SE(cur, cur_edge) + t_j, then ONE projection each for k and v over all local rows
+        k_in = torch.empty((nl, W), dtype=torch.float16, device=dev)
+        for j in range(L):
+            s0 = j * n
+            ops.call("tscd_se_fuse_f16", feat[s0:].data_ptr(), W, edge[s0:].data_ptr(), W, w0f.data_ptr(), w2f.data_ptr(), t_emb[j].data_ptr(),
+                     n, W, k_in[s0:].data_ptr(), ops._stream())
+        k_all, v_all = ops.linear(k_in, wk), ops.linear(feat, wv)
+        mfma = ops.cos_attn_uses_mfma(W, heads)
+        tiles = ops.attn_tiles([(0, n, 0, n)], dev, rows=32 if mfma else 16)
+        q_in = torch.empty((nl, W), dtype=torch.float16, device=dev)
+        q_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
+        t2_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
+        idn_all = torch.empty((nl, W), dtype=torch.float16, device=dev)    # residual inputs: cur (first frame) / cur[c]
+        qedge_all = torch.empty((nl, W), dtype=torch.float16, device=dev)  # query-side edge rows: cur_edge (first) / previous frame's cur_edge[c]
+        out_all = torch.empty((nl, W), dtype=torch.float16, device=dev)    # per-frame outputs in assignment order (= the next frame's tgt)
+        o = torch.empty((nl, W), dtype=torch.float16, device=dev)          # outputs back in proposal order
+        lsums = []
+        for j in range(L):
+            s0, s1 = j * n, (j + 1) * n
+            cur, cur_edge = feat[s0:s1], edge[s0:s1]
+            c = idx[slots[j][0]:slots[j][0] + n] if slots[j][0] >= 0 else None
+            inv = idx[slots[j][1]:slots[j][1] + n]
+            if j == 0:
+                idn_all[s0:s1].copy_(cur)
+                qedge_all[s0:s1].copy_(cur_edge)
+                tgt, qpos = cur, t_emb[0]
+            else:
+                torch.index_select(cur, 0, c, out=idn_all[s0:s1])
+                tgt, qpos = out_all[s0 - n:s0], t_emb[j - 1]
+            ops.call("tscd_se_fuse_f16", tgt.data_ptr(), W, qedge_all[s0:].data_ptr(), W, w0f.data_ptr(), w2f.data_ptr(), qpos.data_ptr(), n, W,
+                     q_in[s0:].data_ptr(), ops._stream())
+            ops.linear(q_in[s0:s1], wq, out=q_all[s0:s1])
+            if mfma:
+                t2, lsum = ops.cos_attn_mfma(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], heads, tiles, True)
+                lsums.append(lsum)
+            else:
+                t2 = ops.cos_attn(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], heads, tiles)
+            t2_all[s0:s1].copy_(t2)
+            ops.call("tscd_add_layernorm_f16", idn_all[s0:].data_ptr(), t2_all[s0:].data_ptr(), g_ln.data_ptr(), b_ln.data_ptr(), n, W, eps_ln,
+                     out_all[s0:].data_ptr(), ops._stream())
+            if j + 1 < L:      # the next frame's query-side edge rows = this frame's edge rows in assignment order
+                if j == 0:
+                    qedge_all[s1:s1 + n].copy_(cur_edge)
+                else:
+                    torch.index_select(cur_edge, 0, c, out=qedge_all[s1:s1 + n])
+            torch.index_select(out_all[s0:s1], 0, inv, out=o[s0:s1])
+        matched = ops.add_layernorm(o, None, g_dec, b_dec, eps_dec)
+        ctx.meta = meta
+        ctx.mfma = mfma
+        ctx.dtypes = (w_pos.dtype, se_w0.dtype, wq.dtype, ln_g.dtype, dec_g.dtype)
+        ctx.save_for_backward(idx, feat, edge, temb16, t_emb, w_pos, w0f, w2f, wq, wk, wv, g_ln, g_dec, k_in, k_all, v_all, q_in, q_all,
+                              t2_all, idn_all, qedge_all, out_all, o, tiles, *lsums)
+        return matched
+
+    @staticmethod
+    def backward(ctx, d_matched):
+        n, L, heads, slots, eps_ln, eps_dec = ctx.meta
+        (idx, feat, edge, temb16, t_emb, w_pos, w0f, w2f, wq, wk, wv, g_ln, g_dec, k_in, k_all, v_all, q_in, q_all, t2_all, idn_all, qedge_all,
+         out_all, o, tiles, *lsums) = ctx.saved_tensors
+        W = feat.shape[1]
+        dev = feat.device
+        nl = n * L
+        h16 = lambda t: t if t.dtype == torch.float16 else t.to(torch.float16)
+        d_o, dg_dec, db_dec = ops.add_layernorm_bwd(o, None, g_dec, h16(d_matched).contiguous(), eps_dec)
+        d_feat = torch.zeros((nl, W), dtype=torch.float32, device=dev)        # several contributions per row: accumulate in fp32
+        d_edge = torch.zeros((nl, W), dtype=torch.float32, device=dev)
+        dk_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
+        dv_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
+        dq_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
+        ln_acc, se_q, se_k = [], [None] * L, [None] * L     # per-frame parameter-gradient partials, summed once at the end
+        carry_out = None        # d loss / d out_j (assignment order) arriving from frame j+1's query path
+        carry_edge = None       # d loss / d (frame j's edge rows in assignment order) arriving from frame j+1's query-side gate
+        for j in range(L - 1, -1, -1):
+            s0, s1 = j * n, (j + 1) * n
+            c = idx[slots[j][0]:slots[j][0] + n] if slots[j][0] >= 0 else None
+            inv = idx[slots[j][1]:slots[j][1] + n]
+            # o[s0:s1] = out_j[inv]  =>  d out_j = d_o[s0:s1][inverse of inv]; that inverse is c for the matched frames
+            cinv = c if c is not None else torch.argsort(inv)
+            d_out = d_o[s0:s1].index_select(0, cinv)
+            if carry_out is not None:
+                d_out += carry_out
+            dx, dg, db = ops.add_layernorm_bwd(idn_all[s0:s1], t2_all[s0:s1], g_ln, d_out, eps_ln)
+            ln_acc.append(dg._base if dg._base is not None else torch.stack((dg, db)))
+            if ctx.mfma:
+                dq, dk, dv = ops.cos_attn_mfma_bwd(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], dx, t2_all[s0:s1], lsums[j], heads, tiles, True)
+            else:
+                dq, dk, dv = ops.cos_attn_bwd(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], dx, heads, tiles)
+            dq_all[s0:s1].copy_(dq)
+            dk_all[s0:s1].copy_(dk)
+            dv_all[s0:s1].copy_(dv)
+            # residual input: cur (first frame) or cur[c]
+            d_feat[s0:s1] += dx if j == 0 else dx.index_select(0, inv)
+            # query path: q = Wq q_in, q_in = SE(tgt, qedge) + qpos  (Wq's own gradient is one GEMM over all frames below)
+            dq_in = ops.linear_dgrad(dq, wq)
+            tgt = feat[s0:s1] if j == 0 else out_all[s0 - n:s0]
+            d_tgt, d_qedge, d_qpos, a0, a2 = ops.se_fuse_bwd(tgt, qedge_all[s0:s1], w0f, w2f, dq_in)
+            se_q[j] = d_qpos._base                                   # [W + 128]: d pos | d w0 | d w2 of this call
+            # edge rows of THIS frame in assignment order fed frame j+1's query gate
+            if carry_edge is not None:
+                d_edge[s0:s1] += carry_edge if j == 0 else carry_edge.index_select(0, inv)
+            if j == 0:
+                d_feat[s0:s1] += d_tgt
+                d_edge[s0:s1] += d_qedge
+                carry_out = carry_edge = None
+            else:
+                carry_out, carry_edge = d_tgt, d_qedge
+        # key / value side of all frames at once
+        dk_in, dwk, _ = ops.linear_bwd(k_in, dk_all, wk, True, True, False)
+        d_mem_v, dwv, _ = ops.linear_bwd(feat, dv_all, wv, True, True, False)
+        _, dwq, _ = ops.linear_bwd(q_in, dq_all, wq, False, True, False)
+        d_feat += d_mem_v
+        for j in range(L):
+            s0, s1 = j * n, (j + 1) * n
+            d_mem, d_ed, d_pos, a0, a2 = ops.se_fuse_bwd(feat[s0:s1], edge[s0:s1], w0f, w2f, dk_in[s0:s1])
+            d_feat[s0:s1] += d_mem
+            d_edge[s0:s1] += d_ed
+            se_k[j] = d_pos._base
+        A, K = torch.stack(se_q), torch.stack(se_k)                # [L, W + 128] each
+        d_temb = K[:, :W].clone()                                   # key-side gate of frame j adds t_j
+        d_temb[0] += A[0, :W]                                       # query-side gate: t_0 for the first frame, t_{j-1} for frame j
+        if L > 1:
+            d_temb[:L - 1] += A[1:, :W]
+        dse = (A[:, W:] + K[:, W:]).sum(0)
+        dw0, dw2 = dse[:64].view(32, 2), dse[64:].view(2, 32)
+        ln_sum = torch.stack(ln_acc).sum(0)
+        dg_ln, db_ln = ln_sum[0], ln_sum[1]
+        _, dw_pos, db_pos = ops.linear_bwd(temb16, d_temb.to(torch.float16), w_pos, False, True, True)
+        dt_pos, dt_se, dt_q, dt_ln, dt_dec = ctx.dtypes
+        cast = lambda t, dt: None if t is None else (t if t.dtype == dt else t.to(dt))
+        return (None, None, d_feat.to(torch.float16), d_edge.to(torch.float16), None, cast(dw_pos, dt_pos), cast(db_pos, dt_pos),
+                cast(dw0, dt_se), cast(dw2, dt_se), cast(dwq, dt_q), cast(dwk, dt_q), cast(dwv, dt_q), cast(dg_ln, dt_ln), cast(db_ln, dt_ln),
+                cast(dg_dec, dt_dec), cast(db_dec, dt_dec))
+
+
 class AwarePositionRegMatcher(nn.Module):
     def __init__(self, hidden_channel=512, feedforward_channel=2048, num_head=8, decoder_layer_num=6, act="silu"):
         super().__init__()
@@ -388,15 +549,39 @@ class AwarePositionRegMatcher(nn.Module):
         return dict(plan=plan, spans=spans, chain=chain, ppf=list(preds_per_frame), resume=resume,
                     features_reg=features_reg, features_cls=features_cls)
 
+    def _finish_fused(self, plan, slots, dev_idx, ppf, resume, features, features_edge, time_embedding, layer, solved):
+        """The clamped training regime -- every local frame with the same number of proposals, no state carried in, gradients wanted --
+        as ONE autograd node (_CafmChain).  Returns None when the clip does not qualify (the per-op path below handles every case)."""
+        if not FUSED_CHAIN or not torch.is_grad_enabled() or resume is not False or not ppf or len(plan) != len(ppf):
+            return None
+        n = ppf[0]
+        if n == 0 or any(m != n for m in ppf) or not (features.requires_grad or features_edge.requires_grad):
+            return None
+        if [k for (_, k, _) in plan] != ["self"] + ["prev"] * (len(ppf) - 1):
+            return None
+        L = len(ppf)
+        attn = layer.multihead_attn
+        if attn.q_reg.bias is not None or attn.k_reg.bias is not None or attn.v_reg.bias is not None:
+            return None
+        self._clear_state()
+        self.last_hungarian = [np.asarray(col_raw) for (_, col_raw, _) in solved]
+        self.last_hungarian_rows = [np.asarray(row) for (row, _, _) in solved]
+        # offsets of c (assignment order; -1 for the first frame, which keeps its own order) and inv in the clip's index table
+        sl = tuple((rec["c"][0] if "c" in rec else -1, rec["inv"][0]) for rec in slots)
+        meta = (n, L, attn.num_heads, sl, layer.norm.eps, self.decoder_norm.eps)
+        nl = n * L
+        out = _CafmChain.apply(meta, dev_idx, features[:nl], features_edge[:nl], time_embedding, self.absolute_position_embedding.weight,
+                               self.absolute_position_embedding.bias, layer.CA.fc[0].weight, layer.CA.fc[2].weight, attn.q_reg.weight,
+                               attn.k_reg.weight, attn.v_reg.weight, layer.norm.weight, layer.norm.bias, self.decoder_norm.weight,
+                               self.decoder_norm.bias)
+        # training always passes resume=False (tscd_trainer.py:168-169): the state this clip would leave behind is cleared by the next call
+        return out.unsqueeze(0)
+
     def finish(self, prep, features, features_edge, time_embedding):
         dev = features.device
         layer = self.transformer_aware_cross_attention_layers[0]
         plan, spans, preds_per_frame, resume = prep["plan"], prep["spans"], prep["ppf"], prep["resume"]
         features_reg, features_cls = prep["features_reg"], prep["features_cls"]
-        t_emb = linear(time_embedding.to(torch.float16).contiguous(), self.absolute_position_embedding)
-        # fp32 rows (the SE gate takes fp32 position vectors: one cast here instead of one per use and per gradient); unbind:
-        # one stack in backward instead of a zero-filled slice gradient per use
-        t_rows = t_emb.float().unbind(0)
         self.last_hungarian, self.last_hungarian_rows = [], []
         solved = prep["chain"].result() if prep["chain"] is not None else []
 
@@ -425,6 +610,13 @@ class AwarePositionRegMatcher(nn.Module):
                 host_idx.append(a)
             slots.append(rec)
         dev_idx = ops.h2d(np.concatenate(host_idx), torch.long, dev) if host_idx else None
+        fused = self._finish_fused(plan, slots, dev_idx, preds_per_frame, resume, features, features_edge, time_embedding, layer, solved)
+        if fused is not None:
+            return fused
+        t_emb = linear(time_embedding.to(torch.float16).contiguous(), self.absolute_position_embedding)
+        # fp32 rows (the SE gate takes fp32 position vectors: one cast here instead of one per use and per gradient); unbind:
+        # one stack in backward instead of a zero-filled slice gradient per use
+        t_rows = t_emb.float().unbind(0)
         view = lambda rec, k: dev_idx[rec[k][0]:rec[k][0] + rec[k][1]]
         # row gathers by index_select: its backward is one index_add into zeros (the indices are distinct rows), where
         # advanced indexing would sort the indices first (8 small launches per gather on a launch-bound stretch)
