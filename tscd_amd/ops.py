@@ -777,28 +777,38 @@ def cos_attn_uses_mfma(C, heads):
     return C % heads == 0 and bool(lib.tscd_cos_attn_mfma_supported(C // heads))
 
 
-def cos_attn_mfma(q, k, v, heads, tiles32, full=False):
-    """-> (out [n,C] fp16, lsum [n,heads] fp32).  ``full``: the tiles cover every query row (no zero fill needed)."""
+def cos_attn_mfma(q, k, v, heads, tiles32, full=False, out=None):
+    """-> (out [n,C] fp16, lsum [n,heads] fp32).  ``full``: the tiles cover every query row (no zero fill needed); ``out``: a
+    contiguous [n,C] fp16 destination (with ``full``)."""
     n, C = q.shape
     for t in (q, k, v):
         assert t.is_contiguous() and t.dtype == torch.float16 and t.shape[1] == C
     alloc = torch.empty if full else torch.zeros                          # rows outside every tile stay zero
-    out = alloc((n, C), dtype=torch.float16, device=q.device)
+    if out is None:
+        out = alloc((n, C), dtype=torch.float16, device=q.device)
+    else:
+        assert full and out.is_contiguous() and out.dtype == torch.float16 and tuple(out.shape) == (n, C)
     lsum = alloc((n, heads), dtype=torch.float32, device=q.device)
     call("tscd_cos_attn_mfma_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), C, heads, tiles32.data_ptr(), tiles32.shape[0],
          out.data_ptr(), lsum.data_ptr(), _stream())
     return out, lsum
 
 
-def cos_attn_mfma_bwd(q, k, v, d_out, out, lsum, heads, tiles32, full=False):
+def cos_attn_mfma_bwd(q, k, v, d_out, out, lsum, heads, tiles32, full=False, outs=None):
+    """``outs``: (dq [n,C], dk [nk,C], dv [nk,C]) contiguous fp16 destinations (with ``full``)."""
     n, C = q.shape
     nk = k.shape[0]
     dev = q.device
     for t in (q, k, v, d_out, out):
         assert t.is_contiguous() and t.dtype == torch.float16 and t.shape[1] == C
     ws = torch.empty((2 * nk * C,), dtype=torch.float32, device=dev)
-    dq = (torch.empty if full else torch.zeros)((n, C), dtype=torch.float16, device=dev)
-    dk, dv = (torch.empty((nk, C), dtype=torch.float16, device=dev) for _ in range(2))
+    if outs is not None:
+        dq, dk, dv = outs
+        assert full and all(t.is_contiguous() and t.dtype == torch.float16 for t in outs) and tuple(dq.shape) == (n, C) \
+            and tuple(dk.shape) == (nk, C) and tuple(dv.shape) == (nk, C)
+    else:
+        dq = (torch.empty if full else torch.zeros)((n, C), dtype=torch.float16, device=dev)
+        dk, dv = (torch.empty((nk, C), dtype=torch.float16, device=dev) for _ in range(2))
     call("tscd_cos_attn_mfma_bwd_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), d_out.data_ptr(), out.data_ptr(), lsum.data_ptr(),
          n, nk, C, heads, tiles32.data_ptr(), tiles32.shape[0], ws.data_ptr(), ws.numel() * 4, dq.data_ptr(), _stream())
     call("tscd_cos_attn_bwd_finish_f16", k.data_ptr(), ws.data_ptr(), nk, C, heads, dk.data_ptr(), dv.data_ptr(), _stream())

@@ -323,28 +323,22 @@ class _CafmChain(torch.autograd.Function):
             c = idx[slots[j][0]:slots[j][0] + n] if slots[j][0] >= 0 else None
             inv = idx[slots[j][1]:slots[j][1] + n]
             if j == 0:
-                idn_all[s0:s1].copy_(cur)
-                qedge_all[s0:s1].copy_(cur_edge)
-                tgt, qpos = cur, t_emb[0]
+                tgt, qedge, idn, qpos = cur, cur_edge, cur, t_emb[0]
             else:
                 torch.index_select(cur, 0, c, out=idn_all[s0:s1])
-                tgt, qpos = out_all[s0 - n:s0], t_emb[j - 1]
-            ops.call("tscd_se_fuse_f16", tgt.data_ptr(), W, qedge_all[s0:].data_ptr(), W, w0f.data_ptr(), w2f.data_ptr(), qpos.data_ptr(), n, W,
+                qedge = edge[:n] if j == 1 else qedge_all[s0:s1]
+                tgt, idn, qpos = out_all[s0 - n:s0], idn_all[s0:s1], t_emb[j - 1]
+            ops.call("tscd_se_fuse_f16", tgt.data_ptr(), W, qedge.data_ptr(), W, w0f.data_ptr(), w2f.data_ptr(), qpos.data_ptr(), n, W,
                      q_in[s0:].data_ptr(), ops._stream())
             ops.linear(q_in[s0:s1], wq, out=q_all[s0:s1])
             if mfma:
-                t2, lsum = ops.cos_attn_mfma(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], heads, tiles, True)
-                lsums.append(lsum)
+                lsums.append(ops.cos_attn_mfma(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], heads, tiles, True, out=t2_all[s0:s1])[1])
             else:
-                t2 = ops.cos_attn(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], heads, tiles)
-            t2_all[s0:s1].copy_(t2)
-            ops.call("tscd_add_layernorm_f16", idn_all[s0:].data_ptr(), t2_all[s0:].data_ptr(), g_ln.data_ptr(), b_ln.data_ptr(), n, W, eps_ln,
+                t2_all[s0:s1].copy_(ops.cos_attn(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], heads, tiles))
+            ops.call("tscd_add_layernorm_f16", idn.data_ptr(), t2_all[s0:].data_ptr(), g_ln.data_ptr(), b_ln.data_ptr(), n, W, eps_ln,
                      out_all[s0:].data_ptr(), ops._stream())
-            if j + 1 < L:      # the next frame's query-side edge rows = this frame's edge rows in assignment order
-                if j == 0:
-                    qedge_all[s1:s1 + n].copy_(cur_edge)
-                else:
-                    torch.index_select(cur_edge, 0, c, out=qedge_all[s1:s1 + n])
+            if 0 < j < L - 1:  # the next frame's query-side edge rows = this frame's edge rows in assignment order (frame 1 reads frame 0's in place)
+                torch.index_select(cur_edge, 0, c, out=qedge_all[s1:s1 + n])
             torch.index_select(out_all[s0:s1], 0, inv, out=o[s0:s1])
         matched = ops.add_layernorm(o, None, g_dec, b_dec, eps_dec)
         ctx.meta = meta
@@ -364,14 +358,13 @@ class _CafmChain(torch.autograd.Function):
         nl = n * L
         h16 = lambda t: t if t.dtype == torch.float16 else t.to(torch.float16)
         d_o, dg_dec, db_dec = ops.add_layernorm_bwd(o, None, g_dec, h16(d_matched).contiguous(), eps_dec)
-        d_feat = torch.zeros((nl, W), dtype=torch.float32, device=dev)        # several contributions per row: accumulate in fp32
-        d_edge = torch.zeros((nl, W), dtype=torch.float32, device=dev)
-        dk_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
-        dv_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
-        dq_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
-        ln_acc, se_q, se_k = [], [None] * L, [None] * L     # per-frame parameter-gradient partials, summed once at the end
+        mk = lambda: torch.empty((nl, W), dtype=torch.float16, device=dev)
+        dk_all, dv_all, dq_all = mk(), mk(), mk()
+        d_idn = mk()                                         # gradient of the residual inputs, in proposal order (added to d_feat at the end)
+        d_edge = mk()                                        # query-side contributions to the edge rows, in proposal order
+        ln_acc, se_q, se_k = [], [None] * L, [None] * L      # per-frame parameter-gradient partials, summed once at the end
         carry_out = None        # d loss / d out_j (assignment order) arriving from frame j+1's query path
-        carry_edge = None       # d loss / d (frame j's edge rows in assignment order) arriving from frame j+1's query-side gate
+        d_tgt0 = d_qedge0 = None
         for j in range(L - 1, -1, -1):
             s0, s1 = j * n, (j + 1) * n
             c = idx[slots[j][0]:slots[j][0] + n] if slots[j][0] >= 0 else None
@@ -381,42 +374,56 @@ class _CafmChain(torch.autograd.Function):
             d_out = d_o[s0:s1].index_select(0, cinv)
             if carry_out is not None:
                 d_out += carry_out
-            dx, dg, db = ops.add_layernorm_bwd(idn_all[s0:s1], t2_all[s0:s1], g_ln, d_out, eps_ln)
-            ln_acc.append(dg._base if dg._base is not None else torch.stack((dg, db)))
+            idn = feat[:n] if j == 0 else idn_all[s0:s1]
+            dx, dg, db = ops.add_layernorm_bwd(idn, t2_all[s0:s1], g_ln, d_out, eps_ln)
+            ln_acc.append(dg._base)
             if ctx.mfma:
-                dq, dk, dv = ops.cos_attn_mfma_bwd(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], dx, t2_all[s0:s1], lsums[j], heads, tiles, True)
+                ops.cos_attn_mfma_bwd(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], dx, t2_all[s0:s1], lsums[j], heads, tiles, True,
+                                      outs=(dq_all[s0:s1], dk_all[s0:s1], dv_all[s0:s1]))
             else:
                 dq, dk, dv = ops.cos_attn_bwd(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], dx, heads, tiles)
-            dq_all[s0:s1].copy_(dq)
-            dk_all[s0:s1].copy_(dk)
-            dv_all[s0:s1].copy_(dv)
-            # residual input: cur (first frame) or cur[c]
-            d_feat[s0:s1] += dx if j == 0 else dx.index_select(0, inv)
-            # query path: q = Wq q_in, q_in = SE(tgt, qedge) + qpos  (Wq's own gradient is one GEMM over all frames below)
-            dq_in = ops.linear_dgrad(dq, wq)
-            tgt = feat[s0:s1] if j == 0 else out_all[s0 - n:s0]
-            d_tgt, d_qedge, d_qpos, a0, a2 = ops.se_fuse_bwd(tgt, qedge_all[s0:s1], w0f, w2f, dq_in)
-            se_q[j] = d_qpos._base                                   # [W + 128]: d pos | d w0 | d w2 of this call
-            # edge rows of THIS frame in assignment order fed frame j+1's query gate
-            if carry_edge is not None:
-                d_edge[s0:s1] += carry_edge if j == 0 else carry_edge.index_select(0, inv)
+                dq_all[s0:s1].copy_(dq)
+                dk_all[s0:s1].copy_(dk)
+                dv_all[s0:s1].copy_(dv)
+            # residual input: cur (first frame) or cur[c]  ->  gradient back in proposal order
             if j == 0:
-                d_feat[s0:s1] += d_tgt
-                d_edge[s0:s1] += d_qedge
-                carry_out = carry_edge = None
+                d_idn[s0:s1].copy_(dx)
             else:
-                carry_out, carry_edge = d_tgt, d_qedge
+                torch.index_select(dx, 0, inv, out=d_idn[s0:s1])
+            # query path: q = Wq q_in, q_in = SE(tgt, qedge) + qpos  (Wq's own gradient is one GEMM over all frames below)
+            dq_in = ops.linear_dgrad(dq_all[s0:s1], wq)
+            tgt = feat[:n] if j == 0 else out_all[s0 - n:s0]
+            qedge = edge[:n] if j <= 1 else qedge_all[s0:s1]
+            d_tgt, d_qedge, d_qpos, _, _ = ops.se_fuse_bwd(tgt, qedge, w0f, w2f, dq_in)
+            se_q[j] = d_qpos._base                                   # [W + 128]: d pos | d w0 | d w2 of this call
+            if j == 0:
+                d_tgt0, d_qedge0 = d_tgt, d_qedge
+                carry_out = None
+            else:
+                carry_out = d_tgt
+                # frame j's query-side edge rows are frame j-1's edge rows in assignment order (frame 0 keeps its own order)
+                if j == 1:
+                    d_edge[0:n].copy_(d_qedge)
+                else:
+                    torch.index_select(d_qedge, 0, idx[slots[j - 1][1]:slots[j - 1][1] + n], out=d_edge[s0 - n:s0])
+        d_edge[nl - n:nl].zero_()                                    # the last frame's edge rows feed no later query gate
         # key / value side of all frames at once
         dk_in, dwk, _ = ops.linear_bwd(k_in, dk_all, wk, True, True, False)
-        d_mem_v, dwv, _ = ops.linear_bwd(feat, dv_all, wv, True, True, False)
+        d_feat, dwv, _ = ops.linear_bwd(feat, dv_all, wv, True, True, False)
         _, dwq, _ = ops.linear_bwd(q_in, dq_all, wq, False, True, False)
-        d_feat += d_mem_v
+        d_mem_all, d_ed_all = mk(), mk()
         for j in range(L):
             s0, s1 = j * n, (j + 1) * n
-            d_mem, d_ed, d_pos, a0, a2 = ops.se_fuse_bwd(feat[s0:s1], edge[s0:s1], w0f, w2f, dk_in[s0:s1])
-            d_feat[s0:s1] += d_mem
-            d_edge[s0:s1] += d_ed
+            d_mem, d_ed, d_pos, _, _ = ops.se_fuse_bwd(feat[s0:s1], edge[s0:s1], w0f, w2f, dk_in[s0:s1])
+            d_mem_all[s0:s1].copy_(d_mem)
+            d_ed_all[s0:s1].copy_(d_ed)
             se_k[j] = d_pos._base
+        # fp16 sums over [nl, W] (the per-op path accumulates in fp16 too): 3 + 2 launches instead of a dozen per-frame ones
+        d_feat += d_idn
+        d_feat += d_mem_all
+        d_feat[:n] += d_tgt0
+        d_edge += d_ed_all
+        d_edge[:n] += d_qedge0
         A, K = torch.stack(se_q), torch.stack(se_k)                # [L, W + 128] each
         d_temb = K[:, :W].clone()                                   # key-side gate of frame j adds t_j
         d_temb[0] += A[0, :W]                                       # query-side gate: t_0 for the first frame, t_{j-1} for frame j
@@ -429,7 +436,7 @@ class _CafmChain(torch.autograd.Function):
         _, dw_pos, db_pos = ops.linear_bwd(temb16, d_temb.to(torch.float16), w_pos, False, True, True)
         dt_pos, dt_se, dt_q, dt_ln, dt_dec = ctx.dtypes
         cast = lambda t, dt: None if t is None else (t if t.dtype == dt else t.to(dt))
-        return (None, None, d_feat.to(torch.float16), d_edge.to(torch.float16), None, cast(dw_pos, dt_pos), cast(db_pos, dt_pos),
+        return (None, None, d_feat, d_edge, None, cast(dw_pos, dt_pos), cast(db_pos, dt_pos),
                 cast(dw0, dt_se), cast(dw2, dt_se), cast(dwq, dt_q), cast(dwk, dt_q), cast(dwv, dt_q), cast(dg_ln, dt_ln), cast(db_ln, dt_ln),
                 cast(dg_dec, dt_dec), cast(db_dec, dt_dec))
 
