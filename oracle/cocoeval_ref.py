@@ -3,9 +3,12 @@ evaluateImg / accumulate / summarize), the scorer behind the reference's OVISEva
 (yolox/evaluators/ovis_evaluator_v2.py:352-424; its own fast path is yolox/layers/cocoeval/cocoeval.cpp).
 
 pycocotools (requirements.txt: ``pycocotools>=2.0.2``) is a third-party dependency that is absent from /root/reference and
-from this image, so this follows the published algorithm; parity with pycocotools itself is "unpinned".  The product's C++
-implementation (tscd_amd/csrc_host/cocoeval.cpp) is checked against this restatement and against hand-computed cases
-(tests/test_cocoeval.py).  Deliberately written per (image, category) with Python loops -- small inputs only."""
+from this image, so this follows the published algorithm.  Pinning: everything downstream of the box IoUs -- score ordering with the
+100-detection cap, ignore / crowd handling, greedy matching, the interpolated precision / recall arrays -- is checked against the
+REFERENCE'S OWN compiled evaluator (oracle/_ref/fast_cocoeval_ref, built by oracle/build_ref.py from yolox/layers/cocoeval/cocoeval.cpp
+as it lies in /root/reference; tests/test_cocoeval_ref_pin.py).  Only the IoU formula itself (pycocotools' maskUtils.iou for boxes:
+inter / union, inter / detection area for crowd regions) stays a restatement.  The product's C++ implementation
+(tscd_amd/csrc_host/cocoeval.cpp) is checked against that module, this restatement and hand-computed cases (tests/test_cocoeval.py).  Deliberately written per (image, category) with Python loops -- small inputs only."""
 import numpy as np
 
 IOU_THRS = np.linspace(0.5, 0.95, 10)

@@ -1,6 +1,7 @@
 """COCO bbox evaluation on the host (tscd_amd/csrc_host/cocoeval.cpp) vs the plain-Python restatement of
 the published algorithm (oracle/cocoeval_ref.py) and hand-computed cases.  pycocotools is absent from the reference tree and
-from this image: parity with pycocotools itself is unpinned (stated in both files)."""
+from this image; the protocol downstream of the box IoUs is pinned by the reference's own compiled evaluator in
+tests/test_cocoeval_ref_pin.py (oracle/_ref)."""
 import numpy as np
 import pytest
 
