@@ -187,10 +187,16 @@ int tscd_gather_det(const void* det, int A, int ndet, const int* sel_idx, int ca
  * tiles: device int[ntiles][4] = (row0, nrows, loc_start, loc_end). */
 int tscd_mca_dp(int d);
 long tscd_mca_workspace_bytes(int N, int N_L, int W, int S);
+/* rows_workspace (optional, tscd_mca_rows_bytes): where the per-head normalised q / k / v rows go -- the part of the forward's state the
+ * backward reads in place (tscd_mca_backward_fws); NULL = the front of `workspace`.  fp16_logits != 0: the reference-faithful
+ * arithmetic of post_trans.py:655-657 -- q.k^T, x 25 and x class score each rounded to fp16 before the softmax (the reference's
+ * autocast / .half() tensors); 0 = fp32 logits (bounded in tests/test_deviation_bounds.py). */
+long tscd_mca_rows_bytes(int N, int N_L, int W);
 int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
                      const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
                      float sim_thresh, float conf_thresh, void* workspace, long workspace_bytes, void* xcat_c,
-                     void* xcat_r, void* cat3_c, void* cat3_r, float* stats_out, void* stream);
+                     void* xcat_r, void* cat3_c, void* cat3_r, float* stats_out, void* rows_workspace, int fp16_logits,
+                     void* stream);
 /* Backward of the fused attention (autograd of post_trans.py:601-714 under tscd_trainer.py:171-176): gradients w.r.t. the
  * projected q / (k|v) rows and the key scores.  stats = stats_out of the forward call; dxcat_* [N_L,2W], dsoft_* / soft_* the
  * first W columns of the [N_L,3W] concat (row strides ld_dsoft / ld_soft). */
@@ -201,14 +207,15 @@ int tscd_mca_backward(const void* q_c, const void* kv_c, const void* q_r, const 
                       float conf_thresh, const float* stats, const void* dxcat_c, const void* dxcat_r, const void* dsoft_c,
                       const void* dsoft_r, int ld_dsoft, const void* soft_c, const void* soft_r, int ld_soft, void* workspace,
                       long workspace_bytes, void* dq_c, void* dkv_c, void* dq_r, void* dkv_r, float* dscore, void* stream);
-/* The same reading the normalised q / k / v rows from the (intact) workspace tscd_mca_forward ran in for the same inputs instead of
- * re-deriving them (no prep launch); fwd_workspace NULL = tscd_mca_backward. */
+/* The same reading the normalised q / k / v rows tscd_mca_forward wrote for the same inputs (its rows_workspace, or the front of its
+ * workspace; fwd_rows_bytes >= tscd_mca_rows_bytes, checked) instead of re-deriving them (no prep launch); fwd_rows NULL =
+ * tscd_mca_backward.  Both files take the layout from one definition (mca_common.h: McaRows). */
 int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
                           const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
                           float sim_thresh, float conf_thresh, const float* stats, const void* dxcat_c,
                           const void* dxcat_r, const void* dsoft_c, const void* dsoft_r, int ld_dsoft, const void* soft_c,
                           const void* soft_r, int ld_soft, void* workspace, long workspace_bytes, void* dq_c, void* dkv_c,
-                          void* dq_r, void* dkv_r, float* dscore, const void* fwd_workspace, void* stream);
+                          void* dq_r, void* dkv_r, float* dscore, const void* fwd_rows, long fwd_rows_bytes, void* stream);
 
 /* ---- CAFM / TaskAligned pieces: PositionMHAttention / MHAttention (tscd_matching.py:31-60,140-181), SEModule
  * (:264-283), LayerNorm of forward_post (:566-589,:394-458), cosine normalisation of double_match_embds (:912-937).

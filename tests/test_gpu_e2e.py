@@ -253,3 +253,84 @@ def test_backbone_prefetch_in_assignment_window_is_exact(golden, model):
     a(imgs, labels, temb, next_x=imgs2, **kw)
     out_c = a(imgs, labels, temb, **kw)
     assert id(a) not in tscd_mod._PREFETCHED and torch.isfinite(out_c["total_loss"])
+
+
+def test_train_with_the_reference_assignment_and_proposal_sets_is_tight(golden, model, monkeypatch):
+    """with the label assignment (SimOTA foreground anchors, matched boxes, matched IoUs) AND the proposal sets forced to
+    the reference's -- both are integer decisions that fp16 noise upstream can flip, and both are bit-exact on identical inputs
+    (tests/test_gpu_head_stages.py, test_simota_parity.py) -- every one of the reference's 8 loss terms is reproduced within 2 %
+    and the 24 golden parameter gradients (towers, wavelet block, both MCAs, CAFM, TaskAligned, prediction heads) all point the same
+    way: at least 10 with cosine >= 0.99, none below 0.95.  The assignment comes from the fp32 oracle on the golden inputs (it
+    reproduces the reference's ``train_fg_idx`` exactly, tests/test_oracle_golden.py)."""
+    import copy
+    from oracle import tscd_oracle as O
+    from tscd_amd import ops
+    cfg, sd, vec, meta = golden
+    L, G, B = int(meta["lframe"]), int(meta["gframe"]), int(meta["B"])
+    imgs32 = torch.from_numpy(vec["evalA_imgs"]).float()
+    labels32 = torch.from_numpy(vec["train_labels"]).float()
+    temb32 = torch.from_numpy(vec["time_embedding"]).float()
+    # ---- the reference's assignment, as the fp32 oracle reproduces it
+    aux = {}
+    with torch.no_grad():
+        O.tscd_forward({k: v.clone() for k, v in sd.items()}, cfg, imgs32, labels32, temb32, 0.5, L, G, False, True, O.MatcherState(), aux)
+    hw = [(f.shape[-2], f.shape[-1]) for f in aux["fpn"]]
+    xs, ys, ss = O.make_grids(hw, cfg.strides)
+    fg_ids, cls_t, reg_t, obj_t, fg_masks, num_fg, num_gts = O.simota_assign(aux["outputs"], labels32, xs, ys, ss, cfg)
+    A = aux["outputs"].shape[1]
+    fg = torch.zeros(B, A, dtype=torch.uint8)
+    mg = torch.full((B, A), -1, dtype=torch.int32)
+    pi = torch.zeros(B, A, dtype=torch.float32)
+    for b in range(B):
+        idx = torch.nonzero(fg_masks[b]).flatten()
+        assert sorted(idx.tolist()) == sorted(vec[f"train_fg_idx{b}"].tolist())          # == the reference's own foreground set
+        fg[b, idx] = 1
+        for r, a in enumerate(idx.tolist()):
+            g = int(torch.nonzero((labels32[b, :, 1:5] == reg_t[b][r]).all(1)).flatten()[0])
+            mg[b, a] = g
+            pi[b, a] = cls_t[b][r].max()
+    nfg = torch.tensor([int(m.sum()) for m in fg_masks], dtype=torch.int32)
+    ngt = (labels32.sum(2) > 0).sum(1).int()
+    ref_idx = [torch.from_numpy(vec[f"train_agg_idx{i}"]).int() for i in range(B)]
+
+    def forced_select(score, conf_thresh, min_keep, max_keep):
+        cap = max(len(r) for r in ref_idx)
+        idx = torch.zeros((B, cap), dtype=torch.int32)
+        for b, r in enumerate(ref_idx):
+            idx[b, :len(r)] = r
+        return idx.to(score.device), torch.tensor([len(r) for r in ref_idx], dtype=torch.int32, device=score.device)
+
+    def forced_simota(outputs, labels, geo, nc, max_gt, **kw):
+        d = outputs.device
+        return fg.to(d), mg.to(d), pi.to(d), nfg.to(d), ngt.to(d)
+
+    monkeypatch.setattr(ops, "select_proposals", forced_select)
+    monkeypatch.setattr(ops, "simota_assign", forced_simota)
+    m = copy.deepcopy(model).train()
+    for mod in (m.backbone, m.head.stems, m.head.reg_convs, m.head.cls_convs, m.head.reg_preds):
+        for p in mod.parameters():
+            p.requires_grad = False
+    m.head.debug = {}
+    out = m(imgs32.cuda().half(), labels32.cuda().half(), temb32.cuda().half(), lframe=L, gframe=G, resume=False)
+    out["total_loss"].backward()
+    torch.cuda.synchronize()
+    assert m.head.debug["preds_per_frame"] == vec["train_n_agg"].tolist()
+    for i in range(int(vec["train_n_hung"])):                                   # the assignment chain on (almost) the reference's costs
+        a, b = np.asarray(m.head.debug["hungarian"][i]), vec[f"train_hung_col{i}"]
+        assert len(a) == len(b) and (a == b).mean() > 0.9, (i, float((a == b).mean()))
+    rel = {}
+    for k in ("total_loss", "iou_loss", "conf_loss", "cls_loss", "num_fg", "loss_matched_cls", "loss_matched_obj", "loss_matched_iou"):
+        ref = float(vec["train_loss_" + k])
+        rel[k] = abs(float(out[k]) - ref) / max(abs(ref), 1e-6)
+    print("loss terms, relative difference to the reference:", {k: round(v, 5) for k, v in rel.items()})
+    assert all(v <= 0.02 for v in rel.values()), rel
+    named = dict(m.named_parameters())
+    cosines = {}
+    for key in vec.files:
+        if key.startswith("train_grad::"):
+            k = key[len("train_grad::"):]
+            g, r = named[k].grad.float().cpu().flatten(), torch.from_numpy(vec[key]).float().flatten()
+            cosines[k] = torch.nn.functional.cosine_similarity(g, r, dim=0).item()
+    print("gradient cosines:", {k.replace("head.", ""): round(v, 4) for k, v in sorted(cosines.items(), key=lambda kv: kv[1])})
+    assert len(cosines) == 24
+    assert sum(v >= 0.99 for v in cosines.values()) >= 10 and min(cosines.values()) >= 0.95, cosines

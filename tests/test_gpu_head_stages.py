@@ -107,6 +107,50 @@ def test_mca_other_widths(W, n_loc, n_glob):
     close(o, ro, 2e-2, 1e-2)
 
 
+def test_mca_reference_faithful_fp16_logits_switch():
+    """FP16_LOGITS (kwarg ``fp16_logits``): the forward kernels round q.k^T, x 25 and x class score to fp16 like the reference's
+    autocast / .half() tensors (post_trans.py:655-657).  Against the oracle in both arithmetics on clustered features: the two product
+    modes differ by what the two oracle modes differ by -- same size, same direction -- and each stays within the fp16 tolerance of
+    its oracle mode."""
+    import dataclasses
+    from yolox.models.post_trans import MCA_tscd_g2l_reg
+    W, n_loc, n_glob = 256, (96, 64), 400
+    g = torch.Generator().manual_seed(7)
+    mod = MCA_tscd_g2l_reg(W, 4 * W, num_heads=4, reconf=True)
+    sd = {"m." + k: v.detach().clone() for k, v in mod.state_dict().items()}
+    N = sum(n_loc) + n_glob
+    centers = torch.randn(12, W, generator=g)
+    lab = torch.randint(0, 12, (N,), generator=g)
+    x_cls = (centers[lab] + 0.15 * torch.randn(N, W, generator=g)).half()
+    x_reg = (centers[lab] + 0.02 * torch.randn(N, W, generator=g)).half()
+    sc = torch.rand(N, generator=g).half()
+    ppf = list(n_loc) + [n_glob]
+    cfg32 = O.TSCDConfig()
+    cfg16 = dataclasses.replace(cfg32)
+    cfg16.mca_fp16_logits = True
+    with torch.no_grad():
+        r32 = O.mca_tscd_g2l_reg(sd, "m", x_cls.float(), x_reg.float(), sc.float(), ppf, len(n_loc), cfg32)
+        r16 = O.mca_tscd_g2l_reg(sd, "m", x_cls.float(), x_reg.float(), sc.float(), ppf, len(n_loc), cfg16)
+        mod = mod.cuda()
+        kw = dict(sim_thresh=0.75, preds_per_frame=ppf, lframe=len(n_loc), conf_sim_thresh=0.99)
+        p32 = mod(x_cls.cuda(), x_reg.cuda(), sc.cuda(), None, fp16_logits=False, **kw)
+        p16 = mod(x_cls.cuda(), x_reg.cuda(), sc.cuda(), None, fp16_logits=True, **kw)
+    torch.cuda.synchronize()
+    dist = lambda a, b: (a.float().cpu() - b.float()).abs().mean().item()
+    for i in range(2):
+        d_oracle = dist(r16[i], r32[i])                       # what the rounding changes, on the oracle
+        assert d_oracle > 0
+        d_prod = dist(p16[i], p32[i].cpu())
+        assert 0.3 * d_oracle < d_prod < 3.0 * d_oracle, (i, d_prod, d_oracle)
+        # the change the switch makes in the product is the change it makes in the oracle (the product's own fp16 operand noise is of
+        # the same size as the effect, so "closer to the matching mode" is not a usable criterion; the direction of the change is)
+        dp, do = (p16[i].float() - p32[i].float()).cpu().flatten().double(), (r16[i] - r32[i]).flatten().double()
+        cosd = torch.nn.functional.cosine_similarity(dp, do, dim=0).item()
+        assert cosd > 0.5, (i, cosd)
+        close(p16[i], r16[i], 2e-2, 1e-2)
+        close(p32[i], r32[i], 2e-2, 1e-2)
+
+
 def test_cafm_and_task_aligned_match_oracle(ctx):
     cfg, meta, aux, res, m, temb = ctx
     L = int(meta["lframe"])

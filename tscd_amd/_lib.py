@@ -39,9 +39,9 @@ SIGNATURES = {
     "tscd_select_proposals": [P, I, I, F, I, I, I, P, P, P],
     "tscd_gather_rows": [P, P, P, I, P, I, I, I, I, I, P, P, P, I, P],
     "tscd_gather_det": [P, I, I, P, I, P, I, I, P, P],
-    "tscd_mca_forward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, L, P, P, P, P, P, P],
+    "tscd_mca_forward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, L, P, P, P, P, P, P, I, P],
     "tscd_mca_backward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, P, P, P, P, I, P, P, I, P, L, P, P, P, P, P, P],
-    "tscd_mca_backward_fws": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, P, P, P, P, I, P, P, I, P, L, P, P, P, P, P, P, P],
+    "tscd_mca_backward_fws": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, P, P, P, P, I, P, P, I, P, L, P, P, P, P, P, P, L, P],
     "tscd_cos_attn_f16": [P, P, P, I, I, P, I, P, P],
     "tscd_se_fuse_f16": [P, I, P, I, P, P, P, L, I, P, P],
     "tscd_add_layernorm_f16": [P, P, P, P, I, I, F, P, P],
@@ -68,7 +68,7 @@ SIGNATURES = {
 }
 PLAIN = {"tscd_ema_chunk_elems": ([], I), "tscd_pack_block_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
          "tscd_bn_silu_bwd_workspace_bytes": ([L, I], L), "tscd_linear_bwd_workspace_bytes": ([I, I, I], L),
-         "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L),
+         "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L), "tscd_mca_rows_bytes": ([I, I, I], L),
          "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),
          "tscd_nms_workspace_bytes": ([I, I, I, I], L), "tscd_simota_workspace_bytes": ([I, I, I, I], L), "tscd_loss_workspace_bytes": ([L, L, L], L),
          "tscd_conv_stat_tiles": ([L, I, I, I, I, I], I), "tscd_conv_stat_tiles_ex": ([L, I, I, I, I, I, I, I, I], I),

@@ -110,7 +110,7 @@ __global__ void mca_prep_kernel(const f16* __restrict__ q_c, const f16* __restri
 }
 
 // -------------------------------------------------------------------------------------------------- pass A
-template <int DP>
+template <int DP, bool F16L>
 __global__ __launch_bounds__(256) void mca_stats_kernel(McaParams p) {
   constexpr int KS = DP / 16;
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void mca_stats_kernel(McaParams p) {
     const float kscore = valid ? (float)p.score[key] : 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      lc[e] += valid ? __expf(p.scale * kscore * sc[e] - p.scale) : 0.f;
-      lr[e] += valid ? __expf(p.scale * sr[e] - p.scale) : 0.f;
+      lc[e] += valid ? __expf(mca_logit_cls<F16L>(sc[e], kscore, p.scale) - p.scale) : 0.f;
+      lr[e] += valid ? __expf(mca_logit_reg<F16L>(sr[e], p.scale) - p.scale) : 0.f;
     }
   }
   // row sums: reduce over the 32 key lanes of each half-wave
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void mca_stats_kernel(McaParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------- pass B
-template <int DP, bool NEED_REG>
+template <int DP, bool NEED_REG, bool F16L>
 __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p) {
   constexpr int KS = DP / 16, NT = DP / 32;
   constexpr int PST = 33;   // fp32 tile row stride
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        float pc = valid ? __expf(p.scale * kscore * sc[e] - p.scale) * invl[h][0][row] : 0.f;
-        float pr = valid ? __expf(p.scale * sr[e] - p.scale) * invl[h][1][row] : 0.f;
+        float pc = valid ? __expf(mca_logit_cls<F16L>(sc[e], kscore, p.scale) - p.scale) * invl[h][0][row] : 0.f;
+        float pr = valid ? __expf(mca_logit_reg<F16L>(sr[e], p.scale) - p.scale) * invl[h][1][row] : 0.f;
         float pp = 0.5f * (pc + pr);
         Pf[h][row][col] = pp;
         Ph[h][row][col] = (f16)pp;
@@ -433,18 +433,26 @@ void mca_launch_prep(hipStream_t st, const f16* q_c, const f16* kv_c, const f16*
 extern "C" int tscd_mca_dp(int d) { return (d + 31) / 32 * 32; }
 
 // Workspace sizes (bytes) so the caller (torch) owns every allocation.
+// The normalised rows (the part of the forward's state the backward reads: tscd_mca_backward_fws) may live in a buffer of their own
+// (rows_workspace, tscd_mca_rows_bytes): the caller then keeps only that small buffer alive until the backward and frees the scratch
+// (the key-split partial sums are ~10x larger).  Without one they are carved from the front of `workspace`.
+extern "C" long tscd_mca_rows_bytes(int N, int N_L, int W) {
+  const int WP = MCA_HEADS * tscd_mca_dp(W / MCA_HEADS);
+  return mca_rows_bytes(N, N_L, WP);
+}
 extern "C" long tscd_mca_workspace_bytes(int N, int N_L, int W, int S) {
   int d = W / MCA_HEADS, DP = tscd_mca_dp(d), WP = MCA_HEADS * DP;
   long Npad = (N + 31) / 32 * 32 + 32;
-  long halves = 2L * N_L * WP + 4L * Npad * WP + 2L * WP * Npad + 6L * Npad * WP;      // + the fragment-major copies
+  long halves = 2L * WP * Npad + 6L * Npad * WP;                                          // V^T (unused slot) + the fragment-major copies
   long floats = (long)S * MCA_HEADS * 2 * N_L + 4L * S * N_L * WP + 2L * S * N_L;
-  return halves * 2 + floats * 4 + 8192;
+  return mca_rows_bytes(N, N_L, WP) + halves * 2 + floats * 4 + 8192;
 }
 
 extern "C" int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
                                 const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
                                 float sim_thresh, float conf_thresh, void* workspace, long workspace_bytes, void* xcat_c,
-                                void* xcat_r, void* cat3_c, void* cat3_r, float* stats_out, void* stream) {
+                                void* xcat_r, void* cat3_c, void* cat3_r, float* stats_out, void* rows_workspace, int fp16_logits,
+                                void* stream) {
   TSCD_CHECK_ARG(q_c && kv_c && q_r && kv_r && score && tiles && workspace && xcat_c && cat3_c, "mca_forward: null pointer");
   TSCD_CHECK_ARG(!need_reg || (xcat_r && cat3_r), "mca_forward: reg outputs requested without buffers");
   TSCD_CHECK_ARG(W % MCA_HEADS == 0 && W % 8 == 0, "mca_forward: W=%d must be a multiple of 8 (4 heads)", W);
@@ -458,12 +466,8 @@ extern "C" int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q
   char* ws = (char*)workspace;
   auto take = [&](long bytes) { char* r = ws; ws += (bytes + 255) / 256 * 256; return r; };
   // (the 256-B rounding is covered by the +8192 slack for <= 20 carve-outs)
-  f16* qn_c = (f16*)take(2L * N_L * WP);
-  f16* qn_r = (f16*)take(2L * N_L * WP);
-  f16* kn_c = (f16*)take(2L * Npad * WP);
-  f16* kn_r = (f16*)take(2L * Npad * WP);
-  f16* vn_c = (f16*)take(2L * Npad * WP);
-  f16* vn_r = (f16*)take(2L * Npad * WP);
+  const McaRows rows = mca_rows_carve(rows_workspace ? rows_workspace : take(mca_rows_bytes(N, N_L, WP)), N, N_L, WP);
+  f16 *qn_c = rows.qn_c, *qn_r = rows.qn_r, *kn_c = rows.kn_c, *kn_r = rows.kn_r, *vn_c = rows.vn_c, *vn_r = rows.vn_r;
   f16* vt_c = (f16*)take(2L * WP * Npad);
   f16* vt_r = (f16*)take(2L * WP * Npad);
   f16* kF_c = (f16*)take(2L * Npad * WP);
@@ -495,19 +499,25 @@ extern "C" int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q
   p.N = N; p.N_L = N_L; p.Npad = Npad; p.WP = WP; p.S = S;
   p.scale = scale; p.sim_thresh = sim_thresh; p.conf_thresh = conf_thresh;
   dim3 grid(ntiles, S), block(256);
+#define MCA_LAUNCH_L(DPV, FL)                                                                        \
+  do {                                                                                              \
+    hipLaunchKernelGGL((mca_stats_kernel<DPV, FL>), grid, block, 0, st, p);                         \
+    if (need_reg)                                                                                   \
+      hipLaunchKernelGGL((mca_aggregate_kernel<DPV, true, FL>), grid, block, 0, st, p);             \
+    else                                                                                            \
+      hipLaunchKernelGGL((mca_aggregate_kernel<DPV, false, FL>), grid, block, 0, st, p);            \
+  } while (0)
 #define MCA_LAUNCH(DPV)                                                                             \
   do {                                                                                              \
-    hipLaunchKernelGGL((mca_stats_kernel<DPV>), grid, block, 0, st, p);                             \
-    if (need_reg)                                                                                   \
-      hipLaunchKernelGGL((mca_aggregate_kernel<DPV, true>), grid, block, 0, st, p);                 \
-    else                                                                                            \
-      hipLaunchKernelGGL((mca_aggregate_kernel<DPV, false>), grid, block, 0, st, p);                \
+    if (fp16_logits) MCA_LAUNCH_L(DPV, true);                                                       \
+    else MCA_LAUNCH_L(DPV, false);                                                                  \
   } while (0)
   if (DP == 32) MCA_LAUNCH(32);
   else if (DP == 64) MCA_LAUNCH(64);
   else if (DP == 96) MCA_LAUNCH(96);
   else MCA_LAUNCH(128);
 #undef MCA_LAUNCH
+#undef MCA_LAUNCH_L
   TSCD_CHECK_LAUNCH("mca_stats/aggregate");
   long total = (long)N_L * W;
   int fg = (int)((total + 255) / 256);

@@ -865,7 +865,7 @@ extern "C" int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const vo
                                      float sim_thresh, float conf_thresh, const float* stats, const void* dxcat_c,
                                      const void* dxcat_r, const void* dsoft_c, const void* dsoft_r, int ld_dsoft, const void* soft_c,
                                      const void* soft_r, int ld_soft, void* workspace, long workspace_bytes, void* dq_c, void* dkv_c,
-                                     void* dq_r, void* dkv_r, float* dscore, const void* fwd_workspace, void* stream);
+                                     void* dq_r, void* dkv_r, float* dscore, const void* fwd_rows, long fwd_rows_bytes, void* stream);
 extern "C" int tscd_mca_backward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
                                  const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
                                  float sim_thresh, float conf_thresh, const float* stats, const void* dxcat_c,
@@ -874,16 +874,17 @@ extern "C" int tscd_mca_backward(const void* q_c, const void* kv_c, const void* 
                                  void* dq_r, void* dkv_r, float* dscore, void* stream) {
   return tscd_mca_backward_fws(q_c, kv_c, q_r, kv_r, score, tiles, ntiles, N, N_L, W, S, need_reg, scale, sim_thresh, conf_thresh, stats,
                                dxcat_c, dxcat_r, dsoft_c, dsoft_r, ld_dsoft, soft_c, soft_r, ld_soft, workspace, workspace_bytes, dq_c,
-                               dkv_c, dq_r, dkv_r, dscore, nullptr, stream);
+                               dkv_c, dq_r, dkv_r, dscore, nullptr, 0, stream);
 }
-// fwd_workspace (optional): the workspace tscd_mca_forward ran in for the same inputs, still intact -- its normalised q / k / v rows are
-// read in place and the prep launch is skipped (the forward carves them first: qn_c, qn_r, kn_c, kn_r, vn_c, vn_r, 256-byte aligned).
+// fwd_rows (optional): the normalised q / k / v rows tscd_mca_forward wrote for the same inputs (its rows_workspace, or the front of its
+// workspace), still intact: read in place, the prep launch is skipped.  The layout is mca_common.h's McaRows -- one definition for
+// both files -- and fwd_rows_bytes must cover it (tscd_mca_rows_bytes).
 extern "C" int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
                                      const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale,
                                      float sim_thresh, float conf_thresh, const float* stats, const void* dxcat_c,
                                      const void* dxcat_r, const void* dsoft_c, const void* dsoft_r, int ld_dsoft, const void* soft_c,
                                      const void* soft_r, int ld_soft, void* workspace, long workspace_bytes, void* dq_c, void* dkv_c,
-                                     void* dq_r, void* dkv_r, float* dscore, const void* fwd_workspace, void* stream) {
+                                     void* dq_r, void* dkv_r, float* dscore, const void* fwd_rows, long fwd_rows_bytes, void* stream) {
   TSCD_CHECK_ARG(q_c && kv_c && q_r && kv_r && score && tiles && stats && dxcat_c && dsoft_c && soft_c && workspace && dq_c &&
                      dkv_c && dq_r && dkv_r && dscore, "mca_backward: null pointer");
   TSCD_CHECK_ARG(!need_reg || (dxcat_r && dsoft_r && soft_r), "mca_backward: reg gradients missing");
@@ -929,12 +930,11 @@ extern "C" int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const vo
   p.dq_stride = dq_stride; p.dk_stride = dk_stride;
   p.scale = scale; p.sim_thresh = sim_thresh; p.conf_thresh = conf_thresh;
 
-  if (fwd_workspace) {
-    const char* fw = (const char*)fwd_workspace;
-    auto ftake = [&](long bytes) { const char* r = fw; fw += (bytes + 255) / 256 * 256; return (f16*)r; };
-    qn_c = ftake(2L * qN); qn_r = ftake(2L * qN);
-    kn_c = ftake(2L * kN); kn_r = ftake(2L * kN);
-    vn_c = ftake(2L * kN); vn_r = ftake(2L * kN);
+  if (fwd_rows) {
+    TSCD_CHECK_ARG(fwd_rows_bytes >= mca_rows_bytes(N, N_L, WP), "mca_backward: the forward's rows buffer is %ld bytes, %ld needed",
+                   fwd_rows_bytes, mca_rows_bytes(N, N_L, WP));
+    const McaRows rows = mca_rows_carve(const_cast<void*>(fwd_rows), N, N_L, WP);
+    qn_c = rows.qn_c; qn_r = rows.qn_r; kn_c = rows.kn_c; kn_r = rows.kn_r; vn_c = rows.vn_c; vn_r = rows.vn_r;
   } else {
     mca_launch_prep(st, (const f16*)q_c, (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, N, N_L, Npad, W, d, DP, qn_c, kn_c, vn_c,
                     nullptr, qn_r, kn_r, vn_r, nullptr, nullptr, nullptr);

@@ -623,16 +623,19 @@ def mca_splits(ntiles):
 
 
 def mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale, sim_thresh, conf_thresh, splits=None,
-                  want_stats=False, keep_workspace=False):
+                  want_stats=False, keep_workspace=False, fp16_logits=False):
     """Fused global-to-local attention.  Returns (xcat_c [N_L,2W], cat3_c [N_L,3W], xcat_r, cat3_r, stats): first W columns
     of xcat = P@v, second W = own values; first W columns of cat3 = the sim_round2 aggregation (rest is filled by the
-    caller's linear); stats (for backward) = softmax row sums [4,2,N_L] ++ sim_round2 denominators [2,N_L]."""
+    caller's linear); stats (for backward) = softmax row sums [4,2,N_L] ++ sim_round2 denominators [2,N_L].
+    ``keep_workspace``: also returns the buffer of normalised q / k / v rows for mca_backward(fwd_rows=...) -- a buffer of its own, so
+    the (10x larger) scratch of the call is free again at once.  ``fp16_logits``: the reference-faithful rounding of the logits."""
     dev = q_c.device
     nt = tiles.shape[0]
     if splits is None:
         splits = mca_splits(nt)
     ws_bytes = lib.tscd_mca_workspace_bytes(N, N_L, W, splits)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    rows = torch.empty((lib.tscd_mca_rows_bytes(N, N_L, W),), dtype=torch.uint8, device=dev) if keep_workspace else None
     mk = lambda c: torch.empty((N_L, c), dtype=torch.float16, device=dev)
     xcat_c, cat3_c = mk(2 * W), mk(3 * W)
     xcat_r, cat3_r = (mk(2 * W), mk(3 * W)) if need_reg else (None, None)
@@ -641,9 +644,10 @@ def mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale
         assert t.is_contiguous() and t.dtype == torch.float16
     call("tscd_mca_forward", q_c.data_ptr(), kv_c.data_ptr(), q_r.data_ptr(), kv_r.data_ptr(), score.data_ptr(),
          tiles.data_ptr(), nt, N, N_L, W, splits, int(need_reg), float(scale), float(sim_thresh), float(conf_thresh),
-         ws.data_ptr(), ws_bytes, xcat_c.data_ptr(), _ptr(xcat_r), cat3_c.data_ptr(), _ptr(cat3_r), _ptr(stats), _stream())
-    if keep_workspace:          # for mca_backward(fwd_ws=...): its normalised q / k / v rows are read in place (no second prep launch)
-        return xcat_c, cat3_c, xcat_r, cat3_r, stats, ws
+         ws.data_ptr(), ws_bytes, xcat_c.data_ptr(), _ptr(xcat_r), cat3_c.data_ptr(), _ptr(cat3_r), _ptr(stats), _ptr(rows),
+         int(bool(fp16_logits)), _stream())
+    if keep_workspace:
+        return xcat_c, cat3_c, xcat_r, cat3_r, stats, rows
     return xcat_c, cat3_c, xcat_r, cat3_r, stats
 
 
@@ -666,7 +670,8 @@ def mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale,
     call("tscd_mca_backward_fws", q_c.data_ptr(), kv_c.data_ptr(), q_r.data_ptr(), kv_r.data_ptr(), score.data_ptr(), tiles.data_ptr(), nt,
          N, N_L, W, S, int(need_reg), float(scale), float(sim_thresh), float(conf_thresh), stats.data_ptr(), dxcat_c.data_ptr(),
          _ptr(dxcat_r), dcat3_c.data_ptr(), _ptr(dcat3_r), 3 * W, cat3_c.data_ptr(), _ptr(cat3_r), 3 * W, ws.data_ptr(), ws_bytes,
-         dq_c.data_ptr(), dkv_c.data_ptr(), dq_r.data_ptr(), dkv_r.data_ptr(), dscore.data_ptr(), _ptr(fwd_ws), _stream())
+         dq_c.data_ptr(), dkv_c.data_ptr(), dq_r.data_ptr(), dkv_r.data_ptr(), dscore.data_ptr(), _ptr(fwd_ws),
+         0 if fwd_ws is None else fwd_ws.numel(), _stream())
     return dq_c, dkv_c, dq_r, dkv_r, dscore
 
 

@@ -8,7 +8,16 @@ materialised, the four projections and the output linears are MFMA GEMMs writing
 import torch
 import torch.nn as nn
 
+import os
+
 from tscd_amd import ops
+
+# Reference-faithful switch for the attention logits: the reference forms q.k^T, x 25 and x class score as fp16 tensors
+# under autocast / .half() (post_trans.py:655-657) and feeds the rounded values to the softmax; the product's default keeps them in fp32
+# (tests/test_deviation_bounds.py bounds the difference at < 1 % of the outputs' scale).  FP16_LOGITS = True (or
+# TSCD_MCA_FP16_LOGITS=1) selects the reference's rounding in the forward kernels -- evaluation and training forward; the backward
+# differentiates the unrounded expression (straight-through).
+FP16_LOGITS = os.environ.get("TSCD_MCA_FP16_LOGITS", "0") == "1"
 
 
 class Attention_mca_g2l(nn.Module):
@@ -34,7 +43,8 @@ class _MCAFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, x_cls, x_reg, score, wq_c, wkv_c, wq_r, wkv_r, w_lin, b_lin, w_linr, b_linr, w_out, b_out, w_obj, b_obj):
-        ppf, lframe, scale, sim_thresh, conf_thresh, need_reg = cfg
+        ppf, lframe, scale, sim_thresh, conf_thresh, need_reg = cfg[:6]
+        f16l = bool(cfg[6]) if len(cfg) > 6 else False
         ctx.set_materialize_grads(False)     # an unused output (agg_iou's cls branch is only used detached) gives None
         N, W = x_cls.shape
         nl = sum(ppf[:lframe])
@@ -46,7 +56,7 @@ class _MCAFunction(torch.autograd.Function):
         # with a backward to come the forward's workspace stays alive: its normalised q / k / v rows are what the backward's first launch
         # would re-derive
         res = ops.mca_attention(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, scale, sim_thresh, conf_thresh, want_stats=want,
-                                keep_workspace=want)
+                                keep_workspace=want, fp16_logits=f16l)
         xcat_c, cat3_c, xcat_r, cat3_r, stats = res[:5]
         fwd_ws = res[5] if want else None
         ops.linear(xcat_c, w_lin, b_lin, out=cat3_c[:, W:])
@@ -63,7 +73,7 @@ class _MCAFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_cls, g_obj=None):
-        ppf, lframe, scale, sim_thresh, conf_thresh, need_reg = ctx.cfg
+        ppf, lframe, scale, sim_thresh, conf_thresh, need_reg = ctx.cfg[:6]
         (xc, xr, sc, q_c, kv_c, q_r, kv_r, tiles, stats, xcat_c, cat3_c, xcat_r, cat3_r, wq_c, wkv_c, wq_r, wkv_r, w_lin, w_linr, w_out,
          w_obj, fwd_ws) = ctx.saved_tensors
         N, W = xc.shape
@@ -124,6 +134,6 @@ class MCA_tscd_g2l_reg(nn.Module):
                   m.linear_reg.weight if need_reg else None, m.linear_reg.bias if need_reg else None,
                   self.linear.weight, self.linear.bias, self.linear_obj.weight if need_reg else None,
                   self.linear_obj.bias if need_reg else None]
-        cfg = (ppf, lframe, float(m.scale), float(sim_thresh), float(conf_thresh), need_reg)
+        cfg = (ppf, lframe, float(m.scale), float(sim_thresh), float(conf_thresh), need_reg, bool(kwargs.get("fp16_logits", FP16_LOGITS)))
         out = _MCAFunction.apply(cfg, x_cls.to(torch.float16), x_reg.to(torch.float16), cls_score, *params)
         return out if need_reg else (out, None)
