@@ -296,7 +296,11 @@ def roofline_dominant_kernel(args, device, step):
     # brackets of a launch include the time it spends queued behind / sharing the CUs with another level's kernels
     streams, head_mod.LEVEL_STREAMS = head_mod.LEVEL_STREAMS, False
     import yolox.models.tscd as tscd_mod
+    from tscd_amd import graphs
     prefetch, tscd_mod.PREFETCH_BACKBONE = tscd_mod.PREFETCH_BACKBONE, False     # same reason: one stream while timing launches
+    # ... and no hipGraph replay of the frozen front: a replayed launch cannot be bracketed, so the backbone / PAFPN / base-tower convs
+    # (55 % of the step's FLOPs) would be missing from the launch average
+    graphs_on, graphs.ENABLED = graphs.ENABLED, False
     try:
         for _ in range(nsteps):
             step()
@@ -304,6 +308,7 @@ def roofline_dominant_kernel(args, device, step):
     finally:
         head_mod.LEVEL_STREAMS = streams
         tscd_mod.PREFETCH_BACKBONE = prefetch
+        graphs.ENABLED = graphs_on
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
     sel = [(f, e0.elapsed_time(e1) * 1e-3) for (bn, cin, f, e0, e1, _) in prof if bn == 128 and cin % 32 == 0]
     if args.conv_table:        # per-shape table of every conv / GEMM launch of the instrumented steps (stderr)
