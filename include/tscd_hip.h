@@ -21,6 +21,10 @@ extern "C" {
 
 int tscd_abi_version(void);
 const char* tscd_last_error(void);
+/* Queues the host function fn(arg) (void (*)(void*)) on `stream`: everything queued after it starts once it has returned.  Used
+ * to park the stream on the assignment chain's latch (include/tscd_host.h: tscd_latch_wait_cb + tscd_latch_ticket) while the
+ * host keeps queueing the work that follows the assignments; the reference blocks in scipy instead (tscd_matching.py:935). */
+int tscd_stream_host_func(void* stream, void* fn, void* arg);
 
 /* ---- convolution / GEMM (MFMA implicit GEMM) -------------------------------------------------------------------
  * Replaces Conv2d inside BaseConv (yolox/models/network_blocks.py:36-61), the prediction convs

@@ -48,6 +48,28 @@ int tscd_lap_chain_f16(int K, const uint16_t* const* cost, const int64_t* nr, co
 int tscd_lap_chain_set_parallel(int on);
 int64_t tscd_lap_chain_spec_hits(int reset);
 
+/* A latch a device stream can be parked on, and the chain call that raises it.  The train step queues everything that follows
+ * the assignments (CAFM, refined heads, the whole backward) while the chain is still being solved on a worker thread: the caller
+ * queues tscd_latch_wait_cb with a ticket through include/tscd_hip.h's tscd_stream_host_func -- hipLaunchHostFunc --, then the copy of
+ * the index table from pinned memory, then the kernels.  The reference has no counterpart: it blocks the interpreter in
+ * linear_sum_assignment (tscd_matching.py:935).  Generations only grow, so one latch serves every step.  tscd_latch_wait
+ * returns 0 once generation `gen` is reached, 1 after timeout_ms (counted by tscd_latch_timeouts). */
+void* tscd_latch_create(void);
+void tscd_latch_destroy(void* latch);
+void tscd_latch_signal(void* latch, uint64_t gen);
+uint64_t tscd_latch_generation(void* latch);
+int64_t tscd_latch_timeouts(void* latch);
+int tscd_latch_wait(void* latch, uint64_t gen, int timeout_ms);
+void* tscd_latch_ticket(void* latch, uint64_t gen, int timeout_ms);   /* heap ticket, consumed by tscd_latch_wait_cb */
+void tscd_latch_wait_cb(void* ticket);                                /* hipHostFn_t */
+/* tscd_lap_chain_f16 for the clamped training regime (K frames of n proposals each, kind = 0,2,2,...): also writes the clip's
+ * index table [inv_0 | c_1 | inv_1 | ... ] (n int64 each; c_k = perm_out of frame k, inv_k its inverse, inv_0 the inverse of the
+ * first frame's self assignment; table_len = (2K-1)*n) and then raises `latch` to `gen` -- on every path; on failure (status as
+ * tscd_lap_chain_f16, 5 = shapes outside the regime) the table holds identity permutations. */
+int tscd_lap_chain_f16_table(int K, const uint16_t* const* cost, const int64_t* nr, const int64_t* nc, const int32_t* kind,
+                             int64_t* row_out, int64_t* col_out, int64_t* perm_out, int64_t* table, int64_t table_len, void* latch,
+                             uint64_t gen);
+
 /* Diagnostics: relaxation passes executed by the fixed-point solver since the last reset. */
 int64_t tscd_lap_debug_steps(int reset);
 /* Diagnostics: solves answered on the int16 (which = 0) / int32 (which = 1) fixed-point matrix so far. */

@@ -321,6 +321,7 @@ def test_train_with_the_reference_assignment_and_proposal_sets_is_tight(golden, 
         return out
 
     monkeypatch.setattr(M, "lap_chain_f16", forced_chain)
+    monkeypatch.setattr(M, "DEFER_CHAIN", False)      # the forced assignments are handed over on the host
     monkeypatch.setattr(ops, "select_proposals", forced_select)
     monkeypatch.setattr(ops, "simota_assign", forced_simota)
     m = copy.deepcopy(model).train()

@@ -643,6 +643,53 @@ def test_cafm_fused_chain_equals_the_per_op_path_and_the_oracle_autograd(W, n, L
         assert gr is not None and cos(v, gr) > 0.99, (k, cos(v, gr))
 
 
+def test_cafm_deferred_join_of_the_assignment_chain_is_the_joined_result():
+    """The clamped training regime parks the stream on the worker's latch (hipLaunchHostFunc) and queues CAFM and its backward before
+    the assignments exist on the host (TSCD_DEFER_ASSIGNMENTS, tscd_lap_chain_f16_table).  Same clip with the chain joined on the host
+    first: identical assignments, bit-identical forward, gradients equal up to the order of the fp32 atomics in the SE gate's backward;
+    repeated steps reuse the pinned table and the latch (generations grow), and nothing times out."""
+    import yolox.models.tscd_matching as M
+    dev = torch.device("cuda:0")
+    W, n, L = 256, 200, 4
+    g = torch.Generator().manual_seed(5)
+    mod = M.AwarePositionRegMatcher(hidden_channel=W, feedforward_channel=W, num_head=8, decoder_layer_num=1).to(dev).train()
+    nl = n * L
+    wgt = torch.randn(nl, W, generator=g).half().to(dev)
+    temb = torch.randn(L, 256, generator=g).half().to(dev)
+
+    def clip(seed):
+        gg = torch.Generator().manual_seed(seed)
+        pool = torch.nn.functional.normalize(torch.randn(n, 4 * W, generator=gg), dim=1)
+        reg = torch.cat([(pool[torch.randperm(n, generator=gg)] + 0.01 * torch.randn(n, 4 * W, generator=gg)).half() for _ in range(L)]).to(dev)
+        cls = torch.cat([(pool[torch.randperm(n, generator=gg)] + 0.01 * torch.randn(n, 4 * W, generator=gg)).half() for _ in range(L)]).to(dev)
+        return reg, cls, torch.randn(nl, W, generator=gg).half(), torch.randn(nl, W, generator=gg).half()
+
+    def run(defer, seed):
+        M.DEFER_CHAIN = defer
+        reg, cls, f0, e0 = clip(seed)
+        mod.zero_grad(set_to_none=True)
+        f, e = f0.to(dev).requires_grad_(), e0.to(dev).requires_grad_()
+        out = mod(f, reg, cls, e, [n] * L, temb, resume=False)[-1]
+        pending = mod._pending is not None
+        (out.float() * wgt.float()).sum().backward()
+        hung = [np.asarray(h) for h in mod.last_hungarian]          # joins the worker in the deferred form
+        torch.cuda.synchronize()
+        return out.detach().cpu(), f.grad.float().cpu(), e.grad.float().cpu(), hung, pending
+
+    try:
+        gen0 = M._latch().generation
+        for seed in (1, 2, 3):
+            o1, df1, de1, h1, p1 = run(True, seed)
+            o0, df0, de0, h0, p0 = run(False, seed)
+            assert p1 and not p0
+            assert len(h1) == L and all(np.array_equal(a, b) for a, b in zip(h0, h1))
+            assert torch.equal(o0, o1)
+            assert torch.allclose(df0, df1, rtol=1e-2, atol=1e-3) and torch.allclose(de0, de1, rtol=1e-2, atol=1e-3)
+        assert M._latch().generation == gen0 + 3 and M._latch().timeouts == 0
+    finally:
+        M.DEFER_CHAIN = True
+
+
 def test_nms_more_candidates_than_one_lds_sort_chunk():
     """The ImageNet-VID regime (no upper proposal clamp, 30 classes): a frame with 1500 proposals has up to 45000
     (proposal, class) candidates -- more than the 16384 keys one LDS sort holds -- next to a small frame.  Kept candidate

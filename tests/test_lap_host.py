@@ -199,3 +199,56 @@ def test_lap_chain_side_by_side_solves_match_in_order_scipy(mode):
             assert hits > 100          # unique optima are answered from the side-by-side solves
         if mode == "ties":
             assert hits < 60           # tie-heavy optima are (almost) never certified unique
+
+
+def test_chain_with_index_table_and_latch():
+    """tscd_lap_chain_f16_table (the clamped training regime's deferred join): the index table [inv_0 | c_1 | inv_1 | ...] equals what
+    AwarePositionRegMatcher.finish builds from the chain's results on the host, and the latch is raised on every path -- on a clip
+    outside the regime the call fails, the table holds in-range identity rows and a parked stream would still be released."""
+    import threading
+    from tscd_amd._host import Latch, lap_chain_f16, KIND_SELF, KIND_PREV
+    rng = np.random.default_rng(77)
+    n, K = 64, 4
+    mats = []
+    for k in range(K):
+        base = rng.standard_normal((1, 16))
+        a = base + 0.03 * rng.standard_normal((n, 16)); b = base + 0.03 * rng.standard_normal((n, 16))
+        a /= np.linalg.norm(a, axis=1, keepdims=True); b /= np.linalg.norm(b, axis=1, keepdims=True)
+        mats.append(np.ascontiguousarray((1 - (a @ a.T if k == 0 else a @ b.T)).astype(np.float16)))
+    mats[0][3] = mats[0][2]                                    # duplicate proposals: the self assignment is not the identity
+    mats[0][:, 3] = mats[0][:, 2]
+    flat = np.concatenate([m.reshape(-1) for m in mats])
+    kinds = [KIND_SELF] + [KIND_PREV] * (K - 1)
+    plain = lap_chain_f16(flat.ctypes.data, [m.shape for m in mats], kinds)
+    latch = Latch()
+    gen = latch.new_generation()
+    table = np.full((2 * K - 1) * n, -1, np.int64)
+    waited = []
+    th = threading.Thread(target=lambda: waited.append(latch.wait(gen, 20000)))
+    th.start()
+    got = lap_chain_f16(flat.ctypes.data, [m.shape for m in mats], kinds, table_ptr=table.ctypes.data, table_len=len(table), latch=latch, gen=gen)
+    th.join()
+    assert waited == [True] and latch.generation == gen and latch.timeouts == 0
+    for a, b in zip(plain, got):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    want = [np.argsort(plain[0][1])]
+    for k in range(1, K):
+        want += [plain[k][2], np.argsort(plain[k][2])]
+    assert np.array_equal(table, np.concatenate(want))
+    # outside the regime (a frame of another size): status 5 -> ValueError, identity rows, latch still raised
+    gen2 = latch.new_generation()
+    bad = [mats[0], np.ascontiguousarray(mats[1][:, :n - 1])]
+    flat2 = np.concatenate([m.reshape(-1) for m in bad])
+    table2 = np.full(3 * n, -1, np.int64)
+    with pytest.raises(ValueError):
+        lap_chain_f16(flat2.ctypes.data, [m.shape for m in bad], kinds[:2], table_ptr=table2.ctypes.data, table_len=len(table2), latch=latch, gen=gen2)
+    assert latch.wait(gen2, 10) and table2.min() == 0 and table2.max() == n - 1
+    # a chain that cannot start (the wait for the cost copy fails) releases the latch as well
+    gen3 = latch.new_generation()
+
+    def boom():
+        raise RuntimeError("copy failed")
+    with pytest.raises(RuntimeError):
+        lap_chain_f16(flat.ctypes.data, [m.shape for m in mats], kinds, before=boom, table_ptr=table.ctypes.data, table_len=len(table), latch=latch, gen=gen3)
+    assert latch.wait(gen3, 10)
+    assert not latch.wait(gen3 + 1, 5) and latch.timeouts == 1

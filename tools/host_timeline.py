@@ -19,11 +19,11 @@ def finish(self, *a, **k):
     return r
 M.AwarePositionRegMatcher.finish = finish
 orig_chain = M.lap_chain_f16
-def chain(base_ptr, shapes, kinds, before=None):
+def chain(base_ptr, shapes, kinds, before=None, **kw):
     marks["chain_submit"] = time.perf_counter()
     if before is not None: before()
     marks["copy_done"] = time.perf_counter()
-    r = orig_chain(base_ptr, shapes, kinds, None)
+    r = orig_chain(base_ptr, shapes, kinds, None, **kw)
     marks["chain_done"] = time.perf_counter()
     marks["shapes"] = shapes
     return r

@@ -36,11 +36,11 @@ def finish(self, *a, **k):
     return r
 
 
-def chain(base_ptr, shapes, kinds, before=None):
+def chain(base_ptr, shapes, kinds, before=None, **kw):
     if before is not None:
         before()
     t = time.perf_counter()
-    r = orig_chain(base_ptr, shapes, kinds, None)
+    r = orig_chain(base_ptr, shapes, kinds, None, **kw)
     marks["chain"] = time.perf_counter() - t
     return r
 

@@ -55,20 +55,28 @@ wrap(M.AwarePositionRegMatcher, "finish", before="finish_in", after="finish_out"
 orig_chain = M.lap_chain_f16
 
 
-def chain(base_ptr, shapes, kinds, before=None):
+CH = []                # (start, end) of every chain on the worker's clock; chain k belongs to step k (the deferred join lets the
+                       # host leave the step before its chain has ended, so the marks are matched to steps by index afterwards)
+
+
+def chain(base_ptr, shapes, kinds, before=None, **kw):
     if before is not None:
         before()
-    H["chain_start"] = time.perf_counter()
-    r = orig_chain(base_ptr, shapes, kinds, None)
-    H["chain_end"] = time.perf_counter()
+    t0 = time.perf_counter()
+    r = orig_chain(base_ptr, shapes, kinds, None, **kw)
+    CH.append((t0, time.perf_counter()))
     return r
 
 
 M.lap_chain_f16 = chain
 
 
+STARTS = []
+
+
 def step(rec=None):
     mark("start")
+    STARTS.append(H["start"])
     model.head.loss_scale = scaler.scale(one)
     out = model(imgs, targets, temb, lframe=args.lframe, gframe=args.frames - args.lframe, resume=False, next_x=imgs)
     mark("forward_out")
@@ -97,11 +105,16 @@ ms = (time.perf_counter() - t) / N * 1e3
 names = ["counts_on_host", "prepare_in", "costs_queued", "chain_start", "finish_in", "chain_end", "finish_out", "forward_out", "backward_out", "step_out"]
 print(f"steady state after {PREROLL} steps: {ms:.2f} ms per step (no drains)")
 print("host clock, ms from the step's start (median of %d steps):" % N)
+M.AwarePositionRegMatcher._join_pending(model.head.local_reg_matcher)
+k0 = len(STARTS) - N
+chain_rel = {"chain_start": [(CH[k][0] - STARTS[k]) * 1e3 for k in range(k0, len(STARTS))],
+             "chain_end": [(CH[k][1] - STARTS[k]) * 1e3 for k in range(k0, len(STARTS))]}
 for n in names:
-    print(f"  {n:16s} {np.median([(h[n] - h['start']) * 1e3 for h, _ in rec]):7.2f}")
+    v = chain_rel[n] if n in chain_rel else [(h[n] - h['start']) * 1e3 for h, _ in rec]
+    print(f"  {n:16s} {np.median(v):7.2f}")
 print("device clock, ms from the step-start event reaching the main stream (median):")
 for n in [x for x in names if x not in ("chain_start", "chain_end")]:
     print(f"  {n:16s} {np.median([d['start'].elapsed_time(d[n]) for _, d in rec]):7.2f}")
 lag = [(h["start"] - rec[0][0]["start"]) * 1e3 - rec[0][1]["start"].elapsed_time(d["start"]) for h, d in rec]
 print(f"host start minus device start of the same step (how far the host runs ahead), ms: median {np.median(lag):.2f}  min {min(lag):.2f}  max {max(lag):.2f}")
-print(f"chain duration {np.median([(h['chain_end'] - h['chain_start']) * 1e3 for h, _ in rec]):.2f} ms")
+print(f"chain duration {np.median([(b - a) * 1e3 for a, b in CH[k0:]]):.2f} ms; deferred join of the chain: {M.DEFER_CHAIN}")

@@ -61,17 +61,69 @@ if os.environ.get("TSCD_LAP_PARALLEL", "1") == "0":       # diagnostics / A-B ru
 KIND_SELF, KIND_STATE, KIND_PREV = 0, 1, 2
 
 
-def lap_chain_f16(base_ptr, shapes, kinds, before=None):
+_lib.tscd_lap_chain_f16_table.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int64, C.c_void_p, C.c_uint64]
+_lib.tscd_lap_chain_f16_table.restype = C.c_int
+_lib.tscd_latch_create.argtypes, _lib.tscd_latch_create.restype = [], C.c_void_p
+_lib.tscd_latch_destroy.argtypes, _lib.tscd_latch_destroy.restype = [C.c_void_p], None
+_lib.tscd_latch_signal.argtypes, _lib.tscd_latch_signal.restype = [C.c_void_p, C.c_uint64], None
+_lib.tscd_latch_generation.argtypes, _lib.tscd_latch_generation.restype = [C.c_void_p], C.c_uint64
+_lib.tscd_latch_timeouts.argtypes, _lib.tscd_latch_timeouts.restype = [C.c_void_p], C.c_int64
+_lib.tscd_latch_wait.argtypes, _lib.tscd_latch_wait.restype = [C.c_void_p, C.c_uint64, C.c_int], C.c_int
+_lib.tscd_latch_ticket.argtypes, _lib.tscd_latch_ticket.restype = [C.c_void_p, C.c_uint64, C.c_int], C.c_void_p
+LATCH_WAIT_CB = C.cast(_lib.tscd_latch_wait_cb, C.c_void_p).value      # address of the hipHostFn_t that consumes a ticket
+
+
+class Latch:
+    """A generation counter a device stream can be parked on (csrc_host/lap.cpp: TscdLatch).  ``ticket(gen)`` is the argument of
+    one queued wait (LATCH_WAIT_CB frees it); the object lives as long as the process queues waits on it (never destroyed while a
+    wait may be pending: it is kept for the life of the process)."""
+
+    def __init__(self):
+        self.handle = _lib.tscd_latch_create()
+        self.next_gen = 0
+
+    def new_generation(self):
+        self.next_gen += 1
+        return self.next_gen
+
+    def ticket(self, gen, timeout_ms=30000):
+        return _lib.tscd_latch_ticket(self.handle, gen, timeout_ms)
+
+    def signal(self, gen):
+        _lib.tscd_latch_signal(self.handle, gen)
+
+    def wait(self, gen, timeout_ms=30000):
+        return _lib.tscd_latch_wait(self.handle, gen, timeout_ms) == 0
+
+    @property
+    def generation(self):
+        return _lib.tscd_latch_generation(self.handle)
+
+    @property
+    def timeouts(self):
+        return _lib.tscd_latch_timeouts(self.handle)
+
+
+def lap_chain_f16(base_ptr, shapes, kinds, before=None, table_ptr=None, table_len=0, latch=None, gen=0):
     """The clip's dependent chain of assignments in ONE foreign call (no Python between the solves; ctypes drops the GIL, so a
     caller on a worker thread leaves the main thread free to queue device work).
 
     base_ptr: address of the fp16 cost matrices laid out back to back ([nr_k, nc_k] each, C order); shapes: [(nr_k, nc_k)];
     kinds: KIND_* per matrix; before: optional callable run first on the calling thread (e.g. wait for the copy).
+    table_ptr / table_len / latch / gen: see tscd_lap_chain_f16_table (include/tscd_host.h) -- the clamped training regime's index
+    table written to pinned memory, then the latch raised; the latch is raised on every path, also when the chain fails.
     Returns [(row_ind, col_ind, perm)] per matrix -- perm: the order in which the reference keeps the frame's rows."""
-    if before is not None:
-        before()
+    try:
+        if before is not None:
+            before()
+    except BaseException:
+        if latch is not None:          # never leave a stream parked on a chain that will not run
+            latch.signal(gen)
+        raise
     K = len(shapes)
     if K == 0:
+        if latch is not None:
+            latch.signal(gen)
         return []
     ptrs = (C.c_void_p * K)()
     off = 0
@@ -83,8 +135,16 @@ def lap_chain_f16(base_ptr, shapes, kinds, before=None):
     kd = np.array(kinds, np.int32)
     npair = np.minimum(nr, nc)
     rows, cols, perms = np.empty(int(npair.sum()), np.int64), np.empty(int(npair.sum()), np.int64), np.empty(int(nc.sum()), np.int64)
-    st = _lib.tscd_lap_chain_f16(K, C.cast(ptrs, C.c_void_p), nr.ctypes.data, nc.ctypes.data, kd.ctypes.data, rows.ctypes.data,
-                                 cols.ctypes.data, perms.ctypes.data)
+    if table_ptr is not None:
+        # the clamped regime: the index table is written to pinned memory and the latch raised inside the call (no interpreter
+        # between the last solve and the device's go-ahead)
+        st = _lib.tscd_lap_chain_f16_table(K, C.cast(ptrs, C.c_void_p), nr.ctypes.data, nc.ctypes.data, kd.ctypes.data, rows.ctypes.data,
+                                           cols.ctypes.data, perms.ctypes.data, table_ptr, table_len, latch.handle if latch else None, gen)
+    else:
+        st = _lib.tscd_lap_chain_f16(K, C.cast(ptrs, C.c_void_p), nr.ctypes.data, nc.ctypes.data, kd.ctypes.data, rows.ctypes.data,
+                                     cols.ctypes.data, perms.ctypes.data)
+        if latch is not None:
+            latch.signal(gen)
     if st:
         raise ValueError("assignment chain failed at matrix %d (status %d)" % (st // 16, st % 16))
     out, a, b = [], 0, 0

@@ -63,6 +63,7 @@ SIGNATURES = {
     "tscd_loss_dense_f16": [P, P, P, P, P, P, I, I, I, I, P, L, P, P, P],
     "tscd_loss_combine_f32": [P, P, P, P, P, I, I, P, P, P],
     "tscd_scale_grad_f16": [P, P, I, I, I, L, I, I, P, P],
+    "tscd_stream_host_func": [P, P, P],
     "tscd_loss_dense_reg_f16": [P, P, P, P, P, P, I, I, I, I, P, P, P, L, P, P, P, P],
     "tscd_loss_rows_f16": [P, P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, L, P, P, P, P, P],
 }

@@ -14,6 +14,17 @@ void tscd_set_error(const char* fmt, ...) {
 }
 extern "C" const char* tscd_last_error(void) { return g_err; }
 extern "C" int tscd_abi_version(void) { return 1; }
+// Queues a host function on the stream (hipLaunchHostFunc): work queued behind it starts when fn(arg) has returned.  The train
+// step parks the stream on the assignment chain's latch this way (include/tscd_host.h: tscd_latch_wait_cb) and keeps queueing.
+extern "C" int tscd_stream_host_func(void* stream, void* fn, void* arg) {
+  TSCD_CHECK_ARG(fn, "stream_host_func: null function");
+  hipError_t e = hipLaunchHostFunc((hipStream_t)stream, (hipHostFn_t)fn, arg);
+  if (e != hipSuccess) {
+    tscd_set_error("stream_host_func: %s", hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
 
 #define EW_BLOCK 256
 static inline int ew_grid(long n) {

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <numeric>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -743,6 +744,77 @@ int tscd_lap_chain_f16(int K, const uint16_t* const* cost, const int64_t* nr, co
     o_perm += Cn;
   }
   return 0;
+}
+// ---- a latch the device's stream can be parked on ---------------------------------------------------------------------------
+// The train step queues everything that FOLLOWS the assignments (CAFM, the refined heads, the whole backward) while the chain is
+// still being solved on a worker thread: the stream is held by a host function (hipLaunchHostFunc -> tscd_latch_wait_cb, run on a
+// runtime thread without the interpreter) until the worker has written the clip's index table to pinned memory and raised the
+// latch.  A latch carries a generation counter so one object serves every step; a wait gives up after its timeout (the stream then
+// continues on the table's previous contents, which are always in-range permutations) and the failure is reported by
+// tscd_latch_timeouts / the worker's own status.
+struct TscdLatch {
+  std::mutex m;
+  std::condition_variable cv;
+  uint64_t gen = 0;
+  std::atomic<int64_t> timeouts{0};
+};
+struct TscdLatchTicket { TscdLatch* latch; uint64_t gen; int timeout_ms; };
+void* tscd_latch_create(void) { return new TscdLatch(); }
+void tscd_latch_destroy(void* l) { delete (TscdLatch*)l; }
+void tscd_latch_signal(void* l, uint64_t gen) {
+  TscdLatch* L = (TscdLatch*)l;
+  { std::lock_guard<std::mutex> g(L->m); if (gen > L->gen) L->gen = gen; }
+  L->cv.notify_all();
+}
+uint64_t tscd_latch_generation(void* l) { TscdLatch* L = (TscdLatch*)l; std::lock_guard<std::mutex> g(L->m); return L->gen; }
+int64_t tscd_latch_timeouts(void* l) { return ((TscdLatch*)l)->timeouts.load(); }
+// 0 when generation `gen` has been reached, 1 after timeout_ms without it
+int tscd_latch_wait(void* l, uint64_t gen, int timeout_ms) {
+  TscdLatch* L = (TscdLatch*)l;
+  std::unique_lock<std::mutex> g(L->m);
+  bool ok = L->cv.wait_for(g, std::chrono::milliseconds(timeout_ms), [&] { return L->gen >= gen; });
+  if (!ok) ++L->timeouts;
+  return ok ? 0 : 1;
+}
+// heap ticket for one queued wait; tscd_latch_wait_cb (signature of hipHostFn_t) consumes it
+void* tscd_latch_ticket(void* l, uint64_t gen, int timeout_ms) { return new TscdLatchTicket{(TscdLatch*)l, gen, timeout_ms}; }
+void tscd_latch_wait_cb(void* ticket) {
+  TscdLatchTicket* t = (TscdLatchTicket*)ticket;
+  tscd_latch_wait(t->latch, t->gen, t->timeout_ms);
+  delete t;
+}
+
+// tscd_lap_chain_f16 for the clamped training regime (every frame n proposals, kinds 0,2,2,...): additionally writes the clip's
+// index table -- [inv_0 | c_1 | inv_1 | c_2 | inv_2 ...], n int64 each: c_k the order in which the reference keeps frame k's rows
+// (perm_out), inv_k its inverse, inv_0 the inverse of the first frame's self assignment -- to `table` (pinned host memory the
+// device copies from) and then raises `latch` to `gen`.  The latch is raised on EVERY path; on failure the table holds identity
+// permutations, so work queued behind the latch stays in range.  table_len must be (2K-1)*n.
+int tscd_lap_chain_f16_table(int K, const uint16_t* const* cost, const int64_t* nr, const int64_t* nc, const int32_t* kind,
+                             int64_t* row_out, int64_t* col_out, int64_t* perm_out, int64_t* table, int64_t table_len, void* latch,
+                             uint64_t gen) {
+  int st = 0;
+  const int64_t n = K > 0 ? nc[0] : 0;
+  bool shape_ok = table && K > 0 && table_len == (2 * (int64_t)K - 1) * n;
+  for (int k = 0; k < K && shape_ok; ++k) shape_ok = nr[k] == n && nc[k] == n && kind[k] == (k ? 2 : 0);
+  if (!shape_ok) st = 5;
+  if (st == 0) st = tscd_lap_chain_f16(K, cost, nr, nc, kind, row_out, col_out, perm_out);
+  if (table) {
+    if (st == 0) {
+      int64_t* t = table;
+      for (int64_t i = 0; i < n; ++i) t[col_out[i]] = i;              // frame 0: inverse of its own column order
+      t += n;
+      for (int k = 1; k < K; ++k) {
+        const int64_t* pk = perm_out + (int64_t)k * n;
+        std::memcpy(t, pk, sizeof(int64_t) * n);
+        for (int64_t i = 0; i < n; ++i) t[n + pk[i]] = i;
+        t += 2 * n;
+      }
+    } else if (n > 0) {
+      for (int64_t i = 0; i < table_len; ++i) table[i] = i % n;
+    }
+  }
+  if (latch) tscd_latch_signal(latch, gen);
+  return st;
 }
 // solves answered on the int16 (which = 0) / int32 (which = 1) fixed-point matrix so far
 int64_t tscd_lap_debug_width(int which, int reset) {

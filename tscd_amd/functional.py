@@ -58,7 +58,8 @@ def _conv_backward(dy, x, weight, stride, need_dx, need_dw, dy_padded=None):
     if need_dw:
         dyp = dy.contiguous() if dyp is None else dyp
         # x may carry zero-padded channels (Focus: 12 -> 16): their weight gradient is computed and dropped
-        dw = ops.conv_wgrad(x, dyp, x.shape[-1], dyp.shape[-1], k)[:cout, :cin].to(weight.dtype)
+        with ops.param_grad_stream([weight], x, dyp):
+            dw = ops.conv_wgrad(x, dyp, x.shape[-1], dyp.shape[-1], k)[:cout, :cin].to(weight.dtype).contiguous()
     return dx, dw
 
 

@@ -29,6 +29,79 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+# ----------------------------------------------------------------------------------------------------
+# parameter gradients on their own stream
+# ----------------------------------------------------------------------------------------------------
+# Nothing in a backward pass waits for a weight gradient: the data gradients form the dependent chain, the weight gradients only
+# feed the optimizer.  Inside a backward pass `param_grad_stream` moves the enclosed launches (a weight-gradient GEMM, its split-K
+# reduce, a bias column sum) to a second stream that follows the current one by an event; the pass's final callback makes the
+# caller's stream wait for it, so whatever reads the gradients next (GradScaler's unscale, the optimizer) is ordered behind them.
+# The tensors the launches READ are kept alive until that join (the caching allocator would otherwise hand their blocks to later
+# work on the first stream); the gradients themselves are allocated under the second stream and reach `param.grad` through
+# autograd's AccumulateGrad, which adopts a fresh contiguous gradient without touching it.  Hence the conditions: the parameter has
+# no gradient yet (`grad is None`), this is its first contribution in this pass, and no reducer hooks are waiting for it
+# (torch.distributed initialised with more than one rank, or TSCD_ONE_GRAD_STREAM=1: every launch stays on the pass's own stream).
+import contextlib
+import os as _os
+
+PARAM_GRAD_STREAM = _os.environ.get("TSCD_PARAM_GRAD_STREAM", "1") != "0"
+_PG = {}
+
+
+class _ParamGradState:
+    def __init__(self, dev):
+        self.stream = torch.cuda.Stream(dev)
+        self.keep, self.seen, self.task = [], set(), -1
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep.clear()
+        self.seen.clear()
+        self.task = -1
+
+
+def _param_grad_state(params):
+    if not PARAM_GRAD_STREAM or _os.environ.get("TSCD_ONE_GRAD_STREAM") == "1":
+        return None
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return None
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        return None
+    dev = _cur_device()
+    st = _PG.get(dev)
+    if st is None:
+        st = _PG[dev] = _ParamGradState(dev)
+    if st.task != task:
+        if st.task >= 0:          # a pass that ended without its callback (an exception in backward): order behind its leftovers
+            st.join()
+        torch.autograd.Variable._execution_engine.queue_callback(st.join)
+        st.task = task
+    for prm in params:
+        if prm.grad is not None or id(prm) in st.seen:
+            # accumulation into an existing gradient runs a kernel on the pass's own stream: stay there, behind what is in flight
+            torch.cuda.current_stream().wait_stream(st.stream)
+            return None
+    st.seen.update(id(prm) for prm in params)
+    return st
+
+
+@contextlib.contextmanager
+def param_grad_stream(params, *reads):
+    """with param_grad_stream([weight, ...], x, dy): dw = conv_wgrad(x, dy, ...)  -- see the note above.  Yields True when the body
+    runs on the second stream."""
+    st = _param_grad_state(params)
+    if st is None:
+        yield False
+        return
+    ev = torch.cuda.Event()
+    ev.record()
+    st.stream.wait_event(ev)
+    st.keep.extend(reads)
+    with torch.cuda.stream(st.stream):
+        yield True
+
+
 def require_gpu(t, name="tensor"):
     if not t.is_cuda:
         raise RuntimeError(f"tscd_amd: {name} is on {t.device}; the TSCD kernels run on an MI355X only "
@@ -689,9 +762,10 @@ def linear_dgrad(dy, weight):
     return linear(dy, None, out=torch.empty((n, in_f), dtype=torch.float16, device=dy.device), wpk=wpk)
 
 
-def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False):
+def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False, grad_params=None):
     """Backward of y = x W^T (+ b) in ONE foreign call -> (dx fp16 [n,in] | None, dw fp32 [out,in] | None, db fp32 [out] | None).
-    x [n,in] fp16 (unit column stride), dy [n,out] fp16."""
+    x [n,in] fp16 (unit column stride), dy [n,out] fp16.  ``grad_params``: the parameters dw / db are the gradients OF (their
+    dtype and shape) -- given, the call is split in two and the parameter half runs on the second stream (param_grad_stream)."""
     n, in_f = x.shape
     out_f = weight.shape[0]
     outp = (out_f + 7) // 8 * 8
@@ -712,8 +786,19 @@ def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False):
         w = w.contiguous()
     # the data-gradient copy of a PARAMETER is cached per version (and refreshed in the optimizer's batched re-pack): no pack launch here
     wdg = LINEAR_WEIGHTS.get(weight, mode=1) if need_dx and isinstance(weight, torch.nn.Parameter) and weight.is_contiguous() else None
-    call("tscd_linear_bwd_packed_f16", x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), w.data_ptr(), int(w.dtype == torch.float32),
-         _ptr(wdg), n, in_f, out_f, outp, _ptr(dx), _ptr(dw), _ptr(db), ws.data_ptr(), ws_bytes, _stream())
+    args = (x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), w.data_ptr(), int(w.dtype == torch.float32), _ptr(wdg), n, in_f, out_f, outp)
+    if (need_dw or need_db) and grad_params is not None:
+        # data gradient on the pass's stream, parameter gradients on the second one (param_grad_stream)
+        if need_dx:
+            call("tscd_linear_bwd_packed_f16", *args, _ptr(dx), 0, 0, ws.data_ptr(), ws_bytes, _stream())
+        with param_grad_stream(grad_params, x, dy) as side:
+            if side:      # allocated under the second stream
+                dw = torch.empty((outp, in_f), dtype=torch.float32, device=dev) if need_dw else None
+                db = torch.empty((outp,), dtype=torch.float32, device=dev) if need_db else None
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            call("tscd_linear_bwd_packed_f16", *args, 0, _ptr(dw), _ptr(db), ws.data_ptr(), ws_bytes, _stream())
+    else:
+        call("tscd_linear_bwd_packed_f16", *args, _ptr(dx), _ptr(dw), _ptr(db), ws.data_ptr(), ws_bytes, _stream())
     return dx, (None if dw is None else dw[:out_f]), (None if db is None else db[:out_f])
 
 

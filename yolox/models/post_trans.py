@@ -85,8 +85,8 @@ class _MCAFunction(torch.autograd.Function):
             if g is None:      # this output was not used downstream: no gradient for its two linears
                 return z16(nl, 3 * W), z16(nl, 2 * W), None, None, None, None
             g = g.to(torch.float16).contiguous()
-            d_cat3, dw_o, db_o = ops.linear_bwd(cat3, g, w_o, True, True, True)
-            d_xcat, dw_l, db_l = ops.linear_bwd(xcat, d_cat3[:, W:], w_l, True, True, True)    # dY = a column slice of d_cat3
+            d_cat3, dw_o, db_o = ops.linear_bwd(cat3, g, w_o, True, True, True, grad_params=[w_o])
+            d_xcat, dw_l, db_l = ops.linear_bwd(xcat, d_cat3[:, W:], w_l, True, True, True, grad_params=[w_l])    # dY = a column slice of d_cat3
             return d_cat3, d_xcat, dw_o, db_o, dw_l, db_l
 
         dc3_c, dxc_c, dw_out, db_out, dw_lin, db_lin = head(g_cls, cat3_c, xcat_c, w_out, w_lin)
@@ -96,11 +96,11 @@ class _MCAFunction(torch.autograd.Function):
             dc3_r = dxc_r = dw_obj = db_obj = dw_linr = db_linr = None
         dq_c, dkv_c, dq_r, dkv_r, dscore = ops.mca_backward(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, scale, sim_thresh,
                                                             conf_thresh, stats, dxc_c, dxc_r, dc3_c, dc3_r, cat3_c, cat3_r, fwd_ws=fwd_ws)
-        dx_c, dw_kv_c, _ = ops.linear_bwd(xc, dkv_c, wkv_c)
-        dxq_c, dw_q_c, _ = ops.linear_bwd(xc[:nl], dq_c, wq_c)
+        dx_c, dw_kv_c, _ = ops.linear_bwd(xc, dkv_c, wkv_c, grad_params=[wkv_c])
+        dxq_c, dw_q_c, _ = ops.linear_bwd(xc[:nl], dq_c, wq_c, grad_params=[wq_c])
         dx_c[:nl] += dxq_c
-        dx_r, dw_kv_r, _ = ops.linear_bwd(xr, dkv_r, wkv_r)
-        dxq_r, dw_q_r, _ = ops.linear_bwd(xr[:nl], dq_r, wq_r)
+        dx_r, dw_kv_r, _ = ops.linear_bwd(xr, dkv_r, wkv_r, grad_params=[wkv_r])
+        dxq_r, dw_q_r, _ = ops.linear_bwd(xr[:nl], dq_r, wq_r, grad_params=[wq_r])
         dx_r[:nl] += dxq_r
         like = lambda g, w: None if g is None else g.to(w.dtype).reshape(w.shape)
         grads = (None, dx_c, dx_r, dscore.to(sc.dtype), like(dw_q_c, wq_c), like(dw_kv_c, wkv_c), like(dw_q_r, wq_r), like(dw_kv_r, wkv_r),

@@ -380,16 +380,18 @@ class TSCDHead(nn.Module):
             hook()
         matched = self.local_reg_matcher.finish(prep, f_reg, f_edge, time_embedding[:lframe])
         matched = f_reg[:nl] if matched is None else matched[-1]
-        self._dbg(agg_cls=features_cls_matched, agg_iou_cls=features_cls, agg_iou_obj=features_reg, cafm=matched,
-                  hungarian=list(self.local_reg_matcher.last_hungarian))
+        if self.debug is not None:
+            self._dbg(agg_cls=features_cls_matched, agg_iou_cls=features_cls, agg_iou_obj=features_reg, cafm=matched,
+                      hungarian=list(self.local_reg_matcher.last_hungarian))
         matched4 = hip_linear(matched, self.fc_reg_matcher)
         obj_refined = self.task_aligned(matched4, features_reg, ppf[:lframe])
         if obj_refined is None:
             obj_refined = features_reg
         m_obj = hip_linear(obj_refined, self.matcher_obj_pred)
         m_reg = hip_linear(matched4, self.matcher_reg_pred)
-        self._dbg(cls_preds=cls_preds, matcher_obj_preds=m_obj, matcher_reg_preds=m_reg, cls_scores=cls_scores, matched4=matched4,
-                  obj_refined=obj_refined, hungarian_rows=list(self.local_reg_matcher.last_hungarian_rows))
+        if self.debug is not None:
+            self._dbg(cls_preds=cls_preds, matcher_obj_preds=m_obj, matcher_reg_preds=m_reg, cls_scores=cls_scores, matched4=matched4,
+                      obj_refined=obj_refined, hungarian_rows=list(self.local_reg_matcher.last_hungarian_rows))
 
         if not training:
             res, res_ori, keep = nms_frames(pred_rows[:nl], ppf[:lframe], nc, cls_preds, m_obj, m_reg, 0.001, nms_thresh,

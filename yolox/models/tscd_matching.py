@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from tscd_amd import ops
-from tscd_amd._host import KIND_PREV, KIND_SELF, KIND_STATE, lap_chain_f16, lap_f16
+from tscd_amd._host import KIND_PREV, KIND_SELF, KIND_STATE, LATCH_WAIT_CB, Latch, lap_chain_f16, lap_f16
 
 
 FUSED_CHAIN = __import__("os").environ.get("TSCD_FUSED_CAFM", "1") != "0"     # _CafmChain: the clamped training regime as one autograd node
@@ -30,6 +30,19 @@ _ASSIGN_WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="tscd-lap"
 
 
 _PINNED = {}            # device index -> pinned fp16 staging buffer of the cost matrices (grow-only)
+# The clamped training regime does not wait for the assignments on the host: the stream is parked on a latch the worker raises after
+# writing the clip's index table to pinned memory, and CAFM, the refined heads and the whole backward are queued behind it while the
+# chain is still being solved (TSCD_DEFER_ASSIGNMENTS=0: join the chain on the host first, as every other regime does).
+DEFER_CHAIN = __import__("os").environ.get("TSCD_DEFER_ASSIGNMENTS", "1") != "0"
+_TABLES = {}            # device index -> pinned int64 index table the worker writes (grow-only; always holds in-range rows)
+_LATCH = None           # one latch for the process (generations only grow)
+
+
+def _latch():
+    global _LATCH
+    if _LATCH is None:
+        _LATCH = Latch()
+    return _LATCH
 
 
 def _wait_copy(device_index, event):
@@ -60,7 +73,7 @@ class _Linear(torch.autograd.Function):
         if g.dtype != torch.float16:
             g = g.to(torch.float16)
         need = ctx.needs_input_grad
-        dx, dw, db = ops.linear_bwd(x, g, w, need[0], need[1], ctx.has_bias and need[2])
+        dx, dw, db = ops.linear_bwd(x, g, w, need[0], need[1], ctx.has_bias and need[2], grad_params=[w])
         if dw is not None and dw.dtype != w.dtype:
             dw = dw.to(w.dtype)
         if db is not None and db.dtype != w.dtype:
@@ -408,9 +421,9 @@ class _CafmChain(torch.autograd.Function):
                     torch.index_select(d_qedge, 0, idx[slots[j - 1][1]:slots[j - 1][1] + n], out=d_edge[s0 - n:s0])
         d_edge[nl - n:nl].zero_()                                    # the last frame's edge rows feed no later query gate
         # key / value side of all frames at once
-        dk_in, dwk, _ = ops.linear_bwd(k_in, dk_all, wk, True, True, False)
-        d_feat, dwv, _ = ops.linear_bwd(feat, dv_all, wv, True, True, False)
-        _, dwq, _ = ops.linear_bwd(q_in, dq_all, wq, False, True, False)
+        dk_in, dwk, _ = ops.linear_bwd(k_in, dk_all, wk, True, True, False, grad_params=[wk])
+        d_feat, dwv, _ = ops.linear_bwd(feat, dv_all, wv, True, True, False, grad_params=[wv])
+        _, dwq, _ = ops.linear_bwd(q_in, dq_all, wq, False, True, False, grad_params=[wq])
         d_mem_all, d_ed_all = mk(), mk()
         for j in range(L):
             s0, s1 = j * n, (j + 1) * n
@@ -456,9 +469,42 @@ class AwarePositionRegMatcher(nn.Module):
         self.absolute_position_embedding = nn.Linear(256, hidden_channel)
         self.edge_feature_embedding = nn.Linear(int(hidden_channel / 4), hidden_channel)
         self.decoder_norm = nn.LayerNorm(hidden_channel)
+        self._pending = None
         self._clear_state()
         self.last_hungarian = []     # test hook: the assignment's column indices per processed frame
         self.last_hungarian_rows = []   # ... and its row indices
+
+    # test hooks: the assignment's column / row indices per processed frame.  With the deferred chain they are filled in when first
+    # read (joining the worker) -- the train step itself never reads them.
+    @property
+    def last_hungarian(self):
+        self._join_pending()
+        return self._last_hungarian
+
+    @last_hungarian.setter
+    def last_hungarian(self, v):
+        self._last_hungarian = v
+
+    @property
+    def last_hungarian_rows(self):
+        self._join_pending()
+        return self._last_hungarian_rows
+
+    @last_hungarian_rows.setter
+    def last_hungarian_rows(self, v):
+        self._last_hungarian_rows = v
+
+    def _join_pending(self):
+        """Joins a chain whose result the device consumed without the host (deferred regime): raises what the worker raised."""
+        pend = self.__dict__.get("_pending")
+        if pend is None:
+            return
+        self._pending = None
+        solved = pend.result()
+        self._last_hungarian = [np.asarray(col_raw) for (_, col_raw, _) in solved]
+        self._last_hungarian_rows = [np.asarray(row) for (row, _, _) in solved]
+        if _LATCH is not None and _LATCH.timeouts:
+            raise RuntimeError("the device's wait for the assignment chain timed out %d time(s)" % _LATCH.timeouts)
 
     def _clear_state(self):
         self.last_outputs = None              # reference name; here the previous frame's output rows [n,C]
@@ -549,30 +595,46 @@ class AwarePositionRegMatcher(nn.Module):
         shapes, pinned, ev = self._cost_matrices_async(pairs, _PINNED.get(dev_index))
         _PINNED[dev_index] = pinned
         kinds = [{"self": KIND_SELF, "state": KIND_STATE, "prev": KIND_PREV}[kind] for (_, kind, _) in plan]
-        chain = None
+        chain, deferred = None, None
+        self._join_pending()          # a failure of the previous clip's chain surfaces here at the latest
         if shapes:
+            kw = {}
+            if DEFER_CHAIN and features_reg.is_cuda and self._fused_regime(plan, list(preds_per_frame), resume):
+                n, L = preds_per_frame[0], len(preds_per_frame)
+                tlen = (2 * L - 1) * n
+                table = _TABLES.get(dev_index)
+                if table is None or table.numel() < tlen:
+                    table = _TABLES[dev_index] = torch.zeros((max(tlen, 1 << 14),), dtype=torch.int64, pin_memory=True)
+                latch = _latch()
+                deferred = dict(table=table, tlen=tlen, latch=latch, gen=latch.new_generation())
+                kw = dict(table_ptr=table.data_ptr(), table_len=tlen, latch=latch, gen=deferred["gen"])
             chain = _ASSIGN_WORKER.submit(lap_chain_f16, pinned.data_ptr(), shapes, kinds,
-                                          functools.partial(_wait_copy, dev_index, ev))
+                                          functools.partial(_wait_copy, dev_index, ev), **kw)
         return dict(plan=plan, spans=spans, chain=chain, ppf=list(preds_per_frame), resume=resume,
-                    features_reg=features_reg, features_cls=features_cls)
+                    features_reg=features_reg, features_cls=features_cls, deferred=deferred)
+
+    def _fused_regime(self, plan, ppf, resume):
+        """What _CafmChain needs of the clip and that is known before the assignments: gradients wanted, no state carried in, every
+        local frame non-empty with the same number of proposals, bias-free q / k / v projections."""
+        if not FUSED_CHAIN or not torch.is_grad_enabled() or resume is not False or not ppf or len(plan) != len(ppf):
+            return False
+        if ppf[0] == 0 or any(m != ppf[0] for m in ppf) or [k for (_, k, _) in plan] != ["self"] + ["prev"] * (len(ppf) - 1):
+            return False
+        attn = self.transformer_aware_cross_attention_layers[0].multihead_attn
+        return attn.q_reg.bias is None and attn.k_reg.bias is None and attn.v_reg.bias is None
 
     def _finish_fused(self, plan, slots, dev_idx, ppf, resume, features, features_edge, time_embedding, layer, solved):
         """The clamped training regime -- every local frame with the same number of proposals, no state carried in, gradients wanted --
-        as ONE autograd node (_CafmChain).  Returns None when the clip does not qualify (the per-op path below handles every case)."""
-        if not FUSED_CHAIN or not torch.is_grad_enabled() or resume is not False or not ppf or len(plan) != len(ppf):
+        as ONE autograd node (_CafmChain).  Returns None when the clip does not qualify (the per-op path below handles every case).
+        ``solved`` None: the deferred form -- ``slots`` / ``dev_idx`` describe the table the device receives once the chain is done."""
+        if not self._fused_regime(plan, ppf, resume) or not (features.requires_grad or features_edge.requires_grad):
             return None
-        n = ppf[0]
-        if n == 0 or any(m != n for m in ppf) or not (features.requires_grad or features_edge.requires_grad):
-            return None
-        if [k for (_, k, _) in plan] != ["self"] + ["prev"] * (len(ppf) - 1):
-            return None
-        L = len(ppf)
+        n, L = ppf[0], len(ppf)
         attn = layer.multihead_attn
-        if attn.q_reg.bias is not None or attn.k_reg.bias is not None or attn.v_reg.bias is not None:
-            return None
         self._clear_state()
-        self.last_hungarian = [np.asarray(col_raw) for (_, col_raw, _) in solved]
-        self.last_hungarian_rows = [np.asarray(row) for (row, _, _) in solved]
+        if solved is not None:
+            self.last_hungarian = [np.asarray(col_raw) for (_, col_raw, _) in solved]
+            self.last_hungarian_rows = [np.asarray(row) for (row, _, _) in solved]
         # offsets of c (assignment order; -1 for the first frame, which keeps its own order) and inv in the clip's index table
         sl = tuple((rec["c"][0] if "c" in rec else -1, rec["inv"][0]) for rec in slots)
         meta = (n, L, attn.num_heads, sl, layer.norm.eps, self.decoder_norm.eps)
@@ -589,7 +651,22 @@ class AwarePositionRegMatcher(nn.Module):
         layer = self.transformer_aware_cross_attention_layers[0]
         plan, spans, preds_per_frame, resume = prep["plan"], prep["spans"], prep["ppf"], prep["resume"]
         features_reg, features_cls = prep["features_reg"], prep["features_cls"]
+        self._pending = None
         self.last_hungarian, self.last_hungarian_rows = [], []
+        d = prep.get("deferred")
+        if d is not None and (features.requires_grad or features_edge.requires_grad):
+            # Deferred join: the stream waits for the worker (a host function parked on the latch), then copies the index table the
+            # worker wrote ([inv_0 | c_1 | inv_1 | ...], tscd_lap_chain_f16_table) -- the host goes on queueing.
+            n, L = preds_per_frame[0], len(preds_per_frame)
+            ops.call("tscd_stream_host_func", ops._stream(), LATCH_WAIT_CB, d["latch"].ticket(d["gen"]))
+            dev_idx = torch.empty((d["tlen"],), dtype=torch.int64, device=dev)
+            dev_idx.copy_(d["table"][:d["tlen"]], non_blocking=True)
+            slots = [{"inv": (0, n)}] + [{"c": ((2 * j - 1) * n, n), "inv": (2 * j * n, n)} for j in range(1, L)]
+            fused = self._finish_fused(plan, slots, dev_idx, preds_per_frame, resume, features, features_edge, time_embedding, layer, None)
+            self._pending = prep["chain"]
+            if fused is not None:
+                return fused
+            self._pending = None       # cannot happen (same predicate as prepare); fall through to the joined path
         solved = prep["chain"].result() if prep["chain"] is not None else []
 
         # every index table of the clip (column orders, unmatched / surviving rows, inverse permutations) goes to the device
