@@ -248,6 +248,13 @@ int tscd_cos_attn_mfma_f16(const void* q, const void* k, const void* v, int C, i
 int tscd_cos_attn_mfma_bwd_f16(const void* q, const void* k, const void* v, const void* dO, const void* out, const float* lsum,
                                int n, int nk, int C, int heads, const int* tiles, int ntiles, void* workspace,
                                long workspace_bytes, void* dq, void* stream);
+/* Two-launch backward for segment lists with disjoint KEY ranges (CAFM's and TaskAligned's per-frame attention,
+ * tscd_matching.py:140-181): a query-stationary launch writes dq and delta = dO.O (delta_ws: n*heads floats), a key-stationary
+ * launch -- one wave per (32-key tile, head), ktiles = (key row0, nkeys <= 32, query0, query1) -- writes dk and dv in their final
+ * fp16 form: no atomics, no fp32 accumulators, no finish pass.  Key rows outside every ktile are not written. */
+int tscd_cos_attn_mfma_bwd2_f16(const void* q, const void* k, const void* v, const void* dO, const void* out, const float* lsum,
+                                int n, int nk, int C, int heads, const int* tiles, int ntiles, const int* ktiles, int nktiles,
+                                float* delta_ws, void* dq, void* dk, void* dv, void* stream);
 int tscd_se_fuse_bwd_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
                          const void* dout, long n, int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2,
                          void* stream);

@@ -643,6 +643,48 @@ def test_cafm_fused_chain_equals_the_per_op_path_and_the_oracle_autograd(W, n, L
         assert gr is not None and cos(v, gr) > 0.99, (k, cos(v, gr))
 
 
+@pytest.mark.parametrize("C,heads,segs,nq,nk", [(1024, 8, [(0, 500, 0, 500), (500, 500, 500, 1000), (1000, 500, 1000, 1500)], 1500, 1500),
+                                                (256, 8, [(0, 70, 10, 131), (70, 45, 140, 173)], 120, 180),
+                                                (320, 8, [(0, 33, 0, 90)], 33, 90)])
+def test_cos_attention_key_stationary_backward_equals_the_atomic_one(C, heads, segs, nq, nk):
+    """The two-launch backward of the cosine attention (query-stationary dq + delta, key-stationary dk / dv in registers) against
+    the one-launch kernel that sums dk / dv over query tiles with fp32 atomics: same dq bit for bit (same code path), dk / dv equal
+    up to the fp16 rounding of the final store vs. fp32 atomics then rounding; key rows no segment attends to get zero gradients;
+    segments that share key rows fall back to the atomic kernel."""
+    from yolox.models import tscd_matching as M
+    from tscd_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + nq)
+    q, k, v, go = (torch.randn(n_, C, generator=g).half().to(dev) for n_ in (nq, nk, nk, nq))
+
+    def run(flag):
+        M.KEY_STATIONARY_BWD = flag
+        qd, kd, vd = (t.clone().requires_grad_() for t in (q, k, v))
+        out = M.cos_attention(qd, kd, vd, heads, segs)
+        out.backward(go)
+        torch.cuda.synchronize()
+        return out.detach(), qd.grad, kd.grad, vd.grad
+
+    try:
+        o1, dq1, dk1, dv1 = run(True)
+        o0, dq0, dk0, dv0 = run(False)
+    finally:
+        M.KEY_STATIONARY_BWD = True
+    assert ops.attn_key_tiles(segs, dev) is not None
+    assert torch.equal(o0, o1) and torch.equal(dq0, dq1)
+    for a, b in ((dk0, dk1), (dv0, dv1)):
+        assert torch.isfinite(b.float()).all()
+        assert torch.allclose(a.float(), b.float(), rtol=4e-3, atol=4e-3 * float(a.float().abs().max())), float((a.float() - b.float()).abs().max())
+        assert _cos(a, b) > 0.99999
+    covered = torch.zeros(nk, dtype=torch.bool)
+    for (_, n_, k0, k1) in segs:
+        covered[k0:k1] = True
+    if (~covered).any():
+        assert float(dk1[~covered.to(dev)].abs().max()) == 0 and float(dv1[~covered.to(dev)].abs().max()) == 0
+    # two segments attending to the same keys: no key-stationary tiling
+    assert ops.attn_key_tiles([(0, 10, 0, 50), (10, 10, 25, 60)], dev) is None
+
+
 def test_cafm_deferred_join_of_the_assignment_chain_is_the_joined_result():
     """The clamped training regime parks the stream on the worker's latch (hipLaunchHostFunc) and queues CAFM and its backward before
     the assignments exist on the host (TSCD_DEFER_ASSIGNMENTS, tscd_lap_chain_f16_table).  Same clip with the chain joined on the host

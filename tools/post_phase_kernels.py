@@ -5,7 +5,7 @@ assignment chain (CAFM + TaskAligned forward, refined-head losses, backward, opt
 A step is cut at its optimizer launch (sgd_ema); inside a step the post phase starts at the first forward se_fuse launch (the first
 kernel of CAFM, queued by matcher.finish once the chain has been joined) -- under the profiler the device is slower than the host's
 chain, so the idle span in front of it is not a usable marker.  Medians over the last `steps` steps.
-Usage: post_phase_kernels.py <kernel_trace.csv> [steps=40]"""
+Usage: post_phase_kernels.py <kernel_trace.csv> [steps=40] [--seq]   (--seq: also the launch sequence of the last step, with queue ids)"""
 import csv
 import re
 import statistics as st
@@ -13,10 +13,12 @@ import sys
 from collections import defaultdict
 
 rows = []
-for r in csv.DictReader(open(sys.argv[1])):
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+SEQ = "--seq" in sys.argv
+argv = [a for a in sys.argv if a != "--seq"]
+for r in csv.DictReader(open(argv[1])):
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
 rows.sort()
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+steps = int(argv[2]) if len(argv) > 2 else 40
 cuts = [i for i, r in enumerate(rows) if re.search(r"sgd_ema", r[2])]
 if len(cuts) < steps + 2:
     sys.exit(f"only {len(cuts)} optimizer launches in the trace")
@@ -36,12 +38,12 @@ for a, b in zip(cuts[:-1], cuts[1:]):
     at = next((i for i, r in enumerate(seg) if re.search(r"se_fuse_kernel", r[2])), None)
     if at is None:
         continue
-    best = seg[at][0] - max(e for _, e, _ in seg[:at])
+    best = seg[at][0] - max(r[1] for r in seg[:at])
     post = seg[at:]
-    t0, t1 = post[0][0], max(e for _, e, _ in post)
+    t0, t1 = post[0][0], max(r[1] for r in post)
     # busy time of the post phase = union of its launch intervals
     u, cur_s, cur_e = 0, post[0][0], post[0][1]
-    for s, e, _ in post[1:]:
+    for s, e, *_ in post[1:]:
         if s > cur_e:
             u += cur_e - cur_s
             cur_s, cur_e = s, e
@@ -52,9 +54,10 @@ for a, b in zip(cuts[:-1], cuts[1:]):
     busy.append(u / 1e6)
     gap_len.append(best / 1e6)
     pre_span.append((seg[at - 1][1] - seg[0][0]) / 1e6 if at else 0.0)
-    win_busy.append(sum(e - s for s, e, _ in seg[:at]) / 1e6)
+    win_busy.append(sum(r[1] - r[0] for r in seg[:at]) / 1e6)
     nlaunch.append(len(post))
-    for s, e, n in post:
+    last_post = post
+    for s, e, n, _q in post:
         p = per_name[short(n)]
         p[0] += 1
         p[1] += (e - s) / 1e3
@@ -70,3 +73,9 @@ for name, (c, us) in sorted(per_name.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"  {c / n:6.1f} {us / c:8.1f} {us / n / 1e3:7.3f}  {name}")
     tot += us
 print(f"  sum of all post-phase kernel durations {sum(v[1] for v in per_name.values()) / n / 1e3:.3f} ms/step")
+if SEQ:
+    print("launch sequence of the last step's post phase (us from its start, duration us, queue, kernel):")
+    qs = {}
+    for s, e, n, q in last_post:
+        qs.setdefault(q, len(qs))
+        print(f"  {(s - last_post[0][0]) / 1e3:9.1f} {(e - s) / 1e3:7.1f}  q{qs[q]}  {short(n)[:70]}")

@@ -49,6 +49,7 @@ SIGNATURES = {
     "tscd_cos_attn_bwd_finish_f16": [P, P, I, I, I, P, P, P],
     "tscd_cos_attn_mfma_f16": [P, P, P, I, I, P, I, P, P, P],
     "tscd_cos_attn_mfma_bwd_f16": [P, P, P, P, P, P, I, I, I, I, P, I, P, L, P, P],
+    "tscd_cos_attn_mfma_bwd2_f16": [P, P, P, P, P, P, I, I, I, I, P, I, P, I, P, P, P, P, P],
     "tscd_se_fuse_bwd_f16": [P, I, P, I, P, P, P, L, I, P, P, P, P, P, P],
     "tscd_add_layernorm_bwd_f16": [P, P, P, P, I, I, F, P, P, P, P],
     "tscd_row_normalize_f16": [P, I, I, I, I, F, P, I, P],

@@ -143,16 +143,18 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_kernel(const f16* __restrict
   }
 }
 
-// workspace: 2 * nk * C floats (dk^ and dv accumulators, zeroed here); dq written directly
-template <int KS>
+// KV = true: the one-launch form -- dq written directly, dk^ / dv summed over query tiles by fp32 atomics into the workspace
+// (2 * nk * C floats, zeroed by the caller).  KV = false: dq only, and delta = dO.O per (query, head) to `delta_out` for the
+// key-stationary kernel below (dkn doubles as delta_out).
+template <int KS, bool KV>
 __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                               const f16* __restrict__ v, const f16* __restrict__ dO,
                                                               const f16* __restrict__ o, const float* __restrict__ lsum, int C,
                                                               int heads, const AttnTile* __restrict__ tiles, f16* __restrict__ dq,
                                                               float* __restrict__ dkn, float* __restrict__ dvacc) {
   constexpr int D = 16 * KS, MT = (KS + 1) / 2, P = tile_pitch(MT * 32), TP = 32;
-  __shared__ __attribute__((aligned(16))) f16 qt[32 * P], gt[32 * P], kt[32 * P];
-  __shared__ __attribute__((aligned(16))) f16 ts[32 * TP], tp[32 * TP];    // dS and P, [query][key]
+  __shared__ __attribute__((aligned(16))) f16 qt[32 * P], gt[KV ? 32 * P : 8], kt[32 * P];
+  __shared__ __attribute__((aligned(16))) f16 ts[KV ? 32 * TP : 8], tp[KV ? 32 * TP : 8];    // dS and P, [query][key]
   const int lane = threadIdx.x, col = lane & 31, half = lane >> 5, blk = (lane >> 4) & 1;
   const AttnTile t = tiles[blockIdx.x / heads];
   const int h = blockIdx.x % heads;
@@ -174,13 +176,18 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __rest
   delta += __shfl_xor(delta, 32, 64);
   const float l = qok ? lsum[qrow * heads + h] : 0.f;
   const float il = l > 0.f ? 1.0f / l : 0.f;
+  if (!KV && qok && half == 0) dkn[qrow * heads + h] = delta;
   // LDS copies of q^ and dO ([query][d], zero pad columns) for the transposed operands of dK^ / dV
-  for (int i = lane; i < 32 * P; i += 64) { qt[i] = (f16)0.f; gt[i] = (f16)0.f; kt[i] = (f16)0.f; }
+  for (int i = lane; i < 32 * P; i += 64) {
+    qt[i] = (f16)0.f;
+    kt[i] = (f16)0.f;
+    if (KV) gt[i] = (f16)0.f;
+  }
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     *(f16x8*)(qt + col * P + 16 * s + 8 * half) = qf[s];
-    *(f16x8*)(gt + col * P + 16 * s + 8 * half) = gf[s];
+    if (KV) *(f16x8*)(gt + col * P + 16 * s + 8 * half) = gf[s];
   }
 
   f32x16 dqacc[MT];
@@ -224,8 +231,10 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __rest
         p4[j] = (f16)pn;
         sb[e >> 3][e & 7] = (f16)ds;
       }
-      *(f16x4*)(ts + col * TP + 8 * g + 4 * half) = s4;     // [query = this lane's column][4 consecutive keys]
-      *(f16x4*)(tp + col * TP + 8 * g + 4 * half) = p4;
+      if (KV) {
+        *(f16x4*)(ts + col * TP + 8 * g + 4 * half) = s4;     // [query = this lane's column][4 consecutive keys]
+        *(f16x4*)(tp + col * TP + 8 * g + 4 * half) = p4;
+      }
     }
     __syncthreads();
     // dQ^^T[d][query] += K^^T dS^T (keys permuted like the forward's V^T P^T)
@@ -238,6 +247,7 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __rest
       }
     // dK^[key][d] = sum_q dS[q][key] q^[q][d],  dV[key][d] = sum_q P[q][key] dO[q][d]: both operands transposed from LDS,
     // k-step s2 <-> queries 16 s2 + 8 half + 0..7
+    if (KV)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       f32x16 akk, avv;
@@ -294,6 +304,130 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __rest
   }
 }
 
+// Key-stationary half of the two-launch backward: one wave = one (32-key tile, head) task looping over the query tiles that attend
+// to it, so dK^ and dV accumulate in registers (no atomics, no fp32 workspace, no finish pass) and k's normalisation gradient is a
+// per-lane scalar like q's above.  The products mirror the query-stationary kernel with the roles of the two sides exchanged:
+//   S   [query x key] = Q^  K^^T     A = q^ rows of the tile, B = k^ rows (registers, loaded once)
+//   dP  [query x key] = dO  V^T
+//   dK^^T [d x key]  += Q^^T dS,  dV^T [d x key] += dO^T P     A by transposing reads of the q^ / dO tiles, B = dS / P straight
+//                                                              from the accumulators (query order permuted alike on both)
+// 1/l and delta = dO.O vary along the accumulator's rows here: the tile's 32 values are staged in LDS.
+// ktiles: (key row0, nkeys <= 32, query0, query1).  delta: [n][heads] fp32 written by cos_attn_mfma_bwd_kernel<KS, false>.
+template <int KS>
+__global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kv_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                                 const f16* __restrict__ v, const f16* __restrict__ dO,
+                                                                 const float* __restrict__ lsum, const float* __restrict__ delta,
+                                                                 int C, int heads, const AttnTile* __restrict__ ktiles,
+                                                                 f16* __restrict__ dk, f16* __restrict__ dv) {
+  constexpr int D = 16 * KS, MT = (KS + 1) / 2, P = tile_pitch(MT * 32);
+  __shared__ __attribute__((aligned(16))) f16 qt[32 * P], gt[32 * P], kt[32 * P];
+  __shared__ float ils[32], dls[32];
+  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5, blk = (lane >> 4) & 1;
+  const AttnTile t = ktiles[blockIdx.x / heads];
+  const int h = blockIdx.x % heads;
+  const bool kok = col < t.nrows;
+  const long krow = t.row0 + (kok ? col : 0);
+
+  f16x8 kf[KS], vf[KS];
+  const float kinv = load_row<KS>(k + krow * C + h * D, kok, half, kf);
+  scale_row<KS>(kf, kinv);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    vf[s] = kok ? *(const f16x8*)(v + krow * C + h * D + 16 * s + 8 * half) : z;
+  }
+  for (int i = lane; i < 32 * P; i += 64) { qt[i] = (f16)0.f; gt[i] = (f16)0.f; kt[i] = (f16)0.f; }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < KS; ++s) *(f16x8*)(kt + col * P + 16 * s + 8 * half) = kf[s];
+
+  f32x16 dkacc[MT], dvacc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dkacc[m][e] = dvacc[m][e] = 0.f;
+
+  for (int qb = t.key0; qb < t.key1; qb += 32) {
+    const bool qok = qb + col < t.key1;
+    const long qrow = qb + (qok ? col : 0);
+    f16x8 qf[KS], gf[KS];
+    scale_row<KS>(qf, load_row<KS>(q + qrow * C + h * D, qok, half, qf));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      gf[s] = qok ? *(const f16x8*)(dO + qrow * C + h * D + 16 * s + 8 * half) : z;
+    }
+    const float l = qok ? lsum[qrow * heads + h] : 0.f;
+    const float dl = qok ? delta[qrow * heads + h] : 0.f;
+    __syncthreads();   // single-wave workgroup: the previous tile's transposing reads are done
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      *(f16x8*)(qt + col * P + 16 * s + 8 * half) = qf[s];
+      *(f16x8*)(gt + col * P + 16 * s + 8 * half) = gf[s];
+    }
+    if (half == 0) {
+      ils[col] = l > 0.f ? 1.0f / l : 0.f;
+      dls[col] = dl;
+    }
+    f32x16 st, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(qf[s], kf[s], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf[s], vf[s], dp, 0, 0, 0);
+    }
+    __syncthreads();
+    // accumulator register e <-> query (e&3) + 8 (e>>2) + 4 half of the tile, this lane's key
+    f16x8 sb[2], pb[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ql = (e & 3) + 8 * (e >> 2) + 4 * half;
+      const float pn = (kok && qb + ql < t.key1) ? __expf(st[e] - 1.0f) * ils[ql] : 0.f;
+      sb[e >> 3][e & 7] = (f16)(pn * (dp[e] - dls[ql]));
+      pb[e >> 3][e & 7] = (f16)pn;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 aq = tr_pair<8>(qt + (16 * s2 + 4 * half) * P + m * 32 + 16 * blk, P, lane);
+        f16x8 ag = tr_pair<8>(gt + (16 * s2 + 4 * half) * P + m * 32 + 16 * blk, P, lane);
+        dkacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, sb[s2], dkacc[m], 0, 0, 0);
+        dvacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ag, pb[s2], dvacc[m], 0, 0, 0);
+      }
+  }
+  // k normalisation backward, per lane: dk = (dk^ - k^ (k^.dk^)) / ||k||; this lane's d set is m*32 + 8 g + 4 half + j
+  float dot = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f16x4 k4 = *(const f16x4*)(kt + col * P + m * 32 + 8 * g + 4 * half);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dot += dkacc[m][4 * g + j] * (float)k4[j];
+    }
+  dot += __shfl_xor(dot, 32, 64);
+  if (kok) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = m * 32 + 8 * g + 4 * half;
+        if (d0 < D) {
+          f16x4 k4 = *(const f16x4*)(kt + col * P + d0), rk, rv;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            rk[j] = (f16)((dkacc[m][4 * g + j] - (float)k4[j] * dot) * kinv);
+            rv[j] = (f16)dvacc[m][4 * g + j];
+          }
+          *(f16x4*)(dk + krow * C + h * D + d0) = rk;
+          *(f16x4*)(dv + krow * C + h * D + d0) = rv;
+        }
+      }
+  }
+}
+
 extern "C" int tscd_cos_attn_mfma_supported(int head_dim) { return head_dim >= 16 && head_dim <= 160 && head_dim % 16 == 0; }
 
 // tiles: (row0, nrows <= 32, key0, key1).  lsum [n][heads] fp32: softmax denominators (sum_k exp(s-1)), kept for backward.
@@ -336,7 +470,7 @@ extern "C" int tscd_cos_attn_mfma_bwd_f16(const void* q, const void* k, const vo
   dim3 grid(ntiles * heads), block(64);
 #define CAB(KSV)                                                                                                               \
   case KSV:                                                                                                                     \
-    hipLaunchKernelGGL((cos_attn_mfma_bwd_kernel<KSV>), grid, block, 0, st, (const f16*)q, (const f16*)k, (const f16*)v,         \
+    hipLaunchKernelGGL((cos_attn_mfma_bwd_kernel<KSV, true>), grid, block, 0, st, (const f16*)q, (const f16*)k, (const f16*)v,   \
                        (const f16*)dO, (const f16*)out, lsum, C, heads, (const AttnTile*)tiles, (f16*)dq, dkn, dva);             \
     break
   switch (D / 16) {
@@ -344,5 +478,37 @@ extern "C" int tscd_cos_attn_mfma_bwd_f16(const void* q, const void* k, const vo
   }
 #undef CAB
   TSCD_CHECK_LAUNCH("cos_attn_mfma_bwd");
+  return TSCD_OK;
+}
+
+// The two-launch backward for segment lists whose KEY ranges are disjoint (every key row belongs to at most one segment: CAFM's and
+// TaskAligned's per-frame attention): a query-stationary launch writes dq and delta = dO.O, a key-stationary launch writes dk and
+// dv (fp16, final) -- no atomics, no fp32 accumulators, no finish pass.  ktiles: (key row0, nkeys <= 32, query0, query1), the
+// queries that attend to that key tile; delta_ws: n * heads floats.  Key rows outside every ktile are not written.
+extern "C" int tscd_cos_attn_mfma_bwd2_f16(const void* q, const void* k, const void* v, const void* dO, const void* out,
+                                           const float* lsum, int n, int nk, int C, int heads, const int* tiles, int ntiles,
+                                           const int* ktiles, int nktiles, float* delta_ws, void* dq, void* dk, void* dv,
+                                           void* stream) {
+  TSCD_CHECK_ARG(q && k && v && dO && out && lsum && tiles && ktiles && delta_ws && dq && dk && dv && heads > 0 && C % heads == 0,
+                 "cos_attn_mfma_bwd2: bad args");
+  const int D = C / heads;
+  TSCD_CHECK_ARG(tscd_cos_attn_mfma_supported(D) && C % 8 == 0, "cos_attn_mfma_bwd2: head dim %d not supported", D);
+  (void)n; (void)nk;
+  hipStream_t st = (hipStream_t)stream;
+  if (ntiles == 0 || nktiles == 0) return TSCD_OK;
+#define CAB2(KSV)                                                                                                                \
+  case KSV:                                                                                                                      \
+    hipLaunchKernelGGL((cos_attn_mfma_bwd_kernel<KSV, false>), dim3(ntiles * heads), dim3(64), 0, st, (const f16*)q, (const f16*)k, \
+                       (const f16*)v, (const f16*)dO, (const f16*)out, lsum, C, heads, (const AttnTile*)tiles, (f16*)dq, delta_ws,  \
+                       (float*)nullptr);                                                                                         \
+    hipLaunchKernelGGL((cos_attn_mfma_bwd_kv_kernel<KSV>), dim3(nktiles * heads), dim3(64), 0, st, (const f16*)q, (const f16*)k,  \
+                       (const f16*)v, (const f16*)dO, lsum, (const float*)delta_ws, C, heads, (const AttnTile*)ktiles, (f16*)dk,  \
+                       (f16*)dv);                                                                                                \
+    break
+  switch (D / 16) {
+    CAB2(1); CAB2(2); CAB2(3); CAB2(4); CAB2(5); CAB2(6); CAB2(7); CAB2(8); CAB2(9); CAB2(10);
+  }
+#undef CAB2
+  TSCD_CHECK_LAUNCH("cos_attn_mfma_bwd2");
   return TSCD_OK;
 }

@@ -863,6 +863,19 @@ def _attn_tiles(segments, device, rows):
     return h2d(t, torch.int32, device).reshape(-1, 4)
 
 
+def attn_key_tiles(segments, device):
+    """The same segments seen from the keys: 32-key tiles (key row0, nkeys, query0, query1) for the key-stationary backward, or None
+    when two segments share key rows (their contributions would have to be summed across tiles: the one-launch backward does that)."""
+    key = (tuple(segments), str(device), "keys")
+    if key in _TILE_CACHE:
+        return _TILE_CACHE[key]
+    spans = sorted((k0, k1) for (_, n, k0, k1) in segments if n > 0 and k1 > k0)
+    disjoint = all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+    t = _attn_tiles([(k0, k1 - k0, r0, r0 + n) for (r0, n, k0, k1) in segments if n > 0 and k1 > k0], device, 32) if disjoint and spans else None
+    _TILE_CACHE[key] = t
+    return t
+
+
 def cos_attn_uses_mfma(C, heads):
     return C % heads == 0 and bool(lib.tscd_cos_attn_mfma_supported(C // heads))
 
@@ -884,21 +897,30 @@ def cos_attn_mfma(q, k, v, heads, tiles32, full=False, out=None):
     return out, lsum
 
 
-def cos_attn_mfma_bwd(q, k, v, d_out, out, lsum, heads, tiles32, full=False, outs=None):
-    """``outs``: (dq [n,C], dk [nk,C], dv [nk,C]) contiguous fp16 destinations (with ``full``)."""
+def cos_attn_mfma_bwd(q, k, v, d_out, out, lsum, heads, tiles32, full=False, outs=None, ktiles32=None, keys_full=False):
+    """``outs``: (dq [n,C], dk [nk,C], dv [nk,C]) contiguous fp16 destinations (with ``full``).  ``ktiles32`` (attn_key_tiles): the
+    two-launch backward without atomics; ``keys_full``: those tiles cover every key row (dk / dv need no zero fill)."""
     n, C = q.shape
     nk = k.shape[0]
     dev = q.device
     for t in (q, k, v, d_out, out):
         assert t.is_contiguous() and t.dtype == torch.float16 and t.shape[1] == C
-    ws = torch.empty((2 * nk * C,), dtype=torch.float32, device=dev)
     if outs is not None:
         dq, dk, dv = outs
         assert full and all(t.is_contiguous() and t.dtype == torch.float16 for t in outs) and tuple(dq.shape) == (n, C) \
             and tuple(dk.shape) == (nk, C) and tuple(dv.shape) == (nk, C)
+        assert ktiles32 is None or keys_full
     else:
         dq = (torch.empty if full else torch.zeros)((n, C), dtype=torch.float16, device=dev)
-        dk, dv = (torch.empty((nk, C), dtype=torch.float16, device=dev) for _ in range(2))
+        kalloc = torch.zeros if (ktiles32 is not None and not keys_full) else torch.empty
+        dk, dv = (kalloc((nk, C), dtype=torch.float16, device=dev) for _ in range(2))
+    if ktiles32 is not None:
+        delta = torch.empty((n * heads,), dtype=torch.float32, device=dev)
+        call("tscd_cos_attn_mfma_bwd2_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), d_out.data_ptr(), out.data_ptr(), lsum.data_ptr(),
+             n, nk, C, heads, tiles32.data_ptr(), tiles32.shape[0], ktiles32.data_ptr(), ktiles32.shape[0], delta.data_ptr(),
+             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _stream())
+        return dq, dk, dv
+    ws = torch.empty((2 * nk * C,), dtype=torch.float32, device=dev)
     call("tscd_cos_attn_mfma_bwd_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), d_out.data_ptr(), out.data_ptr(), lsum.data_ptr(),
          n, nk, C, heads, tiles32.data_ptr(), tiles32.shape[0], ws.data_ptr(), ws.numel() * 4, dq.data_ptr(), _stream())
     call("tscd_cos_attn_bwd_finish_f16", k.data_ptr(), ws.data_ptr(), nk, C, heads, dk.data_ptr(), dv.data_ptr(), _stream())

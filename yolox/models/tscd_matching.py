@@ -22,6 +22,7 @@ from tscd_amd import ops
 from tscd_amd._host import KIND_PREV, KIND_SELF, KIND_STATE, LATCH_WAIT_CB, Latch, lap_chain_f16, lap_f16
 
 
+KEY_STATIONARY_BWD = __import__("os").environ.get("TSCD_ATTN_KEY_STATIONARY_BWD", "1") != "0"   # cosine attention backward: two launches, no atomics
 FUSED_CHAIN = __import__("os").environ.get("TSCD_FUSED_CAFM", "1") != "0"     # _CafmChain: the clamped training regime as one autograd node
 
 
@@ -110,18 +111,19 @@ class _CosAttentionMFMA(torch.autograd.Function):
     """Matrix-core path (attn_mfma.hip): the forward also returns the softmax denominators the backward re-uses."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, tiles32, full):
+    def forward(ctx, q, k, v, heads, tiles32, full, ktiles32=None, keys_full=False):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         out, lsum = ops.cos_attn_mfma(q, k, v, heads, tiles32, full)
         ctx.save_for_backward(q, k, v, tiles32, out, lsum)
-        ctx.heads, ctx.full = heads, full
+        ctx.heads, ctx.full, ctx.ktiles, ctx.keys_full = heads, full, ktiles32, keys_full
         return out
 
     @staticmethod
     def backward(ctx, g):
         q, k, v, tiles32, out, lsum = ctx.saved_tensors
-        dq, dk, dv = ops.cos_attn_mfma_bwd(q, k, v, g.to(torch.float16).contiguous(), out, lsum, ctx.heads, tiles32, ctx.full)
-        return dq, dk, dv, None, None, None
+        dq, dk, dv = ops.cos_attn_mfma_bwd(q, k, v, g.to(torch.float16).contiguous(), out, lsum, ctx.heads, tiles32, ctx.full,
+                                           ktiles32=ctx.ktiles, keys_full=ctx.keys_full)
+        return dq, dk, dv, None, None, None, None, None
 
 
 def cos_attention(q, k, v, heads, segments):
@@ -131,7 +133,10 @@ def cos_attention(q, k, v, heads, segments):
         tiles = ops.attn_tiles(segments, q.device, rows=32)
         full = sum(seg[1] for seg in segments) == q.shape[0]      # every query row is in some tile: outputs need no zero fill
         if grad:
-            return _CosAttentionMFMA.apply(q, k, v, heads, tiles, full)
+            # key-stationary backward (no atomics) when no key row is shared between segments
+            ktiles = ops.attn_key_tiles(segments, q.device) if KEY_STATIONARY_BWD else None
+            keys_full = ktiles is not None and sum(seg[3] - seg[2] for seg in segments if seg[1] > 0) == k.shape[0]
+            return _CosAttentionMFMA.apply(q, k, v, heads, tiles, full, ktiles, keys_full)
         return ops.cos_attn_mfma(q.contiguous(), k.contiguous(), v.contiguous(), heads, tiles, full)[0]
     tiles = ops.attn_tiles(segments, q.device)
     if grad:
@@ -322,6 +327,7 @@ class _CafmChain(torch.autograd.Function):
         k_all, v_all = ops.linear(k_in, wk), ops.linear(feat, wv)
         mfma = ops.cos_attn_uses_mfma(W, heads)
         tiles = ops.attn_tiles([(0, n, 0, n)], dev, rows=32 if mfma else 16)
+        ctx.ktiles = ops.attn_key_tiles([(0, n, 0, n)], dev) if mfma and KEY_STATIONARY_BWD else None
         q_in = torch.empty((nl, W), dtype=torch.float16, device=dev)
         q_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
         t2_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
@@ -392,7 +398,7 @@ class _CafmChain(torch.autograd.Function):
             ln_acc.append(dg._base)
             if ctx.mfma:
                 ops.cos_attn_mfma_bwd(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], dx, t2_all[s0:s1], lsums[j], heads, tiles, True,
-                                      outs=(dq_all[s0:s1], dk_all[s0:s1], dv_all[s0:s1]))
+                                      outs=(dq_all[s0:s1], dk_all[s0:s1], dv_all[s0:s1]), ktiles32=ctx.ktiles, keys_full=True)
             else:
                 dq, dk, dv = ops.cos_attn_bwd(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], dx, heads, tiles)
                 dq_all[s0:s1].copy_(dq)
