@@ -185,6 +185,9 @@ int tscd_gather_rows(const void* const* maps, const int* hw3, const int* sel_idx
                      int N, int W, int map_ld, int nmaps, void* out0, void* out1, void* out2, int scatter, void* stream);
 int tscd_gather_det(const void* det, int A, int ndet, const int* sel_idx, int cap, const int* frame_off, int B, int N,
                     void* out, void* stream);
+/* The same, also returning every gathered row's (frame, anchor) as int32 vectors (both or neither may be NULL). */
+int tscd_gather_det_rows(const void* det, int A, int ndet, const int* sel_idx, int cap, const int* frame_off, int B, int N, void* out,
+                         int* row_b, int* row_a, void* stream);
 
 /* ---- MCA, the fused global-to-local cosine attention: Attention_mca_g2l.forward + find_similar_round2
  * (post_trans.py:581-714) over all local frames of MCA_tscd_g2l_reg.forward (post_trans.py:1127-1162).
@@ -310,6 +313,22 @@ int tscd_loss_combine_f32(const float* dense, const float* rows, const float* r_
  * device scalars (loss scale x weight / num_fg): the product is formed in fp32 and rounded once, as the reference's autograd does
  * (tscd_head.py:1157-1203). */
 int tscd_scale_grad_f16(const void* d, const float* g, int i0, int i1, int split, long rows, int C, int pad, void* out, void* stream);
+
+/* Class score of every selected proposal and its backward: out[r] = sigmoid(raw[row_b[r]][row_a[r]][5 + class(r)]), class(r) =
+ * pred_rows[r][cls_col] (the class id column of the proposal rows, tscd_head.py:1560-1600: pred_result[:, 5] with its gradient kept);
+ * the scatter clears d_raw [B][A][nch] and stores g * s * (1 - s) at the same positions (rows are distinct (frame, anchor) pairs).
+ * Rounding as torch's fp16 sigmoid / sigmoid_backward (fp32 inside, one rounding at the store). */
+int tscd_cls_score_gather_f16(const void* raw, int B, long A, int nch, const int* row_b, const int* row_a, const void* pred_rows,
+                              int ld_rows, int cls_col, long N, void* out, void* stream);
+int tscd_cls_score_scatter_f16(const void* g, const void* s, int B, long A, int nch, const int* row_b, const int* row_a,
+                               const void* pred_rows, int ld_rows, int cls_col, long N, void* d_raw, void* stream);
+/* Gradient of one pyramid level's raw prediction map ([B][HW][nch] fp16, a slice of the clip's [B][A][nch] gradient: batch stride in
+ * elements) split for the two trainable prediction convs (tscd_head.py:213-239): dY zero-padded to 8 (objectness) / ncp (classes,
+ * NC rounded up to 8) channels for the weight-gradient GEMM, and db[4], db[5..] = their bias gradients (column sums, fixed-order
+ * two-stage reduction). */
+long tscd_pred_grad_split_workspace_bytes(long M, int nch);
+int tscd_pred_grad_split_f16(const void* d_raw, long batch_stride, int B, long HW, int nch, int ncp, void* dy_obj, void* dy_cls, float* db,
+                             void* workspace, long workspace_bytes, void* stream);
 
 /* ---- SimOTA label assignment: get_fg_idx / get_assignments / get_in_boxes_info / dynamic_k_matching
  * (tscd_head.py:1712-1851,1330-1544), bboxes_iou (yolox/utils/boxes.py:131-154). */

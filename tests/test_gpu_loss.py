@@ -179,3 +179,69 @@ def test_loss_backward_forms_the_product_in_fp32_at_the_initial_loss_scale():
         assert torch.isfinite(got[(d.float() * s).abs().reshape(got.shape) < 65504]).all() and got.abs().max() > 0
     assert torch.isfinite(cd.grad).all() and torch.isfinite(od.grad).all() and torch.isfinite(gd.grad).float().mean() > 0.3
     assert torch.isfinite(rd.grad).all() and torch.all(rd.grad[..., :4] == 0) and rd.grad[..., 4:].abs().max() > 0
+
+
+@pytest.mark.parametrize("B,A,NC,N", [(4, 6804, 25, 1500), (2, 336, 30, 0), (3, 500, 1, 77)])
+def test_class_score_gather_and_its_scatter_backward_equal_torch_indexing(B, A, NC, N):
+    """TF.cls_score (one gather forward, one scatter backward) against sigmoid(raw[b, a, 5 + class]) with torch's advanced
+    indexing and its autograd (the reference's pred_result[:, 5] path, tscd_head.py:1560-1600): same fp16 values forward; backward
+    the same non-zero entries of d raw (fp16, rounded once from the fp32 product like sigmoid_backward)."""
+    from tscd_amd import functional as TF
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + A + NC)
+    raw = (torch.randn(B, A, 5 + NC, generator=g) * 3).half().to(dev)
+    flat = torch.randperm(B * A, generator=g)[:N].sort().values                      # distinct (frame, anchor) pairs, frame-major
+    rb, ra = (flat // A).int().to(dev), (flat % A).int().to(dev)
+    rows = torch.zeros(N, 7 + NC).half()
+    rows[:, 6] = torch.randint(0, NC, (N,), generator=g).half()
+    rows = rows.to(dev)
+    up = torch.randn(N, generator=g).half().to(dev)
+    r1 = raw.clone().requires_grad_()
+    s1 = TF.cls_score(r1, rb, ra, rows)
+    (s1.float() * up.float()).sum().backward()
+    r0 = raw.clone().requires_grad_()
+    s0 = torch.sigmoid(r0[rb.long(), ra.long(), 5 + rows[:, 6].long()])
+    (s0.float() * up.float()).sum().backward()
+    torch.cuda.synchronize()
+    assert s1.shape == (N,) and torch.allclose(s1.float(), s0.float(), rtol=0, atol=1e-3)
+    assert r1.grad.shape == raw.shape
+    assert torch.equal(r1.grad != 0, r0.grad != 0)
+    assert torch.allclose(r1.grad.float(), r0.grad.float(), rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,h,w,W,NC", [(4, 18, 18, 256, 25), (2, 9, 7, 64, 30), (3, 12, 12, 128, 1)])
+def test_prediction_level_fused_backward_equals_the_per_conv_path(B, h, w, W, NC):
+    """TF.pred_level (one split of the level's raw-map gradient into zero-padded dY's + both bias gradients, weight gradients
+    beside the data-gradient chain) against the per-conv autograd path (cat -> slice gradients -> pad -> column sums -> GEMM) on
+    the same inputs, the level's map being a batch-strided slice of a clip-wide gradient as in the head: forward bit-identical,
+    weight gradients bit-identical (same GEMM on the same padded dY), bias gradients equal to fp32 summation order."""
+    from tscd_amd import functional as TF
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(h * 100 + NC)
+    feat = torch.randn(B, h, w, 2 * W, generator=g).half().to(dev)
+    reg_feat, cls_feat = feat[..., :W], feat[..., W:]
+    reg_o = torch.randn(B, h, w, 4, generator=g).half().to(dev)
+    mk = lambda co: torch.nn.Conv2d(W, co, 1).to(dev)
+    obj_a, cls_a = mk(1), mk(NC)
+    obj_b, cls_b = mk(1), mk(NC)
+    obj_b.load_state_dict(obj_a.state_dict()); cls_b.load_state_dict(cls_a.state_dict())
+    extra = 37                                                                 # other levels' anchors in the clip-wide map
+    up = torch.randn(B, h * w + extra, 5 + NC, generator=g).half().to(dev)
+
+    def run(obj, cls, fused):
+        if fused:
+            raw = TF.pred_level(reg_feat, cls_feat, reg_o, obj, cls)
+            assert type(raw.grad_fn).__name__.startswith("_PredLevel")
+        else:
+            raw = torch.cat([reg_o, TF.conv_bias(reg_feat, obj.weight, obj.bias), TF.conv_bias(cls_feat, cls.weight, cls.bias)], -1)
+        allmap = torch.cat([raw.reshape(B, -1, 5 + NC), torch.zeros(B, extra, 5 + NC, dtype=torch.float16, device=dev)], 1)
+        (allmap.float() * up.float()).sum().backward()
+        torch.cuda.synchronize()
+        return raw.detach(), [p.grad.clone() for p in (obj.weight, obj.bias, cls.weight, cls.bias)]
+
+    raw1, g1 = run(obj_a, cls_a, True)
+    raw0, g0 = run(obj_b, cls_b, False)
+    assert torch.equal(raw0, raw1)
+    assert torch.equal(g0[0], g1[0]) and torch.equal(g0[2], g1[2])
+    for a, b in ((g0[1], g1[1]), (g0[3], g1[3])):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(a.abs().max()) + 1e-6), (a, b)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "tscd_select_proposals": [P, I, I, F, I, I, I, P, P, P],
     "tscd_gather_rows": [P, P, P, I, P, I, I, I, I, I, P, P, P, I, P],
     "tscd_gather_det": [P, I, I, P, I, P, I, I, P, P],
+    "tscd_gather_det_rows": [P, I, I, P, I, P, I, I, P, P, P, P],
     "tscd_mca_forward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, L, P, P, P, P, P, P, I, P],
     "tscd_mca_backward": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, P, P, P, P, I, P, P, I, P, L, P, P, P, P, P, P],
     "tscd_mca_backward_fws": [P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, P, P, P, P, P, I, P, P, I, P, L, P, P, P, P, P, P, L, P],
@@ -65,10 +66,13 @@ SIGNATURES = {
     "tscd_loss_combine_f32": [P, P, P, P, P, I, I, P, P, P],
     "tscd_scale_grad_f16": [P, P, I, I, I, L, I, I, P, P],
     "tscd_stream_host_func": [P, P, P],
+    "tscd_cls_score_gather_f16": [P, I, L, I, P, P, P, I, I, L, P, P],
+    "tscd_cls_score_scatter_f16": [P, P, I, L, I, P, P, P, I, I, L, P, P],
+    "tscd_pred_grad_split_f16": [P, L, I, L, I, I, P, P, P, P, L, P],
     "tscd_loss_dense_reg_f16": [P, P, P, P, P, P, I, I, I, I, P, P, P, L, P, P, P, P],
     "tscd_loss_rows_f16": [P, P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, L, P, P, P, P, P],
 }
-PLAIN = {"tscd_ema_chunk_elems": ([], I), "tscd_pack_block_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
+PLAIN = {"tscd_pred_grad_split_workspace_bytes": ([L, I], L), "tscd_ema_chunk_elems": ([], I), "tscd_pack_block_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
          "tscd_bn_silu_bwd_workspace_bytes": ([L, I], L), "tscd_linear_bwd_workspace_bytes": ([I, I, I], L),
          "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L), "tscd_mca_rows_bytes": ([I, I, I], L),
          "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),

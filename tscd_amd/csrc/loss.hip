@@ -316,3 +316,133 @@ extern "C" int tscd_scale_grad_f16(const void* d, const float* g, int i0, int i1
   TSCD_CHECK_LAUNCH("scale_grad");
   return TSCD_OK;
 }
+
+// ---- class score of every selected proposal: sigmoid of its own class logit (tscd_head.py:1560-1600: pred_result[:, 5] with the
+// gradient the reference keeps through it) and the scatter that is its backward.  raw [B][A][nch] fp16 (nch = 5 + NC), one
+// proposal row r = (frame row_b[r], anchor row_a[r], class = pred_rows[r][cls_col] stored as a float16 class id).  Forward and
+// backward round where torch's sigmoid / sigmoid_backward on fp16 tensors round (fp32 inside, one rounding at the store).
+__global__ void cls_score_gather_kernel(const f16* __restrict__ raw, long A, int nch, const int* __restrict__ row_b,
+                                        const int* __restrict__ row_a, const f16* __restrict__ pred_rows, int ld_rows, int cls_col,
+                                        long N, f16* __restrict__ out) {
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < N; r += (long)gridDim.x * 256) {
+    const int c = (int)(float)pred_rows[r * ld_rows + cls_col];
+    const float x = (float)raw[((long)row_b[r] * A + row_a[r]) * nch + 5 + c];
+    out[r] = (f16)(1.0f / (1.0f + expf(-x)));
+  }
+}
+__global__ void cls_score_scatter_kernel(const f16* __restrict__ g, const f16* __restrict__ s, long A, int nch,
+                                         const int* __restrict__ row_b, const int* __restrict__ row_a,
+                                         const f16* __restrict__ pred_rows, int ld_rows, int cls_col, long N, f16* __restrict__ d_raw) {
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < N; r += (long)gridDim.x * 256) {
+    const int c = (int)(float)pred_rows[r * ld_rows + cls_col];
+    const float sv = (float)s[r];
+    d_raw[((long)row_b[r] * A + row_a[r]) * nch + 5 + c] = (f16)((float)g[r] * (1.0f - sv) * sv);
+  }
+}
+extern "C" int tscd_cls_score_gather_f16(const void* raw, int B, long A, int nch, const int* row_b, const int* row_a, const void* pred_rows,
+                                         int ld_rows, int cls_col, long N, void* out, void* stream) {
+  if (N == 0) return TSCD_OK;
+  TSCD_CHECK_ARG(raw && row_b && row_a && pred_rows && out && B > 0 && A > 0 && nch > 5 && cls_col >= 0 && cls_col < ld_rows,
+                 "cls_score_gather: bad arguments");
+  const int blocks = (int)((N + 255) / 256 < 1024 ? (N + 255) / 256 : 1024);
+  hipLaunchKernelGGL(cls_score_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)raw, A, nch, row_b, row_a,
+                     (const f16*)pred_rows, ld_rows, cls_col, N, (f16*)out);
+  TSCD_CHECK_LAUNCH("cls_score_gather");
+  return TSCD_OK;
+}
+// d_raw [B][A][nch] is cleared here, then receives g * s * (1 - s) at each proposal's (frame, anchor, class) -- the rows are distinct
+// (frame, anchor) pairs, so plain stores.
+extern "C" int tscd_cls_score_scatter_f16(const void* g, const void* s, int B, long A, int nch, const int* row_b, const int* row_a,
+                                          const void* pred_rows, int ld_rows, int cls_col, long N, void* d_raw, void* stream) {
+  TSCD_CHECK_ARG(d_raw && B > 0 && A > 0 && nch > 5, "cls_score_scatter: bad arguments");
+  (void)hipMemsetAsync(d_raw, 0, sizeof(f16) * B * A * nch, (hipStream_t)stream);
+  if (N == 0) return TSCD_OK;
+  TSCD_CHECK_ARG(g && s && row_b && row_a && pred_rows && cls_col >= 0 && cls_col < ld_rows, "cls_score_scatter: bad arguments");
+  const int blocks = (int)((N + 255) / 256 < 1024 ? (N + 255) / 256 : 1024);
+  hipLaunchKernelGGL(cls_score_scatter_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)g, (const f16*)s, A, nch,
+                     row_b, row_a, (const f16*)pred_rows, ld_rows, cls_col, N, (f16*)d_raw);
+  TSCD_CHECK_LAUNCH("cls_score_scatter");
+  return TSCD_OK;
+}
+
+// ---- gradient of one pyramid level's raw prediction map [B][HW][nch] (batch stride given: the level is a slice of the clip's
+// [B][A][nch] gradient) split into what the two trainable prediction convs need (tscd_head.py:213-239: obj_preds 1 channel,
+// cls_preds NC channels): dY zero-padded to 8 / ncp channels for the weight-gradient GEMM, and the bias gradients = column sums
+// over all pixels (fixed-order two-stage reduction: per-block partials, then one wave per column).  One pass over the slice instead
+// of a pad, a copy, a column sum and a contiguous copy per conv.
+template <int NV>
+__global__ __launch_bounds__(256) void pred_grad_split_kernel(const f16* __restrict__ d_raw, long batch_stride, long HW, long M, int nch,
+                                                             f16* __restrict__ dy_obj, f16* __restrict__ dy_cls,
+                                                             float* __restrict__ partial) {
+  constexpr int NCP = 8 * NV;
+  __shared__ float colacc[4][NCP + 1];
+  const int NC = nch - 5, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mo = 0.f, mc[NCP];                    // this thread's column sums (compile-time indices: registers)
+#pragma unroll
+  for (int c = 0; c < NCP; ++c) mc[c] = 0.f;
+  for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+    const long b = m / HW;
+    const f16* src = d_raw + b * batch_stride + (m - b * HW) * nch;
+    const f16 vo = src[4];
+    mo += (float)vo;
+    f16x8 o8 = {vo, 0, 0, 0, 0, 0, 0, 0};
+    *(f16x8*)(dy_obj + m * 8) = o8;
+#pragma unroll
+    for (int v8 = 0; v8 < NV; ++v8) {
+      f16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = 8 * v8 + j;
+        v[j] = c < NC ? src[5 + c] : (f16)0.f;
+        mc[c] += (float)v[j];
+      }
+      *(f16x8*)(dy_cls + m * NCP + 8 * v8) = v;
+    }
+  }
+  mo = wave_sum(mo);
+  if (lane == 0) colacc[wave][NCP] = mo;
+#pragma unroll
+  for (int c = 0; c < NCP; ++c) {
+    const float t = wave_sum(mc[c]);
+    if (lane == 0) colacc[wave][c] = t;
+  }
+  __syncthreads();
+  // partial row layout = the raw map's channels: [.. 4 = objectness, 5 + c = class c]
+  if (threadIdx.x < NC) partial[(long)blockIdx.x * nch + 5 + threadIdx.x] = colacc[0][threadIdx.x] + colacc[1][threadIdx.x] + colacc[2][threadIdx.x] + colacc[3][threadIdx.x];
+  if (threadIdx.x == 64) partial[(long)blockIdx.x * nch + 4] = colacc[0][NCP] + colacc[1][NCP] + colacc[2][NCP] + colacc[3][NCP];
+}
+__global__ void pred_grad_colsum_kernel(const float* __restrict__ partial, int nblocks, int nch, float* __restrict__ db) {
+  const int col = 4 + (threadIdx.x >> 6) + 4 * blockIdx.x, lane = threadIdx.x & 63;
+  if (col >= nch) return;
+  float s = 0.f;
+  for (int i = lane; i < nblocks; i += 64) s += partial[(long)i * nch + col];
+  s = wave_sum(s);
+  if (lane == 0) db[col] = s;
+}
+static int pred_grad_blocks(long M) {
+  long nb = (M + 255) / 256;
+  return (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb));
+}
+extern "C" long tscd_pred_grad_split_workspace_bytes(long M, int nch) { return (long)pred_grad_blocks(M) * nch * 4 + 256; }
+// d_raw: [B][HW][nch] fp16 with batch stride `batch_stride` elements (rows of a frame contiguous); dy_obj [B*HW][8], dy_cls
+// [B*HW][ncp] fp16 (ncp = NC rounded up to 8); db [nch] fp32: entries 4 (objectness) and 5.. (classes) are written.
+extern "C" int tscd_pred_grad_split_f16(const void* d_raw, long batch_stride, int B, long HW, int nch, int ncp, void* dy_obj, void* dy_cls,
+                                        float* db, void* workspace, long workspace_bytes, void* stream) {
+  TSCD_CHECK_ARG(d_raw && dy_obj && dy_cls && db && workspace && B > 0 && HW > 0 && nch > 5 && nch <= 40, "pred_grad_split: bad arguments");
+  TSCD_CHECK_ARG(ncp % 8 == 0 && ncp >= nch - 5 && ncp <= 40 && batch_stride >= HW * nch, "pred_grad_split: bad strides");
+  const long M = (long)B * HW;
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_pred_grad_split_workspace_bytes(M, nch), "pred_grad_split: workspace too small");
+  const int nb = pred_grad_blocks(M);
+#define PGS(NVV)                                                                                                               \
+  case NVV:                                                                                                                     \
+    hipLaunchKernelGGL((pred_grad_split_kernel<NVV>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f16*)d_raw, batch_stride, \
+                       HW, M, nch, (f16*)dy_obj, (f16*)dy_cls, (float*)workspace);                                              \
+    break
+  switch (ncp / 8) {
+    PGS(1); PGS(2); PGS(3); PGS(4); PGS(5);
+  }
+#undef PGS
+  hipLaunchKernelGGL(pred_grad_colsum_kernel, dim3((nch - 4 + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nb, nch, db);
+  TSCD_CHECK_LAUNCH("pred_grad_split");
+  return TSCD_OK;
+}

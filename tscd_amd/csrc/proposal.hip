@@ -277,7 +277,8 @@ extern "C" int tscd_gather_rows(const void* const* maps, const int* hw3, const i
 
 // Gather detection rows (pred_result) + per-proposal scores: det [B,A,ndet] -> out [N,ndet].
 __global__ void gather_det_kernel(const f16* __restrict__ det, int A, int ndet, const int* __restrict__ sel_idx, int cap,
-                                  const int* __restrict__ frame_off, int B, int N, f16* __restrict__ out) {
+                                  const int* __restrict__ frame_off, int B, int N, f16* __restrict__ out, int* __restrict__ row_b,
+                                  int* __restrict__ row_a) {
   long total = (long)N * ndet;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     int n = idx / ndet, c = idx % ndet;
@@ -285,16 +286,23 @@ __global__ void gather_det_kernel(const f16* __restrict__ det, int A, int ndet, 
     while (b + 1 < B && frame_off[b + 1] <= n) ++b;
     int a = sel_idx[(long)b * cap + (n - frame_off[b])];
     out[idx] = det[((long)b * A + a) * ndet + c];
+    if (c == 0 && row_b) { row_b[n] = b; row_a[n] = a; }
   }
 }
-extern "C" int tscd_gather_det(const void* det, int A, int ndet, const int* sel_idx, int cap, const int* frame_off, int B, int N,
-                               void* out, void* stream) {
-  TSCD_CHECK_ARG(det && sel_idx && frame_off && out, "gather_det: null pointer");
+// row_b / row_a (optional, both or neither): the (frame, anchor) of every gathered row -- what the reference rebuilds with
+// torch.where / cat over the per-frame index lists (tscd_head.py:1647-1651).
+extern "C" int tscd_gather_det_rows(const void* det, int A, int ndet, const int* sel_idx, int cap, const int* frame_off, int B, int N,
+                                    void* out, int* row_b, int* row_a, void* stream) {
+  TSCD_CHECK_ARG(det && sel_idx && frame_off && out && (!row_b == !row_a), "gather_det: null pointer");
   if (N == 0) return TSCD_OK;
   long total = (long)N * ndet;
   int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(gather_det_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, (hipStream_t)stream, (const f16*)det, A,
-                     ndet, sel_idx, cap, frame_off, B, N, (f16*)out);
+                     ndet, sel_idx, cap, frame_off, B, N, (f16*)out, row_b, row_a);
   TSCD_CHECK_LAUNCH("gather_det");
   return TSCD_OK;
+}
+extern "C" int tscd_gather_det(const void* det, int A, int ndet, const int* sel_idx, int cap, const int* frame_off, int B, int N,
+                               void* out, void* stream) {
+  return tscd_gather_det_rows(det, A, ndet, sel_idx, cap, frame_off, B, N, out, nullptr, nullptr, stream);
 }

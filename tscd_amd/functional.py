@@ -178,6 +178,72 @@ class _ConvBias(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _PredLevel(torch.autograd.Function):
+    """One pyramid level's raw prediction map cat([reg, obj, cls], -1) (tscd_head.py:213-239, 369-373) with the box branch given
+    (frozen reg_preds, computed by the prefetched prefix) and the objectness / class 1x1 convs trainable on features that need no
+    gradient: the backward splits the map's gradient once (ops.pred_grad_split: padded dY's + both bias gradients) and runs the two
+    weight-gradient GEMMs beside the data-gradient chain -- instead of slicing, padding, summing and copying per conv."""
+
+    @staticmethod
+    def forward(ctx, reg_feat, cls_feat, reg_o, w_obj, b_obj, w_cls, b_cls):
+        obj_o, _ = ops.conv2d(reg_feat, ops.WEIGHTS.get(w_obj), w_obj.shape[0], 1, 1, ops.EPI_BIAS, bias=ops.f32(b_obj))
+        cls_o, _ = ops.conv2d(cls_feat, ops.WEIGHTS.get(w_cls), w_cls.shape[0], 1, 1, ops.EPI_BIAS, bias=ops.f32(b_cls))
+        ctx.save_for_backward(reg_feat, cls_feat, w_obj, w_cls)
+        ctx.bias_dtype = b_obj.dtype
+        return torch.cat([reg_o, obj_o, cls_o], -1)
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        reg_feat, cls_feat, w_obj, w_cls = ctx.saved_tensors
+        nc = w_cls.shape[0]
+        d_raw = d_raw if d_raw.dtype == torch.float16 else d_raw.to(torch.float16)
+        B, h, w, nch = d_raw.shape
+        if not (d_raw.stride(3) == 1 and d_raw.stride(2) == nch and d_raw.stride(1) == w * nch):
+            d_raw = d_raw.contiguous()
+        dy_obj, dy_cls, db = ops.pred_grad_split(d_raw, nc)
+        with ops.param_grad_stream([w_obj], reg_feat, dy_obj):
+            dw_obj = ops.conv_wgrad(reg_feat, dy_obj, reg_feat.shape[-1], 8, 1)[:1].to(w_obj.dtype)
+        with ops.param_grad_stream([w_cls], cls_feat, dy_cls):
+            dw_cls = ops.conv_wgrad(cls_feat, dy_cls, cls_feat.shape[-1], dy_cls.shape[-1], 1)[:nc].to(w_cls.dtype)
+        bd = ctx.bias_dtype
+        return None, None, None, dw_obj, db[4:5].to(bd), dw_cls, db[5:5 + nc].to(bd)
+
+
+def pred_level(reg_feat, cls_feat, reg_o, obj_conv, cls_conv):
+    """raw [B,h,w,5+NC] = cat(reg_o, obj_conv(reg_feat), cls_conv(cls_feat)); the fused backward when only the two convs' parameters
+    need gradients, the per-conv path otherwise."""
+    ps = (obj_conv.weight, obj_conv.bias, cls_conv.weight, cls_conv.bias)
+    fused = (torch.is_grad_enabled() and all(p is not None and p.requires_grad for p in ps)
+             and not (reg_feat.requires_grad or cls_feat.requires_grad or reg_o.requires_grad)
+             and obj_conv.weight.shape[0] == 1 and obj_conv.weight.shape[-1] == 1 and cls_conv.weight.shape[-1] == 1 and cls_conv.weight.shape[0] <= 35)
+    if fused:
+        return _PredLevel.apply(reg_feat, cls_feat, reg_o, *ps)
+    return torch.cat([reg_o, conv_bias(reg_feat, obj_conv.weight, obj_conv.bias), conv_bias(cls_feat, cls_conv.weight, cls_conv.bias)], -1)
+
+
+class _ClsScore(torch.autograd.Function):
+    """sigmoid of every selected proposal's own class logit, gathered from the clip's raw map [B,A,5+NC] (== pred_rows[:, 5], with
+    the gradient the reference keeps through it, tscd_head.py:1560-1600): one gather forward, one scatter backward -- torch's
+    advanced-indexing backward sorts the indices first (two dozen small launches)."""
+
+    @staticmethod
+    def forward(ctx, raw_all, row_b, row_a, pred_rows):
+        s = ops.cls_score_gather(raw_all, row_b, row_a, pred_rows)
+        ctx.save_for_backward(s, row_b, row_a, pred_rows)
+        ctx.shape = tuple(raw_all.shape)
+        return s
+
+    @staticmethod
+    def backward(ctx, g):
+        s, row_b, row_a, pred_rows = ctx.saved_tensors
+        g = g if g.dtype == torch.float16 else g.to(torch.float16)
+        return ops.cls_score_scatter(g.contiguous(), s, ctx.shape, row_b, row_a, pred_rows), None, None, None
+
+
+def cls_score(raw_all, row_b, row_a, pred_rows):
+    return _ClsScore.apply(raw_all.contiguous(), row_b, row_a, pred_rows)
+
+
 def conv_bias(x, weight, bias, relu=False):
     if _needs_grad(x, weight, bias):
         return _ConvBias.apply(x, weight, bias, relu)

@@ -669,9 +669,15 @@ def scatter_rows(grads, grad_maps_per_feature, geo, sel_idx, frame_off, N, W):
          _stream())
 
 
-def gather_det(det, sel_idx, frame_off, N):
+def gather_det(det, sel_idx, frame_off, N, rows=False):
+    """-> pred_result rows [N,nd]; with ``rows`` also the (frame, anchor) of every row as two int32 vectors."""
     B, A, nd = det.shape
     out = torch.empty((N, nd), dtype=torch.float16, device=det.device)
+    if rows:
+        rb = torch.empty((2, N), dtype=torch.int32, device=det.device)
+        call("tscd_gather_det_rows", det.data_ptr(), A, nd, sel_idx.data_ptr(), sel_idx.shape[1], frame_off.data_ptr(), B, N,
+             out.data_ptr(), rb[0].data_ptr(), rb[1].data_ptr(), _stream())
+        return out, rb[0], rb[1]
     call("tscd_gather_det", det.data_ptr(), A, nd, sel_idx.data_ptr(), sel_idx.shape[1], frame_off.data_ptr(), B, N,
          out.data_ptr(), _stream())
     return out
@@ -1104,6 +1110,45 @@ def loss_rows(row_b, row_a, A, num_classes, fg_mask, matched_gt, pred_iou, label
          matched_gt.data_ptr(), pred_iou.data_ptr(), labels.data_ptr(), _ptr(cls_logit), _ptr(obj_logit), _ptr(reg_delta), _ptr(base), ndet,
          part, ws.data_ptr(), ws_bytes, sums.data_ptr(), _ptr(d_cls), _ptr(d_obj), _ptr(d_reg), _stream())
     return sums, d_cls, d_obj, d_reg
+
+
+def cls_score_gather(raw_all, row_b, row_a, pred_rows, cls_col=6):
+    """sigmoid(raw_all[row_b, row_a, 5 + class]) per proposal row -> [N] fp16; raw_all [B,A,nch] fp16 contiguous."""
+    B, A, nch = raw_all.shape
+    N = row_b.shape[0]
+    assert raw_all.is_contiguous() and raw_all.dtype == torch.float16 and pred_rows.dtype == torch.float16 and pred_rows.stride(1) == 1
+    out = torch.empty((N,), dtype=torch.float16, device=raw_all.device)
+    call("tscd_cls_score_gather_f16", raw_all.data_ptr(), B, A, nch, row_b.data_ptr(), row_a.data_ptr(), pred_rows.data_ptr(),
+         pred_rows.stride(0), cls_col, N, out.data_ptr(), _stream())
+    return out
+
+
+def cls_score_scatter(g, s, shape, row_b, row_a, pred_rows, cls_col=6):
+    """Backward of cls_score_gather -> d raw_all [B,A,nch] fp16 (zero outside the proposals' own class logits)."""
+    B, A, nch = shape
+    d = torch.empty(shape, dtype=torch.float16, device=g.device)
+    assert g.is_contiguous() and g.dtype == torch.float16 and s.is_contiguous()
+    call("tscd_cls_score_scatter_f16", g.data_ptr(), s.data_ptr(), B, A, nch, row_b.data_ptr(), row_a.data_ptr(), pred_rows.data_ptr(),
+         pred_rows.stride(0), cls_col, g.shape[0], d.data_ptr(), _stream())
+    return d
+
+
+def pred_grad_split(d_raw, nc):
+    """d_raw [B,h,w,5+nc] fp16 (a level's slice of the clip gradient: rows of a frame contiguous, any batch stride) ->
+    (dY objectness [B,h,w,8], dY classes [B,h,w,ncp] zero-padded fp16, db [5+nc] fp32 with entries 4.. valid)."""
+    B, h, w, nch = d_raw.shape
+    assert nch == 5 + nc and d_raw.dtype == torch.float16 and d_raw.stride(3) == 1 and d_raw.stride(2) == nch and d_raw.stride(1) == w * nch
+    ncp = (nc + 7) // 8 * 8
+    dev = d_raw.device
+    M = B * h * w
+    dy_obj = torch.empty((B, h, w, 8), dtype=torch.float16, device=dev)
+    dy_cls = torch.empty((B, h, w, ncp), dtype=torch.float16, device=dev)
+    db = torch.empty((nch,), dtype=torch.float32, device=dev)
+    ws_bytes = lib.tscd_pred_grad_split_workspace_bytes(M, nch)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    call("tscd_pred_grad_split_f16", d_raw.data_ptr(), d_raw.stride(0) if B > 1 else h * w * nch, B, h * w, nch, ncp, dy_obj.data_ptr(),
+         dy_cls.data_ptr(), db.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+    return dy_obj, dy_cls, db
 
 
 def scale_grad(d, g, i0, i1=None, split=0, pad=0):

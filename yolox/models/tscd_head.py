@@ -240,9 +240,7 @@ class TSCDHead(nn.Module):
             reg_feat, cls_feat = fz[..., :W], fz[..., W:]
             if reg_o is None:
                 reg_o = TF.conv_bias(reg_feat, self.reg_preds[k].weight, self.reg_preds[k].bias)
-            obj_o = TF.conv_bias(reg_feat, self.obj_preds[k].weight, self.obj_preds[k].bias)
-            cls_o = TF.conv_bias(cls_feat, self.cls_preds[k].weight, self.cls_preds[k].bias)
-            raw_levels[k] = torch.cat([reg_o, obj_o, cls_o], -1)      # [B,h,w,5+NC]: tiny, autograd-tracked
+            raw_levels[k] = TF.pred_level(reg_feat, cls_feat, reg_o, self.obj_preds[k], self.cls_preds[k])   # [B,h,w,5+NC], autograd-tracked
 
         # Order of issue: what the proposal COUNTS depend on comes first (prediction convs on the frozen features, decode, selection,
         # the asynchronous copy of the counts), the trained towers -- which the counts do not depend on -- are queued behind the copy and
@@ -295,14 +293,11 @@ class TSCDHead(nn.Module):
         for n in ppf:
             off.append(off[-1] + n)
         frame_off = ops.h2d(off, torch.int32, dev)
-        pred_rows = ops.gather_det(det, sel_idx, frame_off, N)          # pred_result rows, frame-major [N,7+NC]
+        # pred_result rows, frame-major [N,7+NC], and the int32 (frame, anchor) of every proposal row
+        pred_rows, b_idx32, a_idx32 = ops.gather_det(det, sel_idx, frame_off, N, rows=True)
         if not training and B == 1:
             pr = [pred_rows[off[i]:off[i + 1]] for i in range(B)]
             return pr, pr
-        a_idx32 = torch.cat([sel_idx[b, :ppf[b]] for b in range(B)])                    # int32 anchor id of every proposal row
-        a_idx = a_idx32.long()
-        b_idx = torch.repeat_interleave(torch.arange(B, device=dev), ops.h2d(ppf, torch.long, dev), output_size=N)
-        b_idx32 = b_idx.int()
 
         def gather(feature_maps):
             maps = list(feature_maps)               # [B,h,w,W] maps or W-channel slices of the towers' fused output buffers
@@ -315,8 +310,7 @@ class TSCDHead(nn.Module):
         if training:
             raw_all = torch.cat([r.reshape(B, -1, nch) for r in raw_levels], 1)              # [B,A,5+NC] logits with grad
         if grad:
-            cid = pred_rows[:, 6].long()
-            cls_scores = torch.sigmoid(raw_all[b_idx, a_idx, 5 + cid])                       # == pred_rows[:,5], differentiable
+            cls_scores = TF.cls_score(raw_all, b_idx32, a_idx32, pred_rows)                  # == pred_rows[:,5], differentiable
         else:
             cls_scores = pred_rows[:, 5]
 
@@ -404,5 +398,7 @@ class TSCDHead(nn.Module):
         # normalisation by the foreground counts, the clip of the matched-objectness loss at 15 and the weighted total
         # (tscd_head.py:1157-1203) in one launch: st = [total, 3 iou, obj, cls, num_fg / num_gts, refined cls, matched obj, 6 matched iou]
         loss, st = TF.combine_losses(dense, rows, loss_r_cls, num_fg_b, ngt_b, lframe)
-        self._dbg(fg_mask=fg_mask, matched_gt=matched_gt, pred_iou=pred_iou, num_fg=num_fg_b, refined_fg_rows=fg[b_idx[:nl], a_idx[:nl]].sum())
+        if self.debug is not None:
+            self._dbg(fg_mask=fg_mask, matched_gt=matched_gt, pred_iou=pred_iou, num_fg=num_fg_b,
+                      refined_fg_rows=fg[b_idx32[:nl].long(), a_idx32[:nl].long()].sum())
         return (loss, st[1], st[2], st[3], 0.0, st[4], loss_r_cls, st[6], st[7])
