@@ -301,6 +301,8 @@ def roofline_dominant_kernel(args, device, step):
     # ... and no hipGraph replay of the frozen front: a replayed launch cannot be bracketed, so the backbone / PAFPN / base-tower convs
     # (55 % of the step's FLOPs) would be missing from the launch average
     graphs_on, graphs.ENABLED = graphs.ENABLED, False
+    # ... and the weight gradients on the backward pass's own stream (ops.param_grad_stream runs them beside the data-gradient convs)
+    pgs, ops.PARAM_GRAD_STREAM = ops.PARAM_GRAD_STREAM, False
     try:
         for _ in range(nsteps):
             step()
@@ -309,6 +311,7 @@ def roofline_dominant_kernel(args, device, step):
         head_mod.LEVEL_STREAMS = streams
         tscd_mod.PREFETCH_BACKBONE = prefetch
         graphs.ENABLED = graphs_on
+        ops.PARAM_GRAD_STREAM = pgs
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
     sel = [(f, e0.elapsed_time(e1) * 1e-3) for (bn, cin, f, e0, e1, _) in prof if bn == 128 and cin % 32 == 0]
     if args.conv_table:        # per-shape table of every conv / GEMM launch of the instrumented steps (stderr)

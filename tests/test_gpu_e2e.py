@@ -255,6 +255,49 @@ def test_backbone_prefetch_in_assignment_window_is_exact(golden, model):
     assert id(a) not in tscd_mod._PREFETCHED and torch.isfinite(out_c["total_loss"])
 
 
+@pytest.mark.parametrize("layout,param_stream", [("1", True), ("2", True), ("3", False), ("4", True), ("0", True)])
+def test_train_step_is_the_same_under_every_stream_layout(golden, model, monkeypatch, layout, param_stream):
+    """The opt-in stream layouts of the train step (TSCD_LEVEL_STREAMS 1-4: towers or the prediction / selection half on side streams;
+    TSCD_PARAM_GRAD_STREAM: weight gradients beside the data-gradient chain, joined by the backward pass's final callback) against
+    the single-stream default on the same clip: same proposals and assignments, bit-identical losses, gradients equal up to the
+    order of the fp32 atomics of the SE gate / LayerNorm backward."""
+    cfg, sd, vec, meta = golden
+    import copy
+    import yolox.models.tscd_head as head_mod
+    from tscd_amd import ops
+    imgs = torch.from_numpy(vec["evalA_imgs"]).float().cuda().half()
+    labels = torch.from_numpy(vec["train_labels"]).cuda().half()
+    temb = torch.from_numpy(vec["time_embedding"]).cuda().half()
+    kw = dict(lframe=int(meta["lframe"]), gframe=int(meta["gframe"]), resume=False)
+
+    def run(lay, pgs):
+        monkeypatch.setattr(head_mod, "LEVEL_STREAM_LAYOUT", lay)
+        monkeypatch.setattr(head_mod, "LEVEL_STREAMS", lay != "0")
+        monkeypatch.setattr(ops, "PARAM_GRAD_STREAM", pgs)
+        m = copy.deepcopy(model).train()
+        for mod in (m.backbone, m.head.stems, m.head.reg_convs, m.head.cls_convs, m.head.reg_preds):
+            for p in mod.parameters():
+                p.requires_grad = False
+        m.head.debug = {}
+        outs = []
+        for _ in range(2):                       # second step: the streams' buffers are recycled through the caching allocator
+            m.zero_grad(set_to_none=True)
+            out = m(imgs, labels, temb, **kw)
+            out["total_loss"].backward()
+            outs.append({k: float(v) for k, v in out.items() if torch.is_tensor(v)})
+        torch.cuda.synchronize()
+        return outs, m.head.debug["preds_per_frame"], {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    o1, ppf1, g1 = run(layout, param_stream)
+    o0, ppf0, g0 = run("0", False)
+    assert ppf0 == ppf1 and o0 == o1, (o0, o1)
+    assert set(g0) == set(g1) and len(g0) > 40
+    for n in g0:
+        assert torch.isfinite(g1[n]).all(), n
+        scale = float(g0[n].abs().max()) + 1e-12
+        assert float((g0[n] - g1[n]).abs().max()) <= 2e-2 * scale, (n, float((g0[n] - g1[n]).abs().max()), scale)
+
+
 def test_train_with_the_reference_assignment_and_proposal_sets_is_tight(golden, model, monkeypatch):
     """with the label assignment (SimOTA foreground anchors, matched boxes, matched IoUs) AND the proposal sets forced to
     the reference's -- both are integer decisions that fp16 noise upstream can flip, and both are bit-exact on identical inputs

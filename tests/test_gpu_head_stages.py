@@ -685,6 +685,31 @@ def test_cos_attention_key_stationary_backward_equals_the_atomic_one(C, heads, s
     assert ops.attn_key_tiles([(0, 10, 0, 50), (10, 10, 25, 60)], dev) is None
 
 
+def test_clip_wide_cost_matrices_equal_the_per_pair_ones():
+    """ops.match_costs_clip (all proposals' [reg | cls] rows normalised once, one GEMM per matrix over two row ranges, results back to
+    back in the buffer the single D2H copy takes) against ops.match_cost per pair (tscd_matching.py:919-930): bit-identical fp16
+    costs, for equal and ragged frame sizes, the self-match of the first frame included."""
+    from tscd_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    for sizes in ([500, 500, 500, 500], [37, 120, 64], [130]):
+        n, C = sum(sizes), 1024
+        reg = torch.randn(n, C, generator=g).half().to(dev)
+        cls = torch.randn(n, C, generator=g).half().to(dev)
+        off = [0]
+        for m in sizes:
+            off.append(off[-1] + m)
+        ranges = [(off[0], off[1], off[0], off[1])] + [(off[i - 1], off[i], off[i], off[i + 1]) for i in range(1, len(sizes))]
+        flat, shapes = ops.match_costs_clip(reg, cls, ranges)
+        o = 0
+        for (r0, r1, c0, c1), (nr, nc) in zip(ranges, shapes):
+            want = ops.match_cost(reg[r0:r1], reg[c0:c1], cls[r0:r1], cls[c0:c1])
+            assert (nr, nc) == tuple(want.shape)
+            assert torch.equal(flat[o:o + nr * nc].view(nr, nc), want)
+            o += nr * nc
+        assert o == flat.numel()
+
+
 def test_cafm_deferred_join_of_the_assignment_chain_is_the_joined_result():
     """The clamped training regime parks the stream on the worker's latch (hipLaunchHostFunc) and queues CAFM and its backward before
     the assignments exist on the host (TSCD_DEFER_ASSIGNMENTS, tscd_lap_chain_f16_table).  Same clip with the chain joined on the host

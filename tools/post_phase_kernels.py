@@ -56,7 +56,7 @@ for a, b in zip(cuts[:-1], cuts[1:]):
     pre_span.append((seg[at - 1][1] - seg[0][0]) / 1e6 if at else 0.0)
     win_busy.append(sum(r[1] - r[0] for r in seg[:at]) / 1e6)
     nlaunch.append(len(post))
-    last_post = post
+    last_post, last_pre = post, seg[:at]
     for s, e, n, _q in post:
         p = per_name[short(n)]
         p[0] += 1
@@ -74,8 +74,12 @@ for name, (c, us) in sorted(per_name.items(), key=lambda kv: -kv[1][1])[:45]:
     tot += us
 print(f"  sum of all post-phase kernel durations {sum(v[1] for v in per_name.values()) / n / 1e3:.3f} ms/step")
 if SEQ:
-    print("launch sequence of the last step's post phase (us from its start, duration us, queue, kernel):")
     qs = {}
+    print("launch sequence of the last step BEFORE the post phase (us from the first launch, duration us, queue, kernel):")
+    for s, e, n, q in last_pre:
+        qs.setdefault(q, len(qs))
+        print(f"  {(s - last_pre[0][0]) / 1e3:9.1f} {(e - s) / 1e3:7.1f}  q{qs[q]}  {short(n)[:70]}")
+    print("launch sequence of the last step's post phase (us from its start, duration us, queue, kernel):")
     for s, e, n, q in last_post:
         qs.setdefault(q, len(qs))
         print(f"  {(s - last_post[0][0]) / 1e3:9.1f} {(e - s) / 1e3:7.1f}  q{qs[q]}  {short(n)[:70]}")

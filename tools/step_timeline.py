@@ -52,6 +52,11 @@ def wrap(obj, attr, before=None, after=None):
 wrap(ops, "gather_det", before="counts_on_host")                                   # first call behind the D2H of the proposal counts
 wrap(M.AwarePositionRegMatcher, "prepare", before="prepare_in", after="costs_queued")
 wrap(M.AwarePositionRegMatcher, "finish", before="finish_in", after="finish_out")
+import yolox.models.tscd as tscd_mod
+from tscd_amd import functional as TF
+wrap(ops, "simota_assign", before="simota_in")
+wrap(TF, "dense_loss", before="dense_loss_in")
+wrap(tscd_mod.TSCD, "_prefetch", before="prefetch_in", after="prefetch_out")
 orig_chain = M.lap_chain_f16
 
 
@@ -102,7 +107,7 @@ for _ in range(N):
     step(rec)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t) / N * 1e3
-names = ["counts_on_host", "prepare_in", "costs_queued", "chain_start", "finish_in", "chain_end", "finish_out", "forward_out", "backward_out", "step_out"]
+names = ["counts_on_host", "prepare_in", "costs_queued", "chain_start", "simota_in", "dense_loss_in", "prefetch_in", "prefetch_out", "finish_in", "chain_end", "finish_out", "forward_out", "backward_out", "step_out"]
 print(f"steady state after {PREROLL} steps: {ms:.2f} ms per step (no drains)")
 print("host clock, ms from the step's start (median of %d steps):" % N)
 M.AwarePositionRegMatcher._join_pending(model.head.local_reg_matcher)

@@ -44,7 +44,9 @@ def _ptr(t):
 import contextlib
 import os as _os
 
-PARAM_GRAD_STREAM = _os.environ.get("TSCD_PARAM_GRAD_STREAM", "1") != "0"
+# Off by default: with the whole backward queued ahead of the device (deferred assignment chain) a second queue gained 0.05 ms at
+# most on the bench step (profiles/r03_stream_layouts.txt); TSCD_PARAM_GRAD_STREAM=1 turns it on.
+PARAM_GRAD_STREAM = _os.environ.get("TSCD_PARAM_GRAD_STREAM", "0") == "1"
 _PG = {}
 
 
@@ -1000,6 +1002,28 @@ def add_layernorm_bwd(a, b, gamma, d_out, eps=1e-5):
     call("tscd_add_layernorm_bwd_f16", a.data_ptr(), _ptr(b), gamma.data_ptr(), d_out.data_ptr(), n, C, eps, dx.data_ptr(),
          acc[0].data_ptr(), acc[1].data_ptr(), _stream())
     return dx, acc[0], acc[1]
+
+
+def match_costs_clip(reg, cls, pairs):
+    """Every Hungarian cost matrix of a clip whose frames are matched against each other (no carried-over state): the [reg | cls]
+    rows of ALL proposals are normalised once (two launches), each matrix is one GEMM over two row ranges of that buffer, written
+    back to back into one flat fp16 buffer (what the single D2H copy takes).  reg / cls [n,C] fp16; pairs [(ref0, ref1, cur0, cur1)]
+    row ranges.  -> (flat, [(nr, nc)]).  Same arithmetic as match_cost per pair."""
+    n, C = reg.shape
+    dev = reg.device
+    assert reg.stride(1) == 1 and cls.stride(1) == 1 and (2 * C) % 32 == 0
+    pad = 128                                   # the GEMM reads its B rows in tiles of up to 128: zero rows behind the last frame
+    norm = torch.empty((n + pad, 2 * C), dtype=torch.float16, device=dev)
+    call("tscd_row_normalize_f16", reg.data_ptr(), reg.stride(0), n, n + pad, C, 1e-6, norm.data_ptr(), 2 * C, _stream())
+    call("tscd_row_normalize_f16", cls.data_ptr(), cls.stride(0), n, n + pad, C, 1e-6, norm[:, C:].data_ptr(), 2 * C, _stream())
+    shapes = [(r1 - r0, c1 - c0) for (r0, r1, c0, c1) in pairs]
+    flat = torch.empty((sum(a * b for a, b in shapes),), dtype=torch.float16, device=dev)
+    o = 0
+    for (r0, r1, c0, c1), (nr, nc) in zip(pairs, shapes):
+        if nr * nc:
+            conv2d(norm[r0:r1].unsqueeze(0).unsqueeze(0), norm[c0:], nc, 1, 1, EPI_COST, out=flat[o:o + nr * nc].view(1, 1, nr, nc))
+        o += nr * nc
+    return flat, shapes
 
 
 def match_cost(ref_reg, cur_reg, ref_cls, cur_cls):

@@ -14,6 +14,7 @@ masks instead of boolean-mask gathers, so no further syncs occur.
 """
 import math
 
+import contextlib
 import os
 
 import torch
@@ -71,7 +72,15 @@ class HeadPrefix:
         return HeadPrefix([tuple(ts[i:i + 3]) for i in range(0, len(ts), 3)])
 
 
-LEVEL_STREAMS = os.environ.get("TSCD_LEVEL_STREAMS", "1") != "0"
+# Streams of the trained towers: "0" all on the main stream; "1" the 36x36 / 18x18 levels on a side stream each, the 72x72 level on
+# the main stream behind the copy of the proposal counts; "2" the 72x72 level on one side stream, the two small levels on another;
+# "3" one side stream per level; "4" the towers on the main stream and the prediction convs / decode / selection / counts copy on
+# ONE side stream.  Default "0": with the assignment chain joined on the device (tscd_matching.DEFER_CHAIN) the host runs far ahead
+# of the device and a single in-order queue executes back to back; every layout with a side stream measured 0.1-0.2 ms slower in
+# the backward pass (the engine's cross-stream event waits) than it gained in the forward (profiles/r03_stream_layouts.txt).  HIP multiplexes a process's streams onto a few hardware queues (4 by default): with more streams
+# than that two of them share an in-order queue, and the main stream's work was seen queued behind the prefetched backbone graph.
+LEVEL_STREAM_LAYOUT = os.environ.get("TSCD_LEVEL_STREAMS", "0")
+LEVEL_STREAMS = LEVEL_STREAM_LAYOUT != "0"
 FUSE_TOWERS = os.environ.get("TSCD_FUSE_TOWERS", "1") != "0"
 EAGER_CLASS_BRANCH = os.environ.get("TSCD_EAGER_CLASS_BRANCH", "1") != "0"
 
@@ -242,42 +251,53 @@ class TSCDHead(nn.Module):
                 reg_o = TF.conv_bias(reg_feat, self.reg_preds[k].weight, self.reg_preds[k].bias)
             raw_levels[k] = TF.pred_level(reg_feat, cls_feat, reg_o, self.obj_preds[k], self.cls_preds[k])   # [B,h,w,5+NC], autograd-tracked
 
-        # Order of issue: what the proposal COUNTS depend on comes first (prediction convs on the frozen features, decode, selection,
-        # the asynchronous copy of the counts), the trained towers -- which the counts do not depend on -- are queued behind the copy and
-        # run while the host waits for it.  The 36x36 / 18x18 levels' towers run on side streams underneath the 72x72 level (their
-        # launches do not fill the chip).  Also under DistributedDataParallel: the reducer keeps every parameter's AccumulateGrad node
-        # alive from its construction (on the main stream), autograd orders a gradient produced on a side stream in front of that
-        # node with an event wait, and the reducer syncs a bucket's all-reduce with the stream its hook runs on -- the main one
-        # (TSCD_ONE_GRAD_STREAM=1 keeps every gradient-producing kernel on the main stream).
+        # Order of issue.  What the proposal COUNTS depend on (prediction convs on the frozen features, decode, selection, the
+        # asynchronous copy of the counts) and the trained towers (which the counts do not depend on) are independent until the feature
+        # gather; layout "4" runs the former on a side stream and the towers on the main stream: the copy leaves early, the
+        # small launches fill in underneath the towers, and in backward only the prediction convs' (leaf) gradients run off the main
+        # stream.  Layouts "1"-"3" put towers on side streams instead (see LEVEL_STREAM_LAYOUT).  Under DistributedDataParallel the
+        # reducer keeps every parameter's AccumulateGrad node alive from its construction (on the main stream), autograd orders a
+        # gradient produced on a side stream in front of that node with an event wait, and the reducer syncs a bucket's all-reduce with
+        # the stream its hook runs on -- the main one (TSCD_ONE_GRAD_STREAM=1 keeps every gradient-producing kernel on the main stream).
         use_side = LEVEL_STREAMS and nlev > 1 and dev.type == "cuda" and not (grad and os.environ.get("TSCD_ONE_GRAD_STREAM") == "1")
-        joins = []
+        lay = LEVEL_STREAM_LAYOUT if use_side else "0"
+        joins, on_main, head_stream = [], list(range(nlev)), None
         if use_side:
             main = torch.cuda.current_stream()
-            side = _side_streams(dev, nlev - 1)
             fork = torch.cuda.Event()
             fork.record(main)
-            for k in range(1, nlev):
-                side[k - 1].wait_event(fork)
-                with torch.cuda.stream(side[k - 1]):
-                    towers(k)
+        if use_side and lay == "4":
+            head_stream = _side_streams(dev, 1)[0]
+            head_stream.wait_event(fork)
+        elif use_side:
+            where = {"1": [None] + list(range(nlev - 1)), "2": [0] + [1] * (nlev - 1)}.get(lay, list(range(nlev)))   # level -> side stream
+            side = _side_streams(dev, 1 + max(w for w in where if w is not None))
+            for i in sorted({w for w in where if w is not None}):
+                side[i].wait_event(fork)
+                with torch.cuda.stream(side[i]):
+                    for k in range(nlev):
+                        if where[k] == i:
+                            towers(k)
                     ev = torch.cuda.Event()
-                    ev.record(side[k - 1])
+                    ev.record(side[i])
                     joins.append(ev)
-        for k in range(nlev):
-            preds(k)
-        with torch.no_grad():
-            outputs, det, score = ops.decode_score([r.detach().contiguous() for r in raw_levels], geo, nc, training)
-            sel_idx, sel_cnt = ops.select_proposals(score, 0.001, self.kwargs.get("minimal_limit", 0),
-                                                    self.kwargs.get("maximal_limit", 0))
-            counts_host = torch.empty((B,), dtype=torch.int32, pin_memory=True) if dev.type == "cuda" else None
-            if counts_host is not None:
-                counts_host.copy_(sel_cnt, non_blocking=True)
-                counts_ready = torch.cuda.Event()
-                counts_ready.record()
-        towers(0)
-        if not use_side:
-            for k in range(1, nlev):
-                towers(k)
+            on_main = [k for k in range(nlev) if where[k] is None]
+        with (torch.cuda.stream(head_stream) if head_stream is not None else contextlib.nullcontext()):
+            for k in range(nlev):
+                preds(k)
+            with torch.no_grad():
+                outputs, det, score = ops.decode_score([r.detach().contiguous() for r in raw_levels], geo, nc, training)
+                sel_idx, sel_cnt = ops.select_proposals(score, 0.001, self.kwargs.get("minimal_limit", 0),
+                                                        self.kwargs.get("maximal_limit", 0))
+                counts_host = torch.empty((B,), dtype=torch.int32, pin_memory=True) if dev.type == "cuda" else None
+                if counts_host is not None:
+                    counts_host.copy_(sel_cnt, non_blocking=True)
+                    counts_ready = torch.cuda.Event()
+                    counts_ready.record()
+            if head_stream is not None:
+                joins.append(counts_ready)
+        for k in on_main:                      # they run while the host waits for the counts
+            towers(k)
         for ev in joins:
             main.wait_event(ev)
         if counts_host is not None:

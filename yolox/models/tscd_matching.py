@@ -531,13 +531,17 @@ class AwarePositionRegMatcher(nn.Module):
         if not costs:
             return [], None, None
         flat = torch.cat([c.reshape(-1) for c in costs])
+        return AwarePositionRegMatcher._copy_costs_async(flat, [tuple(c.shape) for c in costs], pinned)
+
+    @staticmethod
+    def _copy_costs_async(flat, shapes, pinned):
         if pinned is None or pinned.numel() < flat.numel():
             pinned = torch.empty((max(flat.numel(), 1 << 20),), dtype=torch.float16, pin_memory=True)
         host = pinned[:flat.numel()]
         host.copy_(flat, non_blocking=True)               # the only device->host transfer of the matcher
         ev = torch.cuda.Event()
         ev.record()
-        return [tuple(c.shape) for c in costs], pinned, ev
+        return list(shapes), pinned, ev
 
     @staticmethod
     def _cost_matrices_wait(shapes, pinned, ev):
@@ -598,7 +602,15 @@ class AwarePositionRegMatcher(nn.Module):
                 p0, p1 = spans[pi]
                 pairs.append((features_reg[p0:p1], cur_reg, features_cls[p0:p1], cur_cls))
         dev_index = features_reg.device.index if features_reg.device.index is not None else torch.cuda.current_device()
-        shapes, pinned, ev = self._cost_matrices_async(pairs, _PINNED.get(dev_index))
+        if plan and all(kind != "state" for (_, kind, _) in plan):
+            # every matrix pairs two row ranges of this clip's MCA outputs: normalise all rows once, one GEMM per matrix straight into
+            # the flat buffer the copy takes
+            ranges = [(spans[i] if kind == "self" else spans[pi]) + spans[i] for (i, kind, pi) in plan]
+            with torch.no_grad():
+                flat, shapes = ops.match_costs_clip(features_reg.detach(), features_cls.detach(), ranges)
+            shapes, pinned, ev = self._copy_costs_async(flat, shapes, _PINNED.get(dev_index))
+        else:
+            shapes, pinned, ev = self._cost_matrices_async(pairs, _PINNED.get(dev_index))
         _PINNED[dev_index] = pinned
         kinds = [{"self": KIND_SELF, "state": KIND_STATE, "prev": KIND_PREV}[kind] for (_, kind, _) in plan]
         chain, deferred = None, None
