@@ -60,6 +60,9 @@ void tscd_latch_signal(void* latch, uint64_t gen);
 uint64_t tscd_latch_generation(void* latch);
 int64_t tscd_latch_timeouts(void* latch);
 int tscd_latch_wait(void* latch, uint64_t gen, int timeout_ms);
+/* A wait polls the counter for up to `us` microseconds before it blocks on the condition variable (0, the default: blocks at once):
+ * removes the futex wake-up between the worker's signal and the stream's go-ahead at the price of a busy runtime thread. */
+int64_t tscd_latch_set_spin(void* latch, int64_t us);
 void* tscd_latch_ticket(void* latch, uint64_t gen, int timeout_ms);   /* heap ticket, consumed by tscd_latch_wait_cb */
 void tscd_latch_wait_cb(void* ticket);                                /* hipHostFn_t */
 /* tscd_lap_chain_f16 for the clamped training regime (K frames of n proposals each, kind = 0,2,2,...): also writes the clip's

@@ -714,7 +714,8 @@ def test_cafm_deferred_join_of_the_assignment_chain_is_the_joined_result():
     """The clamped training regime parks the stream on the worker's latch (hipLaunchHostFunc) and queues CAFM and its backward before
     the assignments exist on the host (TSCD_DEFER_ASSIGNMENTS, tscd_lap_chain_f16_table).  Same clip with the chain joined on the host
     first: identical assignments, bit-identical forward, gradients equal up to the order of the fp32 atomics in the SE gate's backward;
-    repeated steps reuse the pinned table and the latch (generations grow), and nothing times out."""
+    repeated steps reuse the pinned table and the latch (one generation per frame: the stream is released frame by frame while the
+    later matrices are still being solved), and nothing times out."""
     import yolox.models.tscd_matching as M
     dev = torch.device("cuda:0")
     W, n, L = 256, 200, 4
@@ -752,7 +753,7 @@ def test_cafm_deferred_join_of_the_assignment_chain_is_the_joined_result():
             assert len(h1) == L and all(np.array_equal(a, b) for a, b in zip(h0, h1))
             assert torch.equal(o0, o1)
             assert torch.allclose(df0, df1, rtol=1e-2, atol=1e-3) and torch.allclose(de0, de1, rtol=1e-2, atol=1e-3)
-        assert M._latch().generation == gen0 + 3 and M._latch().timeouts == 0
+        assert M._latch().generation == gen0 + 3 * L and M._latch().timeouts == 0      # one generation per frame and clip
     finally:
         M.DEFER_CHAIN = True
 

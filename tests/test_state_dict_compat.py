@@ -58,7 +58,7 @@ def test_host_library_exports_every_declared_symbol():
     assert names == {"tscd_lap_solve_f64", "tscd_lap_solve_f16", "tscd_lap_chain_f16", "tscd_lap_fixed_point_available",
                      "tscd_lap_debug_steps", "tscd_lap_debug_width", "tscd_lap_chain_set_parallel", "tscd_lap_chain_spec_hits", "tscd_cocoeval_bbox",
                      "tscd_lap_chain_f16_table", "tscd_latch_create", "tscd_latch_destroy", "tscd_latch_signal", "tscd_latch_generation",
-                     "tscd_latch_timeouts", "tscd_latch_wait", "tscd_latch_ticket", "tscd_latch_wait_cb"}
+                     "tscd_latch_timeouts", "tscd_latch_wait", "tscd_latch_ticket", "tscd_latch_wait_cb", "tscd_latch_set_spin"}
     lib = ctypes.CDLL(_host.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n

@@ -70,6 +70,7 @@ _lib.tscd_latch_generation.argtypes, _lib.tscd_latch_generation.restype = [C.c_v
 _lib.tscd_latch_timeouts.argtypes, _lib.tscd_latch_timeouts.restype = [C.c_void_p], C.c_int64
 _lib.tscd_latch_wait.argtypes, _lib.tscd_latch_wait.restype = [C.c_void_p, C.c_uint64, C.c_int], C.c_int
 _lib.tscd_latch_ticket.argtypes, _lib.tscd_latch_ticket.restype = [C.c_void_p, C.c_uint64, C.c_int], C.c_void_p
+_lib.tscd_latch_set_spin.argtypes, _lib.tscd_latch_set_spin.restype = [C.c_void_p, C.c_int64], C.c_int64
 LATCH_WAIT_CB = C.cast(_lib.tscd_latch_wait_cb, C.c_void_p).value      # address of the hipHostFn_t that consumes a ticket
 
 
@@ -81,6 +82,9 @@ class Latch:
     def __init__(self):
         self.handle = _lib.tscd_latch_create()
         self.next_gen = 0
+        spin = int(os.environ.get("TSCD_LATCH_SPIN_US", "0"))
+        if spin > 0:
+            _lib.tscd_latch_set_spin(self.handle, spin)
 
     def new_generation(self):
         self.next_gen += 1

@@ -669,8 +669,19 @@ static std::atomic<int64_t> g_chain_spec_hits{0};
 // below); 2: always; 0: strictly in order.  Returns the previous setting.  tscd_lap_chain_spec_hits: matrices answered from the side-by-side solve so far.
 int tscd_lap_chain_set_parallel(int on) { return g_chain_parallel.exchange(on); }
 int64_t tscd_lap_chain_spec_hits(int reset) { int64_t h = g_chain_spec_hits; if (reset) g_chain_spec_hits = 0; return h; }
+}  // extern "C"
+// The chain with a hook: done(k) runs as soon as matrix k's row_out / col_out / perm_out entries are final (the deferred join hands
+// each frame's part of the index table to the device while the next matrix is being solved).
+static int lap_chain_core(int K, const uint16_t* const* cost, const int64_t* nr, const int64_t* nc, const int32_t* kind,
+                          int64_t* row_out, int64_t* col_out, int64_t* perm_out, const std::function<void(int)>& on_done);
+extern "C" {
 int tscd_lap_chain_f16(int K, const uint16_t* const* cost, const int64_t* nr, const int64_t* nc, const int32_t* kind,
                        int64_t* row_out, int64_t* col_out, int64_t* perm_out) {
+  return lap_chain_core(K, cost, nr, nc, kind, row_out, col_out, perm_out, [](int) {});
+}
+}  // extern "C"
+static int lap_chain_core(int K, const uint16_t* const* cost, const int64_t* nr, const int64_t* nc, const int32_t* kind,
+                          int64_t* row_out, int64_t* col_out, int64_t* perm_out, const std::function<void(int)>& on_done) {
   std::vector<int64_t> prev_perm;
   int64_t o_pair = 0, o_perm = 0;
 #if defined(__x86_64__)
@@ -742,9 +753,11 @@ int tscd_lap_chain_f16(int K, const uint16_t* const* cost, const int64_t* nr, co
     // frame's reference is the current frame's Cn rows in column order -- prev_perm holds exactly col_out (np == Cn)
     o_pair += np;
     o_perm += Cn;
+    on_done(k);
   }
   return 0;
 }
+extern "C" {
 // ---- a latch the device's stream can be parked on ---------------------------------------------------------------------------
 // The train step queues everything that FOLLOWS the assignments (CAFM, the refined heads, the whole backward) while the chain is
 // still being solved on a worker thread: the stream is held by a host function (hipLaunchHostFunc -> tscd_latch_wait_cb, run on a
@@ -756,6 +769,8 @@ struct TscdLatch {
   std::mutex m;
   std::condition_variable cv;
   uint64_t gen = 0;
+  std::atomic<uint64_t> agen{0};          // the same counter for the lock-free spin phase of a wait
+  std::atomic<int64_t> spin_us{0};        // tscd_latch_set_spin: how long a wait polls before it blocks on the condition variable
   std::atomic<int64_t> timeouts{0};
 };
 struct TscdLatchTicket { TscdLatch* latch; uint64_t gen; int timeout_ms; };
@@ -763,14 +778,32 @@ void* tscd_latch_create(void) { return new TscdLatch(); }
 void tscd_latch_destroy(void* l) { delete (TscdLatch*)l; }
 void tscd_latch_signal(void* l, uint64_t gen) {
   TscdLatch* L = (TscdLatch*)l;
-  { std::lock_guard<std::mutex> g(L->m); if (gen > L->gen) L->gen = gen; }
+  {
+    std::lock_guard<std::mutex> g(L->m);
+    if (gen > L->gen) L->gen = gen;
+    L->agen.store(L->gen, std::memory_order_release);
+  }
   L->cv.notify_all();
 }
+// A wait first polls the counter for up to `us` microseconds (no futex wake-up between the worker's signal and the stream's go-ahead:
+// the waiting thread is a runtime thread that has nothing else to do), then blocks.  0 (default): block at once.  Returns the previous value.
+int64_t tscd_latch_set_spin(void* l, int64_t us) { return ((TscdLatch*)l)->spin_us.exchange(us < 0 ? 0 : us); }
 uint64_t tscd_latch_generation(void* l) { TscdLatch* L = (TscdLatch*)l; std::lock_guard<std::mutex> g(L->m); return L->gen; }
 int64_t tscd_latch_timeouts(void* l) { return ((TscdLatch*)l)->timeouts.load(); }
 // 0 when generation `gen` has been reached, 1 after timeout_ms without it
 int tscd_latch_wait(void* l, uint64_t gen, int timeout_ms) {
   TscdLatch* L = (TscdLatch*)l;
+  const int64_t spin = L->spin_us.load();
+  if (spin > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0;; ++it) {
+      if (L->agen.load(std::memory_order_acquire) >= gen) return 0;
+#if defined(__x86_64__)
+      _mm_pause();
+#endif
+      if ((it & 255) == 255 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spin) break;
+    }
+  }
   std::unique_lock<std::mutex> g(L->m);
   bool ok = L->cv.wait_for(g, std::chrono::milliseconds(timeout_ms), [&] { return L->gen >= gen; });
   if (!ok) ++L->timeouts;
@@ -787,8 +820,9 @@ void tscd_latch_wait_cb(void* ticket) {
 // tscd_lap_chain_f16 for the clamped training regime (every frame n proposals, kinds 0,2,2,...): additionally writes the clip's
 // index table -- [inv_0 | c_1 | inv_1 | c_2 | inv_2 ...], n int64 each: c_k the order in which the reference keeps frame k's rows
 // (perm_out), inv_k its inverse, inv_0 the inverse of the first frame's self assignment -- to `table` (pinned host memory the
-// device copies from) and then raises `latch` to `gen`.  The latch is raised on EVERY path; on failure the table holds identity
-// permutations, so work queued behind the latch stays in range.  table_len must be (2K-1)*n.
+// device copies from), frame by frame: as soon as matrix k is solved its part is written and the latch raised to gen - (K-1-k), so the
+// caller allots K consecutive generations per clip and may park the stream once per frame.  The latch reaches `gen` on EVERY path; on
+// failure the parts not yet announced hold identity permutations, so work queued behind the latch stays in range.  table_len must be (2K-1)*n.
 int tscd_lap_chain_f16_table(int K, const uint16_t* const* cost, const int64_t* nr, const int64_t* nc, const int32_t* kind,
                              int64_t* row_out, int64_t* col_out, int64_t* perm_out, int64_t* table, int64_t table_len, void* latch,
                              uint64_t gen) {
@@ -797,21 +831,26 @@ int tscd_lap_chain_f16_table(int K, const uint16_t* const* cost, const int64_t* 
   bool shape_ok = table && K > 0 && table_len == (2 * (int64_t)K - 1) * n;
   for (int k = 0; k < K && shape_ok; ++k) shape_ok = nr[k] == n && nc[k] == n && kind[k] == (k ? 2 : 0);
   if (!shape_ok) st = 5;
-  if (st == 0) st = tscd_lap_chain_f16(K, cost, nr, nc, kind, row_out, col_out, perm_out);
-  if (table) {
-    if (st == 0) {
-      int64_t* t = table;
-      for (int64_t i = 0; i < n; ++i) t[col_out[i]] = i;              // frame 0: inverse of its own column order
-      t += n;
-      for (int k = 1; k < K; ++k) {
-        const int64_t* pk = perm_out + (int64_t)k * n;
-        std::memcpy(t, pk, sizeof(int64_t) * n);
-        for (int64_t i = 0; i < n; ++i) t[n + pk[i]] = i;
-        t += 2 * n;
-      }
-    } else if (n > 0) {
-      for (int64_t i = 0; i < table_len; ++i) table[i] = i % n;
+  int finished = 0;                                                    // matrices whose table part is written and announced
+  auto done = [&](int k) {
+    // frame k's part: inv_0 (k = 0) or [c_k | inv_k]; then generation gen - (K-1-k): a stream parked on frame k goes on while
+    // frame k+1 is still being solved
+    if (k == 0) {
+      for (int64_t i = 0; i < n; ++i) table[col_out[i]] = i;          // inverse of the first frame's own column order
+    } else {
+      int64_t* t = table + (2 * (int64_t)k - 1) * n;
+      const int64_t* pk = perm_out + (int64_t)k * n;
+      std::memcpy(t, pk, sizeof(int64_t) * n);
+      for (int64_t i = 0; i < n; ++i) t[n + pk[i]] = i;
     }
+    finished = k + 1;
+    const uint64_t back = (uint64_t)(K - 1 - k);
+    if (latch && gen > back) tscd_latch_signal(latch, gen - back);
+  };
+  if (st == 0) st = lap_chain_core(K, cost, nr, nc, kind, row_out, col_out, perm_out, done);
+  if (table && st != 0 && n > 0) {                                     // what was not announced: identity rows
+    const int64_t from = finished == 0 ? 0 : (2 * (int64_t)finished - 1) * n;
+    for (int64_t i = from; i < table_len; ++i) table[i] = i % n;
   }
   if (latch) tscd_latch_signal(latch, gen);
   return st;

@@ -294,6 +294,21 @@ class _PermuteRows(torch.autograd.Function):
         return g.index_select(0, idx_inv), None, None
 
 
+class _TableFeed:
+    """The deferred join, frame by frame: ``wait(j)`` parks the current stream on the worker's latch until matrix j of the clip's chain
+    is solved (tscd_lap_chain_f16_table raises one generation per matrix) and queues the copy of that frame's part of the index table
+    from pinned memory -- [c_j | inv_j], with inv_0 riding along with frame 1 (or alone for a one-frame clip)."""
+
+    def __init__(self, table, dev_idx, latch, gen0, n, L):
+        self.table, self.dev_idx, self.latch, self.gen0, self.n, self.L = table, dev_idx, latch, gen0, n, L
+
+    def wait(self, j):
+        n = self.n
+        a, b = ((0, n) if self.L == 1 else (0, 3 * n)) if j <= 1 else ((2 * j - 1) * n, (2 * j + 1) * n)
+        ops.call("tscd_stream_host_func", ops._stream(), LATCH_WAIT_CB, self.latch.ticket(self.gen0 + j))
+        self.dev_idx[a:b].copy_(self.table[a:b], non_blocking=True)
+
+
 class _CafmChain(torch.autograd.Function):
     """The whole frame-to-frame chain of AwarePositionRegMatcher.forward (tscd_matching.py:761-888) for a clip whose local frames all
     carry the same number of proposals (the clamped regime: every frame at ``maximal_limit``) as ONE autograd node: the per-frame
@@ -308,7 +323,7 @@ class _CafmChain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, idx, feat, edge, temb, w_pos, b_pos, se_w0, se_w2, wq, wk, wv, ln_g, ln_b, dec_g, dec_b):
-        n, L, heads, slots, eps_ln, eps_dec = meta
+        n, L, heads, slots, eps_ln, eps_dec, feed = meta
         W = feat.shape[1]
         dev = feat.device
         f32 = lambda t: t if t.dtype == torch.float32 else t.float()
@@ -339,8 +354,9 @@ class _CafmChain(torch.autograd.Function):
         for j in range(L):
             s0, s1 = j * n, (j + 1) * n
             cur, cur_edge = feat[s0:s1], edge[s0:s1]
+            if feed is not None and j >= 1:
+                feed.wait(j)       # frame j's assignment order: the stream goes on as soon as ITS matrix is solved (frame 0 needs none)
             c = idx[slots[j][0]:slots[j][0] + n] if slots[j][0] >= 0 else None
-            inv = idx[slots[j][1]:slots[j][1] + n]
             if j == 0:
                 tgt, qedge, idn, qpos = cur, cur_edge, cur, t_emb[0]
             else:
@@ -358,9 +374,13 @@ class _CafmChain(torch.autograd.Function):
                      out_all[s0:].data_ptr(), ops._stream())
             if 0 < j < L - 1:  # the next frame's query-side edge rows = this frame's edge rows in assignment order (frame 1 reads frame 0's in place)
                 torch.index_select(cur_edge, 0, c, out=qedge_all[s1:s1 + n])
-            torch.index_select(out_all[s0:s1], 0, inv, out=o[s0:s1])
+        if feed is not None and L == 1:
+            feed.wait(0)
+        for j in range(L):     # back to proposal order (after the loop: frame 0 then never waits for its own self-assignment)
+            s0, s1 = j * n, (j + 1) * n
+            torch.index_select(out_all[s0:s1], 0, idx[slots[j][1]:slots[j][1] + n], out=o[s0:s1])
         matched = ops.add_layernorm(o, None, g_dec, b_dec, eps_dec)
-        ctx.meta = meta
+        ctx.meta = meta[:6]
         ctx.mfma = mfma
         ctx.dtypes = (w_pos.dtype, se_w0.dtype, wq.dtype, ln_g.dtype, dec_g.dtype)
         ctx.save_for_backward(idx, feat, edge, temb16, t_emb, w_pos, w0f, w2f, wq, wk, wv, g_ln, g_dec, k_in, k_all, v_all, q_in, q_all,
@@ -624,8 +644,9 @@ class AwarePositionRegMatcher(nn.Module):
                 if table is None or table.numel() < tlen:
                     table = _TABLES[dev_index] = torch.zeros((max(tlen, 1 << 14),), dtype=torch.int64, pin_memory=True)
                 latch = _latch()
-                deferred = dict(table=table, tlen=tlen, latch=latch, gen=latch.new_generation())
-                kw = dict(table_ptr=table.data_ptr(), table_len=tlen, latch=latch, gen=deferred["gen"])
+                gens = [latch.new_generation() for _ in range(L)]          # one per frame: the worker raises them one solve at a time
+                deferred = dict(table=table, tlen=tlen, latch=latch, gen0=gens[0])
+                kw = dict(table_ptr=table.data_ptr(), table_len=tlen, latch=latch, gen=gens[-1])
             chain = _ASSIGN_WORKER.submit(lap_chain_f16, pinned.data_ptr(), shapes, kinds,
                                           functools.partial(_wait_copy, dev_index, ev), **kw)
         return dict(plan=plan, spans=spans, chain=chain, ppf=list(preds_per_frame), resume=resume,
@@ -641,7 +662,7 @@ class AwarePositionRegMatcher(nn.Module):
         attn = self.transformer_aware_cross_attention_layers[0].multihead_attn
         return attn.q_reg.bias is None and attn.k_reg.bias is None and attn.v_reg.bias is None
 
-    def _finish_fused(self, plan, slots, dev_idx, ppf, resume, features, features_edge, time_embedding, layer, solved):
+    def _finish_fused(self, plan, slots, dev_idx, ppf, resume, features, features_edge, time_embedding, layer, solved, feed=None):
         """The clamped training regime -- every local frame with the same number of proposals, no state carried in, gradients wanted --
         as ONE autograd node (_CafmChain).  Returns None when the clip does not qualify (the per-op path below handles every case).
         ``solved`` None: the deferred form -- ``slots`` / ``dev_idx`` describe the table the device receives once the chain is done."""
@@ -655,7 +676,7 @@ class AwarePositionRegMatcher(nn.Module):
             self.last_hungarian_rows = [np.asarray(row) for (row, _, _) in solved]
         # offsets of c (assignment order; -1 for the first frame, which keeps its own order) and inv in the clip's index table
         sl = tuple((rec["c"][0] if "c" in rec else -1, rec["inv"][0]) for rec in slots)
-        meta = (n, L, attn.num_heads, sl, layer.norm.eps, self.decoder_norm.eps)
+        meta = (n, L, attn.num_heads, sl, layer.norm.eps, self.decoder_norm.eps, feed)
         nl = n * L
         out = _CafmChain.apply(meta, dev_idx, features[:nl], features_edge[:nl], time_embedding, self.absolute_position_embedding.weight,
                                self.absolute_position_embedding.bias, layer.CA.fc[0].weight, layer.CA.fc[2].weight, attn.q_reg.weight,
@@ -676,11 +697,10 @@ class AwarePositionRegMatcher(nn.Module):
             # Deferred join: the stream waits for the worker (a host function parked on the latch), then copies the index table the
             # worker wrote ([inv_0 | c_1 | inv_1 | ...], tscd_lap_chain_f16_table) -- the host goes on queueing.
             n, L = preds_per_frame[0], len(preds_per_frame)
-            ops.call("tscd_stream_host_func", ops._stream(), LATCH_WAIT_CB, d["latch"].ticket(d["gen"]))
             dev_idx = torch.empty((d["tlen"],), dtype=torch.int64, device=dev)
-            dev_idx.copy_(d["table"][:d["tlen"]], non_blocking=True)
             slots = [{"inv": (0, n)}] + [{"c": ((2 * j - 1) * n, n), "inv": (2 * j * n, n)} for j in range(1, L)]
-            fused = self._finish_fused(plan, slots, dev_idx, preds_per_frame, resume, features, features_edge, time_embedding, layer, None)
+            fused = self._finish_fused(plan, slots, dev_idx, preds_per_frame, resume, features, features_edge, time_embedding, layer, None,
+                                       feed=_TableFeed(d["table"], dev_idx, d["latch"], d["gen0"], n, L))
             self._pending = prep["chain"]
             if fused is not None:
                 return fused
