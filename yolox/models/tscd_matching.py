@@ -37,6 +37,7 @@ _PINNED = {}            # device index -> pinned fp16 staging buffer of the cost
 DEFER_CHAIN = __import__("os").environ.get("TSCD_DEFER_ASSIGNMENTS", "1") != "0"
 _TABLES = {}            # device index -> pinned int64 index table the worker writes (grow-only; always holds in-range rows)
 _LATCH = None           # one latch for the process (generations only grow)
+_TIMEOUTS_SEEN = 0      # latch timeouts already reported by _join_pending
 
 
 def _latch():
@@ -529,8 +530,11 @@ class AwarePositionRegMatcher(nn.Module):
         solved = pend.result()
         self._last_hungarian = [np.asarray(col_raw) for (_, col_raw, _) in solved]
         self._last_hungarian_rows = [np.asarray(row) for (row, _, _) in solved]
-        if _LATCH is not None and _LATCH.timeouts:
-            raise RuntimeError("the device's wait for the assignment chain timed out %d time(s)" % _LATCH.timeouts)
+        global _TIMEOUTS_SEEN
+        if _LATCH is not None and _LATCH.timeouts > _TIMEOUTS_SEEN:
+            seen, _TIMEOUTS_SEEN = _TIMEOUTS_SEEN, _LATCH.timeouts          # reported once per occurrence
+            raise RuntimeError("the device's wait for the assignment chain timed out (%d new time(s)): the stream went on with the index "
+                               "table's previous contents" % (_LATCH.timeouts - seen))
 
     def _clear_state(self):
         self.last_outputs = None              # reference name; here the previous frame's output rows [n,C]
