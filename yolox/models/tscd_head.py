@@ -83,6 +83,7 @@ LEVEL_STREAM_LAYOUT = os.environ.get("TSCD_LEVEL_STREAMS", "0")
 LEVEL_STREAMS = LEVEL_STREAM_LAYOUT != "0"
 FUSE_TOWERS = os.environ.get("TSCD_FUSE_TOWERS", "1") != "0"
 EAGER_CLASS_BRANCH = os.environ.get("TSCD_EAGER_CLASS_BRANCH", "1") != "0"
+HOOK_EARLY = os.environ.get("TSCD_PREFETCH_EARLY", "1") != "0"      # the next clip's frozen pass right behind the cost matrices' copy
 
 
 _SIDE_STREAMS = {}      # device -> [torch.cuda.Stream]; process-wide (module attributes must stay deep-copyable for ModelEMA)
@@ -341,6 +342,13 @@ class TSCDHead(nn.Module):
         # block, its gather, the first MCA and the class predictions, none of which depend on the assignments -- runs on
         # the device while the host solves them.
         prep = self.local_reg_matcher.prepare(features_reg, features_cls, ppf[:lframe], resume=resume)
+        hook = getattr(self, "window_hook", None)
+        if hook is not None and HOOK_EARLY:
+            # the next clip's frozen pass (tscd.py: a graph replay on a low-priority stream) starts as soon as the cost matrices are on
+            # their way: it then runs underneath the window's own small launches instead of behind them, and is over before the
+            # backward starts (its tail used to overlap the first convs of the backward: 237 vs 155 us for the wavelet block's wgrad)
+            hook()
+            hook = None
         if training:
             # the label assignment only feeds the losses: queued behind the cost matrices, it runs inside the assignment window
             with torch.no_grad():
@@ -389,7 +397,6 @@ class TSCDHead(nn.Module):
                     branch, [f_cls, f_reg, cls_scores], list(self.agg.parameters()) + list(self.cls_pred.parameters()), seed, track)
             else:
                 loss_r_cls = class_loss(cls_preds)
-        hook = getattr(self, "window_hook", None)
         if hook is not None:          # queued behind the window's own work: the next clip's frozen backbone pass (tscd.py)
             hook()
         matched = self.local_reg_matcher.finish(prep, f_reg, f_edge, time_embedding[:lframe])
