@@ -758,6 +758,42 @@ def test_cafm_deferred_join_of_the_assignment_chain_is_the_joined_result():
         M.DEFER_CHAIN = True
 
 
+def test_cafm_deferred_join_survives_a_failing_chain(monkeypatch):
+    """A chain that fails on the worker (here: a kind the clamped regime does not allow, status 5) must not leave the stream parked nor
+    feed out-of-range rows to the queued gathers: the foreign call writes identity permutations and raises every generation of the
+    clip, the queued forward / backward run to completion with finite values, and the failure surfaces when the worker is joined
+    (reading the test hook, or the next prepare())."""
+    import yolox.models.tscd_matching as M
+    dev = torch.device("cuda:0")
+    W, n, L = 256, 64, 3
+    g = torch.Generator().manual_seed(11)
+    mod = M.AwarePositionRegMatcher(hidden_channel=W, feedforward_channel=W, num_head=8, decoder_layer_num=1).to(dev).train()
+    reg = torch.nn.functional.normalize(torch.randn(n * L, 4 * W, generator=g), dim=1).half().to(dev)
+    cls = torch.nn.functional.normalize(torch.randn(n * L, 4 * W, generator=g), dim=1).half().to(dev)
+    f = torch.randn(n * L, W, generator=g).half().to(dev).requires_grad_()
+    e = torch.randn(n * L, W, generator=g).half().to(dev).requires_grad_()
+    temb = torch.randn(L, 256, generator=g).half().to(dev)
+    real = M.lap_chain_f16
+
+    def broken(base_ptr, shapes, kinds, before=None, **kw):
+        return real(base_ptr, shapes, [kinds[0], M.KIND_STATE] + list(kinds[2:]), before, **kw)
+
+    monkeypatch.setattr(M, "lap_chain_f16", broken)
+    t0 = M._latch().timeouts
+    out = mod(f, reg, cls, e, [n] * L, temb, resume=False)[-1]
+    assert mod._pending is not None
+    out.float().sum().backward()
+    torch.cuda.synchronize()                                  # nothing hangs: the latch was raised on the failure path
+    assert torch.isfinite(out.float()).all() and torch.isfinite(f.grad.float()).all()
+    assert M._latch().timeouts == t0
+    with pytest.raises(ValueError, match="assignment chain failed"):
+        mod.last_hungarian
+    monkeypatch.setattr(M, "lap_chain_f16", real)
+    out2 = mod(f, reg, cls, e, [n] * L, temb, resume=False)[-1]      # the matcher is usable again
+    torch.cuda.synchronize()
+    assert len(mod.last_hungarian) == L and torch.isfinite(out2.float()).all()
+
+
 def test_nms_more_candidates_than_one_lds_sort_chunk():
     """The ImageNet-VID regime (no upper proposal clamp, 30 classes): a frame with 1500 proposals has up to 45000
     (proposal, class) candidates -- more than the 16384 keys one LDS sort holds -- next to a small frame.  Kept candidate
