@@ -263,6 +263,13 @@ int tscd_se_fuse_bwd_f16(const void* reg, int ldr, const void* edge, int lde, co
                          void* stream);
 int tscd_add_layernorm_bwd_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
                                void* dx, float* dgamma, float* dbeta, void* stream);
+/* The two backward entries above ADDING into their fp32 parameter-gradient accumulators instead of clearing them first: a backward chain
+ * (the CAFM recurrence) clears one arena once and lets every frame's call add to its own part. */
+int tscd_se_fuse_bwd_acc_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
+                             const void* dout, long n, int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2,
+                             void* stream);
+int tscd_add_layernorm_bwd_acc_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
+                                   void* dx, float* dgamma, float* dbeta, void* stream);
 int tscd_row_normalize_f16(const void* x, int ldx, int n, int n_pad, int C, float eps, void* out, int ldo, void* stream);
 
 /* ---- eval tail: decode_reg_preds5 (tscd_head.py:914-949) + postprocess (post_process.py:9-85) +

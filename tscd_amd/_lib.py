@@ -53,6 +53,8 @@ SIGNATURES = {
     "tscd_cos_attn_mfma_bwd2_f16": [P, P, P, P, P, P, I, I, I, I, P, I, P, I, P, P, P, P, P],
     "tscd_se_fuse_bwd_f16": [P, I, P, I, P, P, P, L, I, P, P, P, P, P, P],
     "tscd_add_layernorm_bwd_f16": [P, P, P, P, I, I, F, P, P, P, P],
+    "tscd_se_fuse_bwd_acc_f16": [P, I, P, I, P, P, P, L, I, P, P, P, P, P, P],
+    "tscd_add_layernorm_bwd_acc_f16": [P, P, P, P, I, I, F, P, P, P, P],
     "tscd_row_normalize_f16": [P, I, I, I, I, F, P, I, P],
     "tscd_batched_nms": [P, I, P, I, P, P, P, I, F, F, I, I, I, I, P, L, P, P, P, P],
     "tscd_conv_wgrad_nhwc_f16": [P, P, P, I, I, I, I, I, I, I, I, P, L, P],

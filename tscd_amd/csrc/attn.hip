@@ -503,14 +503,27 @@ __global__ __launch_bounds__(256) void se_fuse_bwd_kernel(const f16* __restrict_
   if (threadIdx.x < 64) atomicAdd(dw2 + threadIdx.x, acc[threadIdx.x]);
   else if (threadIdx.x < 128) atomicAdd(dw0 + threadIdx.x - 64, acc[threadIdx.x]);
 }
+static int se_fuse_bwd_launch(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2, const void* dout, long n,
+                              int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2, bool zero, void* stream);
 extern "C" int tscd_se_fuse_bwd_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
                                     const void* dout, long n, int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2,
                                     void* stream) {
+  return se_fuse_bwd_launch(reg, ldr, edge, lde, w0, w2, dout, n, C, dreg, dedge, dpos, dw0, dw2, true, stream);
+}
+// The same ADDING into dpos / dw0 / dw2 (the caller cleared them, e.g. as parts of one arena zeroed once for a whole backward chain).
+extern "C" int tscd_se_fuse_bwd_acc_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
+                                        const void* dout, long n, int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2,
+                                        void* stream) {
+  return se_fuse_bwd_launch(reg, ldr, edge, lde, w0, w2, dout, n, C, dreg, dedge, dpos, dw0, dw2, false, stream);
+}
+static int se_fuse_bwd_launch(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2, const void* dout, long n,
+                              int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2, bool zero, void* stream) {
   TSCD_CHECK_ARG(reg && edge && w0 && w2 && dout && dreg && dedge && dpos && dw0 && dw2, "se_fuse_bwd: null pointer");
   if (n == 0) return TSCD_OK;
   // dpos [C] | dw0 [64] | dw2 [64] are atomic accumulators: cleared here (callers pass them as one C+128 float block or apart)
   hipStream_t sst = (hipStream_t)stream;
-  if (dw0 == dpos + C && dw2 == dw0 + 64) {
+  if (!zero) {
+  } else if (dw0 == dpos + C && dw2 == dw0 + 64) {
     (void)hipMemsetAsync(dpos, 0, sizeof(float) * (C + 128), sst);
   } else {
     (void)hipMemsetAsync(dpos, 0, sizeof(float) * C, sst);
@@ -592,10 +605,22 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const f16* __res
     }
   }
 }
+static int add_layernorm_bwd_launch(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps, void* dx,
+                                    float* dgamma, float* dbeta, bool zero, void* stream);
 extern "C" int tscd_add_layernorm_bwd_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
                                           void* dx, float* dgamma, float* dbeta, void* stream) {
+  return add_layernorm_bwd_launch(a, b, gamma, dy, n, C, eps, dx, dgamma, dbeta, true, stream);
+}
+// The same ADDING into dgamma / dbeta (cleared by the caller).
+extern "C" int tscd_add_layernorm_bwd_acc_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
+                                              void* dx, float* dgamma, float* dbeta, void* stream) {
+  return add_layernorm_bwd_launch(a, b, gamma, dy, n, C, eps, dx, dgamma, dbeta, false, stream);
+}
+static int add_layernorm_bwd_launch(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps, void* dx,
+                                    float* dgamma, float* dbeta, bool zero, void* stream) {
   TSCD_CHECK_ARG(a && gamma && dy && dx && dgamma && dbeta && C > 0, "add_layernorm_bwd: bad args");
-  if (dbeta == dgamma + C) {                                                   // atomic accumulators
+  if (!zero) {
+  } else if (dbeta == dgamma + C) {                                            // atomic accumulators
     (void)hipMemsetAsync(dgamma, 0, sizeof(float) * 2 * C, (hipStream_t)stream);
   } else {
     (void)hipMemsetAsync(dgamma, 0, sizeof(float) * C, (hipStream_t)stream);

@@ -978,28 +978,49 @@ def cos_attn_bwd(q, k, v, d_out, heads, tiles):
     return dq, dk, dv
 
 
-def se_fuse_bwd(reg, edge, w0, w2, d_out):
-    """-> (d_reg, d_edge fp16 [n,C], d_pos [C], d_w0 [32,2], d_w2 [2,32] fp32)."""
+def se_fuse_bwd(reg, edge, w0, w2, d_out, outs=None, acc=None):
+    """-> (d_reg, d_edge fp16 [n,C], d_pos [C], d_w0 [32,2], d_w2 [2,32] fp32).  ``outs``: contiguous [n,C] fp16 destinations for
+    d_reg / d_edge; ``acc``: a ZEROED (or to-be-added-to) fp32 [C + 128] block the parameter gradients are ADDED into (d_pos | d_w0 |
+    d_w2): a chain of calls clears one arena once instead of one accumulator per call."""
     n, C = reg.shape
     dev = reg.device
     assert reg.stride(1) == 1 and edge.stride(1) == 1 and d_out.is_contiguous() and d_out.dtype == torch.float16
-    d_reg = torch.empty((n, C), dtype=torch.float16, device=dev)
-    d_edge = torch.empty((n, C), dtype=torch.float16, device=dev)
-    acc = torch.empty((C + 128,), dtype=torch.float32, device=dev)      # zeroed by the entry point
-    call("tscd_se_fuse_bwd_f16", reg.data_ptr(), reg.stride(0), edge.data_ptr(), edge.stride(0), w0.data_ptr(), w2.data_ptr(),
+    if outs is not None:
+        d_reg, d_edge = outs
+        assert all(t.is_contiguous() and t.dtype == torch.float16 and tuple(t.shape) == (n, C) for t in outs)
+    else:
+        d_reg = torch.empty((n, C), dtype=torch.float16, device=dev)
+        d_edge = torch.empty((n, C), dtype=torch.float16, device=dev)
+    name = "tscd_se_fuse_bwd_f16"
+    if acc is None:
+        acc = torch.empty((C + 128,), dtype=torch.float32, device=dev)      # zeroed by the entry point
+    else:
+        assert acc.dtype == torch.float32 and acc.is_contiguous() and acc.numel() == C + 128
+        name = "tscd_se_fuse_bwd_acc_f16"
+    call(name, reg.data_ptr(), reg.stride(0), edge.data_ptr(), edge.stride(0), w0.data_ptr(), w2.data_ptr(),
          d_out.data_ptr(), n, C, d_reg.data_ptr(), d_edge.data_ptr(), acc.data_ptr(), acc[C:].data_ptr(), acc[C + 64:].data_ptr(),
          _stream())
     return d_reg, d_edge, acc[:C], acc[C:C + 64].view(32, 2), acc[C + 64:].view(2, 32)
 
 
-def add_layernorm_bwd(a, b, gamma, d_out, eps=1e-5):
-    """-> (dx fp16 [n,C] (= da = db), d_gamma [C], d_beta [C] fp32)."""
+def add_layernorm_bwd(a, b, gamma, d_out, eps=1e-5, out=None, acc=None):
+    """-> (dx fp16 [n,C] (= da = db), d_gamma [C], d_beta [C] fp32).  ``out``: contiguous [n,C] fp16 destination of dx; ``acc``: a zeroed
+    (or to-be-added-to) fp32 [2,C] block d_gamma / d_beta are ADDED into."""
     n, C = a.shape
     dev = a.device
     assert a.is_contiguous() and (b is None or b.is_contiguous()) and d_out.is_contiguous() and d_out.dtype == torch.float16
-    dx = torch.empty((n, C), dtype=torch.float16, device=dev)
-    acc = torch.empty((2, C), dtype=torch.float32, device=dev)          # zeroed by the entry point
-    call("tscd_add_layernorm_bwd_f16", a.data_ptr(), _ptr(b), gamma.data_ptr(), d_out.data_ptr(), n, C, eps, dx.data_ptr(),
+    if out is not None:
+        assert out.is_contiguous() and out.dtype == torch.float16 and tuple(out.shape) == (n, C)
+        dx = out
+    else:
+        dx = torch.empty((n, C), dtype=torch.float16, device=dev)
+    name = "tscd_add_layernorm_bwd_f16"
+    if acc is None:
+        acc = torch.empty((2, C), dtype=torch.float32, device=dev)          # zeroed by the entry point
+    else:
+        assert acc.dtype == torch.float32 and acc.is_contiguous() and tuple(acc.shape) == (2, C)
+        name = "tscd_add_layernorm_bwd_acc_f16"
+    call(name, a.data_ptr(), _ptr(b), gamma.data_ptr(), d_out.data_ptr(), n, C, eps, dx.data_ptr(),
          acc[0].data_ptr(), acc[1].data_ptr(), _stream())
     return dx, acc[0], acc[1]
 

@@ -402,7 +402,13 @@ class _CafmChain(torch.autograd.Function):
         dk_all, dv_all, dq_all = mk(), mk(), mk()
         d_idn = mk()                                         # gradient of the residual inputs, in proposal order (added to d_feat at the end)
         d_edge = mk()                                        # query-side contributions to the edge rows, in proposal order
-        ln_acc, se_q, se_k = [], [None] * L, [None] * L      # per-frame parameter-gradient partials, summed once at the end
+        d_mem_all, d_ed_all = mk(), mk()                     # key-side gate: d cur, d cur_edge of every frame
+        # ONE zeroed arena for every fp32 parameter-gradient accumulator of the chain (the kernels ADD into their part): per frame the
+        # query-side gate's [d pos | d w0 | d w2], the key-side gate's, and the residual LayerNorm's [d gamma, d beta]
+        SW = W + 128
+        arena = torch.zeros((2 * L * SW + L * 2 * W,), dtype=torch.float32, device=dev)
+        A, K = arena[:L * SW].view(L, SW), arena[L * SW:2 * L * SW].view(L, SW)
+        ln_acc = arena[2 * L * SW:].view(L, 2, W)
         carry_out = None        # d loss / d out_j (assignment order) arriving from frame j+1's query path
         d_tgt0 = d_qedge0 = None
         for j in range(L - 1, -1, -1):
@@ -415,8 +421,8 @@ class _CafmChain(torch.autograd.Function):
             if carry_out is not None:
                 d_out += carry_out
             idn = feat[:n] if j == 0 else idn_all[s0:s1]
-            dx, dg, db = ops.add_layernorm_bwd(idn, t2_all[s0:s1], g_ln, d_out, eps_ln)
-            ln_acc.append(dg._base)
+            # residual input: cur (first frame: its gradient is already in proposal order) or cur[c]
+            dx, _, _ = ops.add_layernorm_bwd(idn, t2_all[s0:s1], g_ln, d_out, eps_ln, out=d_idn[s0:s1] if j == 0 else None, acc=ln_acc[j])
             if ctx.mfma:
                 ops.cos_attn_mfma_bwd(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], dx, t2_all[s0:s1], lsums[j], heads, tiles, True,
                                       outs=(dq_all[s0:s1], dk_all[s0:s1], dv_all[s0:s1]), ktiles32=ctx.ktiles, keys_full=True)
@@ -425,53 +431,44 @@ class _CafmChain(torch.autograd.Function):
                 dq_all[s0:s1].copy_(dq)
                 dk_all[s0:s1].copy_(dk)
                 dv_all[s0:s1].copy_(dv)
-            # residual input: cur (first frame) or cur[c]  ->  gradient back in proposal order
-            if j == 0:
-                d_idn[s0:s1].copy_(dx)
-            else:
-                torch.index_select(dx, 0, inv, out=d_idn[s0:s1])
+            if j > 0:
+                torch.index_select(dx, 0, inv, out=d_idn[s0:s1])         # back to proposal order
             # query path: q = Wq q_in, q_in = SE(tgt, qedge) + qpos  (Wq's own gradient is one GEMM over all frames below)
             dq_in = ops.linear_dgrad(dq_all[s0:s1], wq)
             tgt = feat[:n] if j == 0 else out_all[s0 - n:s0]
             qedge = edge[:n] if j <= 1 else qedge_all[s0:s1]
-            d_tgt, d_qedge, d_qpos, _, _ = ops.se_fuse_bwd(tgt, qedge, w0f, w2f, dq_in)
-            se_q[j] = d_qpos._base                                   # [W + 128]: d pos | d w0 | d w2 of this call
+            # frame 1's query-side edge rows are frame 0's in place: their gradient goes straight to its destination
+            d_tgt, d_qedge, _, _, _ = ops.se_fuse_bwd(tgt, qedge, w0f, w2f, dq_in, acc=A[j],
+                                                      outs=(torch.empty((n, W), dtype=torch.float16, device=dev), d_edge[0:n]) if j == 1 else None)
             if j == 0:
                 d_tgt0, d_qedge0 = d_tgt, d_qedge
                 carry_out = None
             else:
                 carry_out = d_tgt
                 # frame j's query-side edge rows are frame j-1's edge rows in assignment order (frame 0 keeps its own order)
-                if j == 1:
-                    d_edge[0:n].copy_(d_qedge)
-                else:
+                if j > 1:
                     torch.index_select(d_qedge, 0, idx[slots[j - 1][1]:slots[j - 1][1] + n], out=d_edge[s0 - n:s0])
         d_edge[nl - n:nl].zero_()                                    # the last frame's edge rows feed no later query gate
         # key / value side of all frames at once
         dk_in, dwk, _ = ops.linear_bwd(k_in, dk_all, wk, True, True, False, grad_params=[wk])
         d_feat, dwv, _ = ops.linear_bwd(feat, dv_all, wv, True, True, False, grad_params=[wv])
         _, dwq, _ = ops.linear_bwd(q_in, dq_all, wq, False, True, False, grad_params=[wq])
-        d_mem_all, d_ed_all = mk(), mk()
         for j in range(L):
             s0, s1 = j * n, (j + 1) * n
-            d_mem, d_ed, d_pos, _, _ = ops.se_fuse_bwd(feat[s0:s1], edge[s0:s1], w0f, w2f, dk_in[s0:s1])
-            d_mem_all[s0:s1].copy_(d_mem)
-            d_ed_all[s0:s1].copy_(d_ed)
-            se_k[j] = d_pos._base
+            ops.se_fuse_bwd(feat[s0:s1], edge[s0:s1], w0f, w2f, dk_in[s0:s1], outs=(d_mem_all[s0:s1], d_ed_all[s0:s1]), acc=K[j])
         # fp16 sums over [nl, W] (the per-op path accumulates in fp16 too): 3 + 2 launches instead of a dozen per-frame ones
         d_feat += d_idn
         d_feat += d_mem_all
         d_feat[:n] += d_tgt0
         d_edge += d_ed_all
         d_edge[:n] += d_qedge0
-        A, K = torch.stack(se_q), torch.stack(se_k)                # [L, W + 128] each
         d_temb = K[:, :W].clone()                                   # key-side gate of frame j adds t_j
         d_temb[0] += A[0, :W]                                       # query-side gate: t_0 for the first frame, t_{j-1} for frame j
         if L > 1:
             d_temb[:L - 1] += A[1:, :W]
         dse = (A[:, W:] + K[:, W:]).sum(0)
         dw0, dw2 = dse[:64].view(32, 2), dse[64:].view(2, 32)
-        ln_sum = torch.stack(ln_acc).sum(0)
+        ln_sum = ln_acc.sum(0)
         dg_ln, db_ln = ln_sum[0], ln_sum[1]
         _, dw_pos, db_pos = ops.linear_bwd(temb16, d_temb.to(torch.float16), w_pos, False, True, True)
         dt_pos, dt_se, dt_q, dt_ln, dt_dec = ctx.dtypes
