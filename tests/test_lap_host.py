@@ -251,4 +251,5 @@ def test_chain_with_index_table_and_latch():
     with pytest.raises(RuntimeError):
         lap_chain_f16(flat.ctypes.data, [m.shape for m in mats], kinds, before=boom, table_ptr=table.ctypes.data, table_len=len(table), latch=latch, gen=gen3)
     assert latch.wait(gen3, 10)
+    assert np.array_equal(table, np.arange(len(table)) % n)           # ... and no stale table is handed to the device
     assert not latch.wait(gen3 + 1, 5) and latch.timeouts == 1
