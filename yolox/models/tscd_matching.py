@@ -36,6 +36,7 @@ _PINNED = {}            # device index -> pinned fp16 staging buffer of the cost
 # chain is still being solved (TSCD_DEFER_ASSIGNMENTS=0: join the chain on the host first, as every other regime does).
 DEFER_CHAIN = __import__("os").environ.get("TSCD_DEFER_ASSIGNMENTS", "1") != "0"
 _TABLES = {}            # device index -> pinned int64 index table the worker writes (grow-only; always holds in-range rows)
+_TABLE_N = {}           # device index -> frame size n the table's rows are known to be in range for
 _LATCH = None           # one latch for the process (generations only grow)
 _TIMEOUTS_SEEN = 0      # latch timeouts already reported by _join_pending
 
@@ -644,6 +645,11 @@ class AwarePositionRegMatcher(nn.Module):
                 table = _TABLES.get(dev_index)
                 if table is None or table.numel() < tlen:
                     table = _TABLES[dev_index] = torch.zeros((max(tlen, 1 << 14),), dtype=torch.int64, pin_memory=True)
+                if _TABLE_N.get(dev_index) != n:
+                    # a wait that gives up (30 s) lets the stream go on with the table's previous contents: they must be in range for
+                    # THIS clip's frame size.  (The device's copy of the previous clip's table is long done: its counts were on the host.)
+                    table[:tlen] = torch.arange(tlen, dtype=torch.int64) % n
+                    _TABLE_N[dev_index] = n
                 latch = _latch()
                 gens = [latch.new_generation() for _ in range(L)]          # one per frame: the worker raises them one solve at a time
                 deferred = dict(table=table, tlen=tlen, latch=latch, gen0=gens[0])
