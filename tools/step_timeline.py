@@ -21,6 +21,15 @@ args = bench.parse()
 dev = torch.device("cuda", 0)
 model = bench.build_model(args.depth, args.width, args.props).to(dev).train()
 opt = bench.make_optimizer(model, lr=args.lr)
+net = model
+if os.environ.get("TSCD_TIMELINE_DDP") == "1":      # the step under DistributedDataParallel over a 1-rank RCCL group (reducer hooks, buckets)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from tscd_amd import ddp as tscd_ddp
+    net = tscd_ddp.wrap(model, device_ids=[0])
 scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
 ema = bench.FusedEMA(model, optimizer=opt)
 imgs, t0_, temb = bench.synth_clip(args.frames, args.size, dev, seed=0)
@@ -83,7 +92,7 @@ def step(rec=None):
     mark("start")
     STARTS.append(H["start"])
     model.head.loss_scale = scaler.scale(one)
-    out = model(imgs, targets, temb, lframe=args.lframe, gframe=args.frames - args.lframe, resume=False, next_x=imgs)
+    out = net(imgs, targets, temb, lframe=args.lframe, gframe=args.frames - args.lframe, resume=False, next_x=imgs)
     mark("forward_out")
     opt.zero_grad(set_to_none=True)
     scaler.scale(out["total_loss"]).backward()

@@ -21,13 +21,46 @@ _PREFETCHED = {}        # id(model) -> (clip tensor, pyramid, ready event); modu
 _PREFETCH_STREAM = {}   # device -> low-priority stream
 
 
+_REJECTED_STREAMS = []       # candidates found to share a hardware queue with the main stream (kept alive: their slots stay taken)
+
+
+def _shares_queue(main, cand, dev):
+    """True when work queued on `main` behind work on `cand` does not start until that work is over: HIP multiplexes a process's
+    streams onto a few in-order hardware queues (4 by default), so two streams can be one queue.  Probe: ~3 ms of fills on the
+    candidate, then one tiny fill on the main stream -- if the tiny one is done while the candidate is still busy, they are apart."""
+    big = torch.empty((64 << 20,), dtype=torch.float32, device=dev)
+    small = torch.empty((64,), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(cand):
+        for _ in range(48):
+            big.fill_(0.0)
+        busy = torch.cuda.Event()
+        busy.record(cand)
+    with torch.cuda.stream(main):
+        small.fill_(1.0)
+        done = torch.cuda.Event()
+        done.record(main)
+    done.synchronize()
+    shared = busy.query()            # the candidate's work already over when the main stream's tiny launch got through
+    torch.cuda.synchronize(dev)
+    return shared
+
+
 def _prefetch_stream(dev):
+    """The stream the next clip's frozen pass replays on: low priority where the runtime has such a level, and on a hardware queue of
+    its own -- under DistributedDataParallel (RCCL's streams are created first) a fresh stream was seen to land on the main stream's
+    queue, and the whole assignment window then ran BEHIND the 6 ms graph (15.1 vs 13.5 ms per step)."""
     st = _PREFETCH_STREAM.get(dev)
     if st is None:
-        try:
-            st = torch.cuda.Stream(device=dev, priority=1)      # below the default stream where the runtime has such a level
-        except Exception:
-            st = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        for attempt in range(8):
+            try:
+                st = torch.cuda.Stream(device=dev, priority=1)      # below the default stream where the runtime has such a level
+            except Exception:
+                st = torch.cuda.Stream(device=dev)
+            if attempt == 7 or not _shares_queue(main, st, dev):
+                break
+            _REJECTED_STREAMS.append(st)
         _PREFETCH_STREAM[dev] = st
     return st
 
