@@ -187,6 +187,7 @@ class FusedEMA:
         self.src = [v for k, v in sd.items() if v.dtype.is_floating_point and k not in skip]
         self.ema = [v.detach().clone() for v in self.src]
         self.updates = 0
+        self.model = model
         self.decay = lambda x: decay * (1 - math.exp(-x / 2000))
         self._pending = False
         if stepped:
@@ -206,7 +207,11 @@ class FusedEMA:
         d = self.decay(self.updates)
         if self.ema and self.ema[0].is_cuda and all(v.dtype == torch.float32 for v in self.ema):
             from tscd_amd import ops
-            ops.ema_update(self.ema, self.src, d)          # one launch (elementwise.hip: tscd_ema_update_f32)
+            # the frozen front's running statistics as they were BEFORE the pending prefetched pass of the next clip (the
+            # reference's EMA after step t has seen clip t only: tscd_trainer.py:171-176)
+            early = self.model.pre_prefetch_buffers() if hasattr(self.model, "pre_prefetch_buffers") else {}
+            src = [early.get(b.data_ptr(), b) for b in self.src] if early else self.src
+            ops.ema_update(self.ema, src, d, tag="ema_snapshot" if early else "ema")   # one launch (elementwise.hip: tscd_ema_update_f32)
         else:
             torch._foreach_mul_(self.ema, d)
             torch._foreach_add_(self.ema, self.src, alpha=1.0 - d)
@@ -531,10 +536,10 @@ def main():
         loss = out["total_loss"]
         opt.zero_grad(set_to_none=True)
         scaler.scale(loss).backward()
+        model.check_assignments()      # a failed / timed-out assignment chain raises before its step is applied (as the trainer does)
         scaler.step(opt)
         scaler.update()
-        model.join_prefetch()          # the EMA reads the backbone's running statistics: behind the prefetched pass that updates them
-        ema.update()
+        ema.update()                   # (reads the front's running statistics from the snapshot taken before the prefetched pass)
         return loss
 
     step = step_train if train else step_eval

@@ -5,15 +5,28 @@ calls of its fast_coco_eval_api.py:104-140.  What that module takes as INPUT -- 
 from pycocotools' maskUtils.iou (absent here) -- is computed by the plain box formula of the COCO protocol; everything downstream of
 the IoUs (sorting by score with the 100-detection cap, ignore / crowd handling, greedy matching, the 101-point interpolated
 precision) is the reference's compiled code.  The product's C++ evaluator (tscd_amd/csrc_host/cocoeval.cpp) and the Python
-restatement (oracle/cocoeval_ref.py) must both reproduce its precision and recall arrays."""
+restatement (oracle/cocoeval_ref.py) must both reproduce its precision and recall arrays.
+
+Those arrays are committed as a fixture (tests/golden/cocoeval_ref_curves.npz, written by oracle/make_golden_cocoeval.py from the
+compiled reference): the pin holds everywhere, and the reference-derived shared object is loaded ONLY in the build container (where
+/root/reference exists) -- lazily, inside the one test that compares the live build with the fixture -- never on the GPU box."""
 import numpy as np
 import pytest
 
-from oracle import build_ref
+import os
+
 from oracle import cocoeval_ref as R
 
-REF = build_ref.load()
-pytestmark = pytest.mark.skipif(REF is None, reason="oracle/_ref not built (python -m oracle.build_ref needs /root/reference)")
+SEEDS = (0, 1, 2, 3)
+FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cocoeval_ref_curves.npz")
+
+
+def reference_module():
+    """The compiled reference evaluator -- only where the reference tree itself is present (the build container)."""
+    if not os.path.isdir("/root/reference"):
+        return None
+    from oracle import build_ref
+    return build_ref.load()
 
 
 def _scene(seed, n_img=7, n_cat=4):
@@ -44,7 +57,7 @@ def _scene(seed, n_img=7, n_cat=4):
     return gts, dts, n_img, n_cat
 
 
-def _reference_curves(gts, dts, n_img, n_cat):
+def _reference_curves(REF, gts, dts, n_img, n_cat):
     """precision [T,R,K,A,M], recall [T,K,A,M] from the reference's compiled evaluator."""
     nid = [0]
 
@@ -77,11 +90,12 @@ def _reference_curves(gts, dts, n_img, n_cat):
     return np.array(out["precision"]).reshape(T, Rn, K, A, M), np.array(out["recall"]).reshape(T, K, A, M)
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+@pytest.mark.parametrize("seed", SEEDS)
 def test_product_and_restatement_reproduce_the_reference_evaluator(seed):
     from test_cocoeval import run_cpp
     gts, dts, n_img, n_cat = _scene(seed)
-    p_ref, r_ref = _reference_curves(gts, dts, n_img, n_cat)
+    fx = np.load(FIXTURE)
+    p_ref, r_ref = fx[f"precision_{seed}"], fx[f"recall_{seed}"]
     s, p, r = run_cpp(gts, dts, n_img, n_cat)
     np.testing.assert_allclose(p, p_ref, atol=1e-6)
     np.testing.assert_allclose(r, r_ref, atol=1e-6)
@@ -95,3 +109,16 @@ def test_product_and_restatement_reproduce_the_reference_evaluator(seed):
     assert abs(s[1] - p50[p50 > -1].mean()) < 1e-6
     ra = r_ref[:, :, 0, 2]
     assert abs(s[8] - ra[ra > -1].mean()) < 1e-6
+
+
+def test_fixture_is_what_the_compiled_reference_produces():
+    """Build container only: the live build of the reference's cocoeval.cpp reproduces the committed fixture exactly."""
+    ref = reference_module()
+    if ref is None:
+        pytest.skip("the compiled reference evaluator is only loaded where /root/reference exists (oracle/build_ref.py)")
+    fx = np.load(FIXTURE)
+    for seed in SEEDS:
+        gts, dts, n_img, n_cat = _scene(seed)
+        p, r = _reference_curves(ref, gts, dts, n_img, n_cat)
+        np.testing.assert_array_equal(p, fx[f"precision_{seed}"])
+        np.testing.assert_array_equal(r, fx[f"recall_{seed}"])

@@ -169,3 +169,39 @@ def test_original_detections_at_scale(n, NC, trick, spread):
         ref = nms_ref.batched_nms_vanilla(d[:, :4], score, d[:, 6].long(), 0.5)
     assert torch.equal(k, ref), (len(k), len(ref))
     assert torch.equal(rows[0, :len(k), :4].float().cpu(), d[ref, :4]) and torch.equal(rows[0, :len(k), 6].float().cpu(), d[ref, 6])
+
+
+@pytest.mark.parametrize("n,mode_trick", [(1900, "exact"), (2048, "exact"), (1800, "exact"), (1900, "trick"), (2048, "trick"),
+                                          (1900, "agnostic")])
+def test_one_class_between_the_flush_threshold_and_one_tile(n, mode_trick):
+    """Round-3 advisor finding: with 1793..2048 boxes of ONE (frame, class) and max_rows <= 2048 the pull loop flushed a tile at 1792
+    boxes although no kept list existed, and the class' lowest-score boxes were suppressed only among themselves.  All n rows are one
+    class here (mode 1 / mode 2 / the coordinate-trick pass), max_rows = n <= 2048; keep lists index for index against oracle/nms_ref.py."""
+    from tscd_amd import ops
+    NC = 1 if mode_trick == "agnostic" else 3
+    g = torch.Generator().manual_seed(7 * n + len(mode_trick))
+    cxy = torch.rand(n, 2, generator=g) * 300 + 40
+    wh = torch.rand(n, 2, generator=g) * 120 + 20
+    det = torch.zeros(n, 7 + NC)
+    det[:, 0:2], det[:, 2:4] = cxy - wh / 2, cxy + wh / 2
+    det[:, 4], det[:, 5] = torch.rand(n, generator=g) * 0.9 + 0.1, torch.rand(n, generator=g) * 0.9 + 0.1
+    det[:, 6] = 0 if mode_trick == "agnostic" else 2         # every box in one class
+    det = det.half()
+    frame_off = ops.h2d([0, n], torch.int32, "cuda")
+    mode = 2 if mode_trick == "agnostic" else 1
+    rows, idx, cnt = ops.batched_nms(det.cuda(), frame_off, 1, NC, 0.001, 0.5, n, mode, max_rows=n,
+                                     coord_trick=(2 ** 30 if mode_trick == "trick" else 0))
+    torch.cuda.synchronize()
+    k = idx[0, :int(cnt[0])].cpu().long()
+    d = det.float()
+    score = (d[:, 4].half() * d[:, 5].half()).float()
+    if mode_trick == "trick":
+        ref = nms_ref.batched_nms(d[:, :4].half(), score, d[:, 6].half(), 0.5)
+    else:
+        ref = nms_ref.batched_nms_vanilla(d[:, :4], score, d[:, 6].long(), 0.5)
+    assert torch.equal(k, ref), (len(k), len(ref))
+
+
+def test_refined_set_with_a_class_in_the_flush_window():
+    """Mode 0 (refined set) with 1950 proposals, class 3 passing on every row: 1950 boxes of one class with max_rows = 1950 <= 2048."""
+    _check([1950, 40], 30, 11, 10000, 1792, pass_frac_bias=-1.0, one_class_heavy=True, spread=260.0, size=(60.0, 220.0))

@@ -97,9 +97,11 @@ def step(rec=None):
     opt.zero_grad(set_to_none=True)
     scaler.scale(out["total_loss"]).backward()
     mark("backward_out")
+    if os.environ.get("TSCD_TL_NO_CHECK") != "1":
+        model.check_assignments()
+    mark("check_out")
     scaler.step(opt)
     scaler.update()
-    model.join_prefetch()
     ema.update()
     mark("step_out")
     if rec is not None:

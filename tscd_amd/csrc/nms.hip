@@ -28,6 +28,7 @@
 
 #define NMS_MAXC32 65536  // candidates per frame the 32-bit sort key can index (16-bit index field); more: 64-bit keys
 #define NMS_MAXPC 2048    // boxes per (frame, class) in one LDS tile of the greedy pass
+#define NMS_FLUSH (NMS_MAXPC - 256)  // a tile is processed (and its survivors appended to the kept list) once more than this many boxes are pulled
 
 // ---- candidate record arrays, all [L][capM] -------------------------------------------------------------
 struct Cand {
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const float* __restrict
   };
   // pull this class' boxes out of the score-sorted list, preserving order; a full tile is processed before the pull goes on
   for (int i0 = 0; i0 < M; i0 += 256) {
-    if (base > NMS_MAXPC - 256) {            // uniform (shared): the next 256 candidates might not fit
+    if (base > NMS_FLUSH) {                  // uniform (shared): the next 256 candidates might not fit
       process_tile(base, true);
       if (tid == 0) base = 0;
       __syncthreads();
@@ -454,13 +455,13 @@ static int nms_pow2_64(int capM) {
 }
 
 // max_rows: the largest number of detection rows (proposals) in one frame -- a class of a frame has at most that many boxes; the
-// kept-box lists of the tiled greedy pass are only reserved when it exceeds one tile.
+// kept-box lists of the tiled greedy pass are reserved whenever the pull loop can flush a tile (more than NMS_FLUSH boxes of one class).
 extern "C" long tscd_nms_workspace_bytes(int L, int capM, int NC, int max_rows) {
   long per = (long)capM * (16 + 4 + 6 + 4 + 4 + 1) + 64 + 8 * 256;
   per += 16L * capM + 256;                                      // kept boxes of the class-agnostic coordinate-trick pass (worst case)
   if (capM > NMS_MAXC32) per += 8L * nms_pow2_64(capM) + 256;   // 64-bit sort keys
   else if (capM > NMS_CHUNK) per += 4L * nms_pow2(capM) + 256;  // global 32-bit sort keys of frames with more than one LDS chunk
-  if (max_rows > NMS_MAXPC) per += 16L * (NC > 0 ? NC : 1) * max_rows + 256;
+  if (max_rows > NMS_FLUSH) per += 16L * (NC > 0 ? NC : 1) * max_rows + 256;
   return (long)L * per + 8192;
 }
 
@@ -522,14 +523,14 @@ extern "C" int tscd_batched_nms(const void* det, int ndet, const int* frame_off,
     TSCD_CHECK_LAUNCH("nms_sort64");
   }
   const int ncg = mode == 2 ? 1 : NC;
-  float* kept_box = max_rows > NMS_MAXPC ? (float*)take(16L * L * ncg * max_rows) : nullptr;
+  float* kept_box = max_rows > NMS_FLUSH ? (float*)take(16L * L * ncg * max_rows) : nullptr;
   hipLaunchKernelGGL(nms_greedy_kernel, dim3(L, ncg), dim3(256), 0, st, c.box, c.cls, order, c.count, capM, iou_thresh, keep, kept_box,
                      max_rows, c.maxc, coord_trick, 0);
   TSCD_CHECK_LAUNCH("nms_greedy");
   if (coord_trick > 0) {
     // the class-agnostic pass over the shifted boxes of the frames with at most coord_trick candidates
     const int rows = coord_trick < capM ? coord_trick : capM;
-    float* kept_all = rows > NMS_MAXPC ? (float*)take(16L * L * rows) : nullptr;
+    float* kept_all = rows > NMS_FLUSH ? (float*)take(16L * L * rows) : nullptr;
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(L, 1), dim3(256), 0, st, c.box, c.cls, order, c.count, capM, iou_thresh, keep, kept_all,
                        rows, c.maxc, coord_trick, 1);
     TSCD_CHECK_LAUNCH("nms_greedy (coordinate trick)");

@@ -355,8 +355,8 @@ class _CombineLosses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dense, rows, r_cls, num_fg_b, ngt_b, lframe):
         dev = dense.device
-        out = torch.empty(8, dtype=torch.float32, device=dev)
-        w = torch.empty(6, dtype=torch.float32, device=dev)
+        out = ops.temp(8, dtype=torch.float32, device=dev)
+        w = ops.temp(6, dtype=torch.float32, device=dev)
         rc = r_cls.detach().float().reshape(1)
         ops.call("tscd_loss_combine_f32", dense.data_ptr(), rows.data_ptr(), rc.data_ptr(), num_fg_b.data_ptr(), ngt_b.data_ptr(),
                  num_fg_b.numel(), int(lframe), out.data_ptr(), w.data_ptr(), ops._stream())

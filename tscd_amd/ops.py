@@ -30,6 +30,89 @@ def _ptr(t):
 
 
 # ----------------------------------------------------------------------------------------------------
+# stream safety of per-call temporaries
+# ----------------------------------------------------------------------------------------------------
+# RULE.  A wrapper's per-call temporaries (workspaces, BatchNorm partial sums, scale / shift rows, outputs) are allocated with
+# ``temp`` / ``ztemp`` while the stream the kernel will be launched on is torch's CURRENT stream, and the launch passes ``_stream()``:
+# the caching allocator hands a freed block only to later work of the SAME stream, so a temporary can die on the host while its
+# kernel is still queued.  A launch on any other stream than the one that was current at allocation reads memory the allocating
+# stream's pool may recycle underneath it (round 3: a "launch-stream override" variant faulted exactly so).  A tensor that does cross
+# streams (an output consumed behind an event wait) is handed over with ``share(t, stream)`` (= Tensor.record_stream).
+# TSCD_DEBUG_STREAMS=1 checks the rule at every C-ABI call: each pointer argument that lies in a ``temp`` allocation must have
+# been allocated under -- or shared with -- the launching stream.
+import bisect as _bisect
+import os as _os0
+
+DEBUG_STREAMS = _os0.environ.get("TSCD_DEBUG_STREAMS", "0") == "1"
+_TEMP_STARTS, _TEMP_ENTRIES = [], {}       # sorted block starts; start -> [end, allocating raw stream, set(streams shared with)]
+_STREAM_FIRST = {"tscd_stream_host_func"}  # entry points whose stream is not the last argument
+
+
+def _register_temp(t):
+    n = t.numel() * t.element_size()
+    if n == 0 or not t.is_cuda:
+        return t
+    a = t.data_ptr()
+    i = _bisect.bisect_left(_TEMP_STARTS, a)
+    # a new allocation replaces whatever the registry still knows about the bytes it covers
+    while i < len(_TEMP_STARTS) and _TEMP_STARTS[i] < a + n:
+        del _TEMP_ENTRIES[_TEMP_STARTS[i]]
+        del _TEMP_STARTS[i]
+    if i > 0 and _TEMP_ENTRIES[_TEMP_STARTS[i - 1]][0] > a:
+        _TEMP_ENTRIES[_TEMP_STARTS[i - 1]][0] = a
+    _TEMP_STARTS.insert(i, a)
+    _TEMP_ENTRIES[a] = [a + n, _stream(), set()]
+    return t
+
+
+def _temp_entry(ptr):
+    i = _bisect.bisect_right(_TEMP_STARTS, ptr) - 1
+    if i < 0:
+        return None
+    e = _TEMP_ENTRIES[_TEMP_STARTS[i]]
+    return e if ptr < e[0] else None
+
+
+if DEBUG_STREAMS:
+    def temp(*a, **k):
+        """torch.empty for a per-call temporary (see RULE above); registered for the TSCD_DEBUG_STREAMS check."""
+        return _register_temp(torch.empty(*a, **k))
+
+    def ztemp(*a, **k):
+        return _register_temp(torch.zeros(*a, **k))
+
+    _plain_call = call
+
+    def call(name, *args):      # noqa: F811  (the checking form of _lib.call)
+        launch = args[0] if name in _STREAM_FIRST else args[-1]
+        launch = 0 if launch is None else int(launch)
+        cur = _stream()
+        if launch != cur:
+            raise AssertionError(f"TSCD_DEBUG_STREAMS: {name} launches on stream {launch:#x} while torch's current stream is {cur:#x}")
+        for j, v in enumerate(args):
+            if isinstance(v, int) and v >= (1 << 32):
+                e = _temp_entry(v)
+                if e is not None and e[1] != launch and launch not in e[2]:
+                    raise AssertionError(f"TSCD_DEBUG_STREAMS: argument {j} of {name} is a temporary allocated under stream {e[1]:#x} "
+                                         f"but the launch is on stream {launch:#x} (allocate under the launching stream or ops.share it)")
+        return _plain_call(name, *args)
+else:
+    temp, ztemp = torch.empty, torch.zeros
+
+
+def share(t, stream=None):
+    """Hands a tensor allocated under another stream over to ``stream`` (default: the current one): Tensor.record_stream, so its
+    block is not recycled before that stream's queued work has passed, plus the debug registry's note."""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    t.record_stream(st)
+    if DEBUG_STREAMS:
+        e = _temp_entry(t.data_ptr())
+        if e is not None:
+            e[2].add(int(st.cuda_stream))
+    return t
+
+
+# ----------------------------------------------------------------------------------------------------
 # parameter gradients on their own stream
 # ----------------------------------------------------------------------------------------------------
 # Nothing in a backward pass waits for a weight gradient: the data gradients form the dependent chain, the weight gradients only
@@ -123,7 +206,7 @@ def nhwc_ld(t):
 
 
 def empty_nhwc(B, H, W, C, device):
-    return torch.empty((B, H, W, C), dtype=torch.float16, device=device)
+    return temp((B, H, W, C), dtype=torch.float16, device=device)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -142,7 +225,7 @@ def pack_conv_weight(w, cin_pad=None, mode=0):
     require_gpu(w, "weight")
     Cout, Cin, inner, KH, KW, rows_pad, kpad = _pack_dims(w.shape, cin_pad, mode)
     w = w.detach().contiguous()
-    out = torch.empty((rows_pad, kpad), dtype=torch.float16, device=w.device)
+    out = torch.empty((rows_pad, kpad), dtype=torch.float16, device=w.device)    # cached by WeightCache: persistent, not a per-call temporary
     assert w.dtype in (torch.float32, torch.float16)
     call("tscd_pack_conv_weight", w.data_ptr(), int(w.dtype == torch.float32), out.data_ptr(), Cout, Cin, inner, KH, KW,
          rows_pad, kpad, mode, _stream())
@@ -295,7 +378,7 @@ def conv2d(x, wpk, cout, ksize, stride=1, epilogue=EPI_RAW, bias=None, scale_shi
         # one partial-sum entry per M-tile of the main loop the launch takes
         mt = lib.tscd_conv_stat_tiles(B * Ho * Wo, Wo, Cin, cout, ksize, stride) if plain else \
             lib.tscd_conv_stat_tiles_ex(B * Ho * Wo, Wo, Cin, cout, ksize, stride, groups, variant, tile_m)
-        partial = torch.empty((2, wpk.shape[0], mt), dtype=torch.float32, device=x.device)
+        partial = temp((2, wpk.shape[0], mt), dtype=torch.float32, device=x.device)
     scale = shift = None
     if scale_shift is not None:
         scale, shift = scale_shift[0], scale_shift[1]
@@ -319,9 +402,9 @@ def conv2d(x, wpk, cout, ksize, stride=1, epilogue=EPI_RAW, bias=None, scale_shi
 def bn_finalize(partial, count, gamma, beta, running_mean, running_var, eps=BN_EPS, momentum=BN_MOMENTUM):
     """-> (scale_shift [2,C], save_mean [C], save_invstd [C]); updates running stats in place when given."""
     C = gamma.shape[0]
-    ss = torch.empty((2, C), dtype=torch.float32, device=partial.device)
-    mean = torch.empty(C, dtype=torch.float32, device=partial.device)
-    invstd = torch.empty(C, dtype=torch.float32, device=partial.device)
+    ss = temp((2, C), dtype=torch.float32, device=partial.device)
+    mean = temp(C, dtype=torch.float32, device=partial.device)
+    invstd = temp(C, dtype=torch.float32, device=partial.device)
     call("tscd_bn_finalize", partial.data_ptr(), partial.shape[2], partial.shape[1], C, int(count), gamma.data_ptr(),
          beta.data_ptr(), eps, momentum, _ptr(running_mean), _ptr(running_var), ss.data_ptr(), mean.data_ptr(),
          invstd.data_ptr(), _stream())
@@ -347,8 +430,8 @@ def conv_bn_act_train(x, wpk, cout, ksize, stride, gamma, beta, running_mean, ru
         out = empty_nhwc(B, Ho, Wo, cout, dev)
     raw = empty_nhwc(B, Ho, Wo, cout, dev) if keep_raw else out
     mt = lib.tscd_conv_stat_tiles(B * Ho * Wo, Wo, Cin, cout, ksize, stride)     # one partial-sum entry per M-tile of the variant taken
-    partial = torch.empty((2, wpk.shape[0], mt), dtype=torch.float32, device=dev)
-    small = torch.empty((4, cout), dtype=torch.float32, device=dev)
+    partial = temp((2, wpk.shape[0], mt), dtype=torch.float32, device=dev)
+    small = temp((4, cout), dtype=torch.float32, device=dev)
     call("tscd_conv_bn_act_train_f16", x.data_ptr(), wpk.data_ptr(), raw.data_ptr(), nhwc_ld(raw), partial.data_ptr(), wpk.shape[0],
          B, H, W, Cin, cout, ksize, stride, nhwc_ld(x), gamma.data_ptr(), beta.data_ptr(), eps, momentum, _ptr(running_mean),
          _ptr(running_var), small.data_ptr(), out.data_ptr(), nhwc_ld(out), _ptr(residual),
@@ -393,8 +476,8 @@ def conv_bn_act_train_multi(x, wpk, seg_c, bns, ksize, groups, eps=BN_EPS, momen
         bn_act(raw, ss, act, out=out if keep_raw else None)
         return out, raw, ss, mean, invstd
     mt = lib.tscd_conv_stat_tiles_ex(B * H * W, W, Cin, cout_launch, ksize, 1, groups, -1, 0)
-    partial = torch.empty((2, wpk.shape[0], mt), dtype=torch.float32, device=dev)
-    small = torch.empty((4, Ctot), dtype=torch.float32, device=dev)
+    partial = temp((2, wpk.shape[0], mt), dtype=torch.float32, device=dev)
+    small = temp((4, Ctot), dtype=torch.float32, device=dev)
     rms = [t[2] for t in bns]
     call("tscd_conv_bn_act_train_multi_f16", x.data_ptr(), wpk.data_ptr(), raw.data_ptr(), nhwc_ld(raw), partial.data_ptr(), B, H, W, Cin,
          seg_c, nseg, groups, ksize, nhwc_ld(x), _ptr_array([t[0] for t in bns]), _ptr_array([t[1] for t in bns]), eps, momentum,
@@ -407,7 +490,7 @@ def conv_bn_act_train_multi(x, wpk, seg_c, bns, ksize, groups, eps=BN_EPS, momen
 
 def bn_fold(gamma, beta, running_mean, running_var, eps=BN_EPS):
     C = gamma.shape[0]
-    ss = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
+    ss = torch.empty((2, C), dtype=torch.float32, device=gamma.device)      # cached per BatchNorm state by the callers: persistent
     call("tscd_bn_fold", gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), eps, C,
          ss.data_ptr(), _stream())
     return ss
@@ -535,7 +618,7 @@ def linear(x, weight, bias=None, out=None, wpk=None):
     nout = weight.shape[0] if weight is not None else out.shape[1]
     wpk = LINEAR_WEIGHTS.get(weight) if wpk is None else wpk
     if out is None:
-        out = torch.empty((n, nout), dtype=torch.float16, device=x.device)
+        out = temp((n, nout), dtype=torch.float16, device=x.device)
     if n == 0:
         return out
     if not (x.is_cuda and x.dtype == torch.float16 and x.stride(1) == 1 and out.stride(1) == 1 and K % 8 == 0
@@ -607,9 +690,9 @@ def decode_score(raw_levels, geo, num_classes, want_outputs):
     nch = 5 + num_classes
     for r in raw_levels:
         assert r.is_contiguous() and r.shape[-1] == nch and r.dtype == torch.float16
-    outputs = torch.empty((B, geo.A, nch), dtype=torch.float16, device=dev) if want_outputs else None
-    det = torch.empty((B, geo.A, 7 + num_classes), dtype=torch.float16, device=dev)
-    score = torch.empty((B, geo.A), dtype=torch.float16, device=dev)
+    outputs = temp((B, geo.A, nch), dtype=torch.float16, device=dev) if want_outputs else None
+    det = temp((B, geo.A, 7 + num_classes), dtype=torch.float16, device=dev)
+    score = temp((B, geo.A), dtype=torch.float16, device=dev)
     call("tscd_decode_score", raw_levels[0].data_ptr(), raw_levels[1].data_ptr(), raw_levels[2].data_ptr(), geo.c_hw, geo.c_w,
          geo.c_stride, B, num_classes, _ptr(outputs), det.data_ptr(), score.data_ptr(), _stream())
     return outputs, det, score
@@ -620,8 +703,8 @@ def select_proposals(score, conf_thresh, min_keep, max_keep):
     B, A = score.shape
     cap = max_keep if max_keep > 0 else A
     cap = max(cap, min_keep, 1)
-    idx = torch.empty((B, cap), dtype=torch.int32, device=score.device)
-    cnt = torch.empty((B,), dtype=torch.int32, device=score.device)
+    idx = temp((B, cap), dtype=torch.int32, device=score.device)
+    cnt = temp((B,), dtype=torch.int32, device=score.device)
     call("tscd_select_proposals", score.data_ptr(), B, A, float(conf_thresh), int(min_keep), int(max_keep), cap, idx.data_ptr(),
          cnt.data_ptr(), _stream())
     return idx, cnt
@@ -652,7 +735,7 @@ def gather_rows(maps_per_feature, geo, sel_idx, frame_off, N, W):
     -> list of [N, W] tensors."""
     nm = len(maps_per_feature)
     dev = sel_idx.device
-    outs = [torch.empty((N, W), dtype=torch.float16, device=dev) for _ in range(nm)]
+    outs = [temp((N, W), dtype=torch.float16, device=dev) for _ in range(nm)]
     ld = _maps_ld(maps_per_feature, W)
     B = maps_per_feature[0][0].shape[0]
     call("tscd_gather_rows", _map_table(maps_per_feature), geo.c_hw, sel_idx.data_ptr(), sel_idx.shape[1], frame_off.data_ptr(),
@@ -674,9 +757,9 @@ def scatter_rows(grads, grad_maps_per_feature, geo, sel_idx, frame_off, N, W):
 def gather_det(det, sel_idx, frame_off, N, rows=False):
     """-> pred_result rows [N,nd]; with ``rows`` also the (frame, anchor) of every row as two int32 vectors."""
     B, A, nd = det.shape
-    out = torch.empty((N, nd), dtype=torch.float16, device=det.device)
+    out = temp((N, nd), dtype=torch.float16, device=det.device)
     if rows:
-        rb = torch.empty((2, N), dtype=torch.int32, device=det.device)
+        rb = temp((2, N), dtype=torch.int32, device=det.device)
         call("tscd_gather_det_rows", det.data_ptr(), A, nd, sel_idx.data_ptr(), sel_idx.shape[1], frame_off.data_ptr(), B, N,
              out.data_ptr(), rb[0].data_ptr(), rb[1].data_ptr(), _stream())
         return out, rb[0], rb[1]
@@ -715,12 +798,12 @@ def mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale
     if splits is None:
         splits = mca_splits(nt)
     ws_bytes = lib.tscd_mca_workspace_bytes(N, N_L, W, splits)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    rows = torch.empty((lib.tscd_mca_rows_bytes(N, N_L, W),), dtype=torch.uint8, device=dev) if keep_workspace else None
-    mk = lambda c: torch.empty((N_L, c), dtype=torch.float16, device=dev)
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=dev)
+    rows = temp((lib.tscd_mca_rows_bytes(N, N_L, W),), dtype=torch.uint8, device=dev) if keep_workspace else None
+    mk = lambda c: temp((N_L, c), dtype=torch.float16, device=dev)
     xcat_c, cat3_c = mk(2 * W), mk(3 * W)
     xcat_r, cat3_r = (mk(2 * W), mk(3 * W)) if need_reg else (None, None)
-    stats = torch.empty((10 * N_L,), dtype=torch.float32, device=dev) if want_stats else None
+    stats = temp((10 * N_L,), dtype=torch.float32, device=dev) if want_stats else None
     for t in (q_c, kv_c, q_r, kv_r, score):
         assert t.is_contiguous() and t.dtype == torch.float16
     call("tscd_mca_forward", q_c.data_ptr(), kv_c.data_ptr(), q_r.data_ptr(), kv_r.data_ptr(), score.data_ptr(),
@@ -740,12 +823,12 @@ def mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale,
     nt = tiles.shape[0]
     S = mca_splits(nt)
     ws_bytes = lib.tscd_mca_backward_workspace_bytes(N, N_L, W, S, nt)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    dq_c = torch.empty((N_L, W), dtype=torch.float16, device=dev)
-    dq_r = torch.empty((N_L, W), dtype=torch.float16, device=dev)
-    dkv_c = torch.empty((N, 2 * W), dtype=torch.float16, device=dev)
-    dkv_r = torch.empty((N, 2 * W), dtype=torch.float16, device=dev)
-    dscore = torch.empty((N,), dtype=torch.float32, device=dev)
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=dev)
+    dq_c = temp((N_L, W), dtype=torch.float16, device=dev)
+    dq_r = temp((N_L, W), dtype=torch.float16, device=dev)
+    dkv_c = temp((N, 2 * W), dtype=torch.float16, device=dev)
+    dkv_r = temp((N, 2 * W), dtype=torch.float16, device=dev)
+    dscore = temp((N,), dtype=torch.float32, device=dev)
     for t in (dxcat_c, dcat3_c, cat3_c) + ((dxcat_r, dcat3_r, cat3_r) if need_reg else ()):
         assert t.is_contiguous() and t.dtype == torch.float16
     call("tscd_mca_backward_fws", q_c.data_ptr(), kv_c.data_ptr(), q_r.data_ptr(), kv_r.data_ptr(), score.data_ptr(), tiles.data_ptr(), nt,
@@ -767,7 +850,7 @@ def linear_dgrad(dy, weight):
         d2[:, :out_f] = dy
         dy = d2
     wpk = LINEAR_WEIGHTS.get(weight, mode=1)        # data-gradient packing, cached per parameter version like the forward copy
-    return linear(dy, None, out=torch.empty((n, in_f), dtype=torch.float16, device=dy.device), wpk=wpk)
+    return linear(dy, None, out=temp((n, in_f), dtype=torch.float16, device=dy.device), wpk=wpk)
 
 
 def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False, grad_params=None):
@@ -782,13 +865,13 @@ def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False, grad_pa
         d2[:, :out_f] = dy
         dy = d2
     dev = x.device
-    dx = torch.empty((n, in_f), dtype=torch.float16, device=dev) if need_dx else None
-    dw = torch.empty((outp, in_f), dtype=torch.float32, device=dev) if need_dw else None
-    db = torch.empty((outp,), dtype=torch.float32, device=dev) if need_db else None
+    dx = temp((n, in_f), dtype=torch.float16, device=dev) if need_dx else None
+    dw = temp((outp, in_f), dtype=torch.float32, device=dev) if need_dw else None
+    db = temp((outp,), dtype=torch.float32, device=dev) if need_db else None
     if n == 0:
         return (dx, None if dw is None else dw.zero_()[:out_f], None if db is None else db.zero_())
     ws_bytes = lib.tscd_linear_bwd_workspace_bytes(n, in_f, outp)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=dev)
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
@@ -801,9 +884,9 @@ def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False, grad_pa
             call("tscd_linear_bwd_packed_f16", *args, _ptr(dx), 0, 0, ws.data_ptr(), ws_bytes, _stream())
         with param_grad_stream(grad_params, x, dy) as side:
             if side:      # allocated under the second stream
-                dw = torch.empty((outp, in_f), dtype=torch.float32, device=dev) if need_dw else None
-                db = torch.empty((outp,), dtype=torch.float32, device=dev) if need_db else None
-                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+                dw = temp((outp, in_f), dtype=torch.float32, device=dev) if need_dw else None
+                db = temp((outp,), dtype=torch.float32, device=dev) if need_db else None
+                ws = temp((ws_bytes,), dtype=torch.uint8, device=dev)
             call("tscd_linear_bwd_packed_f16", *args, 0, _ptr(dw), _ptr(db), ws.data_ptr(), ws_bytes, _stream())
     else:
         call("tscd_linear_bwd_packed_f16", *args, _ptr(dx), _ptr(dw), _ptr(db), ws.data_ptr(), ws_bytes, _stream())
@@ -817,13 +900,13 @@ def bias_relu_bwd(dy, y=None):
     M = dy.numel() // C
     assert dy.dtype == torch.float16 and C % 8 == 0
     ldg = nhwc_ld(dy) if dy.dim() == 4 else dy.stride(0)
-    db = torch.empty((C,), dtype=torch.float32, device=dy.device)
+    db = temp((C,), dtype=torch.float32, device=dy.device)
     ws_bytes = lib.tscd_bias_relu_bwd_workspace_bytes(M, C)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=dy.device)
     if y is None:
         call("tscd_bias_relu_bwd_f16", dy.data_ptr(), ldg, 0, 0, 0, 0, M, C, db.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
         return dy, db
-    gm = torch.empty(dy.shape, dtype=torch.float16, device=dy.device)
+    gm = temp(dy.shape, dtype=torch.float16, device=dy.device)
     ldy = nhwc_ld(y) if y.dim() == 4 else y.stride(0)
     call("tscd_bias_relu_bwd_f16", dy.data_ptr(), ldg, y.data_ptr(), ldy, gm.data_ptr(), C, M, C, db.data_ptr(), ws.data_ptr(), ws_bytes,
          _stream())
@@ -923,12 +1006,12 @@ def cos_attn_mfma_bwd(q, k, v, d_out, out, lsum, heads, tiles32, full=False, out
         kalloc = torch.zeros if (ktiles32 is not None and not keys_full) else torch.empty
         dk, dv = (kalloc((nk, C), dtype=torch.float16, device=dev) for _ in range(2))
     if ktiles32 is not None:
-        delta = torch.empty((n * heads,), dtype=torch.float32, device=dev)
+        delta = temp((n * heads,), dtype=torch.float32, device=dev)
         call("tscd_cos_attn_mfma_bwd2_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), d_out.data_ptr(), out.data_ptr(), lsum.data_ptr(),
              n, nk, C, heads, tiles32.data_ptr(), tiles32.shape[0], ktiles32.data_ptr(), ktiles32.shape[0], delta.data_ptr(),
              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _stream())
         return dq, dk, dv
-    ws = torch.empty((2 * nk * C,), dtype=torch.float32, device=dev)
+    ws = temp((2 * nk * C,), dtype=torch.float32, device=dev)
     call("tscd_cos_attn_mfma_bwd_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), d_out.data_ptr(), out.data_ptr(), lsum.data_ptr(),
          n, nk, C, heads, tiles32.data_ptr(), tiles32.shape[0], ws.data_ptr(), ws.numel() * 4, dq.data_ptr(), _stream())
     call("tscd_cos_attn_bwd_finish_f16", k.data_ptr(), ws.data_ptr(), nk, C, heads, dk.data_ptr(), dv.data_ptr(), _stream())
@@ -937,7 +1020,7 @@ def cos_attn_mfma_bwd(q, k, v, d_out, out, lsum, heads, tiles32, full=False, out
 
 def cos_attn(q, k, v, heads, tiles):
     n, C = q.shape
-    out = torch.empty((n, C), dtype=torch.float16, device=q.device)
+    out = temp((n, C), dtype=torch.float16, device=q.device)
     for t in (q, k, v):
         assert t.is_contiguous() and t.dtype == torch.float16 and t.shape[1] == C
     call("tscd_cos_attn_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), C, heads, tiles.data_ptr(), tiles.shape[0],
@@ -947,7 +1030,7 @@ def cos_attn(q, k, v, heads, tiles):
 
 def se_fuse(reg, edge, w0, w2, pos):
     n, C = reg.shape
-    out = torch.empty((n, C), dtype=torch.float16, device=reg.device)
+    out = temp((n, C), dtype=torch.float16, device=reg.device)
     assert reg.stride(1) == 1 and edge.stride(1) == 1
     call("tscd_se_fuse_f16", reg.data_ptr(), reg.stride(0), edge.data_ptr(), edge.stride(0), w0.data_ptr(), w2.data_ptr(),
          _ptr(pos), n, C, out.data_ptr(), _stream())
@@ -956,7 +1039,7 @@ def se_fuse(reg, edge, w0, w2, pos):
 
 def add_layernorm(a, b, gamma, beta, eps=1e-5):
     n, C = a.shape
-    out = torch.empty((n, C), dtype=torch.float16, device=a.device)
+    out = temp((n, C), dtype=torch.float16, device=a.device)
     assert a.is_contiguous() and (b is None or b.is_contiguous())
     call("tscd_add_layernorm_f16", a.data_ptr(), _ptr(b), gamma.data_ptr(), beta.data_ptr(), n, C, eps, out.data_ptr(), _stream())
     return out
@@ -970,9 +1053,9 @@ def cos_attn_bwd(q, k, v, d_out, heads, tiles):
     for t in (q, k, v, d_out):
         assert t.is_contiguous() and t.dtype == torch.float16 and t.shape[1] == C
     assert d_out.shape == q.shape and v.shape == k.shape
-    ws = torch.empty((2 * nk * C,), dtype=torch.float32, device=dev)
-    dq = torch.zeros((n, C), dtype=torch.float16, device=dev)        # rows outside every tile keep a zero gradient
-    dk, dv = (torch.empty((nk, C), dtype=torch.float16, device=dev) for _ in range(2))
+    ws = temp((2 * nk * C,), dtype=torch.float32, device=dev)
+    dq = ztemp((n, C), dtype=torch.float16, device=dev)        # rows outside every tile keep a zero gradient
+    dk, dv = (temp((nk, C), dtype=torch.float16, device=dev) for _ in range(2))
     call("tscd_cos_attn_bwd_f16", q.data_ptr(), k.data_ptr(), v.data_ptr(), d_out.data_ptr(), n, nk, C, heads, tiles.data_ptr(),
          tiles.shape[0], ws.data_ptr(), ws.numel() * 4, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _stream())
     return dq, dk, dv
@@ -989,11 +1072,11 @@ def se_fuse_bwd(reg, edge, w0, w2, d_out, outs=None, acc=None):
         d_reg, d_edge = outs
         assert all(t.is_contiguous() and t.dtype == torch.float16 and tuple(t.shape) == (n, C) for t in outs)
     else:
-        d_reg = torch.empty((n, C), dtype=torch.float16, device=dev)
-        d_edge = torch.empty((n, C), dtype=torch.float16, device=dev)
+        d_reg = temp((n, C), dtype=torch.float16, device=dev)
+        d_edge = temp((n, C), dtype=torch.float16, device=dev)
     name = "tscd_se_fuse_bwd_f16"
     if acc is None:
-        acc = torch.empty((C + 128,), dtype=torch.float32, device=dev)      # zeroed by the entry point
+        acc = temp((C + 128,), dtype=torch.float32, device=dev)      # zeroed by the entry point
     else:
         assert acc.dtype == torch.float32 and acc.is_contiguous() and acc.numel() == C + 128
         name = "tscd_se_fuse_bwd_acc_f16"
@@ -1013,10 +1096,10 @@ def add_layernorm_bwd(a, b, gamma, d_out, eps=1e-5, out=None, acc=None):
         assert out.is_contiguous() and out.dtype == torch.float16 and tuple(out.shape) == (n, C)
         dx = out
     else:
-        dx = torch.empty((n, C), dtype=torch.float16, device=dev)
+        dx = temp((n, C), dtype=torch.float16, device=dev)
     name = "tscd_add_layernorm_bwd_f16"
     if acc is None:
-        acc = torch.empty((2, C), dtype=torch.float32, device=dev)          # zeroed by the entry point
+        acc = temp((2, C), dtype=torch.float32, device=dev)          # zeroed by the entry point
     else:
         assert acc.dtype == torch.float32 and acc.is_contiguous() and tuple(acc.shape) == (2, C)
         name = "tscd_add_layernorm_bwd_acc_f16"
@@ -1034,11 +1117,11 @@ def match_costs_clip(reg, cls, pairs):
     dev = reg.device
     assert reg.stride(1) == 1 and cls.stride(1) == 1 and (2 * C) % 32 == 0
     pad = 128                                   # the GEMM reads its B rows in tiles of up to 128: zero rows behind the last frame
-    norm = torch.empty((n + pad, 2 * C), dtype=torch.float16, device=dev)
+    norm = temp((n + pad, 2 * C), dtype=torch.float16, device=dev)
     call("tscd_row_normalize_f16", reg.data_ptr(), reg.stride(0), n, n + pad, C, 1e-6, norm.data_ptr(), 2 * C, _stream())
     call("tscd_row_normalize_f16", cls.data_ptr(), cls.stride(0), n, n + pad, C, 1e-6, norm[:, C:].data_ptr(), 2 * C, _stream())
     shapes = [(r1 - r0, c1 - c0) for (r0, r1, c0, c1) in pairs]
-    flat = torch.empty((sum(a * b for a, b in shapes),), dtype=torch.float16, device=dev)
+    flat = temp((sum(a * b for a, b in shapes),), dtype=torch.float16, device=dev)
     o = 0
     for (r0, r1, c0, c1), (nr, nc) in zip(pairs, shapes):
         if nr * nc:
@@ -1054,13 +1137,13 @@ def match_cost(ref_reg, cur_reg, ref_cls, cur_cls):
     dev = ref_reg.device
     bn = lib.tscd_conv_tile_n(ncur)
     rows_pad = (ncur + bn - 1) // bn * bn
-    a = torch.empty((nr, 2 * C), dtype=torch.float16, device=dev)
-    b = torch.empty((rows_pad, 2 * C), dtype=torch.float16, device=dev)
+    a = temp((nr, 2 * C), dtype=torch.float16, device=dev)
+    b = temp((rows_pad, 2 * C), dtype=torch.float16, device=dev)
     for src, dst, n, npad in ((ref_reg, a[:, :C], nr, nr), (ref_cls, a[:, C:], nr, nr), (cur_reg, b[:, :C], ncur, rows_pad),
                               (cur_cls, b[:, C:], ncur, rows_pad)):
         assert src.stride(1) == 1
         call("tscd_row_normalize_f16", src.data_ptr(), src.stride(0), n, npad, C, 1e-6, dst.data_ptr(), 2 * C, _stream())
-    cost = torch.empty((nr, ncur), dtype=torch.float16, device=dev)
+    cost = temp((nr, ncur), dtype=torch.float16, device=dev)
     assert (2 * C) % 32 == 0
     conv2d(a.unsqueeze(0).unsqueeze(0), b, ncur, 1, 1, EPI_COST, out=cost.unsqueeze(0).unsqueeze(0))
     return cost
@@ -1076,10 +1159,10 @@ def batched_nms(det, frame_off, L, num_classes, conf_thresh, iou_thresh, cap_m, 
     dev = det.device
     max_rows = int(max_rows) if max_rows else max(int(det.shape[0]), 1)
     ws_bytes = lib.tscd_nms_workspace_bytes(L, cap_m, num_classes, max_rows)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    out = torch.empty((L, cap_m, 7), dtype=torch.float16, device=dev)
-    idx = torch.empty((L, cap_m), dtype=torch.int32, device=dev)
-    cnt = torch.zeros((L,), dtype=torch.int32, device=dev)
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=dev)
+    out = temp((L, cap_m, 7), dtype=torch.float16, device=dev)
+    idx = temp((L, cap_m), dtype=torch.int32, device=dev)
+    cnt = ztemp((L,), dtype=torch.int32, device=dev)
     call("tscd_batched_nms", det.data_ptr(), det.shape[1], frame_off.data_ptr(), L, _ptr(cls_logit), _ptr(obj_logit),
          _ptr(reg_delta), num_classes, float(conf_thresh), float(iou_thresh), cap_m, max_rows, mode, int(coord_trick), ws.data_ptr(),
          ws_bytes, out.data_ptr(), idx.data_ptr(), cnt.data_ptr(), _stream())
@@ -1094,12 +1177,12 @@ def simota_assign(outputs, labels, geo, num_classes, max_gt, topk=10, emu16=True
     lab = labels.float().contiguous()
     G = min(max_gt, lab.shape[1])
     ws_bytes = lib.tscd_simota_workspace_bytes(B, A, G, topk)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    fg = torch.empty((B, A), dtype=torch.uint8, device=dev)
-    mg = torch.empty((B, A), dtype=torch.int32, device=dev)
-    pi = torch.empty((B, A), dtype=torch.float32, device=dev)
-    nfg = torch.empty((B,), dtype=torch.int32, device=dev)
-    ngt = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=dev)
+    fg = temp((B, A), dtype=torch.uint8, device=dev)
+    mg = temp((B, A), dtype=torch.int32, device=dev)
+    pi = temp((B, A), dtype=torch.float32, device=dev)
+    nfg = temp((B,), dtype=torch.int32, device=dev)
+    ngt = temp((B,), dtype=torch.int32, device=dev)
     assert outputs.is_contiguous() and outputs.dtype == torch.float16
     call("tscd_simota_assign_r", outputs.data_ptr(), lab.data_ptr(), B, A, num_classes, lab.shape[1], G, geo.c_hw, geo.c_w,
          geo.c_stride, topk, int(emu16), float(center_radius), ws.data_ptr(), ws_bytes, fg.data_ptr(), mg.data_ptr(), pi.data_ptr(),
@@ -1118,11 +1201,11 @@ def loss_dense(raw_all, outputs, fg_mask, matched_gt, pred_iou, labels, num_clas
     assert raw_all.is_contiguous() and outputs.is_contiguous() and raw_all.dtype == torch.float16 and outputs.dtype == torch.float16
     assert labels.dtype == torch.float32 and labels.is_contiguous() and pred_iou.dtype == torch.float32
     ws_bytes = lib.tscd_loss_workspace_bytes(B, A, 0)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    sums = torch.empty((3,), dtype=torch.float32, device=dev)
-    d = torch.empty((B, A, 1 + num_classes), dtype=torch.float16, device=dev) if want_grad else None
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=dev)
+    sums = temp((3,), dtype=torch.float32, device=dev)
+    d = temp((B, A, 1 + num_classes), dtype=torch.float16, device=dev) if want_grad else None
     if geo is not None and want_grad:      # base-detector training: also d(IoU-loss sum) / d raw box logits, [B,A,4]
-        d_reg = torch.empty((B, A, 4), dtype=torch.float16, device=dev)
+        d_reg = temp((B, A, 4), dtype=torch.float16, device=dev)
         call("tscd_loss_dense_reg_f16", raw_all.data_ptr(), outputs.data_ptr(), fg_mask.data_ptr(), matched_gt.data_ptr(), pred_iou.data_ptr(),
              labels.data_ptr(), B, A, num_classes, labels.shape[1], geo.c_hw, geo.c_stride, ws.data_ptr(), ws_bytes, sums.data_ptr(), _ptr(d),
              d_reg.data_ptr(), _stream())
@@ -1143,8 +1226,8 @@ def loss_rows(row_b, row_a, A, num_classes, fg_mask, matched_gt, pred_iou, label
         assert t is None or (t.is_contiguous() and t.dtype == torch.float16)
     assert row_b.dtype == torch.int32 and row_a.dtype == torch.int32 and row_b.is_contiguous() and row_a.is_contiguous()
     ws_bytes = lib.tscd_loss_workspace_bytes(0, 0, N)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    sums = torch.empty((3,), dtype=torch.float32, device=dev)
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=dev)
+    sums = temp((3,), dtype=torch.float32, device=dev)
     mk = lambda t: torch.empty_like(t) if (t is not None and want_grad) else None
     d_cls, d_obj, d_reg = mk(cls_logit), mk(obj_logit), mk(reg_delta)
     ndet = 0
@@ -1162,7 +1245,7 @@ def cls_score_gather(raw_all, row_b, row_a, pred_rows, cls_col=6):
     B, A, nch = raw_all.shape
     N = row_b.shape[0]
     assert raw_all.is_contiguous() and raw_all.dtype == torch.float16 and pred_rows.dtype == torch.float16 and pred_rows.stride(1) == 1
-    out = torch.empty((N,), dtype=torch.float16, device=raw_all.device)
+    out = temp((N,), dtype=torch.float16, device=raw_all.device)
     call("tscd_cls_score_gather_f16", raw_all.data_ptr(), B, A, nch, row_b.data_ptr(), row_a.data_ptr(), pred_rows.data_ptr(),
          pred_rows.stride(0), cls_col, N, out.data_ptr(), _stream())
     return out
@@ -1171,7 +1254,7 @@ def cls_score_gather(raw_all, row_b, row_a, pred_rows, cls_col=6):
 def cls_score_scatter(g, s, shape, row_b, row_a, pred_rows, cls_col=6):
     """Backward of cls_score_gather -> d raw_all [B,A,nch] fp16 (zero outside the proposals' own class logits)."""
     B, A, nch = shape
-    d = torch.empty(shape, dtype=torch.float16, device=g.device)
+    d = temp(shape, dtype=torch.float16, device=g.device)
     assert g.is_contiguous() and g.dtype == torch.float16 and s.is_contiguous()
     call("tscd_cls_score_scatter_f16", g.data_ptr(), s.data_ptr(), B, A, nch, row_b.data_ptr(), row_a.data_ptr(), pred_rows.data_ptr(),
          pred_rows.stride(0), cls_col, g.shape[0], d.data_ptr(), _stream())
@@ -1186,11 +1269,11 @@ def pred_grad_split(d_raw, nc):
     ncp = (nc + 7) // 8 * 8
     dev = d_raw.device
     M = B * h * w
-    dy_obj = torch.empty((B, h, w, 8), dtype=torch.float16, device=dev)
-    dy_cls = torch.empty((B, h, w, ncp), dtype=torch.float16, device=dev)
-    db = torch.empty((nch,), dtype=torch.float32, device=dev)
+    dy_obj = temp((B, h, w, 8), dtype=torch.float16, device=dev)
+    dy_cls = temp((B, h, w, ncp), dtype=torch.float16, device=dev)
+    db = temp((nch,), dtype=torch.float32, device=dev)
     ws_bytes = lib.tscd_pred_grad_split_workspace_bytes(M, nch)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=dev)
     call("tscd_pred_grad_split_f16", d_raw.data_ptr(), d_raw.stride(0) if B > 1 else h * w * nch, B, h * w, nch, ncp, dy_obj.data_ptr(),
          dy_cls.data_ptr(), db.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
     return dy_obj, dy_cls, db
@@ -1203,7 +1286,7 @@ def scale_grad(d, g, i0, i1=None, split=0, pad=0):
     assert d.is_contiguous() and d.dtype == torch.float16 and g.dtype == torch.float32 and g.is_contiguous()
     C = d.shape[-1] if d.dim() > 1 else 1
     rows = d.numel() // C
-    out = torch.empty(d.shape[:-1] + (C + pad,) if d.dim() > 1 else d.shape, dtype=torch.float16, device=d.device)
+    out = temp(d.shape[:-1] + (C + pad,) if d.dim() > 1 else d.shape, dtype=torch.float16, device=d.device)
     i1 = i0 if i1 is None else i1
     call("tscd_scale_grad_f16", d.data_ptr(), g.data_ptr(), i0, i1, split if i1 != i0 else C, rows, C, pad, out.data_ptr(), _stream())
     return out
@@ -1218,15 +1301,15 @@ def conv_wgrad(x, dy, cin, cout, ksize, groups=1, variant=1):
     ``variant`` (tests): 0 = the register-staged cross-check loop."""
     B, H, W, _ = x.shape
     M = B * H * W
-    dw = torch.empty((groups * cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    dw = temp((groups * cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
     if groups == 1 and variant == 1:
         ws_bytes = lib.tscd_conv_wgrad_workspace_bytes(M, cout, cin, ksize)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+        ws = temp((ws_bytes,), dtype=torch.uint8, device=x.device)
         call("tscd_conv_wgrad_nhwc_f16", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, cin, cout, ksize, nhwc_ld(x), nhwc_ld(dy),
              ws.data_ptr(), ws_bytes, _stream())
         return dw
     ws_bytes = lib.tscd_conv_wgrad_workspace_bytes_ex(M, cout, cin, ksize, groups)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=x.device)
     call("tscd_conv_wgrad_nhwc_f16_ex", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, cin, cout, ksize, nhwc_ld(x), nhwc_ld(dy),
          groups, variant, ws.data_ptr(), ws_bytes, _stream())
     return dw
@@ -1247,9 +1330,9 @@ def bn_silu_bwd(dy, raw, scale_shift, mean, invstd, gamma):
     dy = dy.contiguous()
     assert raw.is_contiguous()
     ws_bytes = lib.tscd_bn_silu_bwd_workspace_bytes(M, C)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=raw.device)
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=raw.device)
     draw = torch.empty_like(raw)
-    sums = torch.empty((2, C), dtype=torch.float32, device=raw.device)
+    sums = temp((2, C), dtype=torch.float32, device=raw.device)
     call("tscd_bn_silu_bwd_f16", dy.data_ptr(), raw.data_ptr(), scale_shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
          gamma.data_ptr(), M, C, draw.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
     return draw, sums[1], sums[0]
@@ -1264,9 +1347,9 @@ def bn_silu_bwd_multi(dys, raw, scale_shift, mean, invstd, gammas):
     assert len(dys) in (1, 2) and sum(d.shape[-1] for d in dys) == C and all(d.dtype == torch.float16 for d in dys)
     assert len(gammas) in (1, 2) and sum(g.shape[0] for g in gammas) == C and all(g.dtype == torch.float32 for g in gammas)
     ws_bytes = lib.tscd_bn_silu_bwd_workspace_bytes(M, C)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=raw.device)
+    ws = temp((ws_bytes,), dtype=torch.uint8, device=raw.device)
     draw = empty_nhwc(B, H, W, C, raw.device)
-    sums = torch.empty((2, C), dtype=torch.float32, device=raw.device)
+    sums = temp((2, C), dtype=torch.float32, device=raw.device)
     d1 = dys[1] if len(dys) == 2 else None
     call("tscd_bn_silu_bwd_f16_ex", dys[0].data_ptr(), nhwc_ld(dys[0]), _ptr(d1), nhwc_ld(d1) if d1 is not None else 0, dys[0].shape[-1],
          raw.data_ptr(), nhwc_ld(raw), scale_shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gammas[0].data_ptr(),
@@ -1281,8 +1364,9 @@ def bn_silu_bwd_multi(dys, raw, scale_shift, mean, invstd, gammas):
 _EMA_TABLES = {}
 
 
-def ema_update(dst, src, decay):
-    """dst[i] = decay * dst[i] + (1 - decay) * src[i] for lists of same-shaped contiguous fp32 CUDA tensors, one launch.
+def ema_update(dst, src, decay, tag=None):
+    """dst[i] = decay * dst[i] + (1 - decay) * src[i] for lists of same-shaped contiguous fp32 CUDA tensors, one launch
+    (decay 0 with finite dst = a multi-tensor copy).  ``tag`` keeps the cached pointer tables of different callers apart.
     The chunk table (device pointers) is cached and validated against EVERY address on each call (parameters and buffers are
     updated in place, so the addresses only change when a tensor is replaced, moved or cast -- the table is rebuilt then;
     ~0.1 ms of host time for ~1300 addresses).  The kernel writes through raw pointers, which autograd's version counters do
@@ -1292,7 +1376,7 @@ def ema_update(dst, src, decay):
         return
     dev = dst[0].device
     sig = tuple(t.data_ptr() for t in dst) + tuple(t.data_ptr() for t in src)
-    key = (len(dst), dev)
+    key = (len(dst), dev, tag)
     hit = _EMA_TABLES.get(key)
     if hit is None or hit[0] != sig:
         import numpy as np

@@ -154,10 +154,11 @@ class Trainer:
         loss = outputs["total_loss"]
         self.optimizer.zero_grad()
         self.scaler.scale(loss).backward()
+        if hasattr(m, "check_assignments"):
+            m.check_assignments()       # a failed / timed-out assignment chain raises here, BEFORE its step is applied
         self.scaler.step(self.optimizer)
         self.scaler.update()
-        self._join_prefetch()          # EMA (and anything after the step) sees the backbone's buffers behind the prefetched pass
-        if self.use_model_ema:
+        if self.use_model_ema:         # (reads the frozen front's running statistics as they were BEFORE a pending prefetched pass)
             self.ema_model.update(self.model)
         lr = self.lr_scheduler.update_lr(self.progress_in_iter + 1)
         for g in self.optimizer.param_groups:
@@ -188,6 +189,9 @@ class Trainer:
             return
         model = self.ema_model.ema if self.use_model_ema else self.model
         model = model.module if is_parallel(model) else model
-        self._join_prefetch()             # a prefetched backbone pass may still be writing BatchNorm statistics
-        state = {"start_epoch": self.epoch + 1, "model": model.state_dict(), "optimizer": self.optimizer.state_dict()}
+        # a prefetched pass of the next clip may be pending: the live model is saved with the statistics it had before that pass
+        # (step_state_dict), so a resumed run applies that clip once; the EMA copy never saw the pass (ModelEMA.update)
+        live = self.model.module if is_parallel(self.model) else self.model
+        sd = live.step_state_dict() if (model is live and hasattr(live, "step_state_dict")) else model.state_dict()
+        state = {"start_epoch": self.epoch + 1, "model": sd, "optimizer": self.optimizer.state_dict()}
         checkpoint.save_checkpoint(state, update_best_ckpt, self.file_name, ckpt_name, non_blocking=getattr(self.args, "async_ckpt", True))

@@ -84,6 +84,11 @@ class BaseConv(nn.Module):
                 _DEFERRED_TICKS.append(bn.num_batches_tracked)
             else:
                 bn.num_batches_tracked += 1
+        if self.training and not training and _grad_path(self):
+            # BatchNorm in eval() inside a TRAINING model with trainable weights (the exps' fix_bn=True option,
+            # ovis_tscd_large.py:153-160; every shipped exp sets fix_bn=False) needs the running-statistics backward, which is not
+            # built: refuse instead of silently dropping the gradient
+            raise NotImplementedError("BaseConv: gradients through an eval-mode BatchNorm (fix_bn=True) are not implemented")
         if not training:
             # evaluation: scale / shift of the folded BatchNorm, computed once per state of the four BN tensors (a .half() model
             # paid four dtype conversions and a fold kernel per conv and clip otherwise: 5 of its 6 launches)

@@ -78,7 +78,7 @@ class _MCAFunction(torch.autograd.Function):
          w_obj, fwd_ws) = ctx.saved_tensors
         N, W = xc.shape
         nl = q_c.shape[0]
-        z16 = lambda *shape: torch.zeros(shape, dtype=torch.float16, device=xc.device)
+        z16 = lambda *shape: ops.ztemp(shape, dtype=torch.float16, device=xc.device)
 
         def head(g, cat3, xcat, w_o, w_l):
             """through linear(3W->4W) and mca.linear(2W->2W): -> d cat3 [nl,3W], d xcat [nl,2W], dW_o, db_o, dW_l, db_l"""

@@ -36,11 +36,21 @@ def fusable(convs, x=None):
     cout, cin, k, _ = w0.shape
     if not w0.is_cuda or cout % ops.lib.tscd_conv_tile_n(cout) != 0:
         return False
+    mode0 = batch_stats(convs[0])
     for c in convs:
         w = c.conv.weight
         if tuple(w.shape) != (cout, cin, k, k) or c.stride != 1 or w.dtype not in (torch.float32, torch.float16) or not w.is_contiguous():
             return False
+        # one launch normalises all of them: they must agree on batch vs running statistics (fix_bn puts BatchNorms in eval() inside a
+        # training model, ovis_tscd_large.py:153-160), eps and momentum
+        if batch_stats(c) != mode0 or c.bn.eps != convs[0].bn.eps or c.bn.momentum != convs[0].bn.momentum:
+            return False
     return True
+
+
+def batch_stats(conv):
+    """BaseConv.forward's rule (network_blocks.py:58-61 over nn.BatchNorm2d): batch statistics iff the module AND its BatchNorm train."""
+    return bool(conv.training and conv.bn.training)
 
 
 def _fused_weights(params, mode, layout):
@@ -82,10 +92,21 @@ def _fused_weights(params, mode, layout):
         cache._c[(id(p), mode, None)] = (cache._tag(p), blk, weakref.ref(p), tuple(p.shape), None, mode)
         offs.append(i * rows * kpad * 2)
     ops._REFRESH_TABLES.clear()
-    if len(_FUSED) > 256:
-        _FUSED.clear()
+    if key in _FUSED:
+        # the fused buffer of a live key is being replaced: captured graphs of the frozen front hold raw pointers into the old one
+        from tscd_amd import graphs
+        graphs.clear()
     _FUSED[key] = (big, offs, [weakref.ref(p) for p in params])
+    if len(_FUSED) > 64:
+        _evict_dead()
     return big
+
+
+def _evict_dead():
+    """Drop the entries whose parameters are gone (discarded models, EMA copies): per key, never the live ones -- a live entry owns
+    the packed storage that ops.WEIGHTS and captured graphs point into."""
+    for k in [k for k, (_, _, refs) in _FUSED.items() if any(r() is None for r in refs)]:
+        del _FUSED[k]
 
 
 def _bn_tuple(conv):
@@ -128,7 +149,7 @@ def towers_nograd(x, firsts, seconds):
     wa = _fused_weights([c.conv.weight for c in firsts], 0, "dense")
     wb = _fused_weights([c.conv.weight for c in seconds], 0, "grouped")
     k = firsts[0].conv.kernel_size[0]
-    training = firsts[0].training and firsts[0].bn.training
+    training = batch_stats(firsts[0])
     if training:
         _tick(firsts)
         _tick(seconds)
@@ -169,7 +190,7 @@ class _TowerPairTrain(torch.autograd.Function):
         W = wa0.shape[0]
         k = wa0.shape[-1]
         B, H, Wd, _ = b_raw.shape
-        h16 = lambda g: (torch.zeros((B, H, Wd, W), dtype=torch.float16, device=b_raw.device) if g is None else
+        h16 = lambda g: (ops.ztemp((B, H, Wd, W), dtype=torch.float16, device=b_raw.device) if g is None else
                          (g if g.dtype == torch.float16 else g.to(torch.float16)))
         g0, g1 = h16(g0), h16(g1)
         try:

@@ -4,7 +4,7 @@ import os
 import torch
 import torch.nn as nn
 
-from tscd_amd import graphs
+from tscd_amd import graphs, ops
 
 from .network_blocks import defer_bn_ticks
 from .tscd_head import HeadPrefix
@@ -17,7 +17,7 @@ from .tscd_head import HeadPrefix
 # those of an in-place pass, and this clip's step no longer has them on its critical path (forward up to the cost matrices -> host
 # assignment chain -> rest).  TSCD_PREFETCH_BACKBONE=0 disables it.
 PREFETCH_BACKBONE = os.environ.get("TSCD_PREFETCH_BACKBONE", "1") != "0"
-_PREFETCHED = {}        # id(model) -> (clip tensor, pyramid, ready event); module-level: the model must stay deep-copyable
+_PREFETCHED = {}        # id(model) -> (clip tensor, pyramid, ready event, BatchNorm snapshot record); module-level: the model must stay deep-copyable
 _PREFETCH_STREAM = {}   # device -> low-priority stream
 
 
@@ -118,7 +118,7 @@ class TSCD(nn.Module):
         if hit is not None and hit[0] is x:
             torch.cuda.current_stream().wait_event(hit[2])
             for t in hit[1]:
-                t.record_stream(torch.cuda.current_stream())
+                ops.share(t)        # allocated under the prefetch stream, consumed on this one (ops.py: stream-safety rule)
             return HeadPrefix.from_tensors(hit[1])
         front = self._front() if x.is_cuda else None
         if front is not None:
@@ -135,15 +135,77 @@ class TSCD(nn.Module):
         if hit is not None:
             torch.cuda.current_stream().wait_event(hit[2])
 
+    def check_assignments(self):
+        """Joins the assignment chain the device consumed without the host (deferred regime, tscd_matching.py) and raises what its
+        worker raised, or a latch timeout: call between backward and the optimizer step, so that a step computed with the fallback
+        (identity / stale) permutations is never applied.  By then the chain is over (it ends ~2/3 into the step, the host queues the
+        backward until later): the join does not wait in the steady state."""
+        m = getattr(self.head, "local_reg_matcher", None)
+        if m is not None and hasattr(m, "_join_pending"):
+            m._join_pending()
+
+    def _bn_snapshot_lists(self, front):
+        """(live, snapshot) lists of the running_mean / running_var buffers the frozen front updates, the snapshot tensors allocated
+        once; re-collected when a buffer object was replaced (.half() / .to())."""
+        hit = self.__dict__.get("_bn_snap")
+        if hit is not None and all(b is m._buffers[n] for (m, n), b in zip(hit[2], hit[0])):
+            return hit[0], hit[1]
+        owners = [(m, n) for m in front.modules() if isinstance(m, nn.BatchNorm2d) and m.track_running_stats
+                  for n in ("running_mean", "running_var")]
+        live = [m._buffers[n] for m, n in owners]
+        if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in live):
+            self.__dict__["_bn_snap"] = None
+            return None, None
+        snap = [torch.zeros_like(t) for t in live]
+        self.__dict__["_bn_snap"] = (live, snap, owners)
+        return live, snap
+
+    def pre_prefetch_buffers(self):
+        """{data_ptr of a live running-statistics buffer: its value BEFORE the pending prefetched pass} -- empty without a pending pass.
+        The prefetched pass of clip t+1 runs inside step t and advances the frozen front's BatchNorm running statistics; the
+        reference's EMA / checkpoint after step t see them with clip t only (tscd_trainer.py:171-176, utils/ema.py:48-60): those
+        readers take the snapshot the pass left behind.  The current stream is ordered behind the snapshot copy (not behind the pass)."""
+        hit = _PREFETCHED.get(id(self))
+        if hit is None or len(hit) < 4 or hit[3] is None:
+            return {}
+        live, snap, ev = hit[3]
+        torch.cuda.current_stream().wait_event(ev)
+        return {a.data_ptr(): b for a, b in zip(live, snap)}
+
+    def step_state_dict(self):
+        """state_dict() as the reference's loop would see it after the current step: with a prefetched pass pending, the frozen
+        front's running statistics are the pre-pass snapshot and its num_batches_tracked counters are one lower (a resumed run
+        then applies that clip once, not twice)."""
+        sd = self.state_dict()
+        snap = self.pre_prefetch_buffers()
+        if not snap:
+            return sd
+        hit = self.__dict__.get("_bn_snap")
+        fronts = {id(m) for (m, _) in hit[2]}
+        for name, mod in self.named_modules():
+            if id(mod) in fronts:
+                for n in ("running_mean", "running_var"):
+                    sd[f"{name}.{n}"] = snap[mod._buffers[n].data_ptr()].clone()
+                # (under defer_bn_ticks the counters of a pass tick when the step's forward returns: they already include the pass)
+                sd[f"{name}.num_batches_tracked"] = sd[f"{name}.num_batches_tracked"] - 1
+        return sd
+
     def _prefetch(self, next_x):
         side = _prefetch_stream(next_x.device)
         side.wait_stream(torch.cuda.current_stream())            # next_x and every buffer the pass recycles are settled
         front = self._front()
         with torch.cuda.stream(side), torch.no_grad():
+            live, snap = self._bn_snapshot_lists(front)
+            snap_rec = None
+            if live:
+                ops.ema_update(snap, live, 0.0, tag="bn_snapshot")   # snap = 0 * snap + 1 * live: one launch, 0.6 MB
+                sev = torch.cuda.Event()
+                sev.record(side)
+                snap_rec = (live, snap, sev)
             outs = graphs.frozen_pass(front, next_x)               # hipGraph replay after the first clip of a shape
             ev = torch.cuda.Event()
             ev.record(side)
-        _PREFETCHED[id(self)] = (next_x, outs, ev)
+        _PREFETCHED[id(self)] = (next_x, outs, ev, snap_rec)
 
     def _forward(self, x, targets, time_embedding, nms_thresh, lframe, gframe, resume, next_x=None):
         fpn_outs = self._pyramid(x)

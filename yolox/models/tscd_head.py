@@ -46,9 +46,9 @@ class _GatherRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        zeros = [torch.zeros(s, dtype=torch.float16, device=grads[0].device) for s in ctx.shapes]
+        zeros = [ops.ztemp(s, dtype=torch.float16, device=grads[0].device) for s in ctx.shapes]
         per_feature = [zeros[f * 3:(f + 1) * 3] for f in range(ctx.nmaps)]
-        gs = [g if g is not None else torch.zeros((ctx.N, ctx.W), dtype=torch.float16, device=zeros[0].device) for g in grads]
+        gs = [g if g is not None else ops.ztemp((ctx.N, ctx.W), dtype=torch.float16, device=zeros[0].device) for g in grads]
         ops.scatter_rows([g.to(torch.float16) for g in gs], per_feature, ctx.geo, ctx.sel_idx, ctx.frame_off, ctx.N, ctx.W)
         return (None,) * 6 + tuple(zeros)
 
@@ -237,9 +237,9 @@ class TSCDHead(nn.Module):
             x = pre.levels[k][0]
             t0, t1 = self.cls_convs2[k], self.reg_convs2[k]
             fus = FUSE_TOWERS and not x.requires_grad and TW.fusable([t0[0], t1[0], t0[1], t1[1]])
-            if fus and grad and all(p.requires_grad for p in list(t0.parameters()) + list(t1.parameters())):
+            if fus and grad and TW.batch_stats(t0[0]) and all(p.requires_grad for p in list(t0.parameters()) + list(t1.parameters())):
                 cls_maps[k], reg_maps[k] = TW.tower_pair_train(x, t0, t1)
-            elif fus and not grad:
+            elif fus and not grad:                   # (towers_nograd follows the modules' own BatchNorm mode)
                 b2 = TW.towers_nograd(x, [t0[0], t1[0]], [t0[1], t1[1]])
                 cls_maps[k], reg_maps[k] = b2[..., :W], b2[..., W:]
             else:

@@ -336,7 +336,7 @@ class _CafmChain(torch.autograd.Function):
         temb16 = temb.to(torch.float16).contiguous()
         t_emb = ops.linear(temb16, w_pos, b_pos).float()                   # [L, W] fp32 rows (the SE gate takes fp32 position vectors)
         # key side of every frame: k_in = SE(cur, cur_edge) + t_j, then ONE projection each for k and v over all local rows
-        k_in = torch.empty((nl, W), dtype=torch.float16, device=dev)
+        k_in = ops.temp((nl, W), dtype=torch.float16, device=dev)
         for j in range(L):
             s0 = j * n
             ops.call("tscd_se_fuse_f16", feat[s0:].data_ptr(), W, edge[s0:].data_ptr(), W, w0f.data_ptr(), w2f.data_ptr(), t_emb[j].data_ptr(),
@@ -345,13 +345,13 @@ class _CafmChain(torch.autograd.Function):
         mfma = ops.cos_attn_uses_mfma(W, heads)
         tiles = ops.attn_tiles([(0, n, 0, n)], dev, rows=32 if mfma else 16)
         ctx.ktiles = ops.attn_key_tiles([(0, n, 0, n)], dev) if mfma and KEY_STATIONARY_BWD else None
-        q_in = torch.empty((nl, W), dtype=torch.float16, device=dev)
-        q_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
-        t2_all = torch.empty((nl, W), dtype=torch.float16, device=dev)
-        idn_all = torch.empty((nl, W), dtype=torch.float16, device=dev)    # residual inputs: cur (first frame) / cur[c]
-        qedge_all = torch.empty((nl, W), dtype=torch.float16, device=dev)  # query-side edge rows: cur_edge (first) / previous frame's cur_edge[c]
-        out_all = torch.empty((nl, W), dtype=torch.float16, device=dev)    # per-frame outputs in assignment order (= the next frame's tgt)
-        o = torch.empty((nl, W), dtype=torch.float16, device=dev)          # outputs back in proposal order
+        q_in = ops.temp((nl, W), dtype=torch.float16, device=dev)
+        q_all = ops.temp((nl, W), dtype=torch.float16, device=dev)
+        t2_all = ops.temp((nl, W), dtype=torch.float16, device=dev)
+        idn_all = ops.temp((nl, W), dtype=torch.float16, device=dev)    # residual inputs: cur (first frame) / cur[c]
+        qedge_all = ops.temp((nl, W), dtype=torch.float16, device=dev)  # query-side edge rows: cur_edge (first) / previous frame's cur_edge[c]
+        out_all = ops.temp((nl, W), dtype=torch.float16, device=dev)    # per-frame outputs in assignment order (= the next frame's tgt)
+        o = ops.temp((nl, W), dtype=torch.float16, device=dev)          # outputs back in proposal order
         lsums = []
         for j in range(L):
             s0, s1 = j * n, (j + 1) * n
@@ -399,7 +399,7 @@ class _CafmChain(torch.autograd.Function):
         nl = n * L
         h16 = lambda t: t if t.dtype == torch.float16 else t.to(torch.float16)
         d_o, dg_dec, db_dec = ops.add_layernorm_bwd(o, None, g_dec, h16(d_matched).contiguous(), eps_dec)
-        mk = lambda: torch.empty((nl, W), dtype=torch.float16, device=dev)
+        mk = lambda: ops.temp((nl, W), dtype=torch.float16, device=dev)
         dk_all, dv_all, dq_all = mk(), mk(), mk()
         d_idn = mk()                                         # gradient of the residual inputs, in proposal order (added to d_feat at the end)
         d_edge = mk()                                        # query-side contributions to the edge rows, in proposal order
@@ -407,7 +407,7 @@ class _CafmChain(torch.autograd.Function):
         # ONE zeroed arena for every fp32 parameter-gradient accumulator of the chain (the kernels ADD into their part): per frame the
         # query-side gate's [d pos | d w0 | d w2], the key-side gate's, and the residual LayerNorm's [d gamma, d beta]
         SW = W + 128
-        arena = torch.zeros((2 * L * SW + L * 2 * W,), dtype=torch.float32, device=dev)
+        arena = ops.ztemp((2 * L * SW + L * 2 * W,), dtype=torch.float32, device=dev)
         A, K = arena[:L * SW].view(L, SW), arena[L * SW:2 * L * SW].view(L, SW)
         ln_acc = arena[2 * L * SW:].view(L, 2, W)
         carry_out = None        # d loss / d out_j (assignment order) arriving from frame j+1's query path
@@ -440,7 +440,7 @@ class _CafmChain(torch.autograd.Function):
             qedge = edge[:n] if j <= 1 else qedge_all[s0:s1]
             # frame 1's query-side edge rows are frame 0's in place: their gradient goes straight to its destination
             d_tgt, d_qedge, _, _, _ = ops.se_fuse_bwd(tgt, qedge, w0f, w2f, dq_in, acc=A[j],
-                                                      outs=(torch.empty((n, W), dtype=torch.float16, device=dev), d_edge[0:n]) if j == 1 else None)
+                                                      outs=(ops.temp((n, W), dtype=torch.float16, device=dev), d_edge[0:n]) if j == 1 else None)
             if j == 0:
                 d_tgt0, d_qedge0 = d_tgt, d_qedge
                 carry_out = None
@@ -704,7 +704,7 @@ class AwarePositionRegMatcher(nn.Module):
             # Deferred join: the stream waits for the worker (a host function parked on the latch), then copies the index table the
             # worker wrote ([inv_0 | c_1 | inv_1 | ...], tscd_lap_chain_f16_table) -- the host goes on queueing.
             n, L = preds_per_frame[0], len(preds_per_frame)
-            dev_idx = torch.empty((d["tlen"],), dtype=torch.int64, device=dev)
+            dev_idx = ops.temp((d["tlen"],), dtype=torch.int64, device=dev)
             slots = [{"inv": (0, n)}] + [{"c": ((2 * j - 1) * n, n), "inv": (2 * j * n, n)} for j in range(1, L)]
             fused = self._finish_fused(plan, slots, dev_idx, preds_per_frame, resume, features, features_edge, time_embedding, layer, None,
                                        feed=_TableFeed(d["table"], dev_idx, d["latch"], d["gen0"], n, L))

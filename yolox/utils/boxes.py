@@ -31,38 +31,50 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agn
     return [rows[i, :counts[i]].to(prediction.dtype) if counts[i] > 0 else None for i in range(B)]
 
 
-def bboxes_iou(bboxes_a, bboxes_b, xyxy=True):
-    if bboxes_a.shape[1] != 4 or bboxes_b.shape[1] != 4:
-        raise IndexError
+def _corners(b, xyxy):
+    """[n,4] boxes -> (top-left [n,2], bottom-right [n,2]); centre format is (cx, cy, w, h)."""
     if xyxy:
-        tl = torch.max(bboxes_a[:, None, :2], bboxes_b[:, :2])
-        br = torch.min(bboxes_a[:, None, 2:], bboxes_b[:, 2:])
-        area_a = torch.prod(bboxes_a[:, 2:] - bboxes_a[:, :2], 1)
-        area_b = torch.prod(bboxes_b[:, 2:] - bboxes_b[:, :2], 1)
-    else:
-        tl = torch.max(bboxes_a[:, None, :2] - bboxes_a[:, None, 2:] / 2, bboxes_b[:, :2] - bboxes_b[:, 2:] / 2)
-        br = torch.min(bboxes_a[:, None, :2] + bboxes_a[:, None, 2:] / 2, bboxes_b[:, :2] + bboxes_b[:, 2:] / 2)
-        area_a, area_b = torch.prod(bboxes_a[:, 2:], 1), torch.prod(bboxes_b[:, 2:], 1)
-    en = (tl < br).type(tl.type()).prod(dim=2)
-    area_i = torch.prod(br - tl, 2) * en
-    return area_i / (area_a[:, None] + area_b - area_i)
+        return b[:, :2], b[:, 2:4]
+    ctr, ext = b[:, :2], b[:, 2:4] * 0.5
+    return ctr - ext, ctr + ext
+
+
+def bboxes_iou(bboxes_a, bboxes_b, xyxy=True):
+    """Pairwise IoU [len(a), len(b)] (reference contract: utils/boxes.py:131-154 -- IndexError for anything but [n,4] inputs,
+    an empty intersection counts as 0, no epsilon in the denominator)."""
+    for b in (bboxes_a, bboxes_b):
+        if b.dim() != 2 or b.shape[1] != 4:
+            raise IndexError(f"bboxes_iou expects [n,4] boxes, got {tuple(b.shape)}")
+    lo_a, hi_a = _corners(bboxes_a, xyxy)
+    lo_b, hi_b = _corners(bboxes_b, xyxy)
+    lo = torch.maximum(lo_a.unsqueeze(1), lo_b.unsqueeze(0))
+    hi = torch.minimum(hi_a.unsqueeze(1), hi_b.unsqueeze(0))
+    side = hi - lo
+    overlap = side[..., 0] * side[..., 1] * (side > 0).all(dim=2).to(side.dtype)
+    ext_a, ext_b = hi_a - lo_a, hi_b - lo_b
+    area_a, area_b = ext_a[:, 0] * ext_a[:, 1], ext_b[:, 0] * ext_b[:, 1]
+    return overlap / (area_a.unsqueeze(1) + area_b.unsqueeze(0) - overlap)
 
 
 def adjust_box_anns(bbox, scale_ratio, padw, padh, w_max, h_max):
-    bbox[:, 0::2] = np.clip(bbox[:, 0::2] * scale_ratio + padw, 0, w_max)
-    bbox[:, 1::2] = np.clip(bbox[:, 1::2] * scale_ratio + padh, 0, h_max)
+    """Annotation boxes (x1,y1,x2,y2 numpy rows) after a resize by ``scale_ratio`` and a shift by (padw, padh), clipped to the
+    canvas -- in place, like the mosaic code expects (mosaicdetection.py:109-111)."""
+    for axis, (shift, limit) in enumerate(((padw, w_max), (padh, h_max))):
+        cols = bbox[:, axis::2]
+        cols *= scale_ratio
+        cols += shift
+        np.clip(cols, 0, limit, out=cols)
     return bbox
 
 
 def xyxy2xywh(bboxes):
-    bboxes[:, 2] = bboxes[:, 2] - bboxes[:, 0]
-    bboxes[:, 3] = bboxes[:, 3] - bboxes[:, 1]
+    """Corners -> (x1, y1, w, h), in place."""
+    bboxes[:, 2:4] -= bboxes[:, 0:2]
     return bboxes
 
 
 def xyxy2cxcywh(bboxes):
-    bboxes[:, 2] = bboxes[:, 2] - bboxes[:, 0]
-    bboxes[:, 3] = bboxes[:, 3] - bboxes[:, 1]
-    bboxes[:, 0] = bboxes[:, 0] + bboxes[:, 2] * 0.5
-    bboxes[:, 1] = bboxes[:, 1] + bboxes[:, 3] * 0.5
+    """Corners -> (cx, cy, w, h), in place."""
+    bboxes[:, 2:4] -= bboxes[:, 0:2]
+    bboxes[:, 0:2] += bboxes[:, 2:4] * 0.5
     return bboxes

@@ -68,10 +68,17 @@ class ModelEMA:
             self._objs_of = id(inner)
         dst = [a for a, _ in self._pairs]
         src = [b if b.dtype == a.dtype else b.to(a.dtype) for a, b in self._pairs]
+        # A prefetched pass of the NEXT clip (yolox/models/tscd.py) may already have advanced the frozen front's running statistics:
+        # the reference's EMA after step t sees them with clip t only (tscd_trainer.py:171-176) -- read the pre-pass snapshot instead
+        early = inner.pre_prefetch_buffers() if hasattr(inner, "pre_prefetch_buffers") else {}
+        tag = "ema"
+        if early:
+            src = [early.get(b.data_ptr(), b) for b in src]
+            tag = "ema_snapshot"
         if dst and all(a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous()
                        and b.is_contiguous() for a, b in zip(dst, src)):
             from tscd_amd import ops          # one launch, every element read and written once (elementwise.hip)
-            ops.ema_update(dst, src, d)
+            ops.ema_update(dst, src, d, tag=tag)
         else:                                 # CPU models (tests), half-precision copies
             torch._foreach_mul_(dst, d)
             torch._foreach_add_(dst, src, alpha=1.0 - d)
