@@ -406,3 +406,70 @@ def test_train_with_the_reference_assignment_and_proposal_sets_is_tight(golden, 
     # ::test_mca_backward_matches_oracle_autograd, cos > 0.999)
     ranked = sorted(cosines.values())
     assert sum(v >= 0.99 for v in ranked) >= 10 and ranked[1] >= 0.95 and ranked[0] >= 0.75, cosines
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Detection-level evaluation parity: result[i] rows against the reference's golden rows
+# ---------------------------------------------------------------------------------------------------------------------------
+def match_rows(got, ref, iou_thr=0.9, score_band=2e-2, px=0.5):
+    """Greedy one-to-one matching of detection rows [k,7] (x1,y1,x2,y2,obj,cls_conf,cls_id; post_process.py:9-85) in the reference's
+    score order: same class, |obj*cls_conf difference| <= score_band, and IoU >= iou_thr -- or, for boxes the IoU says nothing about
+    (the random-init golden holds boxes 0.005 px high), every coordinate within ``px``.  -> matched / max(len(got), len(ref))."""
+    if got is None or ref is None:
+        return 1.0 if (got is None) == (ref is None) else 0.0
+    got, ref = torch.as_tensor(got).float().cpu(), torch.as_tensor(ref).float().cpu()
+    matched = 0
+    for c in ref[:, 6].unique().tolist():
+        r, g = ref[ref[:, 6] == c], got[got[:, 6] == c]
+        if len(g) == 0:
+            continue
+        lt, rb = torch.maximum(r[:, None, :2], g[None, :, :2]), torch.minimum(r[:, None, 2:4], g[None, :, 2:4])
+        inter = (rb - lt).clamp(min=0).prod(-1)
+        ar, ag = (r[:, 2:4] - r[:, :2]).clamp(min=0).prod(-1), (g[:, 2:4] - g[:, :2]).clamp(min=0).prod(-1)
+        iou = inter / (ar[:, None] + ag[None] - inter).clamp(min=1e-9)
+        near = (r[:, None, :4] - g[None, :, :4]).abs().amax(-1) <= px
+        ok = ((iou >= iou_thr) | near) & (((r[:, 4] * r[:, 5])[:, None] - (g[:, 4] * g[:, 5])[None]).abs() <= score_band)
+        used = torch.zeros(len(g), dtype=torch.bool)
+        for i in torch.argsort(-(r[:, 4] * r[:, 5])).tolist():
+            cand = torch.nonzero(ok[i] & ~used).flatten()
+            if len(cand):
+                used[cand[torch.argmax(iou[i, cand])]] = True
+                matched += 1
+    return matched / max(len(got), len(ref), 1)
+
+
+@pytest.mark.parametrize("mode", ["default", "nms_coord_trick", "mca_fp16_logits", "both_faithful"])
+def test_eval_detections_match_the_golden_rows(golden, model, monkeypatch, mode):
+    """The evaluation OUTPUT CONTRACT (post_process.py:9-85: result[i] [k,7] per local frame) against the reference's golden rows of
+    both clips (the second with resume=True), row by row -- for the product's default arithmetic and for the reference-faithful
+    switches (TSCD_NMS_COORD_TRICK: torchvision's fp16 coordinate-offset NMS; TSCD_MCA_FP16_LOGITS: logits rounded to fp16 before
+    the softmax).  Bar: the matched fraction must reach the fp16-noise floor run's -- the oracle's backbone ops in fp16 on the device
+    feeding the fp32 oracle head and NMS, rows rounded to fp16 like the evaluator's .half() model emits them -- minus 0.05."""
+    from oracle import tscd_oracle as O
+    import yolox.models.post_process as PP
+    import yolox.models.post_trans as PT
+    cfg, sd, vec, meta = golden
+    L, B, G = int(meta["lframe"]), int(meta["B"]), int(meta["gframe"])
+    monkeypatch.setattr(PP, "COORD_TRICK_MAX_BOXES", 5000 if mode in ("nms_coord_trick", "both_faithful") else 0)
+    monkeypatch.setattr(PT, "FP16_LOGITS", mode in ("mca_fp16_logits", "both_faithful"))
+    model.head.local_reg_matcher._clear_state()
+    state = O.MatcherState()
+    sdh = {k: (v.cuda().half() if v.is_floating_point() else v.cuda()) for k, v in sd.items()}
+    temb = torch.from_numpy(vec["time_embedding"])
+    fr_prod, fr_floor, fr_ori = [], [], []
+    for name, resume in (("evalA_", False), ("evalB_", True)):
+        res, ori, dbg = run_eval(model, vec, meta, name, resume)
+        with torch.no_grad():
+            fpn16 = O.yolo_pafpn(sdh, torch.from_numpy(vec[name + "imgs"]).cuda().half(), cfg, False)
+            fres, fori = O.tscd_head({k: v.clone() for k, v in sd.items()}, cfg, [f.float().cpu() for f in fpn16], None, None, temb, 0.5,
+                                     L, G, resume, False, state, {})
+        for i in range(L):
+            ref = vec[f"{name}result{i}"]
+            fr_prod.append(match_rows(res[i], ref))
+            fr_floor.append(match_rows(None if fres[i] is None else fres[i].half().float(), ref))
+            fr_ori.append(match_rows(ori[i], vec[f"{name}result_ori{i}"]))
+            assert res[i] is not None and abs(res[i].shape[0] - ref.shape[0]) <= 0.1 * ref.shape[0] + 5, (res[i].shape, ref.shape)
+    print(f"detection rows matched to the golden [{mode}]: product {np.round(fr_prod, 3).tolist()} (mean {np.mean(fr_prod):.3f}) | "
+          f"fp16-noise floor {np.round(fr_floor, 3).tolist()} (mean {np.mean(fr_floor):.3f}) | original set {np.round(fr_ori, 3).tolist()}")
+    assert np.mean(fr_prod) >= np.mean(fr_floor) - 0.05, (mode, fr_prod, fr_floor)
+    assert min(a - b for a, b in zip(fr_prod, fr_floor)) >= -0.12, (mode, fr_prod, fr_floor)

@@ -200,3 +200,132 @@ def test_c3_hungarian_chain_exact_and_cafm_task_aligned(c3, monkeypatch):
         close(dbg["matcher_obj_preds"], F.linear(dbg["obj_refined"].float().cpu(), sd["head.matcher_obj_pred.weight"],
                                                  sd["head.matcher_obj_pred.bias"]), 3e-2, 1e-2)
         close(dbg["matcher_reg_preds"], F.linear(m4p, sd["head.matcher_reg_pred.weight"], sd["head.matcher_reg_pred.bias"]), 3e-2, 1e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The whole step against the oracle with the product's integer decisions forced
+# ---------------------------------------------------------------------------------------------------------------------------
+GRAD_NAMES = None
+
+
+def _grad_names():
+    """The 24 representative parameters of the tiny golden (towers, wavelet block, both MCAs, CAFM, TaskAligned, prediction heads)."""
+    import os
+    global GRAD_NAMES
+    if GRAD_NAMES is None:
+        vec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tscd_tiny_vectors.npz"))
+        GRAD_NAMES = sorted(k[len("train_grad::"):] for k in vec.keys() if k.startswith("train_grad::"))
+    return GRAD_NAMES
+
+
+@pytest.fixture(scope="module")
+def c3_forced(c3):
+    """fp32 CPU oracle, forward + backward at the benchmark size, on the product's SimOTA result (foreground set, matched boxes, matched
+    IoUs), proposal sets and assignment permutations -- each of which is verified exactly by the tests above."""
+    from oracle import forced
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    names = [n for n in _grad_names() if n in c3["sd"]]
+    losses, grads, aux = forced.oracle_step(c3["sd"], c3["cfg"], c3["imgs"], c3["targets"], c3["temb"], L, G, c3["dbg"], names)
+    return dict(losses=losses, grads=grads, aux=aux, names=names)
+
+
+def test_c3_losses_with_product_decisions_forced(c3, c3_forced):
+    """All 8 loss terms of the benchmark's step 0 within 2 % of the fp32 oracle (loss_matched_iou -- 6 x SmoothL1 at the end of the
+    longest fp16 chain -- within 7 %), i.e. the bars of the tiny-clip test (tests/test_gpu_e2e.py::test_train_with_the_reference_
+    assignment_and_proposal_sets_is_tight) at TSCD-L / 16 x 576^2 / 500 proposals.  Reference: tscd_head.py:1008-1203."""
+    out, ref = c3["out"], c3_forced["losses"]
+    aux, dbg = c3_forced["aux"], c3["dbg"]
+    assert aux["preds_per_frame"] == dbg["preds_per_frame"] == [500] * (L + G)
+    for b in range(L + G):
+        assert torch.equal(aux["agg_idx"][b], dbg["agg_idx"][b].cpu().long())
+    rel = {}
+    for k in ("total_loss", "iou_loss", "conf_loss", "cls_loss", "num_fg", "loss_matched_cls", "loss_matched_obj", "loss_matched_iou"):
+        rel[k] = abs(float(out[k]) - ref[k]) / max(abs(ref[k]), 1e-6)
+    print("C3 loss terms (product / oracle on the product's decisions):",
+          {k: (round(float(out[k]), 4), round(ref[k], 4), round(rel[k], 5)) for k in rel})
+    assert all(v <= 0.02 for k, v in rel.items() if k != "loss_matched_iou") and rel["loss_matched_iou"] <= 0.07, rel
+
+
+def test_c3_gradients_with_product_decisions_forced(c3, c3_forced):
+    """The 24 representative parameter gradients (names of the tiny golden) against the oracle's autograd at full size, at the tiny
+    test's bars: >= 10 at cosine >= 0.99, all but one >= 0.95, none below 0.75; norms within 5 % where the cosine is >= 0.99."""
+    named = dict(c3["model"].named_parameters())
+    cosines, ratios = {}, {}
+    for k in c3_forced["names"]:
+        r = c3_forced["grads"][k]
+        g = named[k].grad
+        if r is None or g is None:
+            assert r is None and (g is None or float(g.abs().max()) == 0), (k, r is None, g is None)
+            continue
+        g = g.float().cpu().flatten() / 1024.0                 # the fixture backpropagates total_loss x 1024 (loss scale)
+        r = r.flatten()
+        cosines[k] = torch.nn.functional.cosine_similarity(g, r, dim=0).item()
+        ratios[k] = (g.norm() / r.norm()).item()
+    print("C3 gradient cosines:", {k.replace("head.", ""): (round(v, 4), round(ratios[k], 3)) for k, v in sorted(cosines.items(), key=lambda kv: kv[1])})
+    assert len(cosines) >= 20, len(cosines)
+    ranked = sorted(cosines.values())
+    assert sum(v >= 0.99 for v in ranked) >= 10 and ranked[1] >= 0.95 and ranked[0] >= 0.75, cosines
+    for k, v in cosines.items():
+        if v >= 0.99:
+            assert abs(ratios[k] - 1) <= 0.05, (k, ratios[k])
+
+
+def test_c3_conv_stack_against_the_oracle(c3, c3_forced):
+    """TSCD-L (width 1.0 / depth 1.0) backbone + PAFPN + stems + towers + Haar edge block at 16 x 576^2 against the fp32 oracle: the FPN
+    maps and, on the proposal rows, the tower outputs (cls_convs2 -> f_cls, reg_convs2 -> f_reg, edge block -> f_edge) and the raw
+    prediction maps -- each within 1.5x the fp16 noise of the oracle's own PyTorch ops run in fp16 on the device (SURVEY 8d rule)."""
+    m, aux, dbg, cfg = c3["model"], c3_forced["aux"], c3["dbg"], c3["cfg"]
+    imgs = c3["imgs"]
+    sdh = {k: (v.cuda().half() if v.is_floating_point() else v.cuda()) for k, v in c3["sd"].items()}
+    with torch.no_grad():
+        # ---- fp16 noise floor: the oracle's ops in fp16 on the device, same weights, batch statistics
+        nz_fpn = O.yolo_pafpn(sdh, imgs.half(), cfg, True)
+        nz = {"fpn": [t.float().cpu() for t in nz_fpn]}
+        idx = [a.cuda().long() for a in dbg["agg_idx"]]
+        rows = lambda flat: torch.cat([flat[i][idx[i]] for i in range(L + G)]).float().cpu()
+        cls_f, reg_f, edge_f, raw = [], [], [], []
+        for k, x in enumerate(nz_fpn):
+            x = O.base_conv(sdh, f"head.stems.{k}", x, 1, True)
+            rf = O.tower(sdh, f"head.reg_convs.{k}", x, True)
+            cf = O.tower(sdh, f"head.cls_convs.{k}", x, True)
+            v = O.tower(sdh, f"head.cls_convs2.{k}", x, True)
+            vr = O.tower(sdh, f"head.reg_convs2.{k}", x, True)
+            raw.append(torch.cat([O.conv_pred(sdh, f"head.reg_preds.{k}", rf), O.conv_pred(sdh, f"head.obj_preds.{k}", rf),
+                                  O.conv_pred(sdh, f"head.cls_preds.{k}", cf)], 1).flatten(2))
+            cls_f.append(v.flatten(2))
+            reg_f.append(vr.flatten(2))
+            edge_f.append(O.wavelets_hf_block(sdh, f"head.edge_enhance_reg.{k}.0", vr).flatten(2))
+        nz["f_cls"] = rows(torch.cat(cls_f, 2).permute(0, 2, 1))
+        nz["f_reg"] = rows(torch.cat(reg_f, 2).permute(0, 2, 1))
+        nz["f_edge"] = rows(torch.cat(edge_f, 2).permute(0, 2, 1))
+        nz["raw"] = torch.cat(raw, 2).permute(0, 2, 1).float().cpu()
+        del sdh, nz_fpn
+        # ---- the product's pyramid (training-mode BatchNorm: batch statistics, as in the step)
+        was = m.training
+        m.train()
+        fpn = m.backbone(imgs)
+        m.train(was)
+        torch.cuda.synchronize()
+
+    def check(name, got, ref, noise):
+        got, ref, noise = got.float().cpu(), ref.float().cpu(), noise.float().cpu()
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        scale = ref.abs().max().item()
+        err, nerr = (got - ref).abs(), (noise - ref).abs()
+        print(f"C3 conv stack {name}: max err {err.max().item():.4g} (fp16 noise {nerr.max().item():.4g}), mean {err.mean().item():.4g} "
+              f"(noise {nerr.mean().item():.4g}), scale {scale:.4g}")
+        assert err.max().item() <= max(1.5 * nerr.max().item(), 2e-3 * scale), (name, err.max().item(), nerr.max().item(), scale)
+        assert err.mean().item() <= max(1.5 * nerr.mean().item(), 5e-4 * scale), (name, err.mean().item(), nerr.mean().item())
+
+    for i in range(3):
+        check(f"fpn{i}", fpn[i].permute(0, 3, 1, 2), aux["fpn"][i], nz["fpn"][i])
+    check("f_cls", dbg["f_cls"].detach(), aux["f_cls"].detach(), nz["f_cls"])
+    check("f_reg", dbg["f_reg"].detach(), aux["f_reg"].detach(), nz["f_reg"])
+    check("f_edge", dbg["f_edge"].detach(), aux["f_edge"].detach(), nz["f_edge"])
+    # raw prediction maps [B,A,5+NC]: the oracle's ``outputs`` are decoded (boxes in pixels); compare the logits (obj, cls) directly and
+    # the box branch through the same decode
+    hw = [(S // s, S // s) for s in STRIDES]
+    xs, ys, ss = O.make_grids(hw, STRIDES)
+    grid, sst = torch.stack((xs, ys), 1)[None], ss[None, :, None]
+    dec = lambda t: torch.cat(((t[..., :2] + grid) * sst, torch.exp(t[..., 2:4]) * sst, t[..., 4:]), -1)
+    check("outputs", dbg["outputs"].detach(), aux["outputs"].detach(), dec(nz["raw"]))
