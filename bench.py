@@ -176,6 +176,13 @@ def make_optimizer(model, lr=0.002 / 64 * 16, momentum=0.9, weight_decay=5e-4, s
     return opt
 
 
+def make_scaler(init_scale=2.0 ** 10):
+    """The trainer's GradScaler (yolox/core/tscd_trainer.py: tscd_amd.optim.GradScaler -- torch's scaler whose inf check over a FusedSGD
+    is that optimizer's one-launch pass).  init_scale 2^10: see main()."""
+    from tscd_amd.optim import GradScaler
+    return GradScaler("cuda", init_scale=init_scale)
+
+
 class FusedEMA:
     """ModelEMA.update (yolox/utils/ema.py:48-60) without the deep copy of the module: EMA tensors of the state that can change.  As in
     the trainer (ModelEMA.attach_to), the EMA of the parameters the optimizer steps rides in the optimizer's launch, frozen parameters
@@ -543,7 +550,7 @@ def main():
     # init_scale 2^10: the loss of the random-init head is ~2e3, so the default 2^16 overflows fp16 activation gradients and the
     # scaler would spend its first ~8 steps skipping (found_inf) while it backs off; start where it settles so that every timed
     # step applies its update
-    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
+    scaler = make_scaler()
     ema = FusedEMA(model, optimizer=opt)
     net = model
     if world > 1 or force_ddp:

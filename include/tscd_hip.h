@@ -170,6 +170,21 @@ int tscd_sgd_ema_step_f32(const void* table, long nchunks, const float* lr, cons
 int tscd_sgd_ema_step_indirect_f32(const void* table, long nchunks, const void* grad_base, const float* lr, const float* wd, int ngroups,
                                    float momentum, int nesterov, const float* grad_scale, const float* found_inf, float d,
                                    float one_minus_d, void* stream);
+/* Weight gradients of SEVERAL nn.Linear layers in one launch (autograd of the proposal stage's linears: tscd_head.py:123,130-133
+ * fc_reg_matcher / cls_pred / matcher_*_pred, post_trans.py:566-577,1119-1125 MCA projections, tscd_matching.py:31-60,704 attention
+ * projections -- ~25 per step, a few thousand rows each, none of which the backward pass waits for).  jobs: HOST array of njobs
+ * (<= tscd_linear_wgrad_batch_max_jobs()) records {const void* x [M][in_f] fp16; const void* dy [M][out_f] fp16; float* dw
+ * [out_f][in_f]; long M; int in_f, out_f, ldx, lddy} (features and row strides multiples of 8, pointers 16-byte aligned);
+ * dw_j = dy_j^T x_j, each job unsplit and written once (deterministic). */
+int tscd_linear_wgrad_batch_max_jobs(void);
+int tscd_linear_wgrad_batch_f16(const void* jobs_host, int njobs, void* stream);
+/* The step's gradients into one flat fp32 arena and / or their non-finite check, one launch: replaces the GradScaler's inf check
+ * inside scaler.step (tscd_trainer.py:171-176; torch: 6 multi-tensor launches) and the flattening of gradients into all-reduce
+ * buckets that DistributedDataParallel does per parameter (tscd_trainer.py:230-231).  table: device array of nrows records
+ * {float* dst or NULL (check only), long src_off (bytes), long n (<= tscd_ema_chunk_elems()), long pi}; the source of a row is
+ * src_base[pi] + src_off (src_base: device array of per-parameter gradient pointers); dst = src * scale; *found_inf (device scalar or
+ * NULL) is set to 1 when any element read is Inf / NaN and never cleared. */
+int tscd_grad_gather_check_f32(const void* table, long nrows, const void* src_base, float scale, float* found_inf, void* stream);
 int tscd_haar_idwt_mul_bwd_nhwc_f16(const void* d, const void* hf, const void* content, int ldc, void* dcontent, void* dhf,
                                     int B, int H, int W, int C, void* stream);
 

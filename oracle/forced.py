@@ -66,7 +66,7 @@ class replay_assignments:
         return False
 
 
-def oracle_step(sd, cfg, imgs, targets, temb, lframe, gframe, dbg, grad_names=(), backward=True):
+def oracle_step(sd, cfg, imgs, targets, temb, lframe, gframe, dbg, grad_names=(), backward=True, retain=()):
     """fp32 oracle train forward (+ backward into ``grad_names``) on the product's decisions.  sd: CPU fp32 state dict (cloned here).
     -> (loss dict of floats, {name: gradient}, aux)."""
     sd = {k: (v.detach().float().clone() if v.is_floating_point() else v.detach().clone()) for k, v in sd.items()}
@@ -77,6 +77,9 @@ def oracle_step(sd, cfg, imgs, targets, temb, lframe, gframe, dbg, grad_names=()
         out = O.tscd_forward(sd, cfg, imgs.float().cpu(), targets.float().cpu(), temb.float().cpu(), 0.5, lframe, gframe, False, True,
                              O.MatcherState(), aux)
         if grad_names and backward:
+            for k in retain:                    # activation gradients for diagnostics (e.g. the size of d f_edge next to fp16's range)
+                if torch.is_tensor(aux.get(k)) and aux[k].requires_grad:
+                    aux[k].retain_grad()
             out["total_loss"].backward()
     losses = {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in out.items()}
     grads = {k: sd[k].grad for k in grad_names} if backward else {}

@@ -56,6 +56,11 @@ class TSCDConfig:
     # anchor that has a NaN IoU with ANY other gt (far-apart boxes: prod(br - tl) overflows fp16, times the zero overlap flag).
     # False = the reference's expression (tscd_head.py:1540-1543).
     simota_matched_pair_iou: bool = False
+    # Under autocast the head's conv outputs are fp16 tensors and decode_outputs (tscd_head.py:755-770: grids.type(dtype), (xy + grid) *
+    # stride, exp(wh) * stride) runs on them op by op in fp16: box coordinates beyond 256 / 512 px then sit on a 0.25 / 0.5 px lattice,
+    # which moves the IoU loss of a ~10 px box by several %.  True = that arithmetic for the TRAINING ``outputs`` boxes (logits stay
+    # fp32); False = the fp32 evaluation.
+    decode_autocast: bool = False
 
     @property
     def head_width(self):
@@ -748,6 +753,11 @@ def tscd_head(sd, cfg, xin, labels=None, imgs=None, time_embedding=None, nms_thr
     ota_idxs = None
     if training:
         outputs = decode(raw_out)
+        if cfg.decode_autocast:
+            t16 = torch.cat(raw_out, 2).permute(0, 2, 1)[..., :4].half()
+            g16, s16 = grid.half(), sst.half()
+            box16 = torch.cat(((t16[..., :2] + g16) * s16, torch.exp(t16[..., 2:4]) * s16), -1)
+            outputs = torch.cat((box16.float(), outputs[..., 4:]), -1)
         if aux.get("force_simota") is not None:       # test hook: the assignment handed in (see select_proposals)
             (ota_idxs, cls_targets, reg_targets, obj_targets, fg_masks, num_fg, num_gts) = aux["force_simota"](outputs, labels)
         elif cfg.simota_autocast:

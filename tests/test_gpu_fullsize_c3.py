@@ -43,7 +43,7 @@ def c3():
     targets = bench.targets_on_top_proposals(model, imgs, t0, temb, L, G)
     sd = {k: v.detach().float().cpu().clone() if v.is_floating_point() else v.detach().cpu().clone() for k, v in model.state_dict().items()}
     model.head.debug = {}
-    scale = torch.full((), 1024.0, device="cuda")
+    scale = torch.full((), float(__import__("os").environ.get("TSCD_C3_SCALE", "1024")), device="cuda")
     model.head.loss_scale = scale
     out = model(imgs, targets, temb, lframe=L, gframe=G, resume=False)
     (out["total_loss"] * scale).backward()
@@ -51,7 +51,7 @@ def c3():
     dbg = dict(model.head.debug)
     model.head.debug = None
     cfg = O.TSCDConfig(num_classes=NC, minimal_limit=50, maximal_limit=500)
-    return dict(model=model, imgs=imgs, targets=targets, temb=temb, out=out, dbg=dbg, sd=sd, cfg=cfg)
+    return dict(model=model, imgs=imgs, targets=targets, temb=temb, out=out, dbg=dbg, sd=sd, cfg=cfg, scale=float(scale))
 
 
 def test_c3_step_is_the_workload(c3):
@@ -225,7 +225,11 @@ def c3_forced(c3):
     from oracle import forced
     torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
     names = [n for n in _grad_names() if n in c3["sd"]]
-    losses, grads, aux = forced.oracle_step(c3["sd"], c3["cfg"], c3["imgs"], c3["targets"], c3["temb"], L, G, c3["dbg"], names)
+    import dataclasses
+    # the reference's training arithmetic for the box decode: fp16 under autocast (oracle TSCDConfig.decode_autocast)
+    cfg = dataclasses.replace(c3["cfg"], decode_autocast=True)
+    losses, grads, aux = forced.oracle_step(c3["sd"], cfg, c3["imgs"], c3["targets"], c3["temb"], L, G, c3["dbg"], names,
+                                            retain=("f_edge", "f_reg", "f_cls"))
     return dict(losses=losses, grads=grads, aux=aux, names=names)
 
 
@@ -257,10 +261,17 @@ def test_c3_gradients_with_product_decisions_forced(c3, c3_forced):
         if r is None or g is None:
             assert r is None and (g is None or float(g.abs().max()) == 0), (k, r is None, g is None)
             continue
-        g = g.float().cpu().flatten() / 1024.0                 # the fixture backpropagates total_loss x 1024 (loss scale)
+        g = g.float().cpu().flatten() / c3["scale"]            # the fixture backpropagates total_loss x the loss scale
         r = r.flatten()
         cosines[k] = torch.nn.functional.cosine_similarity(g, r, dim=0).item()
         ratios[k] = (g.norm() / r.norm()).item()
+    for k in ("f_edge", "f_reg", "f_cls"):
+        ga = c3_forced["aux"][k].grad
+        if ga is not None:
+            a = ga.abs() * c3["scale"]
+            print(f"oracle d {k} x loss scale: max {float(a.max()):.3g}, median {float(a.median()):.3g}, "
+                  f"share below fp16's smallest normal (6.1e-5) {float((a < 6.1e-5).float().mean()):.3f}, below its smallest subnormal (6e-8) "
+                  f"{float((a < 6e-8).float().mean()):.3f}")
     print("C3 gradient cosines:", {k.replace("head.", ""): (round(v, 4), round(ratios[k], 3)) for k, v in sorted(cosines.items(), key=lambda kv: kv[1])})
     assert len(cosines) >= 20, len(cosines)
     ranked = sorted(cosines.values())
@@ -318,7 +329,7 @@ def test_c3_conv_stack_against_the_oracle(c3, c3_forced):
         assert err.mean().item() <= max(1.5 * nerr.mean().item(), 5e-4 * scale), (name, err.mean().item(), nerr.mean().item())
 
     for i in range(3):
-        check(f"fpn{i}", fpn[i].permute(0, 3, 1, 2), aux["fpn"][i], nz["fpn"][i])
+        check(f"fpn{i}", fpn[i], aux["fpn"][i], nz["fpn"][i])         # the pyramid maps are NCHW-logical (channels-last memory)
     check("f_cls", dbg["f_cls"].detach(), aux["f_cls"].detach(), nz["f_cls"])
     check("f_reg", dbg["f_reg"].detach(), aux["f_reg"].detach(), nz["f_reg"])
     check("f_edge", dbg["f_edge"].detach(), aux["f_edge"].detach(), nz["f_edge"])

@@ -16,7 +16,7 @@ model = bench.build_model(1.0, 1.0, "500").to(dev).train()
 imgs, t0, temb = bench.synth_clip(16, 576, dev)
 targets = bench.targets_on_top_proposals(model, imgs, t0, temb, 4, 12)
 opt = bench.make_optimizer(model, lr=1e-6)
-scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
+scaler = bench.make_scaler()
 one = torch.ones((), device=dev)
 
 

@@ -8,7 +8,7 @@ sys.argv = ["bench.py"]
 args = bench.parse()
 dev = torch.device("cuda", 0)
 model = bench.build_model(args.depth, args.width, args.props).to(dev).train()
-opt = bench.make_optimizer(model, lr=args.lr); scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10); ema = bench.FusedEMA(model)
+opt = bench.make_optimizer(model, lr=args.lr); scaler = bench.make_scaler(); ema = bench.FusedEMA(model)
 imgs, targets, temb = bench.synth_clip(args.frames, args.size, dev, seed=0)
 marks = {}
 orig_finish = M.AwarePositionRegMatcher.finish

@@ -17,7 +17,7 @@ args = bench.parse()
 dev = torch.device("cuda", 0)
 model = bench.build_model(args.depth, args.width, args.props).to(dev).train()
 opt = bench.make_optimizer(model, lr=args.lr)
-scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
+scaler = bench.make_scaler()
 ema = bench.FusedEMA(model, optimizer=opt)
 imgs, t0_, temb = bench.synth_clip(args.frames, args.size, dev, seed=0)
 targets = bench.targets_on_top_proposals(model, imgs, t0_, temb, args.lframe, args.frames - args.lframe)

@@ -30,7 +30,7 @@ if os.environ.get("TSCD_TIMELINE_DDP") == "1":      # the step under Distributed
     dist.init_process_group("nccl", rank=0, world_size=1)
     from tscd_amd import ddp as tscd_ddp
     net = tscd_ddp.wrap(model, device_ids=[0])
-scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
+scaler = bench.make_scaler()
 ema = bench.FusedEMA(model, optimizer=opt)
 imgs, t0_, temb = bench.synth_clip(args.frames, args.size, dev, seed=0)
 targets = bench.targets_on_top_proposals(model, imgs, t0_, temb, args.lframe, args.frames - args.lframe)

@@ -20,7 +20,8 @@ for m in model.modules():
 model.head.initialize_biases(1e-2)
 model = model.cuda().train()
 opt = FusedSGD([p for p in model.parameters()], lr=1e-4, momentum=0.9, nesterov=True, weight_decay=5e-4)
-scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
+from tscd_amd.optim import GradScaler
+scaler = GradScaler("cuda", init_scale=2.0 ** 10)
 g = torch.Generator().manual_seed(1)
 imgs = (torch.rand(B, 3, 640, 640, generator=g) * 255).half().cuda()
 labels = torch.zeros(B, 50, 5)

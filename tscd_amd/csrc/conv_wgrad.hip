@@ -192,25 +192,13 @@ template <int OFF> __device__ __forceinline__ f16x8 tr_frag_asm(unsigned addr) {
   return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(WgradParams p) {
+// One 128 x 128 tile of one split: the body shared by the single-problem kernel and the job-table kernel below.
+__device__ __forceinline__ void wgrad_glds_tile(const WgradParams& p, const int s, const int mt, const int nt) {
   constexpr int BM = 128, BN = 128, BK = 32, NS = 4, LD = 4;
   constexpr int T_BYTES = BK * 256, STAGE = 2 * T_BYTES;
   __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware order: the workgroups of one split (same pixel range) share an L2
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tiles = p.mtiles * p.ntiles;
-  const int per_group = tiles * p.S;
-  const int grp = lid / per_group;
-  const int lid_g = lid - grp * per_group;
-  p.x += grp * p.Cin;
-  p.dy += grp * p.Cout;
-  p.part += (long)grp * p.S * p.Cout * p.Ncols;
-  const int s = lid_g / tiles, tile = lid_g - s * tiles;
-  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
   const int c0 = mt * BM, n0 = nt * BN;
   const int ktotal = (p.M + BK - 1) / BK;
   const int kt0 = s * p.ktiles_per_split;
@@ -384,6 +372,48 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(WgradParams p) 
   }
 }
 
+__global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(WgradParams p) {
+  // XCD-aware order: the workgroups of one split (same pixel range) share an L2
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tiles = p.mtiles * p.ntiles;
+  const int per_group = tiles * p.S;
+  const int grp = lid / per_group;
+  const int lid_g = lid - grp * per_group;
+  p.x += grp * p.Cin;
+  p.dy += grp * p.Cout;
+  p.part += (long)grp * p.S * p.Cout * p.Ncols;
+  const int s = lid_g / tiles, tile = lid_g - s * tiles;
+  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+  wgrad_glds_tile(p, s, mt, nt);
+}
+
+// Job-table form: SEVERAL independent weight-gradient GEMMs of Linear layers (1x1: dW_j[out_j][in_j] = dY_j^T X_j over M_j rows) in
+// ONE launch.  The proposal stage's ~25 linears have a few thousand rows each: launched one by one their weight gradients are
+// launch- and latency-bound (4 GFLOP in 50 us, tools/wgrad_census.py); nothing in the backward pass waits for them, so the host
+// collects them and flushes them together (tscd_amd/ops.py: deferred weight gradients).  A workgroup finds its job by its index
+// (jobs are laid out back to back, heaviest first); S == 1 jobs write straight into dw (torch layout for 1x1).
+#define WGRAD_MAX_JOBS 32
+struct WgradJob { const f16* x; const f16* dy; float* part; int M, Cin, Cout, ldx, lddy, S, ktiles_per_split, mtiles, ntiles, wg_begin; };
+struct WgradJobTable { WgradJob job[WGRAD_MAX_JOBS]; int njobs; };
+__global__ __launch_bounds__(256, 2) void conv_wgrad_glds_jobs_kernel(WgradJobTable t) {
+  const int bid = blockIdx.x;
+  int j = 0;
+  for (int i = 1; i < t.njobs; ++i) j = bid >= t.job[i].wg_begin ? i : j;        // uniform: scalar loads and compares
+  const WgradJob q = t.job[j];
+  WgradParams p;
+  p.x = q.x; p.dy = q.dy; p.part = q.part;
+  p.B = 1; p.H = 1; p.W = q.M; p.Cin = q.Cin; p.Cout = q.Cout; p.KH = 1; p.KW = 1; p.pad = 0;
+  p.ldx = q.ldx; p.lddy = q.lddy;
+  p.M = q.M; p.Ncols = q.Cin; p.S = q.S; p.ktiles_per_split = q.ktiles_per_split; p.mtiles = q.mtiles; p.ntiles = q.ntiles;
+  p.G = 1;
+  const int lid = bid - q.wg_begin, tiles = q.mtiles * q.ntiles;
+  const int s = lid / tiles, tile = lid - s * tiles;
+  const int mt = tile / q.ntiles, nt = tile - mt * q.ntiles;
+  wgrad_glds_tile(p, s, mt, nt);
+}
+
 // dW[cout][cin][kh][kw] (fp32, torch layout) = sum_s part[s][cout][(kh*KW+kw)*Cin + cin].  Threads walk the slabs in SLAB
 // order (a wave reads 256 contiguous bytes of every slab; the S-times smaller dw stream takes the scattered side), four
 // wave-groups share the splits of 64 outputs and combine through LDS in a fixed order (deterministic, no atomics).
@@ -481,6 +511,44 @@ extern "C" int tscd_conv_wgrad_nhwc_f16(const void* x, const void* dy, float* dw
 extern "C" int tscd_conv_wgrad_nhwc_f16_ex(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int ksize,
                                            int ldx, int lddy, int groups, int variant, void* workspace, long workspace_bytes, void* stream) {
   return wgrad_launch(x, dy, dw, B, H, W, Cin, Cout, ksize, ldx, lddy, groups, variant, workspace, workspace_bytes, stream);
+}
+
+// Several Linear weight gradients in one launch (see conv_wgrad_glds_jobs_kernel).  jobs: host array of njobs records
+// {x, dy, dw, M rows, in_f, out_f (multiple of 8; dw is [out_f][in_f] fp32), ldx, lddy}.  Every job runs unsplit (S = 1) and writes its
+// dw directly -- deterministic, no workspace.  At most 32 jobs per call.
+struct WgradJobHost { const void* x; const void* dy; float* dw; long M; int in_f, out_f, ldx, lddy; };
+extern "C" int tscd_linear_wgrad_batch_max_jobs(void) { return WGRAD_MAX_JOBS; }
+extern "C" int tscd_linear_wgrad_batch_f16(const void* jobs_host, int njobs, void* stream) {
+  TSCD_CHECK_ARG(jobs_host && njobs > 0 && njobs <= WGRAD_MAX_JOBS, "linear_wgrad_batch: 1..%d jobs", WGRAD_MAX_JOBS);
+  const WgradJobHost* h = (const WgradJobHost*)jobs_host;
+  // heaviest (most k-tiles) first: they start first and the short ones fill in behind them
+  int order[WGRAD_MAX_JOBS];
+  for (int i = 0; i < njobs; ++i) order[i] = i;
+  for (int i = 1; i < njobs; ++i) {
+    int o = order[i], k = i;
+    while (k > 0 && h[order[k - 1]].M < h[o].M) { order[k] = order[k - 1]; --k; }
+    order[k] = o;
+  }
+  WgradJobTable t;
+  int wg = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const WgradJobHost& a = h[order[i]];
+    TSCD_CHECK_ARG(a.x && a.dy && a.dw && a.M > 0 && a.M < (1L << 31), "linear_wgrad_batch: job %d: null pointer / bad row count", order[i]);
+    TSCD_CHECK_ARG(a.in_f % 8 == 0 && a.out_f % 8 == 0 && a.ldx % 8 == 0 && a.lddy % 8 == 0 && a.ldx >= a.in_f && a.lddy >= a.out_f,
+                   "linear_wgrad_batch: job %d: features / strides must be multiples of 8", order[i]);
+    TSCD_CHECK_ARG(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.dy & 15) == 0, "linear_wgrad_batch: job %d: pointers must be 16-byte aligned", order[i]);
+    WgradJob& q = t.job[i];
+    q.x = (const f16*)a.x; q.dy = (const f16*)a.dy; q.part = a.dw;
+    q.M = (int)a.M; q.Cin = a.in_f; q.Cout = a.out_f; q.ldx = a.ldx; q.lddy = a.lddy;
+    q.S = 1; q.ktiles_per_split = (q.M + 31) / 32;
+    q.mtiles = cdiv(a.out_f, 128); q.ntiles = cdiv(a.in_f, 128);
+    q.wg_begin = wg;
+    wg += q.mtiles * q.ntiles;
+  }
+  t.njobs = njobs;
+  hipLaunchKernelGGL(conv_wgrad_glds_jobs_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
+  TSCD_CHECK_LAUNCH("linear_wgrad_batch");
+  return TSCD_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- BN + SiLU backward

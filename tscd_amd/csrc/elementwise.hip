@@ -868,6 +868,54 @@ extern "C" int tscd_sgd_ema_step_indirect_f32(const void* table, long nchunks, c
 
 
 // ------------------------------------------------------------------------------------------------------
+// Gradients of a step into one flat arena and / or their non-finite check, one launch (reference: the GradScaler's inf check inside
+// scaler.step, tscd_trainer.py:171-176, and DDP's flattening of the gradients into buckets, :230-231).
+//   row = {float* dst (or null: check only), long src_off (bytes into the parameter's gradient), long n, long pi}; src = src_base[pi] + src_off
+//   dst[i] = src[i] * scale      (scale = 1, or 1 / world for backends without an averaging all-reduce)
+//   *found_inf = 1 if any element read is Inf / NaN (never cleared here)
+// torch's _amp_foreach_non_finite_check_and_unscale_ needs 6 launches for the ~150 gradient tensors of a TSCD-L step; this is one.
+// ------------------------------------------------------------------------------------------------------
+struct GradRow { float* dst; long src_off; long n; long pi; };
+__global__ __launch_bounds__(256) void grad_gather_check_kernel(const GradRow* __restrict__ table, const float* const* __restrict__ src_base,
+                                                                float scale, float* __restrict__ found_inf) {
+  const GradRow r = table[blockIdx.x];
+  const float* src = (const float*)((const char*)src_base[r.pi] + r.src_off);
+  bool bad = false;
+  auto fin = [](float v) { return fabsf(v) <= 3.402823466e+38f; };      // false for Inf and NaN
+  if ((((uintptr_t)src | (uintptr_t)r.dst) & 15) == 0) {
+    const long n4 = r.n >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+      float4 v = ((const float4*)src)[i];
+      bad |= !(fin(v.x) && fin(v.y) && fin(v.z) && fin(v.w));
+      if (r.dst) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; ((float4*)r.dst)[i] = v; }
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < r.n; i += 256) {
+      const float v = src[i];
+      bad |= !fin(v);
+      if (r.dst) r.dst[i] = v * scale;
+    }
+  } else {
+    for (long i = threadIdx.x; i < r.n; i += 256) {
+      const float v = src[i];
+      bad |= !fin(v);
+      if (r.dst) r.dst[i] = v * scale;
+    }
+  }
+  if (found_inf && __ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *found_inf = 1.0f;      // every writer stores the same value
+}
+// table: device array of nrows {float* dst or NULL, long src_off, long n (<= tscd_ema_chunk_elems()), long pi}; src_base: device array of
+// per-parameter gradient pointers; found_inf: device scalar or NULL.
+extern "C" int tscd_grad_gather_check_f32(const void* table, long nrows, const void* src_base, float scale, float* found_inf, void* stream) {
+  TSCD_CHECK_ARG((table && src_base) || nrows == 0, "grad_gather_check: null table");
+  if (nrows == 0) return TSCD_OK;
+  TSCD_CHECK_ARG(nrows < (1L << 31), "grad_gather_check: too many rows");
+  hipLaunchKernelGGL(grad_gather_check_kernel, dim3((unsigned)nrows), dim3(256), 0, (hipStream_t)stream, (const GradRow*)table,
+                     (const float* const*)src_base, scale, found_inf);
+  TSCD_CHECK_LAUNCH("grad_gather_check");
+  return TSCD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // BaseConv in training mode as ONE host call: conv (raw output + per-tile BN partial sums) -> batch statistics
 // (scale/shift, saved mean / invstd, running statistics) -> apply + activation (+ residual).  Three launches, the same three
 // kernels as the separate entry points -- what it saves is the host side: one foreign call and one set of argument

@@ -48,6 +48,15 @@ _TEMP_STARTS, _TEMP_ENTRIES = [], {}       # sorted block starts; start -> [end,
 _STREAM_FIRST = {"tscd_stream_host_func"}  # entry points whose stream is not the last argument
 
 
+def _drop_temp(a, token):
+    e = _TEMP_ENTRIES.get(a)
+    if e is not None and e[3] is token:
+        del _TEMP_ENTRIES[a]
+        i = _bisect.bisect_left(_TEMP_STARTS, a)
+        if i < len(_TEMP_STARTS) and _TEMP_STARTS[i] == a:
+            del _TEMP_STARTS[i]
+
+
 def _register_temp(t):
     n = t.numel() * t.element_size()
     if n == 0 or not t.is_cuda:
@@ -61,7 +70,12 @@ def _register_temp(t):
     if i > 0 and _TEMP_ENTRIES[_TEMP_STARTS[i - 1]][0] > a:
         _TEMP_ENTRIES[_TEMP_STARTS[i - 1]][0] = a
     _TEMP_STARTS.insert(i, a)
-    _TEMP_ENTRIES[a] = [a + n, _stream(), set()]
+    token = object()
+    # the entry lives as long as the tensor OBJECT it was made for: once that is gone the block may belong to anything (a parameter
+    # created later, a torch-internal buffer), which this registry knows nothing about.  (A view that outlives its base is then no
+    # longer checked: the check errs on the quiet side.)
+    ref = weakref.ref(t, lambda _r, a=a, token=token: _drop_temp(a, token))
+    _TEMP_ENTRIES[a] = [a + n, _stream(), set(), token, ref]
     return t
 
 
@@ -853,6 +867,97 @@ def linear_dgrad(dy, weight):
     return linear(dy, None, out=temp((n, in_f), dtype=torch.float16, device=dy.device), wpk=wpk)
 
 
+# ----------------------------------------------------------------------------------------------------
+# deferred weight gradients of the proposal stage's linears
+# ----------------------------------------------------------------------------------------------------
+# Nothing in a backward pass waits for a weight gradient.  The ~25 nn.Linear layers of the proposal stage (MCA projections, CAFM /
+# TaskAligned attention projections, fc_reg_matcher, the prediction linears) have a few thousand rows each: launched one by one their
+# dW GEMMs are launch- and latency-bound (tools/wgrad_census.py: 24 calls, 0.7 ms, < 90 TFLOP/s).  Inside a backward pass
+# ``linear_bwd`` therefore only REGISTERS the weight gradient -- (x, dY) kept alive, dW allocated and handed to autograd -- and the
+# pass's final callback computes all of them in ONE launch (tscd_linear_wgrad_batch_f16, conv_wgrad.hip) on the pass's stream.
+# Conditions (as for param_grad_stream): the parameter has no gradient yet and this is its first contribution in this pass, so
+# AccumulateGrad adopts the tensor without reading it; a gradient that was cloned instead (found at the flush) is repaired by a copy.
+# Anything that must read the gradients before the pass ends (the flat-arena reducer of tscd_amd/ddp.py) calls
+# ``flush_deferred_wgrads()`` first.  TSCD_DEFER_LINEAR_WGRAD=0 switches the deferral off.
+import ctypes as _C
+
+DEFER_LINEAR_WGRAD = _os.environ.get("TSCD_DEFER_LINEAR_WGRAD", "1") != "0"
+FOREIGN_GRAD_HOOKS_OK = False      # set by tscd_amd.ddp.ArenaReducer (it flushes before it reads); torch's DDP reducer does not
+
+
+class _WgradJobC(_C.Structure):
+    _fields_ = [("x", _C.c_void_p), ("dy", _C.c_void_p), ("dw", _C.c_void_p), ("M", _C.c_long), ("in_f", _C.c_int), ("out_f", _C.c_int),
+                ("ldx", _C.c_int), ("lddy", _C.c_int)]
+
+
+class _WgradBatch:
+    def __init__(self):
+        self.jobs, self.keep, self.check, self.seen, self.task = [], [], [], set(), -1
+
+    def compute(self):
+        """Launches the registered jobs on the current stream (the pass may go on afterwards: ``seen`` stays)."""
+        jobs, self.jobs = self.jobs, []
+        keep, self.keep = self.keep, []
+        check, self.check = self.check, []
+        if not jobs:
+            return
+        maxj = lib.tscd_linear_wgrad_batch_max_jobs()
+        for i in range(0, len(jobs), maxj):
+            part = jobs[i:i + maxj]
+            arr = (_WgradJobC * len(part))(*part)
+            call("tscd_linear_wgrad_batch_f16", _C.cast(arr, _C.c_void_p), len(part), _stream())
+        for prm, dw in check:
+            g = prm.grad
+            if g is not None and g.untyped_storage().data_ptr() != dw.untyped_storage().data_ptr():
+                # AccumulateGrad cloned the (then unwritten) tensor instead of adopting it: overwrite the clone with the real gradient
+                g.copy_(dw[:g.shape[0]].view_as(g))
+        del keep
+
+    def end_of_pass(self):
+        self.compute()
+        self.seen.clear()
+        self.task = -1
+
+
+_WB = {}
+
+
+def _wgrad_batch(params):
+    if not DEFER_LINEAR_WGRAD or PARAM_GRAD_STREAM:
+        return None
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return None
+    if not FOREIGN_GRAD_HOOKS_OK and torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1:
+        return None
+    dev = _cur_device()
+    b = _WB.get(dev)
+    if b is None:
+        b = _WB[dev] = _WgradBatch()
+    if b.task != task:
+        if b.task >= 0:          # a pass that ended without its callback (an exception in backward)
+            b.end_of_pass()
+        torch.autograd.Variable._execution_engine.queue_callback(b.end_of_pass)
+        b.task = task
+    keys = [prm.data_ptr() for prm in params]
+    if any(k in b.seen for k in keys):
+        # a further contribution to a parameter of this pass: autograd ADDS it to the first one, which therefore has to exist now
+        b.compute()
+        return None
+    if any(prm.grad is not None for prm in params):     # accumulation into a gradient of an earlier pass reads it: not deferred
+        return None
+    b.seen.update(keys)
+    return b
+
+
+def flush_deferred_wgrads():
+    """Computes every registered weight gradient now, on the current stream (no-op when none is pending)."""
+    b = _WB.get(_cur_device())
+    if b is not None:
+        b.compute()
+
+
 def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False, grad_params=None):
     """Backward of y = x W^T (+ b) in ONE foreign call -> (dx fp16 [n,in] | None, dw fp32 [out,in] | None, db fp32 [out] | None).
     x [n,in] fp16 (unit column stride), dy [n,out] fp16.  ``grad_params``: the parameters dw / db are the gradients OF (their
@@ -878,6 +983,16 @@ def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False, grad_pa
     # the data-gradient copy of a PARAMETER is cached per version (and refreshed in the optimizer's batched re-pack): no pack launch here
     wdg = LINEAR_WEIGHTS.get(weight, mode=1) if need_dx and isinstance(weight, torch.nn.Parameter) and weight.is_contiguous() else None
     args = (x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), w.data_ptr(), int(w.dtype == torch.float32), _ptr(wdg), n, in_f, out_f, outp)
+    batch = _wgrad_batch(grad_params) if (need_dw and grad_params is not None and x.stride(1) == 1 and x.stride(0) % 8 == 0
+                                          and x.data_ptr() % 16 == 0 and in_f % 8 == 0) else None
+    if batch is not None:
+        # deferred: data gradient (and the bias column sums) now, the weight-gradient GEMM with all the others at the end of the pass
+        if need_dx or need_db:
+            call("tscd_linear_bwd_packed_f16", *args, _ptr(dx), 0, _ptr(db), ws.data_ptr(), ws_bytes, _stream())
+        batch.jobs.append(_WgradJobC(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, in_f, outp, x.stride(0), dy.stride(0)))
+        batch.keep.append((x, dy))
+        batch.check.append((grad_params[0], dw))
+        return dx, dw[:out_f], (None if db is None else db[:out_f])
     if (need_dw or need_db) and grad_params is not None:
         # data gradient on the pass's stream, parameter gradients on the second one (param_grad_stream)
         if need_dx:

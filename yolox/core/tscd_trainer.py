@@ -28,7 +28,8 @@ class Trainer:
         self.exp, self.args, self.val_loader, self.val = exp, args, val_loader, val
         self.max_epoch = exp.max_epoch
         self.amp_training = getattr(args, "fp16", True)
-        self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp_training)
+        from tscd_amd.optim import GradScaler          # torch.amp.GradScaler with FusedSGD's one-launch inf check (tscd_trainer.py:113)
+        self.scaler = GradScaler("cuda", enabled=self.amp_training)
         self.is_distributed = get_world_size() > 1
         self.rank, self.local_rank = get_rank(), get_local_rank()
         self.device = "cuda:{}".format(self.local_rank)
