@@ -555,7 +555,8 @@ def main():
     net = model
     if world > 1 or force_ddp:
         from tscd_amd import ddp as tscd_ddp
-        net = tscd_ddp.wrap(model, device_ids=[local_rank])
+        net = tscd_ddp.wrap(model, device_ids=[local_rank])       # flat-arena gradient all-reduce (tscd_amd/ddp.py)
+        net.attach(opt)
     imgs, targets0, temb = synth_clip(args.frames, args.size, device, seed=rank)
     gframe = args.frames - args.lframe
     one = torch.ones((), dtype=torch.float32, device=device)

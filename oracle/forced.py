@@ -66,13 +66,19 @@ class replay_assignments:
         return False
 
 
-def oracle_step(sd, cfg, imgs, targets, temb, lframe, gframe, dbg, grad_names=(), backward=True, retain=()):
+def oracle_step(sd, cfg, imgs, targets, temb, lframe, gframe, dbg, grad_names=(), backward=True, retain=(), tower_outputs=False):
     """fp32 oracle train forward (+ backward into ``grad_names``) on the product's decisions.  sd: CPU fp32 state dict (cloned here).
+    ``tower_outputs``: additionally hand in the product's trained-tower outputs -- the gathered rows f_cls / f_reg, the class scores and
+    the edge block's input maps (dbg["reg_maps"], NHWC) -- so that the proposal stage and the edge block run on IDENTICAL inputs on both
+    sides (the towers themselves then receive no gradient in this run).
     -> (loss dict of floats, {name: gradient}, aux)."""
     sd = {k: (v.detach().float().clone() if v.is_floating_point() else v.detach().clone()) for k, v in sd.items()}
     for k in grad_names:
         sd[k].requires_grad_(True)
     aux = forced_aux(dbg, cfg.num_classes)
+    if tower_outputs:
+        aux["force_rows"] = tuple(dbg[k].detach().float().cpu() for k in ("f_cls", "f_reg", "cls_scores"))
+        aux["force_reg_maps"] = [m.detach().permute(0, 3, 1, 2).float().cpu().contiguous() for m in dbg["reg_maps"]]
     with replay_assignments(dbg), torch.set_grad_enabled(bool(grad_names) and backward):
         out = O.tscd_forward(sd, cfg, imgs.float().cpu(), targets.float().cpu(), temb.float().cpu(), 0.5, lframe, gframe, False, True,
                              O.MatcherState(), aux)

@@ -731,6 +731,8 @@ def tscd_head(sd, cfg, xin, labels=None, imgs=None, time_embedding=None, nms_thr
         cls_feat = tower(sd, f"{p}.cls_convs.{k}", x, training)
         vid_feat = tower(sd, f"{p}.cls_convs2.{k}", x, training)
         vid_feat_reg = tower(sd, f"{p}.reg_convs2.{k}", x, training)
+        if aux.get("force_reg_maps") is not None:     # test hook: the edge block's input handed in (see select_proposals)
+            vid_feat_reg = aux["force_reg_maps"][k]
         obj_o = conv_pred(sd, f"{p}.obj_preds.{k}", reg_feat)
         reg_o = conv_pred(sd, f"{p}.reg_preds.{k}", reg_feat)
         cls_o = conv_pred(sd, f"{p}.cls_preds.{k}", cls_feat)
@@ -789,6 +791,8 @@ def tscd_head(sd, cfg, xin, labels=None, imgs=None, time_embedding=None, nms_thr
     f_reg = torch.cat([reg_flat[i][agg_idx[i]] for i in range(len(agg_idx))])
     f_edge = torch.cat([edge_flat[i][agg_idx[i]] for i in range(len(agg_idx))])
     cls_scores = torch.cat([pr[:, 5] for pr in pred_result])
+    if aux.get("force_rows") is not None:             # test hook: the gathered tower rows / class scores handed in
+        f_cls, f_reg, cls_scores = aux["force_rows"]
     aux.update(f_cls=f_cls, f_reg=f_reg, f_edge=f_edge, cls_scores=cls_scores, preds_per_frame=ppf)
 
     features_cls_matched, _ = mca_tscd_g2l_reg(sd, p + ".agg", f_cls, f_reg, cls_scores, ppf, lframe, cfg)

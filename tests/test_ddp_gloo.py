@@ -32,17 +32,34 @@ def _worker(rank, world, port, ref_names, q):
     model = bench.build_model(0.33, 0.125, "500")
     trainable = {k for k, p in model.named_parameters() if p.requires_grad}
     from tscd_amd import ddp as tscd_ddp
-    ddp = tscd_ddp.wrap(model)                             # the product's DDP wiring (bucket views, averaging hook: gloo = divide + sum)
-    # surrogate "step": every trainable parameter contributes, scaled by (rank + 1)
-    loss = sum(p.sum() for p in model.parameters() if p.requires_grad) * float(rank + 1)
-    ddp.reducer.prepare_for_backward([])   # forward of the wrapped module is bypassed on CPU
-    loss.backward()
-    g = next(p for p in model.parameters() if p.requires_grad).grad
+    ddp = tscd_ddp.wrap(model)                             # the product's DDP wiring: flat-arena all-reduce (gloo: divide + sum)
     opt = bench.make_optimizer(model)
+    ddp.attach(opt)
     ema = bench.FusedEMA(model)
-    opt.step()
-    ema.update()
-    q.put((rank, sorted(trainable) == sorted(ref_names), float(g.flatten()[0]), len(opt.param_groups)))
+    # surrogate "step": every trainable parameter contributes, scaled by (rank + 1).  Two steps: the first runs on the provisional
+    # one-chunk layout and learns the gradient-ready order (broadcast from rank 0), the second on the 4-chunk arena
+    firsts, layouts = [], []
+    for step in range(2):
+        opt.zero_grad(set_to_none=True)
+        loss = sum(p.sum() for p in model.parameters() if p.requires_grad) * float(rank + 1)
+        loss.backward()
+        g = next(p for p in model.parameters() if p.requires_grad).grad
+        firsts.append(float(g.flatten()[0]))
+        layouts.append(len(ddp.reducer.chunks))
+        # every published gradient is a slice of the arena and equals the mean over the ranks
+        assert all(p.grad.untyped_storage().data_ptr() == ddp.reducer.arena.untyped_storage().data_ptr()
+                   for p in model.parameters() if p.requires_grad)
+        assert all(bool((p.grad == 1.5).all()) for p in model.parameters() if p.requires_grad)
+        opt.step()
+        ema.update()
+    assert layouts[1] == 4, layouts
+    g0 = firsts[0] if firsts[0] == firsts[1] else float("nan")
+    # the ranks' parameters stay identical
+    chk = [float(p.double().sum()) for p in model.parameters() if p.requires_grad]
+    both = [None] * world
+    dist.all_gather_object(both, chk)
+    assert all(b == both[0] for b in both)
+    q.put((rank, sorted(trainable) == sorted(ref_names), g0, len(opt.param_groups)))
     dist.barrier()
     dist.destroy_process_group()
 

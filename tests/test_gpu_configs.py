@@ -306,7 +306,7 @@ def _ddp_worker(rank, world, port, q):
     scale = torch.full((), 64.0, device="cuda")
     model = fresh()
     from tscd_amd import ddp as tscd_ddp
-    ddp = tscd_ddp.wrap(model, device_ids=[0])               # the product's DDP wiring (bucket views, averaging hook)
+    ddp = tscd_ddp.wrap(model, device_ids=[0])               # the product's DDP wiring: flat-arena gradient all-reduce (tscd_amd/ddp.py)
     model.head.loss_scale = scale
     out = ddp(clips[rank], labels, temb, **kw)               # eager class branch + level streams on (defaults)
     (out["total_loss"] * scale).backward()
@@ -336,10 +336,12 @@ def _ddp_worker(rank, world, port, q):
                 worst = (cos, k)
             assert cos > 0.99 and abs(ratio - 1) < 0.05, (k, cos, ratio)
         res = (len(acc), worst)
-    # two optimizer steps on the wrapped model: FusedSGD on the bucket-view gradients, the next clip's backbone pass prefetched in the
+    # two optimizer steps on the wrapped model: FusedSGD on the arena's gradients, the next clip's backbone pass prefetched in the
     # assignment window (second step: hipGraph replay) -- the ranks' parameters must stay identical bit for bit
     from tscd_amd.optim import FusedSGD
     opt = FusedSGD([p for p in model.parameters() if p.requires_grad], lr=1e-3, momentum=0.9, nesterov=True)
+    ddp.attach(opt)                                          # the optimizer reads the reduced arena (static addresses)
+    assert len(ddp.reducer.chunks) == 4                      # re-laid out in gradient-ready order after the first pass
     for _ in range(2):
         opt.zero_grad(set_to_none=True)
         o2 = ddp(clips[rank], labels, temb, next_x=clips[rank], **kw)

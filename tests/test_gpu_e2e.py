@@ -70,7 +70,7 @@ def _oracle_with_forced_sets(sd, cfg, fpn, temb, L, G, resume, state, ref_idx, m
     from oracle import tscd_oracle as O
     orig = O.select_proposals
 
-    def forced(decode_res, c, ota_idxs=None):
+    def forced(decode_res, c, ota_idxs=None, forced_idx=None):
         out, idx, masks, ro = orig(decode_res, dataclasses.replace(c, conf_thresh=-1.0, minimal_limit=0, maximal_limit=0), ota_idxs)
         out = [o[r.long()] for o, r in zip(out, ref_idx)]
         return out, [r.long() for r in ref_idx], torch.zeros(sum(len(r) for r in ref_idx), 1, dtype=torch.int64), ro

@@ -30,6 +30,7 @@ if os.environ.get("TSCD_TIMELINE_DDP") == "1":      # the step under Distributed
     dist.init_process_group("nccl", rank=0, world_size=1)
     from tscd_amd import ddp as tscd_ddp
     net = tscd_ddp.wrap(model, device_ids=[0])
+    net.attach(opt)
 scaler = bench.make_scaler()
 ema = bench.FusedEMA(model, optimizer=opt)
 imgs, t0_, temb = bench.synth_clip(args.frames, args.size, dev, seed=0)

@@ -38,8 +38,9 @@ def _ptr(t):
 # kernel is still queued.  A launch on any other stream than the one that was current at allocation reads memory the allocating
 # stream's pool may recycle underneath it (round 3: a "launch-stream override" variant faulted exactly so).  A tensor that does cross
 # streams (an output consumed behind an event wait) is handed over with ``share(t, stream)`` (= Tensor.record_stream).
-# TSCD_DEBUG_STREAMS=1 checks the rule at every C-ABI call: each pointer argument that lies in a ``temp`` allocation must have
-# been allocated under -- or shared with -- the launching stream.
+# TSCD_DEBUG_STREAMS=1 checks the rule at every C-ABI call: the launch stream must be torch's current stream, and (outside backward
+# passes, where the autograd engine does the hand-over) each pointer argument that lies in a live ``temp`` allocation must have been
+# allocated under -- or shared with -- the launching stream.
 import bisect as _bisect
 import os as _os0
 
@@ -103,7 +104,13 @@ if DEBUG_STREAMS:
         cur = _stream()
         if launch != cur:
             raise AssertionError(f"TSCD_DEBUG_STREAMS: {name} launches on stream {launch:#x} while torch's current stream is {cur:#x}")
+        # Inside a backward pass the autograd engine hands tensors across streams itself: it orders the consumer behind the producer
+        # and records the consumer's stream on the gradient (torch/csrc/autograd/input_buffer.cpp), which this registry cannot
+        # see -- there only the launch stream is checked.
+        in_backward = torch._C._current_graph_task_id() >= 0
         for j, v in enumerate(args):
+            if in_backward:
+                break
             if isinstance(v, int) and v >= (1 << 32):
                 e = _temp_entry(v)
                 if e is not None and e[1] != launch and launch not in e[2]:

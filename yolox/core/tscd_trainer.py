@@ -59,7 +59,10 @@ class Trainer:
         self.max_iter = len(self.train_loader)
         self.lr_scheduler = self.exp.get_lr_scheduler(self.exp.basic_lr_per_img * self.args.batch_size, self.max_iter)
         if self.is_distributed:
-            model = tscd_ddp.wrap(model, device_ids=[self.local_rank])        # DDP(model, device_ids=[local_rank], broadcast_buffers=False) + bucket views and an averaging hook
+            # DDP(model, device_ids=[local_rank], broadcast_buffers=False) of the reference (tscd_trainer.py:230-231) as a flat-arena
+            # gradient all-reduce (tscd_amd/ddp.py); the fused optimizer reads the reduced arena
+            model = tscd_ddp.wrap(model, device_ids=[self.local_rank])
+            model.attach(self.optimizer)
         if self.use_model_ema:
             self.ema_model = ModelEMA(model, 0.9998)
             self.ema_model.updates = self.max_iter * self.start_epoch

@@ -9,7 +9,10 @@ import torch.nn as nn
 
 
 def is_parallel(model):
-    return isinstance(model, (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel))
+    """torch's wrappers, or tscd_amd.ddp.ArenaDDP (flat-arena gradient all-reduce): anything that holds the model as ``.module``."""
+    if isinstance(model, (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel)):
+        return True
+    return type(model).__name__ == "ArenaDDP" and hasattr(model, "module")
 
 
 class ModelEMA:
