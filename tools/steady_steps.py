@@ -29,9 +29,9 @@ for i in range(N):
     out = model(imgs, targets, temb, lframe=args.lframe, gframe=args.frames - args.lframe, resume=False, next_x=imgs)
     opt.zero_grad(set_to_none=True)
     scaler.scale(out["total_loss"]).backward()
+    model.check_assignments()
     scaler.step(opt)
     scaler.update()
-    model.join_prefetch()
     ema.update()
     if i == N - 51:
         torch.cuda.synchronize()
