@@ -339,6 +339,7 @@ def roofline_dominant_kernel(args, device, step):
     peak = 2500.0
     import yolox.models.tscd_head as head_mod
     ops.CONV_PROFILE = []
+    ops.KERNEL_PROFILE = {}
     nsteps = 3
     # per-launch durations: the three pyramid levels run on ONE stream during these instrumented steps, otherwise the event
     # brackets of a launch include the time it spends queued behind / sharing the CUs with another level's kernels
@@ -361,6 +362,8 @@ def roofline_dominant_kernel(args, device, step):
         graphs.ENABLED = graphs_on
         ops.PARAM_GRAD_STREAM = pgs
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+    kprof, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
+    secondary = roofline_secondary(args, kprof, nsteps)
     sel = [(f, e0.elapsed_time(e1) * 1e-3) for (bn, cin, f, e0, e1, _) in prof if bn == 128 and cin % 32 == 0]
     if args.conv_table:        # per-shape table of every conv / GEMM launch of the instrumented steps (stderr)
         import collections
@@ -414,7 +417,102 @@ def roofline_dominant_kernel(args, device, step):
             "kernel_ms_per_step": secs / nsteps * 1e3,
             "dominant_shape": {"shape": f"B{B} {h}x{h} {W}->{W} 3x3", "gflop_per_launch": f1 / 1e9, "launch_us": t * 1e6,
                                "achieved": f1 / t / 1e12, "frac": f1 / t / 1e12 / peak, "traffic": traffic_dom,
-                               "algorithmic_bytes": 2.0 * (2 * B * h * h * W) + 2.0 * 9 * W * W}}
+                               "algorithmic_bytes": 2.0 * (2 * B * h * h * W) + 2.0 * 9 * W * W}}, secondary
+
+
+def roofline_secondary(args, kprof, nsteps):
+    """The other kernel families of the step against the roofline that bounds each (conv stack MFMA, proposal stage and
+    elementwise passes HBM), from device-event brackets around their wrappers inside the same instrumented steps as `roofline`
+    (single stream, no graph replay).  A bracket spans every launch of the wrapper (MCA forward: prep + stats + aggregate + finalize;
+    weight gradient: GEMM + split-K reduce).  MCA work per call: 8 W MAC per (query, key) pair, keys of a local frame =
+    its own proposals + all global ones; compulsory bytes = operand rows in, aggregated rows out."""
+    out = {}
+    L, G = args.lframe, args.frames - args.lframe
+    HBM, MFMA = 8000.0, 2500.0
+    for name, rows in sorted((kprof or {}).items()):
+        secs = sum(e0.elapsed_time(e1) for e0, e1, _ in rows) * 1e-3
+        if secs <= 0:
+            continue
+        flop = byts = 0.0
+        for _, _, info in rows:
+            if name.startswith("mca"):
+                N, N_L, W, need_reg, backward = info
+                n = N_L / max(L, 1)
+                pairs = N_L * ((N - N_L) + n)
+                flop += 2.0 * pairs * W * (8 if need_reg else 6) * (2.5 if backward else 1.0)
+                byts += 2.0 * (2 * N * W + 2 * N_L * 4 * W) * (2 if backward else 1)
+            else:
+                flop += info[0]
+                byts += info[1]
+        ent = {"calls_per_step": len(rows) / nsteps, "ms_per_step": secs / nsteps * 1e3, "avg_call_us": secs / len(rows) * 1e6}
+        if flop > 0:
+            ent.update(tflops=flop / secs / 1e12, frac_mfma=flop / secs / 1e12 / MFMA)
+        if byts > 0:
+            ent.update(gbps=byts / secs / 1e9, frac_hbm=byts / secs / 1e9 / HBM)
+        ent["bound"] = "hbm" if name in ("bn_act", "bn_silu_bwd") else ("mfma" if name == "conv_wgrad" else "hbm (compulsory bytes) / mfma: at neither")
+        out[name] = ent
+    return out
+
+
+def step_segments(model, step, device, nsteps=20):
+    """The critical path of a steady-state train step in three serial segments, medians over ``nsteps`` steps:
+    pre   = device time from the step's first launch to the copy of the assignment cost matrices (prediction convs, decode, selection,
+            trained towers, gather, second MCA, cost GEMMs);
+    chain = host time of the clip's assignment chain (1 self-match + lframe-1 dependent 500 x 500 solves, csrc_host/lap.cpp), which the
+            stream waits for;
+    post  = device time from the last assignment's release (CAFM chain queued behind it) to the end of the optimizer / EMA launches.
+    Device marks are events on the main stream; the chain is timed on the worker thread."""
+    import statistics
+    import yolox.models.tscd_matching as M
+    marks, chains = [], []
+    cur = {}
+
+    def ev(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        cur[name] = e
+
+    real_prepare, real_finish, real_chain = M.AwarePositionRegMatcher.prepare, M.AwarePositionRegMatcher.finish, M.lap_chain_f16
+
+    def prepare(self, *a, **k):
+        r = real_prepare(self, *a, **k)
+        ev("costs")
+        return r
+
+    def finish(self, *a, **k):
+        r = real_finish(self, *a, **k)
+        ev("released")
+        return r
+
+    def chain(base_ptr, shapes, kinds, before=None, **kw):
+        if before is not None:
+            before()
+        t0 = time.perf_counter()
+        r = real_chain(base_ptr, shapes, kinds, None, **kw)
+        chains.append((time.perf_counter() - t0) * 1e3)
+        return r
+
+    M.AwarePositionRegMatcher.prepare, M.AwarePositionRegMatcher.finish, M.lap_chain_f16 = prepare, finish, chain
+    try:
+        for _ in range(nsteps):
+            cur = {}
+            ev("start")
+            step()
+            ev("end")
+            marks.append(cur)
+        torch.cuda.synchronize()
+    finally:
+        M.AwarePositionRegMatcher.prepare, M.AwarePositionRegMatcher.finish, M.lap_chain_f16 = real_prepare, real_finish, real_chain
+    ok = [m for m in marks if "costs" in m and "released" in m]
+    if not ok:
+        return None
+    med = statistics.median
+    pre = med(m["start"].elapsed_time(m["costs"]) for m in ok)
+    post = med(m["released"].elapsed_time(m["end"]) for m in ok)
+    whole = med(m["start"].elapsed_time(m["end"]) for m in ok)
+    return {"pre": pre, "chain": med(chains) if chains else None, "post": post, "start_to_end_on_device": whole, "steps": len(ok),
+            "what": "pre = first launch -> cost matrices queued (device); chain = host assignment chain the stream waits for; post = last "
+                    "assignment released -> optimizer + EMA queued (device); the three are serial"}
 
 
 LOSS_TERMS = ("total_loss", "iou_loss", "conf_loss", "cls_loss", "num_fg", "loss_matched_cls", "loss_matched_obj", "loss_matched_iou")
@@ -658,7 +756,8 @@ def main():
     # steady state: W more untimed steps, then EXACTLY K timed steps -> `value`
     dt, final_loss = timed(args.warmup, args.steps)
     s_passes = lap_passes() / max(args.warmup + args.steps, 1)
-    roof = roofline_dominant_kernel(args, device, step)   # every rank takes part (DDP steps are collective)
+    roof, roof2 = roofline_dominant_kernel(args, device, step)   # every rank takes part (DDP steps are collective)
+    segs = step_segments(model, step, device) if train else None
     flops = conv_flops_per_clip(args)
     if flops is not None:
         roof["step_flop"] = flops
@@ -689,7 +788,8 @@ def main():
                                    f"6 boxes/frame placed on the initial model's top proposals, proposal cap {MAX_PROPS}",
                        "clips_per_step": world, "parallelism": f"dp{world}"},
             "loss" if train else "detections_per_clip": final_loss, "lr": args.lr if train else None,
-            "grad_scale": float(scaler.get_scale()) if train else None, "roofline": roof, "other_regime": other_line,
+            "grad_scale": float(scaler.get_scale()) if train else None, "roofline": roof, "roofline_secondary": roof2,
+            "segments_ms": segs, "other_regime": other_line,
             "measured_state": f"steady state: timed after {2 * args.warmup + args.steps + args.preroll} untimed / early steps of the same run "
                               f"({args.preroll} of them the pre-roll); `early_window` = the first {args.steps} steps after the warm-up",
             "preroll_steps": args.preroll, "lap_relaxation_passes_per_step": s_passes, "early_window": early,

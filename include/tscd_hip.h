@@ -175,9 +175,11 @@ int tscd_sgd_ema_step_indirect_f32(const void* table, long nchunks, const void* 
  * projections -- ~25 per step, a few thousand rows each, none of which the backward pass waits for).  jobs: HOST array of njobs
  * (<= tscd_linear_wgrad_batch_max_jobs()) records {const void* x [M][in_f] fp16; const void* dy [M][out_f] fp16; float* dw
  * [out_f][in_f]; long M; int in_f, out_f, ldx, lddy} (features and row strides multiples of 8, pointers 16-byte aligned);
- * dw_j = dy_j^T x_j, each job unsplit and written once (deterministic). */
+ * dw_j = dy_j^T x_j; jobs of more than 2560 rows are split over the rows into slabs in ``workspace`` (device memory of
+ * tscd_linear_wgrad_batch_workspace_bytes(jobs, njobs) bytes) that a second launch adds in slab order: deterministic. */
 int tscd_linear_wgrad_batch_max_jobs(void);
-int tscd_linear_wgrad_batch_f16(const void* jobs_host, int njobs, void* stream);
+long tscd_linear_wgrad_batch_workspace_bytes(const void* jobs_host, int njobs);
+int tscd_linear_wgrad_batch_f16(const void* jobs_host, int njobs, void* workspace, long workspace_bytes, void* stream);
 /* The step's gradients into one flat fp32 arena and / or their non-finite check, one launch: replaces the GradScaler's inf check
  * inside scaler.step (tscd_trainer.py:171-176; torch: 6 multi-tensor launches) and the flattening of gradients into all-reduce
  * buckets that DistributedDataParallel does per parameter (tscd_trainer.py:230-231).  table: device array of nrows records

@@ -247,9 +247,10 @@ def test_c3_losses_with_product_decisions_forced(c3, c3_forced):
         rel[k] = abs(float(out[k]) - ref[k]) / max(abs(ref[k]), 1e-6)
     print("C3 loss terms (product / oracle on the product's decisions):",
           {k: (round(float(out[k]), 4), round(ref[k], 4), round(rel[k], 5)) for k in rel})
-    # iou_loss -- 3 (1 - IoU^2) of ~10 px boxes whose sizes are exp() of fp16 conv outputs -- carries the conv stack's fp16 noise, not the
-    # loss kernel's: test_c3_conv_stack_against_the_oracle evaluates the SAME term on the fp16-oracle's outputs and bounds the product's
-    # deviation by 1.5x that run's; here it shares the 7 % bar of the other regression term
+    # iou_loss: the benchmark's targets are the product's own boxes of 6 proposals per frame, so every other evaluation of the network
+    # scores ~5 % worse against them -- the fp32 oracle AND the reference's fp16 arithmetic alike; test_c3_conv_stack_against_the_oracle
+    # shows the boxes agree box for box within fp16 noise and that the bias flips with the source of the targets.  Bar: 7 %, as for the
+    # other regression term
     assert all(v <= 0.02 for k, v in rel.items() if k not in ("loss_matched_iou", "iou_loss")), rel
     assert rel["loss_matched_iou"] <= 0.07 and rel["iou_loss"] <= 0.07, rel
 
@@ -385,30 +386,35 @@ def test_c3_conv_stack_against_the_oracle(c3, c3_forced):
     z = lambda t: torch.where(ok, t, torch.zeros_like(t))
     check("raw prediction logits", z(got), z(ref), z(noise))
     # ---- the IoU-loss term (3 (1 - IoU^2) summed over the foreground anchors, tscd_head.py:1157-1160) on the three sets of boxes, same
-    # anchors, same targets.  The benchmark's targets ARE the product's own decoded boxes of 6 proposals per frame
-    # (bench.targets_on_top_proposals): at those "seed" anchors the product's IoU is 1 by construction while any other evaluation of the
-    # network -- the fp32 oracle, the reference's fp16 arithmetic -- sees its own box against the product's, IoU ~0.95.  That is the 5 %
-    # of test_c3_losses_with_product_decisions_forced.  Checked here: (1) on the non-seed anchors the product's sum is within 1.5x the
-    # fp16 oracle's deviation (or 2 %) of the fp32 oracle's; (2) at the seeds, the fp32 oracle's boxes are as close to the product's
-    # boxes as they are to the fp16 oracle's (1.5x); (3) the seeds account for the difference of the full sums.
+    # anchors, same targets.  The product's sum is ~5 % below BOTH oracles' (which agree to 0.2 %): the benchmark's targets are the
+    # product's own decoded boxes of 6 proposals per frame (bench.targets_on_top_proposals), and the foreground anchors are those
+    # proposals' neighbours, whose random-init predictions are correlated with them -- any OTHER evaluation of the network (fp32, or the
+    # reference's fp16 arithmetic) adds independent noise to that correlation and scores a lower IoU against targets taken from the
+    # product.  Checked here, independent of the targets: (1) box for box, the product is as close to the fp32 oracle as the fp16 oracle
+    # is (1.5x); (2) the bias follows the evaluation the targets are taken from: with the SAME six proposals' boxes read from the fp32
+    # oracle instead, the fp32 oracle's sum is the lower one, by a comparable margin.
     fg = dbg["fg_mask"].bool().cpu()
     lab = c3["targets"].float().cpu()
     mg = dbg["matched_gt"].cpu().long()
-    tgt = torch.cat([lab[b, mg[b, fg[b]], 1:5] for b in range(L + G)])
+    o_prod, o_ref, o_noise = dbg["outputs"].detach().float().cpu(), aux["outputs"].detach().float(), dec(nz["raw"])
     boxes = lambda o: o[..., :4].reshape(-1, 4)[fg.reshape(-1)]
-    b_prod, b_ref, b_noise = boxes(dbg["outputs"].detach().float().cpu()), boxes(aux["outputs"].detach().float()), boxes(dec(nz["raw"]))
-    l_prod, l_ref, l_noise = O.iou_loss(b_prod, tgt), O.iou_loss(b_ref, tgt), O.iou_loss(b_noise, tgt)
-    seed = l_prod < 1e-3
-    rest = ~seed
-    print(f"C3 IoU-loss sums over {int(fg.sum())} foreground anchors ({int(seed.sum())} seeds): product {float(l_prod.sum()):.4f}, fp32 oracle "
-          f"{float(l_ref.sum()):.4f}, fp16 oracle {float(l_noise.sum()):.4f}; non-seed anchors only: {float(l_prod[rest].sum()):.4f} / "
-          f"{float(l_ref[rest].sum()):.4f} / {float(l_noise[rest].sum()):.4f}")
-    assert int(seed.sum()) >= (L + G) * 3
-    d_rest, n_rest = abs(float(l_prod[rest].sum() - l_ref[rest].sum())), abs(float(l_noise[rest].sum() - l_ref[rest].sum()))
-    assert d_rest <= max(1.5 * n_rest, 0.02 * float(l_ref[rest].sum())), (d_rest, n_rest)
-    dist_prod = float(O.iou_loss(b_ref[seed], b_prod[seed]).mean())      # fp32 oracle box vs product box (= the targets at the seeds)
-    dist_noise = float(O.iou_loss(b_ref[seed], b_noise[seed]).mean())    # fp32 oracle box vs fp16 oracle box
-    print(f"C3 seed anchors: 1 - IoU^2 between the fp32 oracle's box and the product's {dist_prod:.4f}, and the fp16 oracle's {dist_noise:.4f}")
-    assert dist_prod <= max(1.5 * dist_noise, 0.02), (dist_prod, dist_noise)
-    whole = float(l_ref.sum() - l_prod.sum())
-    assert abs(whole - float(l_ref[seed].sum() - l_prod[seed].sum())) <= max(1.5 * n_rest, 0.02 * float(l_ref[rest].sum())) + 1e-6
+    b_prod, b_ref, b_noise = boxes(o_prod), boxes(o_ref), boxes(o_noise)
+    tgt = torch.cat([lab[b, mg[b, fg[b]], 1:5] for b in range(L + G)])
+    s_prod, s_ref, s_noise = (float(O.iou_loss(b, tgt).sum()) for b in (b_prod, b_ref, b_noise))
+    d_prod, d_noise = float(O.iou_loss(b_prod, b_ref).mean()), float(O.iou_loss(b_noise, b_ref).mean())
+    print(f"C3 IoU-loss sums over {int(fg.sum())} foreground anchors: product {s_prod:.4f}, fp32 oracle {s_ref:.4f}, fp16 oracle {s_noise:.4f}; "
+          f"mean 1 - IoU^2 box for box against the fp32 oracle: product {d_prod:.4f}, fp16 oracle {d_noise:.4f}")
+    assert d_prod <= max(1.5 * d_noise, 0.01), (d_prod, d_noise)
+    # the same proposals' boxes as the fp32 oracle sees them: per ground-truth box, the anchor whose PRODUCT box it was taken from
+    lab2 = lab.clone()
+    for b in range(L + G):
+        for j in range(lab.shape[1]):
+            if float(lab[b, j, 3]) <= 0:
+                continue
+            a = int((o_prod[b, :, :4] - lab[b, j, 1:5]).abs().sum(1).argmin())
+            lab2[b, j, 1:5] = torch.cat((o_ref[b, a, :2], o_ref[b, a, 2:4].clamp(8.0, 400.0)))
+    tgt2 = torch.cat([lab2[b, mg[b, fg[b]], 1:5] for b in range(L + G)])
+    s2_prod, s2_ref = float(O.iou_loss(b_prod, tgt2).sum()), float(O.iou_loss(b_ref, tgt2).sum())
+    print(f"C3 IoU-loss sums with the targets read from the fp32 oracle instead: product {s2_prod:.4f}, fp32 oracle {s2_ref:.4f}")
+    assert s_ref > s_prod and s2_prod > s2_ref
+    assert 0.4 * (s_ref - s_prod) <= (s2_prod - s2_ref) <= 2.5 * (s_ref - s_prod), (s_prod, s_ref, s2_prod, s2_ref)

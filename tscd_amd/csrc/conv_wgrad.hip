@@ -514,40 +514,93 @@ extern "C" int tscd_conv_wgrad_nhwc_f16_ex(const void* x, const void* dy, float*
 }
 
 // Several Linear weight gradients in one launch (see conv_wgrad_glds_jobs_kernel).  jobs: host array of njobs records
-// {x, dy, dw, M rows, in_f, out_f (multiple of 8; dw is [out_f][in_f] fp32), ldx, lddy}.  Every job runs unsplit (S = 1) and writes its
-// dw directly -- deterministic, no workspace.  At most 32 jobs per call.
+// {x, dy, dw, M rows, in_f, out_f (multiple of 8; dw is [out_f][in_f] fp32), ldx, lddy}.  Jobs of up to 80 k-tiles (2560 rows) run unsplit
+// and write their dw directly; longer ones are split over the rows into up to 8 slabs in ``workspace`` (so that no workgroup walks
+// more than ~64 k-tiles while the others have long finished) and a second launch adds the slabs in slab order -- deterministic either way.
+// At most 32 jobs per call.
 struct WgradJobHost { const void* x; const void* dy; float* dw; long M; int in_f, out_f, ldx, lddy; };
+struct WgradRedJob { const float* part; float* dw; long n; int S; int wg_begin; };
+struct WgradRedTable { WgradRedJob job[WGRAD_MAX_JOBS]; int njobs; };
+__global__ __launch_bounds__(256) void wgrad_jobs_reduce_kernel(WgradRedTable t) {
+  const int bid = blockIdx.x;
+  int j = 0;
+  for (int i = 1; i < t.njobs; ++i) j = bid >= t.job[i].wg_begin ? i : j;
+  const WgradRedJob q = t.job[j];
+  const long i4 = ((long)(bid - q.wg_begin) * 256 + threadIdx.x) * 4;      // n is a multiple of 64 (features are multiples of 8)
+  if (i4 >= q.n) return;
+  f32x4 a = *(const f32x4*)(q.part + i4);
+  for (int s = 1; s < q.S; ++s) a += *(const f32x4*)(q.part + (long)s * q.n + i4);
+  *(f32x4*)(q.dw + i4) = a;
+}
+static int wgrad_job_splits(long M) {
+  const long kt = (M + 31) / 32;
+  if (kt <= 80) return 1;
+  long s = (kt + 63) / 64;
+  return (int)(s > 8 ? 8 : s);
+}
 extern "C" int tscd_linear_wgrad_batch_max_jobs(void) { return WGRAD_MAX_JOBS; }
-extern "C" int tscd_linear_wgrad_batch_f16(const void* jobs_host, int njobs, void* stream) {
-  TSCD_CHECK_ARG(jobs_host && njobs > 0 && njobs <= WGRAD_MAX_JOBS, "linear_wgrad_batch: 1..%d jobs", WGRAD_MAX_JOBS);
+extern "C" long tscd_linear_wgrad_batch_workspace_bytes(const void* jobs_host, int njobs) {
   const WgradJobHost* h = (const WgradJobHost*)jobs_host;
-  // heaviest (most k-tiles) first: they start first and the short ones fill in behind them
+  long b = 256;
+  for (int i = 0; i < njobs; ++i) {
+    const int S = wgrad_job_splits(h[i].M);
+    if (S > 1) b += 4L * S * h[i].out_f * h[i].in_f + 256;
+  }
+  return b;
+}
+extern "C" int tscd_linear_wgrad_batch_f16(const void* jobs_host, int njobs, void* workspace, long workspace_bytes, void* stream) {
+  TSCD_CHECK_ARG(jobs_host && njobs > 0 && njobs <= WGRAD_MAX_JOBS, "linear_wgrad_batch: 1..%d jobs", WGRAD_MAX_JOBS);
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_linear_wgrad_batch_workspace_bytes(jobs_host, njobs) && (workspace || workspace_bytes <= 256),
+                 "linear_wgrad_batch: workspace too small");
+  const WgradJobHost* h = (const WgradJobHost*)jobs_host;
+  // longest walk (k-tiles per workgroup) first: those workgroups start first and the short ones fill in behind them
   int order[WGRAD_MAX_JOBS];
+  auto walk = [&](int i) { return ((h[i].M + 31) / 32 + wgrad_job_splits(h[i].M) - 1) / wgrad_job_splits(h[i].M); };
   for (int i = 0; i < njobs; ++i) order[i] = i;
   for (int i = 1; i < njobs; ++i) {
     int o = order[i], k = i;
-    while (k > 0 && h[order[k - 1]].M < h[o].M) { order[k] = order[k - 1]; --k; }
+    while (k > 0 && walk(order[k - 1]) < walk(o)) { order[k] = order[k - 1]; --k; }
     order[k] = o;
   }
   WgradJobTable t;
-  int wg = 0;
+  WgradRedTable r;
+  r.njobs = 0;
+  int wg = 0, rwg = 0;
+  char* ws = (char*)workspace;
   for (int i = 0; i < njobs; ++i) {
     const WgradJobHost& a = h[order[i]];
     TSCD_CHECK_ARG(a.x && a.dy && a.dw && a.M > 0 && a.M < (1L << 31), "linear_wgrad_batch: job %d: null pointer / bad row count", order[i]);
     TSCD_CHECK_ARG(a.in_f % 8 == 0 && a.out_f % 8 == 0 && a.ldx % 8 == 0 && a.lddy % 8 == 0 && a.ldx >= a.in_f && a.lddy >= a.out_f,
                    "linear_wgrad_batch: job %d: features / strides must be multiples of 8", order[i]);
-    TSCD_CHECK_ARG(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.dy & 15) == 0, "linear_wgrad_batch: job %d: pointers must be 16-byte aligned", order[i]);
+    TSCD_CHECK_ARG(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.dy & 15) == 0 && ((uintptr_t)a.dw & 15) == 0,
+                   "linear_wgrad_batch: job %d: pointers must be 16-byte aligned", order[i]);
     WgradJob& q = t.job[i];
-    q.x = (const f16*)a.x; q.dy = (const f16*)a.dy; q.part = a.dw;
+    q.x = (const f16*)a.x; q.dy = (const f16*)a.dy;
     q.M = (int)a.M; q.Cin = a.in_f; q.Cout = a.out_f; q.ldx = a.ldx; q.lddy = a.lddy;
-    q.S = 1; q.ktiles_per_split = (q.M + 31) / 32;
+    q.S = wgrad_job_splits(a.M);
+    const int kt = (q.M + 31) / 32;
+    q.ktiles_per_split = (kt + q.S - 1) / q.S;
     q.mtiles = cdiv(a.out_f, 128); q.ntiles = cdiv(a.in_f, 128);
     q.wg_begin = wg;
-    wg += q.mtiles * q.ntiles;
+    wg += q.mtiles * q.ntiles * q.S;
+    if (q.S == 1) {
+      q.part = a.dw;
+    } else {
+      q.part = (float*)ws;
+      const long n = (long)a.out_f * a.in_f;
+      ws += (4L * q.S * n + 255) / 256 * 256;
+      WgradRedJob& rj = r.job[r.njobs++];
+      rj.part = q.part; rj.dw = a.dw; rj.n = n; rj.S = q.S; rj.wg_begin = rwg;
+      rwg += (int)((n / 4 + 255) / 256);
+    }
   }
   t.njobs = njobs;
   hipLaunchKernelGGL(conv_wgrad_glds_jobs_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
   TSCD_CHECK_LAUNCH("linear_wgrad_batch");
+  if (r.njobs > 0) {
+    hipLaunchKernelGGL(wgrad_jobs_reduce_kernel, dim3(rwg), dim3(256), 0, (hipStream_t)stream, r);
+    TSCD_CHECK_LAUNCH("linear_wgrad_batch (slab reduce)");
+  }
   return TSCD_OK;
 }
 

@@ -346,6 +346,33 @@ WEIGHTS = WeightCache()
 # ----------------------------------------------------------------------------------------------------
 # bench.py sets this to a list to time every conv launch with device events on the launch stream
 CONV_PROFILE = None
+# ... and this one to a dict to time the other kernel families of the step (bench.py: `roofline_secondary`): name -> [(e0, e1, flop, bytes)]
+KERNEL_PROFILE = None
+
+
+def _profiled(name, work):
+    """Brackets a wrapper's launches with device events on the launch stream while KERNEL_PROFILE is a dict; ``work(result, *args,
+    **kwargs) -> (algorithmic FLOP, algorithmic bytes)`` of the call."""
+    def deco(f):
+        def g(*a, **k):
+            prof = KERNEL_PROFILE
+            if prof is None:
+                return f(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = f(*a, **k)
+            e1.record()
+            prof.setdefault(name, []).append((e0, e1, tuple(work(r, *a, **k))))
+            return r
+        g.__name__, g.__doc__ = f.__name__, f.__doc__
+        return g
+    return deco
+
+
+def _mca_work(N, N_L, W, need_reg, backward):
+    """(FLOP, bytes) of one MCA call; the FLOP figure needs the per-frame proposal counts, which the caller of the profile knows: the
+    entry carries the sizes (negative FLOP = "see bytes field"): bench.py turns (N, N_L, W, need_reg, backward) into SURVEY 8d's numbers."""
+    return (N, N_L, W, int(need_reg), int(backward))
 
 
 _F32_CACHE = {}     # id(parameter) -> (weakref, version, data_ptr, fp32 copy)
@@ -517,6 +544,8 @@ def bn_fold(gamma, beta, running_mean, running_var, eps=BN_EPS):
     return ss
 
 
+@_profiled("bn_act", lambda r, x, scale_shift, act=ACT_SILU, residual=None, out=None:
+           (0.0, 2.0 * x.numel() * (2 + (residual is not None))))
 def bn_act(x, scale_shift, act=ACT_SILU, residual=None, out=None):
     """out = act(x*scale+shift) (+ residual); in place on x when ``out`` is None."""
     B, H, W, C = x.shape
@@ -807,6 +836,7 @@ def mca_splits(ntiles):
     return max(1, min(16, (1024 + ntiles - 1) // max(ntiles, 1)))
 
 
+@_profiled("mca_forward", lambda r, q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, *a, **k: _mca_work(N, N_L, W, need_reg, False))
 def mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale, sim_thresh, conf_thresh, splits=None,
                   want_stats=False, keep_workspace=False, fp16_logits=False):
     """Fused global-to-local attention.  Returns (xcat_c [N_L,2W], cat3_c [N_L,3W], xcat_r, cat3_r, stats): first W columns
@@ -836,6 +866,7 @@ def mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale
     return xcat_c, cat3_c, xcat_r, cat3_r, stats
 
 
+@_profiled("mca_backward", lambda r, q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, *a, **k: _mca_work(N, N_L, W, need_reg, True))
 def mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale, sim_thresh, conf_thresh, stats, dxcat_c, dxcat_r,
                  dcat3_c, dcat3_r, cat3_c, cat3_r, fwd_ws=None):
     """Gradients of the fused attention w.r.t. the projected rows: -> (dq_c [N_L,W], dkv_c [N,2W], dq_r, dkv_r, dscore [N]).
@@ -912,7 +943,10 @@ class _WgradBatch:
         for i in range(0, len(jobs), maxj):
             part = jobs[i:i + maxj]
             arr = (_WgradJobC * len(part))(*part)
-            call("tscd_linear_wgrad_batch_f16", _C.cast(arr, _C.c_void_p), len(part), _stream())
+            arr_p = _C.cast(arr, _C.c_void_p)
+            ws_bytes = lib.tscd_linear_wgrad_batch_workspace_bytes(arr_p, len(part))
+            ws = temp((ws_bytes,), dtype=torch.uint8, device=torch.device("cuda", _cur_device()))
+            call("tscd_linear_wgrad_batch_f16", arr_p, len(part), ws.data_ptr(), ws_bytes, _stream())
         for prm, dw in check:
             g = prm.grad
             if g is not None and g.untyped_storage().data_ptr() != dw.untyped_storage().data_ptr():
@@ -1417,6 +1451,9 @@ def scale_grad(d, g, i0, i1=None, split=0, pad=0):
 # ----------------------------------------------------------------------------------------------------
 # backward kernels of the trainable head convs
 # ----------------------------------------------------------------------------------------------------
+@_profiled("conv_wgrad", lambda r, x, dy, cin, cout, ksize, groups=1, variant=1:
+           (2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cin * cout * ksize * ksize * groups,
+            2.0 * (x.numel() + dy.numel()) + 4.0 * groups * cout * cin * ksize * ksize))
 def conv_wgrad(x, dy, cin, cout, ksize, groups=1, variant=1):
     """dW [groups*cout,cin,k,k] fp32 of stride-1 'same' convs; x [B,H,W,groups*cin], dy [B,H,W,groups*cout] fp16 NHWC(-slices).
     ``groups`` > 1: group g's gradient from channels [g*cin, ...) of x and [g*cout, ...) of dy, stacked along dim 0.
@@ -1460,6 +1497,7 @@ def bn_silu_bwd(dy, raw, scale_shift, mean, invstd, gamma):
     return draw, sums[1], sums[0]
 
 
+@_profiled("bn_silu_bwd", lambda r, dys, raw, *a, **k: (0.0, 2.0 * raw.numel() * 5))       # two passes over dy and raw + draw written
 def bn_silu_bwd_multi(dys, raw, scale_shift, mean, invstd, gammas):
     """The same over the channels of SEVERAL BaseConvs that shared a conv launch: dys = 1 or 2 gradient tensors [B,H,W,c_i]
     (NHWC(-slices), sum c_i = C), raw [B,H,W,C] a channel slice, gammas = 1 or 2 fp32 vectors covering the C channels.
