@@ -449,7 +449,7 @@ def roofline_secondary(args, kprof, nsteps):
             ent.update(tflops=flop / secs / 1e12, frac_mfma=flop / secs / 1e12 / MFMA)
         if byts > 0:
             ent.update(gbps=byts / secs / 1e9, frac_hbm=byts / secs / 1e9 / HBM)
-        ent["bound"] = "hbm" if name in ("bn_act", "bn_silu_bwd") else ("mfma" if name == "conv_wgrad" else "hbm (compulsory bytes) / mfma: at neither")
+        ent["bound"] = "hbm" if name in ("bn_act", "bn_silu_bwd") else ("mfma" if name in ("conv_wgrad", "wgrad_batch") else "hbm (compulsory bytes) / mfma: at neither")
         out[name] = ent
     return out
 

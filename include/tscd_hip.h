@@ -170,16 +170,19 @@ int tscd_sgd_ema_step_f32(const void* table, long nchunks, const float* lr, cons
 int tscd_sgd_ema_step_indirect_f32(const void* table, long nchunks, const void* grad_base, const float* lr, const float* wd, int ngroups,
                                    float momentum, int nesterov, const float* grad_scale, const float* found_inf, float d,
                                    float one_minus_d, void* stream);
-/* Weight gradients of SEVERAL nn.Linear layers in one launch (autograd of the proposal stage's linears: tscd_head.py:123,130-133
- * fc_reg_matcher / cls_pred / matcher_*_pred, post_trans.py:566-577,1119-1125 MCA projections, tscd_matching.py:31-60,704 attention
- * projections -- ~25 per step, a few thousand rows each, none of which the backward pass waits for).  jobs: HOST array of njobs
- * (<= tscd_linear_wgrad_batch_max_jobs()) records {const void* x [M][in_f] fp16; const void* dy [M][out_f] fp16; float* dw
- * [out_f][in_f]; long M; int in_f, out_f, ldx, lddy} (features and row strides multiples of 8, pointers 16-byte aligned);
- * dw_j = dy_j^T x_j; jobs of more than 2560 rows are split over the rows into slabs in ``workspace`` (device memory of
- * tscd_linear_wgrad_batch_workspace_bytes(jobs, njobs) bytes) that a second launch adds in slab order: deterministic. */
-int tscd_linear_wgrad_batch_max_jobs(void);
-long tscd_linear_wgrad_batch_workspace_bytes(const void* jobs_host, int njobs);
-int tscd_linear_wgrad_batch_f16(const void* jobs_host, int njobs, void* workspace, long workspace_bytes, void* stream);
+/* SEVERAL weight gradients in one launch + one slab-reduce launch: the autograd of the proposal stage's nn.Linear layers
+ * (tscd_head.py:123,130-133 fc_reg_matcher / cls_pred / matcher_*_pred, post_trans.py:566-577,1119-1125 MCA projections,
+ * tscd_matching.py:31-60,704 attention projections -- ~25 per step, a few thousand rows each) and of the trained head convs
+ * (tscd_head.py:240-281 cls_convs2 / reg_convs2, surrounding_extraction.py:223-232 wavelet filters, :213-239 prediction convs), none of
+ * which the backward pass waits for.  jobs: HOST array of njobs (<= tscd_wgrad_batch_max_jobs()) records {const void* x; const void*
+ * dy; float* dw; int B, H, W, cin, cout, ksize, ldx, lddy, groups, pad}: a stride-1 "same" conv over B x H x W pixels (a Linear over M
+ * rows: B = H = 1, W = M, ksize = 1); x [pixels][groups*cin], dy [pixels][groups*cout] fp16 with pixel strides ldx / lddy; dw
+ * [groups*cout][cin][k][k] fp32.  tscd_wgrad_batch_supported(...) says whether a shape can be a job.  workspace: device memory of
+ * tscd_wgrad_batch_workspace_bytes(jobs, njobs) bytes (fp32 slabs of the split jobs, added in slab order: deterministic). */
+int tscd_wgrad_batch_max_jobs(void);
+int tscd_wgrad_batch_supported(int B, int H, int W, int cin, int cout, int ksize, int ldx, int lddy, int groups);
+long tscd_wgrad_batch_workspace_bytes(const void* jobs_host, int njobs);
+int tscd_wgrad_batch_f16(const void* jobs_host, int njobs, void* workspace, long workspace_bytes, void* stream);
 /* The step's gradients into one flat fp32 arena and / or their non-finite check, one launch: replaces the GradScaler's inf check
  * inside scaler.step (tscd_trainer.py:171-176; torch: 6 multi-tensor launches) and the flattening of gradients into all-reduce
  * buckets that DistributedDataParallel does per parameter (tscd_trainer.py:230-231).  table: device array of nrows records

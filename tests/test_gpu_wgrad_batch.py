@@ -56,9 +56,9 @@ def test_deferred_linear_weight_gradients_match_fp32_products(monkeypatch, twice
 
     monkeypatch.setattr(ops, "call", spy)
     got = _run(layers, True, monkeypatch, twice)
-    assert launched.count("tscd_linear_wgrad_batch_f16") >= 1
+    assert launched.count("tscd_wgrad_batch_f16") >= 1
     if not twice:
-        assert launched.count("tscd_linear_wgrad_batch_f16") == 1          # all ten weight gradients in ONE launch
+        assert launched.count("tscd_wgrad_batch_f16") == 1          # all ten weight gradients in ONE launch
     imm = _run(layers, False, monkeypatch, twice)
     k = 1.5 if twice else 1.0
     for (lin, x, gy), (dw, db, dx), (dw_i, db_i, dx_i) in zip(layers, got, imm):
@@ -156,3 +156,43 @@ def test_fused_grad_scaler_skips_and_backs_off_like_torch():
     assert sa == sb == [1024.0, 512.0, 512.0]
     for x, y in zip(a, b):
         assert torch.allclose(x, y, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 18, 18, 64, 64, 3, 1), (4, 36, 36, 256, 256, 3, 2), (3, 20, 24, 96, 32, 1, 1), (2, 9, 9, 768, 768, 1, 1),
+                                   (16, 72, 72, 64, 128, 3, 1)])
+def test_deferred_conv_weight_gradients_match_the_immediate_kernels_and_torch(monkeypatch, shape):
+    """ops.conv_wgrad(..., grad_params=...) inside a backward pass (registered, computed by the pass's batched launch) against the
+    immediate path and torch's conv weight gradient in fp32: 3x3 and 1x1, grouped (the towers' second convs), split and unsplit."""
+    import torch.nn.functional as F
+    from tscd_amd import ops
+    B, H, W, cin, cout, k, groups = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(B, H, W, groups * cin, generator=g) * 0.5).half().cuda()
+    dy = (torch.randn(B, H, W, groups * cout, generator=g) * 0.1).half().cuda()
+    params = [torch.nn.Parameter(torch.zeros(cout, cin, k, k, device="cuda")) for _ in range(groups)]
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, *ps):
+            return torch.zeros((), device="cuda")
+
+        @staticmethod
+        def backward(ctx, g_):
+            dw = ops.conv_wgrad(x, dy, cin, cout, k, groups=groups, grad_params=list(params))
+            return tuple(dw[i * cout:(i + 1) * cout] for i in range(groups))
+
+    launched = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda name, *a: (launched.append(name), real(name, *a))[1])
+    Fn.apply(*params).backward()
+    torch.cuda.synchronize()
+    assert launched.count("tscd_wgrad_batch_f16") == 1 and not any(n.startswith("tscd_conv_wgrad") for n in launched)
+    imm = ops.conv_wgrad(x, dy, cin, cout, k, groups=groups)
+    torch.cuda.synchronize()
+    for i, p in enumerate(params):
+        xi = x[..., i * cin:(i + 1) * cin].permute(0, 3, 1, 2).float()
+        dyi = dy[..., i * cout:(i + 1) * cout].permute(0, 3, 1, 2).float()
+        ref = torch.nn.grad.conv2d_weight(xi, (cout, cin, k, k), dyi, padding=(k - 1) // 2)
+        sc = float(ref.abs().max()) + 1e-12
+        assert float((p.grad - ref).abs().max()) <= 2e-3 * sc + 1e-5, (shape, i, float((p.grad - ref).abs().max()), sc)
+        assert float((imm[i * cout:(i + 1) * cout] - ref).abs().max()) <= 2e-3 * sc + 1e-5

@@ -64,6 +64,18 @@ def counters(d):
     return rows, names
 
 
+def derive(e):
+    """MFMA pipe occupancy from the per-launch sums.  GRBM_GUI_ACTIVE is reported once per XCD (8 instances, summed here): / 8 = the
+    launch's active cycles; the chip has 256 CUs x 4 SIMDs = 1024 MFMA pipes.  SQ_BUSY_CU_CYCLES (cycles, summed over the CUs) gives the
+    second figure: per SIMD-cycle of a CU that had work."""
+    m = e.get("SQ_VALU_MFMA_BUSY_CYCLES_per_launch", 0.0)
+    if e.get("GRBM_GUI_ACTIVE_per_launch"):
+        e["mfma_busy_frac_of_all_simd_cycles"] = m / (e["GRBM_GUI_ACTIVE_per_launch"] / 8.0 * 1024.0)
+    if e.get("SQ_BUSY_CU_CYCLES_per_launch"):
+        e["mfma_busy_frac_of_busy_cu_simd_cycles"] = m / (e["SQ_BUSY_CU_CYCLES_per_launch"] * 4.0)
+    return e
+
+
 # ---- MFMA busy
 sq, sq_names = counters(os.path.join(out, "pmc_sq"))
 sq_dur = durations(os.path.join(out, "pmc_sq"))
@@ -85,17 +97,14 @@ for fam, a in agg.items():
     for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"):
         if k in a:
             e[k + "_per_launch"] = a[k] / a["launches"]
-    if a.get("SQ_BUSY_CU_CYCLES"):
-        # MFMA pipe busy cycles per SIMD-cycle in which the CU was busy: BUSY_CU counts quad-cycles summed over CUs; 4 SIMDs per CU
-        e["mfma_busy_over_busy_cu"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["SQ_BUSY_CU_CYCLES"] * 4.0 * 4.0)
-    if a.get("GRBM_GUI_ACTIVE"):
-        e["mfma_busy_over_gui_active_all_simds"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] * 256 * 4.0)
+    derive(e)
     mf[fam] = e
 json.dump({"what": "MFMA pipe occupancy per kernel family of a steady-state TSCD-L train step (MI355X, rocprofv3 PMC)",
            "command": f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 tools/steady_steps.py {nsteps}",
-           "method": "counter values summed over the shader engines per dispatch, then over the family's dispatches; mfma_busy_over_gui_active_all_simds = "
-                     "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs) (the gfx94x MfmaUtil formula; ROCm 7.2 ships no gfx950 derived metrics); "
-                     "mfma_busy_over_busy_cu = the same numerator over the SIMD-cycles of busy CUs (SQ_BUSY_CU_CYCLES is in quad-cycles)",
+           "method": "counter values summed over their instances per dispatch, then averaged over the family's dispatches; "
+                     "mfma_busy_frac_of_all_simd_cycles = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCD instances) x 1024 SIMDs) -- the gfx94x "
+                     "MfmaUtil formula (ROCm 7.2 ships no gfx950 derived metrics; check: avg duration x ~2.4 GHz ~ GRBM_GUI_ACTIVE / 8); "
+                     "mfma_busy_frac_of_busy_cu_simd_cycles = the same numerator over 4 x SQ_BUSY_CU_CYCLES",
            "families": mf}, open(os.path.join(out, "pmc_mfma.json"), "w"), indent=1)
 # ---- HBM-side traffic
 fe, fe_names = counters(os.path.join(out, "pmc_fetch"))
@@ -134,5 +143,5 @@ json.dump({"what": "HBM-side (fabric) traffic and bandwidth per kernel family of
            "families": res}, open(os.path.join(out, "pmc_hbm.json"), "w"), indent=1)
 for fam in sorted(set(mf) | set(res)):
     m, h = mf.get(fam, {}), res.get(fam, {})
-    print(f"{fam:48s} {m.get('launches_per_step', 0):6.1f}/step {m.get('avg_us', 0):8.1f} us  mfma busy {100 * m.get('mfma_busy_over_gui_active_all_simds', 0):5.1f} %"
+    print(f"{fam:48s} {m.get('launches_per_step', 0):6.1f}/step {m.get('avg_us', 0):8.1f} us  mfma busy {100 * m.get('mfma_busy_frac_of_all_simd_cycles', 0):5.1f} %"
           f"  | {h.get('bytes_per_launch', 0) / 1e6:8.2f} MB/launch {h.get('gbps') or 0:8.0f} GB/s")

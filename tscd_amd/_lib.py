@@ -34,7 +34,7 @@ SIGNATURES = {
     "tscd_clip_preproc_u8": [P, I, I, I, P, P, I, I, I, P],
     "tscd_sgd_ema_step_f32": [P, L, P, P, I, F, I, P, P, F, F, P],
     "tscd_grad_gather_check_f32": [P, L, P, F, P, P],
-    "tscd_linear_wgrad_batch_f16": [P, I, P, L, P],
+    "tscd_wgrad_batch_f16": [P, I, P, L, P],
     "tscd_sgd_ema_step_indirect_f32": [P, L, P, P, P, I, F, I, P, P, F, F, P],
     "tscd_conv_bn_act_train_f16": [P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, P, F, F, P, P, P, P, I, P, I, I, P],
     "tscd_decode_score": [P, P, P, P, P, P, I, I, P, P, P, P],
@@ -76,7 +76,7 @@ SIGNATURES = {
     "tscd_loss_dense_reg_f16": [P, P, P, P, P, P, I, I, I, I, P, P, P, L, P, P, P, P],
     "tscd_loss_rows_f16": [P, P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, L, P, P, P, P, P],
 }
-PLAIN = {"tscd_linear_wgrad_batch_max_jobs": ([], I), "tscd_linear_wgrad_batch_workspace_bytes": ([P, I], L), "tscd_pred_grad_split_workspace_bytes": ([L, I], L), "tscd_ema_chunk_elems": ([], I), "tscd_pack_block_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
+PLAIN = {"tscd_wgrad_batch_max_jobs": ([], I), "tscd_wgrad_batch_workspace_bytes": ([P, I], L), "tscd_wgrad_batch_supported": ([I] * 9, I), "tscd_pred_grad_split_workspace_bytes": ([L, I], L), "tscd_ema_chunk_elems": ([], I), "tscd_pack_block_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
          "tscd_bn_silu_bwd_workspace_bytes": ([L, I], L), "tscd_linear_bwd_workspace_bytes": ([I, I, I], L),
          "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L), "tscd_mca_rows_bytes": ([I, I, I], L),
          "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),

@@ -389,13 +389,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(WgradParams p) 
   wgrad_glds_tile(p, s, mt, nt);
 }
 
-// Job-table form: SEVERAL independent weight-gradient GEMMs of Linear layers (1x1: dW_j[out_j][in_j] = dY_j^T X_j over M_j rows) in
-// ONE launch.  The proposal stage's ~25 linears have a few thousand rows each: launched one by one their weight gradients are
-// launch- and latency-bound (4 GFLOP in 50 us, tools/wgrad_census.py); nothing in the backward pass waits for them, so the host
-// collects them and flushes them together (tscd_amd/ops.py: deferred weight gradients).  A workgroup finds its job by its index
-// (jobs are laid out back to back, heaviest first); S == 1 jobs write straight into dw (torch layout for 1x1).
+// Job-table form: SEVERAL independent weight-gradient GEMMs -- nn.Linear layers (1x1: dW_j[out_j][in_j] = dY_j^T X_j over M_j rows) and
+// stride-1 convs (3x3 / 1x1, grouped or not) -- in ONE launch.  The proposal stage's ~25 linears have a few thousand rows each and the
+// 36x36 / 18x18 pyramid levels' convs a few thousand pixels: launched one by one their weight gradients are launch- and latency-bound
+// (4 GFLOP in 50 us, tools/wgrad_census.py); nothing in the backward pass waits for them, so the host collects them and flushes them
+// together (tscd_amd/ops.py: deferred weight gradients).  A workgroup finds its job by its index (jobs are laid out back to back,
+// longest walk first); unsplit 1x1 jobs write straight into dw (torch layout), the others fp32 slabs that ONE more launch reduces.
 #define WGRAD_MAX_JOBS 32
-struct WgradJob { const f16* x; const f16* dy; float* part; int M, Cin, Cout, ldx, lddy, S, ktiles_per_split, mtiles, ntiles, wg_begin; };
+struct WgradJob {
+  const f16* x; const f16* dy; float* part;
+  int B, H, W, Cin, Cout, KH, ldx, lddy, M, Ncols, S, ktiles_per_split, mtiles, ntiles, G, wg_begin;
+};
 struct WgradJobTable { WgradJob job[WGRAD_MAX_JOBS]; int njobs; };
 __global__ __launch_bounds__(256, 2) void conv_wgrad_glds_jobs_kernel(WgradJobTable t) {
   const int bid = blockIdx.x;
@@ -403,13 +407,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_glds_jobs_kernel(WgradJobTa
   for (int i = 1; i < t.njobs; ++i) j = bid >= t.job[i].wg_begin ? i : j;        // uniform: scalar loads and compares
   const WgradJob q = t.job[j];
   WgradParams p;
-  p.x = q.x; p.dy = q.dy; p.part = q.part;
-  p.B = 1; p.H = 1; p.W = q.M; p.Cin = q.Cin; p.Cout = q.Cout; p.KH = 1; p.KW = 1; p.pad = 0;
+  p.B = q.B; p.H = q.H; p.W = q.W; p.Cin = q.Cin; p.Cout = q.Cout; p.KH = q.KH; p.KW = q.KH; p.pad = (q.KH - 1) / 2;
   p.ldx = q.ldx; p.lddy = q.lddy;
-  p.M = q.M; p.Ncols = q.Cin; p.S = q.S; p.ktiles_per_split = q.ktiles_per_split; p.mtiles = q.mtiles; p.ntiles = q.ntiles;
-  p.G = 1;
-  const int lid = bid - q.wg_begin, tiles = q.mtiles * q.ntiles;
-  const int s = lid / tiles, tile = lid - s * tiles;
+  p.M = q.M; p.Ncols = q.Ncols; p.S = q.S; p.ktiles_per_split = q.ktiles_per_split; p.mtiles = q.mtiles; p.ntiles = q.ntiles;
+  p.G = q.G;
+  const int lid = bid - q.wg_begin, tiles = q.mtiles * q.ntiles, per_group = tiles * q.S;
+  const int grp = lid / per_group, lid_g = lid - grp * per_group;
+  p.x = q.x + grp * q.Cin;
+  p.dy = q.dy + grp * q.Cout;
+  p.part = q.part + (long)grp * q.S * q.Cout * q.Ncols;
+  const int s = lid_g / tiles, tile = lid_g - s * tiles;
   const int mt = tile / q.ntiles, nt = tile - mt * q.ntiles;
   wgrad_glds_tile(p, s, mt, nt);
 }
@@ -513,49 +520,82 @@ extern "C" int tscd_conv_wgrad_nhwc_f16_ex(const void* x, const void* dy, float*
   return wgrad_launch(x, dy, dw, B, H, W, Cin, Cout, ksize, ldx, lddy, groups, variant, workspace, workspace_bytes, stream);
 }
 
-// Several Linear weight gradients in one launch (see conv_wgrad_glds_jobs_kernel).  jobs: host array of njobs records
-// {x, dy, dw, M rows, in_f, out_f (multiple of 8; dw is [out_f][in_f] fp32), ldx, lddy}.  Jobs of up to 80 k-tiles (2560 rows) run unsplit
-// and write their dw directly; longer ones are split over the rows into up to 8 slabs in ``workspace`` (so that no workgroup walks
-// more than ~64 k-tiles while the others have long finished) and a second launch adds the slabs in slab order -- deterministic either way.
-// At most 32 jobs per call.
-struct WgradJobHost { const void* x; const void* dy; float* dw; long M; int in_f, out_f, ldx, lddy; };
-struct WgradRedJob { const float* part; float* dw; long n; int S; int wg_begin; };
+// Several weight gradients in one launch (see conv_wgrad_glds_jobs_kernel).  jobs: host array of njobs records
+// {x, dy, dw, B, H, W, cin, cout, ksize, ldx, lddy, groups}: a stride-1 "same" conv of B x H x W pixels (an nn.Linear over M rows is
+// B = H = 1, W = M, ksize = 1), dw [groups * cout][cin][k][k] fp32 (torch layout).  Every workgroup walks at most ~48 k-tiles (1536
+// pixels): longer jobs are split over the pixels into fp32 slabs in ``workspace``, which a second launch adds in slab order and lays
+// out as dw -- deterministic.  Unsplit ungrouped 1x1 jobs write dw directly.  At most 32 jobs per call.
+struct WgradJobHost { const void* x; const void* dy; float* dw; int B, H, W, cin, cout, ksize, ldx, lddy, groups, pad_; };
+struct WgradRedJob { const float* part; float* dw; int S, Cout, Cin, K, G, wg_begin; };
 struct WgradRedTable { WgradRedJob job[WGRAD_MAX_JOBS]; int njobs; };
+// one job's slabs -> dw (the body of wgrad_reduce_kernel over a block range of its own)
 __global__ __launch_bounds__(256) void wgrad_jobs_reduce_kernel(WgradRedTable t) {
+  __shared__ float red[4][64];
   const int bid = blockIdx.x;
   int j = 0;
   for (int i = 1; i < t.njobs; ++i) j = bid >= t.job[i].wg_begin ? i : j;
   const WgradRedJob q = t.job[j];
-  const long i4 = ((long)(bid - q.wg_begin) * 256 + threadIdx.x) * 4;      // n is a multiple of 64 (features are multiples of 8)
-  if (i4 >= q.n) return;
-  f32x4 a = *(const f32x4*)(q.part + i4);
-  for (int s = 1; s < q.S; ++s) a += *(const f32x4*)(q.part + (long)s * q.n + i4);
-  *(f32x4*)(q.dw + i4) = a;
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int taps = q.K * q.K, Ncols = taps * q.Cin;
+  const long total_g = (long)q.Cout * Ncols, total = total_g * q.G;
+  const long src = (long)(bid - q.wg_begin) * 64 + o;
+  const long grp = src / total_g, r = src - grp * total_g;
+  float a = 0.f;
+  if (src < total) {
+    const float* pg = q.part + grp * q.S * total_g + r;
+#pragma unroll 4
+    for (int s = g; s < q.S; s += 4) a += pg[(long)s * total_g];
+  }
+  red[g][o] = a;
+  __syncthreads();
+  if (g == 0 && src < total) {
+    a = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    const int co = (int)(r / Ncols), col = (int)(r - (long)co * Ncols);
+    const int tap = col / q.Cin, ci = col - tap * q.Cin;
+    q.dw[grp * total_g + ((long)co * q.Cin + ci) * taps + tap] = a;
+  }
 }
-static int wgrad_job_splits(long M) {
+// Splits of a job: none up to 80 k-tiles (2560 pixels); beyond, ~48 k-tiles per workgroup, but never more than ~1024 workgroups per
+// job (the 72 x 72 level's convs: 14 slabs of 185 k-tiles instead of 54 -- their slab traffic would otherwise rival the operand reads).
+static int wgrad_job_splits_t(long M, long tiles) {
   const long kt = (M + 31) / 32;
   if (kt <= 80) return 1;
-  long s = (kt + 63) / 64;
-  return (int)(s > 8 ? 8 : s);
+  long s = (kt + 47) / 48, cap = 1024 / (tiles > 0 ? tiles : 1);
+  if (cap < 2) cap = 2;
+  if (s > cap) s = cap;
+  return (int)(s < 2 ? 2 : s);
 }
-extern "C" int tscd_linear_wgrad_batch_max_jobs(void) { return WGRAD_MAX_JOBS; }
-extern "C" long tscd_linear_wgrad_batch_workspace_bytes(const void* jobs_host, int njobs) {
+static int wgrad_job_splits(const WgradJobHost& a) {
+  return wgrad_job_splits_t((long)a.B * a.H * a.W, (long)cdiv(a.cout, 128) * cdiv(a.ksize * a.ksize * a.cin, 128) * a.groups);
+}
+static bool wgrad_job_direct(const WgradJobHost& a) { return a.ksize == 1 && a.groups == 1 && wgrad_job_splits(a) == 1; }
+extern "C" int tscd_wgrad_batch_max_jobs(void) { return WGRAD_MAX_JOBS; }
+extern "C" long tscd_wgrad_batch_workspace_bytes(const void* jobs_host, int njobs) {
   const WgradJobHost* h = (const WgradJobHost*)jobs_host;
   long b = 256;
-  for (int i = 0; i < njobs; ++i) {
-    const int S = wgrad_job_splits(h[i].M);
-    if (S > 1) b += 4L * S * h[i].out_f * h[i].in_f + 256;
-  }
+  for (int i = 0; i < njobs; ++i)
+    if (!wgrad_job_direct(h[i]))
+      b += 4L * h[i].groups * wgrad_job_splits(h[i]) * h[i].cout * h[i].ksize * h[i].ksize * h[i].cin + 256;
   return b;
 }
-extern "C" int tscd_linear_wgrad_batch_f16(const void* jobs_host, int njobs, void* workspace, long workspace_bytes, void* stream) {
-  TSCD_CHECK_ARG(jobs_host && njobs > 0 && njobs <= WGRAD_MAX_JOBS, "linear_wgrad_batch: 1..%d jobs", WGRAD_MAX_JOBS);
-  TSCD_CHECK_ARG(workspace_bytes >= tscd_linear_wgrad_batch_workspace_bytes(jobs_host, njobs) && (workspace || workspace_bytes <= 256),
-                 "linear_wgrad_batch: workspace too small");
+// 1 when the LDS-DMA loop can take the job (3x3: images at least 32 / W + 1 rows high; channels / strides multiples of 8)
+extern "C" int tscd_wgrad_batch_supported(int B, int H, int W, int cin, int cout, int ksize, int ldx, int lddy, int groups) {
+  if (!(ksize == 1 || ksize == 3) || groups < 1 || cin % 8 || cout % 8 || ldx % 8 || lddy % 8) return 0;
+  if (ldx < groups * cin || lddy < groups * cout || (long)B * H * W >= (1L << 31) || (long)B * H * W <= 0) return 0;
+  return (ksize == 1 || 32 / W + 1 <= H) ? 1 : 0;
+}
+extern "C" int tscd_wgrad_batch_f16(const void* jobs_host, int njobs, void* workspace, long workspace_bytes, void* stream) {
+  TSCD_CHECK_ARG(jobs_host && njobs > 0 && njobs <= WGRAD_MAX_JOBS, "wgrad_batch: 1..%d jobs", WGRAD_MAX_JOBS);
+  TSCD_CHECK_ARG(workspace_bytes >= tscd_wgrad_batch_workspace_bytes(jobs_host, njobs) && (workspace || workspace_bytes <= 256),
+                 "wgrad_batch: workspace too small");
   const WgradJobHost* h = (const WgradJobHost*)jobs_host;
   // longest walk (k-tiles per workgroup) first: those workgroups start first and the short ones fill in behind them
   int order[WGRAD_MAX_JOBS];
-  auto walk = [&](int i) { return ((h[i].M + 31) / 32 + wgrad_job_splits(h[i].M) - 1) / wgrad_job_splits(h[i].M); };
+  auto walk = [&](int i) {
+    const long M = (long)h[i].B * h[i].H * h[i].W;
+    const int S = wgrad_job_splits(h[i]);
+    return ((M + 31) / 32 + S - 1) / S * (h[i].ksize == 3 ? 2 : 1);      // (3x3 k-tiles carry the halo test: a little longer)
+  };
   for (int i = 0; i < njobs; ++i) order[i] = i;
   for (int i = 1; i < njobs; ++i) {
     int o = order[i], k = i;
@@ -565,41 +605,44 @@ extern "C" int tscd_linear_wgrad_batch_f16(const void* jobs_host, int njobs, voi
   WgradJobTable t;
   WgradRedTable r;
   r.njobs = 0;
-  int wg = 0, rwg = 0;
+  long wg = 0, rwg = 0;
   char* ws = (char*)workspace;
   for (int i = 0; i < njobs; ++i) {
     const WgradJobHost& a = h[order[i]];
-    TSCD_CHECK_ARG(a.x && a.dy && a.dw && a.M > 0 && a.M < (1L << 31), "linear_wgrad_batch: job %d: null pointer / bad row count", order[i]);
-    TSCD_CHECK_ARG(a.in_f % 8 == 0 && a.out_f % 8 == 0 && a.ldx % 8 == 0 && a.lddy % 8 == 0 && a.ldx >= a.in_f && a.lddy >= a.out_f,
-                   "linear_wgrad_batch: job %d: features / strides must be multiples of 8", order[i]);
+    TSCD_CHECK_ARG(a.x && a.dy && a.dw, "wgrad_batch: job %d: null pointer", order[i]);
+    TSCD_CHECK_ARG(tscd_wgrad_batch_supported(a.B, a.H, a.W, a.cin, a.cout, a.ksize, a.ldx, a.lddy, a.groups),
+                   "wgrad_batch: job %d: unsupported shape (B=%d H=%d W=%d cin=%d cout=%d k=%d groups=%d)", order[i], a.B, a.H, a.W, a.cin, a.cout,
+                   a.ksize, a.groups);
     TSCD_CHECK_ARG(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.dy & 15) == 0 && ((uintptr_t)a.dw & 15) == 0,
-                   "linear_wgrad_batch: job %d: pointers must be 16-byte aligned", order[i]);
+                   "wgrad_batch: job %d: pointers must be 16-byte aligned", order[i]);
     WgradJob& q = t.job[i];
     q.x = (const f16*)a.x; q.dy = (const f16*)a.dy;
-    q.M = (int)a.M; q.Cin = a.in_f; q.Cout = a.out_f; q.ldx = a.ldx; q.lddy = a.lddy;
-    q.S = wgrad_job_splits(a.M);
+    q.B = a.B; q.H = a.H; q.W = a.W; q.Cin = a.cin; q.Cout = a.cout; q.KH = a.ksize; q.ldx = a.ldx; q.lddy = a.lddy; q.G = a.groups;
+    q.M = a.B * a.H * a.W; q.Ncols = a.ksize * a.ksize * a.cin;
+    q.S = wgrad_job_splits(a);
     const int kt = (q.M + 31) / 32;
     q.ktiles_per_split = (kt + q.S - 1) / q.S;
-    q.mtiles = cdiv(a.out_f, 128); q.ntiles = cdiv(a.in_f, 128);
-    q.wg_begin = wg;
-    wg += q.mtiles * q.ntiles * q.S;
-    if (q.S == 1) {
+    q.mtiles = cdiv(a.cout, 128); q.ntiles = cdiv(q.Ncols, 128);
+    q.wg_begin = (int)wg;
+    wg += (long)q.mtiles * q.ntiles * q.S * q.G;
+    if (wgrad_job_direct(a)) {
       q.part = a.dw;
     } else {
       q.part = (float*)ws;
-      const long n = (long)a.out_f * a.in_f;
+      const long n = (long)q.G * a.cout * q.Ncols;
       ws += (4L * q.S * n + 255) / 256 * 256;
       WgradRedJob& rj = r.job[r.njobs++];
-      rj.part = q.part; rj.dw = a.dw; rj.n = n; rj.S = q.S; rj.wg_begin = rwg;
-      rwg += (int)((n / 4 + 255) / 256);
+      rj.part = q.part; rj.dw = a.dw; rj.S = q.S; rj.Cout = a.cout; rj.Cin = a.cin; rj.K = a.ksize; rj.G = q.G; rj.wg_begin = (int)rwg;
+      rwg += (n + 63) / 64;
     }
   }
+  TSCD_CHECK_ARG(wg < (1L << 31) && rwg < (1L << 31), "wgrad_batch: grid too large");
   t.njobs = njobs;
-  hipLaunchKernelGGL(conv_wgrad_glds_jobs_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
-  TSCD_CHECK_LAUNCH("linear_wgrad_batch");
+  hipLaunchKernelGGL(conv_wgrad_glds_jobs_kernel, dim3((unsigned)wg), dim3(256), 0, (hipStream_t)stream, t);
+  TSCD_CHECK_LAUNCH("wgrad_batch");
   if (r.njobs > 0) {
-    hipLaunchKernelGGL(wgrad_jobs_reduce_kernel, dim3(rwg), dim3(256), 0, (hipStream_t)stream, r);
-    TSCD_CHECK_LAUNCH("linear_wgrad_batch (slab reduce)");
+    hipLaunchKernelGGL(wgrad_jobs_reduce_kernel, dim3((unsigned)rwg), dim3(256), 0, (hipStream_t)stream, r);
+    TSCD_CHECK_LAUNCH("wgrad_batch (slab reduce)");
   }
   return TSCD_OK;
 }

@@ -59,7 +59,9 @@ def _conv_backward(dy, x, weight, stride, need_dx, need_dw, dy_padded=None):
         dyp = dy.contiguous() if dyp is None else dyp
         # x may carry zero-padded channels (Focus: 12 -> 16): their weight gradient is computed and dropped
         with ops.param_grad_stream([weight], x, dyp):
-            dw = ops.conv_wgrad(x, dyp, x.shape[-1], dyp.shape[-1], k)[:cout, :cin].to(weight.dtype).contiguous()
+            # (registered for the pass's batched launch when the result's rows ARE the parameter's gradient: no padded input channels)
+            gp = [weight] if (x.shape[-1] == cin and weight.dtype == torch.float32) else None
+            dw = ops.conv_wgrad(x, dyp, x.shape[-1], dyp.shape[-1], k, grad_params=gp)[:cout, :cin].to(weight.dtype).contiguous()
     return dx, dw
 
 
@@ -202,9 +204,9 @@ class _PredLevel(torch.autograd.Function):
             d_raw = d_raw.contiguous()
         dy_obj, dy_cls, db = ops.pred_grad_split(d_raw, nc)
         with ops.param_grad_stream([w_obj], reg_feat, dy_obj):
-            dw_obj = ops.conv_wgrad(reg_feat, dy_obj, reg_feat.shape[-1], 8, 1)[:1].to(w_obj.dtype)
+            dw_obj = ops.conv_wgrad(reg_feat, dy_obj, reg_feat.shape[-1], 8, 1, grad_params=[w_obj] if w_obj.dtype == torch.float32 else None)[:1].to(w_obj.dtype)
         with ops.param_grad_stream([w_cls], cls_feat, dy_cls):
-            dw_cls = ops.conv_wgrad(cls_feat, dy_cls, cls_feat.shape[-1], dy_cls.shape[-1], 1)[:nc].to(w_cls.dtype)
+            dw_cls = ops.conv_wgrad(cls_feat, dy_cls, cls_feat.shape[-1], dy_cls.shape[-1], 1, grad_params=[w_cls] if w_cls.dtype == torch.float32 else None)[:nc].to(w_cls.dtype)
         bd = ctx.bias_dtype
         return None, None, None, dw_obj, db[4:5].to(bd), dw_cls, db[5:5 + nc].to(bd)
 

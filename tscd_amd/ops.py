@@ -924,8 +924,9 @@ FOREIGN_GRAD_HOOKS_OK = False      # set by tscd_amd.ddp.ArenaReducer (it flushe
 
 
 class _WgradJobC(_C.Structure):
-    _fields_ = [("x", _C.c_void_p), ("dy", _C.c_void_p), ("dw", _C.c_void_p), ("M", _C.c_long), ("in_f", _C.c_int), ("out_f", _C.c_int),
-                ("ldx", _C.c_int), ("lddy", _C.c_int)]
+    _fields_ = [("x", _C.c_void_p), ("dy", _C.c_void_p), ("dw", _C.c_void_p), ("B", _C.c_int), ("H", _C.c_int), ("W", _C.c_int),
+                ("cin", _C.c_int), ("cout", _C.c_int), ("ksize", _C.c_int), ("ldx", _C.c_int), ("lddy", _C.c_int), ("groups", _C.c_int),
+                ("pad_", _C.c_int)]
 
 
 class _WgradBatch:
@@ -939,19 +940,28 @@ class _WgradBatch:
         check, self.check = self.check, []
         if not jobs:
             return
-        maxj = lib.tscd_linear_wgrad_batch_max_jobs()
+        maxj = lib.tscd_wgrad_batch_max_jobs()
+        prof = KERNEL_PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for i in range(0, len(jobs), maxj):
             part = jobs[i:i + maxj]
             arr = (_WgradJobC * len(part))(*part)
             arr_p = _C.cast(arr, _C.c_void_p)
-            ws_bytes = lib.tscd_linear_wgrad_batch_workspace_bytes(arr_p, len(part))
+            ws_bytes = lib.tscd_wgrad_batch_workspace_bytes(arr_p, len(part))
             ws = temp((ws_bytes,), dtype=torch.uint8, device=torch.device("cuda", _cur_device()))
-            call("tscd_linear_wgrad_batch_f16", arr_p, len(part), ws.data_ptr(), ws_bytes, _stream())
-        for prm, dw in check:
+            call("tscd_wgrad_batch_f16", arr_p, len(part), ws.data_ptr(), ws_bytes, _stream())
+        if prof is not None:
+            e1.record()
+            fl = sum(2.0 * j.B * j.H * j.W * j.cin * j.cout * j.ksize * j.ksize * j.groups for j in jobs)
+            by = sum(2.0 * j.B * j.H * j.W * (j.ldx + j.lddy) + 4.0 * j.groups * j.cout * j.cin * j.ksize * j.ksize for j in jobs)
+            prof.setdefault("wgrad_batch", []).append((e0, e1, (fl, by)))
+        for prm, dw in check:           # dw: the rows of the registered tensor that are this parameter's gradient
             g = prm.grad
             if g is not None and g.untyped_storage().data_ptr() != dw.untyped_storage().data_ptr():
                 # AccumulateGrad cloned the (then unwritten) tensor instead of adopting it: overwrite the clone with the real gradient
-                g.copy_(dw[:g.shape[0]].view_as(g))
+                g.copy_(dw.reshape(g.shape))
         del keep
 
     def end_of_pass(self):
@@ -989,6 +999,8 @@ def _wgrad_batch(params):
     if any(prm.grad is not None for prm in params):     # accumulation into a gradient of an earlier pass reads it: not deferred
         return None
     b.seen.update(keys)
+    if len(b.jobs) >= lib.tscd_wgrad_batch_max_jobs():
+        b.compute()             # a full launch is pending (a backbone's ~100 convs): go, and let go of the operands held so far
     return b
 
 
@@ -1030,9 +1042,9 @@ def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False, grad_pa
         # deferred: data gradient (and the bias column sums) now, the weight-gradient GEMM with all the others at the end of the pass
         if need_dx or need_db:
             call("tscd_linear_bwd_packed_f16", *args, _ptr(dx), 0, _ptr(db), ws.data_ptr(), ws_bytes, _stream())
-        batch.jobs.append(_WgradJobC(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, in_f, outp, x.stride(0), dy.stride(0)))
+        batch.jobs.append(_WgradJobC(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 1, 1, n, in_f, outp, 1, x.stride(0), dy.stride(0), 1, 0))
         batch.keep.append((x, dy))
-        batch.check.append((grad_params[0], dw))
+        batch.check.append((grad_params[0], dw[:out_f]))
         return dx, dw[:out_f], (None if db is None else db[:out_f])
     if (need_dw or need_db) and grad_params is not None:
         # data gradient on the pass's stream, parameter gradients on the second one (param_grad_stream)
@@ -1451,16 +1463,34 @@ def scale_grad(d, g, i0, i1=None, split=0, pad=0):
 # ----------------------------------------------------------------------------------------------------
 # backward kernels of the trainable head convs
 # ----------------------------------------------------------------------------------------------------
-@_profiled("conv_wgrad", lambda r, x, dy, cin, cout, ksize, groups=1, variant=1:
+@_profiled("conv_wgrad", lambda r, x, dy, cin, cout, ksize, groups=1, variant=1, grad_params=None:
            (2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cin * cout * ksize * ksize * groups,
             2.0 * (x.numel() + dy.numel()) + 4.0 * groups * cout * cin * ksize * ksize))
-def conv_wgrad(x, dy, cin, cout, ksize, groups=1, variant=1):
+def conv_wgrad(x, dy, cin, cout, ksize, groups=1, variant=1, grad_params=None):
     """dW [groups*cout,cin,k,k] fp32 of stride-1 'same' convs; x [B,H,W,groups*cin], dy [B,H,W,groups*cout] fp16 NHWC(-slices).
     ``groups`` > 1: group g's gradient from channels [g*cin, ...) of x and [g*cout, ...) of dy, stacked along dim 0.
-    ``variant`` (tests): 0 = the register-staged cross-check loop."""
+    ``variant`` (tests): 0 = the register-staged cross-check loop.
+    ``grad_params``: the parameters whose gradients the rows of dW are, in row order (each takes its own shape[0] rows; the caller hands
+    plain row slices of the result to autograd) -- inside a backward pass the GEMM is then only REGISTERED and runs with the pass's
+    other weight gradients in one launch (deferred weight gradients, above)."""
     B, H, W, _ = x.shape
     M = B * H * W
     dw = temp((groups * cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    if grad_params is not None and variant == 1 and M > 0:
+        ldx, lddy = nhwc_ld(x), nhwc_ld(dy)
+        rows = sum(p.shape[0] for p in grad_params)
+        same_cols = all(tuple(p.shape[1:]) == (cin, ksize, ksize) for p in grad_params)
+        if same_cols and rows <= groups * cout and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 \
+                and lib.tscd_wgrad_batch_supported(B, H, W, cin, cout, ksize, ldx, lddy, groups):
+            batch = _wgrad_batch(grad_params)
+            if batch is not None:
+                batch.jobs.append(_WgradJobC(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, cin, cout, ksize, ldx, lddy, groups, 0))
+                batch.keep.append((x, dy))
+                r0 = 0
+                for p in grad_params:
+                    batch.check.append((p, dw[r0:r0 + p.shape[0]]))
+                    r0 += p.shape[0] if groups == 1 or p.shape[0] == cout else cout
+                return dw
     if groups == 1 and variant == 1:
         ws_bytes = lib.tscd_conv_wgrad_workspace_bytes(M, cout, cin, ksize)
         ws = temp((ws_bytes,), dtype=torch.uint8, device=x.device)

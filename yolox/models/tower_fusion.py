@@ -201,13 +201,13 @@ class _TowerPairTrain(torch.autograd.Function):
         draw_b, dgam_b, dbet_b = ops.bn_silu_bwd_multi([g0, g1], b_raw, b_ss, b_mean, b_inv, [gb0, gb1])
         wd = wa0.dtype
         with ops.param_grad_stream([wb0, wb1], a_out, draw_b):      # weight gradients run beside the data-gradient chain
-            dwb = ops.conv_wgrad(a_out, draw_b, W, W, k, groups=2).to(wd)
+            dwb = ops.conv_wgrad(a_out, draw_b, W, W, k, groups=2, grad_params=[wb0, wb1]).to(wd)
         wdg = _fused_weights([wb0, wb1], 1, "grouped")
         da, _ = ops.conv2d(draw_b, wdg, W, k, 1, ops.EPI_RAW, groups=2)
         # first convs: one BatchNorm + SiLU backward over the 2W channels, one dense weight gradient (the stem output needs none)
         draw_a, dgam_a, dbet_a = ops.bn_silu_bwd_multi([da], a_raw, a_ss, a_mean, a_inv, [ga0, ga1])
         with ops.param_grad_stream([wa0, wa1], x, draw_a):
-            dwa = ops.conv_wgrad(x, draw_a, x.shape[-1], 2 * W, k).to(wd)
+            dwa = ops.conv_wgrad(x, draw_a, x.shape[-1], 2 * W, k, grad_params=[wa0, wa1]).to(wd)
         pd = ctx.pdtype
         c = lambda t: t if t.dtype == pd else t.to(pd)
         return (None, None, dwa[:W], dwa[W:], dwb[:W], dwb[W:],
