@@ -50,8 +50,10 @@ def c3():
     torch.cuda.synchronize()
     dbg = dict(model.head.debug)
     model.head.debug = None
+    # the step's parameter gradients, before any later test runs a backward of its own through these modules
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
     cfg = O.TSCDConfig(num_classes=NC, minimal_limit=50, maximal_limit=500)
-    return dict(model=model, imgs=imgs, targets=targets, temb=temb, out=out, dbg=dbg, sd=sd, cfg=cfg, scale=float(scale))
+    return dict(model=model, imgs=imgs, targets=targets, temb=temb, out=out, dbg=dbg, sd=sd, cfg=cfg, scale=float(scale), grads=grads)
 
 
 def test_c3_step_is_the_workload(c3):
@@ -256,10 +258,9 @@ def test_c3_losses_with_product_decisions_forced(c3, c3_forced):
 
 
 def _grad_cosines(c3, names, ref_grads):
-    named = dict(c3["model"].named_parameters())
     cosines, ratios = {}, {}
     for k in names:
-        r, g = ref_grads.get(k), named[k].grad
+        r, g = ref_grads.get(k), c3["grads"].get(k)
         if r is None or g is None:
             continue
         g = g.float().cpu().flatten() / c3["scale"]            # the fixture backpropagates total_loss x the loss scale

@@ -555,12 +555,12 @@ __global__ __launch_bounds__(256) void wgrad_jobs_reduce_kernel(WgradRedTable t)
     q.dw[grp * total_g + ((long)co * q.Cin + ci) * taps + tap] = a;
   }
 }
-// Splits of a job: none up to 80 k-tiles (2560 pixels); beyond, ~48 k-tiles per workgroup, but never more than ~1024 workgroups per
-// job (the 72 x 72 level's convs: 14 slabs of 185 k-tiles instead of 54 -- their slab traffic would otherwise rival the operand reads).
+// Splits of a job: none up to 80 k-tiles (2560 pixels); beyond, ~48 k-tiles per workgroup, but never more than ~512 workgroups per
+// job (the 72 x 72 level's convs: 7 slabs of 370 k-tiles instead of 54 -- their slab traffic would otherwise rival the operand reads).
 static int wgrad_job_splits_t(long M, long tiles) {
   const long kt = (M + 31) / 32;
   if (kt <= 80) return 1;
-  long s = (kt + 47) / 48, cap = 1024 / (tiles > 0 ? tiles : 1);
+  long s = (kt + 47) / 48, cap = 512 / (tiles > 0 ? tiles : 1);
   if (cap < 2) cap = 2;
   if (s > cap) s = cap;
   return (int)(s < 2 ? 2 : s);
