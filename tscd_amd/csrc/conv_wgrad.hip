@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(WgradParams p) 
 // (4 GFLOP in 50 us, tools/wgrad_census.py); nothing in the backward pass waits for them, so the host collects them and flushes them
 // together (tscd_amd/ops.py: deferred weight gradients).  A workgroup finds its job by its index (jobs are laid out back to back,
 // longest walk first); unsplit 1x1 jobs write straight into dw (torch layout), the others fp32 slabs that ONE more launch reduces.
-#define WGRAD_MAX_JOBS 32
+#define WGRAD_MAX_JOBS 40
 struct WgradJob {
   const f16* x; const f16* dy; float* part;
   int B, H, W, Cin, Cout, KH, ldx, lddy, M, Ncols, S, ktiles_per_split, mtiles, ntiles, G, wg_begin;
@@ -524,35 +524,32 @@ extern "C" int tscd_conv_wgrad_nhwc_f16_ex(const void* x, const void* dy, float*
 // {x, dy, dw, B, H, W, cin, cout, ksize, ldx, lddy, groups}: a stride-1 "same" conv of B x H x W pixels (an nn.Linear over M rows is
 // B = H = 1, W = M, ksize = 1), dw [groups * cout][cin][k][k] fp32 (torch layout).  Every workgroup walks at most ~48 k-tiles (1536
 // pixels): longer jobs are split over the pixels into fp32 slabs in ``workspace``, which a second launch adds in slab order and lays
-// out as dw -- deterministic.  Unsplit ungrouped 1x1 jobs write dw directly.  At most 32 jobs per call.
+// out as dw -- deterministic.  Unsplit ungrouped 1x1 jobs write dw directly.  At most 40 jobs per call (the job table travels as a kernel argument: 40 x 88 bytes).
 struct WgradJobHost { const void* x; const void* dy; float* dw; int B, H, W, cin, cout, ksize, ldx, lddy, groups, pad_; };
 struct WgradRedJob { const float* part; float* dw; int S, Cout, Cin, K, G, wg_begin; };
 struct WgradRedTable { WgradRedJob job[WGRAD_MAX_JOBS]; int njobs; };
-// one job's slabs -> dw (the body of wgrad_reduce_kernel over a block range of its own)
+// one job's slabs -> dw: a thread adds the S slabs of four consecutive input channels of one (cout, tap) -- 16-byte loads, coalesced
+// along the slab rows -- in slab order, and stores them at their places in the torch layout [cout][cin][k][k]
 __global__ __launch_bounds__(256) void wgrad_jobs_reduce_kernel(WgradRedTable t) {
-  __shared__ float red[4][64];
   const int bid = blockIdx.x;
   int j = 0;
   for (int i = 1; i < t.njobs; ++i) j = bid >= t.job[i].wg_begin ? i : j;
   const WgradRedJob q = t.job[j];
-  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int taps = q.K * q.K, Ncols = taps * q.Cin;
   const long total_g = (long)q.Cout * Ncols, total = total_g * q.G;
-  const long src = (long)(bid - q.wg_begin) * 64 + o;
+  const long src = ((long)(bid - q.wg_begin) * 256 + threadIdx.x) * 4;       // Cin % 8 == 0: the four never straddle a tap or a row
+  if (src >= total) return;
   const long grp = src / total_g, r = src - grp * total_g;
-  float a = 0.f;
-  if (src < total) {
-    const float* pg = q.part + grp * q.S * total_g + r;
-#pragma unroll 4
-    for (int s = g; s < q.S; s += 4) a += pg[(long)s * total_g];
-  }
-  red[g][o] = a;
-  __syncthreads();
-  if (g == 0 && src < total) {
-    a = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
-    const int co = (int)(r / Ncols), col = (int)(r - (long)co * Ncols);
-    const int tap = col / q.Cin, ci = col - tap * q.Cin;
-    q.dw[grp * total_g + ((long)co * q.Cin + ci) * taps + tap] = a;
+  const float* pg = q.part + grp * q.S * total_g + r;
+  f32x4 a = *(const f32x4*)pg;
+  for (int s = 1; s < q.S; ++s) a += *(const f32x4*)(pg + (long)s * total_g);
+  const int co = (int)(r / Ncols), col = (int)(r - (long)co * Ncols);
+  const int tap = col / q.Cin, ci = col - tap * q.Cin;
+  float* d = q.dw + grp * total_g + ((long)co * q.Cin + ci) * taps + tap;
+  if (taps == 1) {
+    *(f32x4*)d = a;
+  } else {
+    d[0] = a[0]; d[taps] = a[1]; d[2 * taps] = a[2]; d[3 * taps] = a[3];
   }
 }
 // Splits of a job: none up to 80 k-tiles (2560 pixels); beyond, ~48 k-tiles per workgroup, but never more than ~512 workgroups per
@@ -633,7 +630,7 @@ extern "C" int tscd_wgrad_batch_f16(const void* jobs_host, int njobs, void* work
       ws += (4L * q.S * n + 255) / 256 * 256;
       WgradRedJob& rj = r.job[r.njobs++];
       rj.part = q.part; rj.dw = a.dw; rj.S = q.S; rj.Cout = a.cout; rj.Cin = a.cin; rj.K = a.ksize; rj.G = q.G; rj.wg_begin = (int)rwg;
-      rwg += (n + 63) / 64;
+      rwg += (n / 4 + 255) / 256;
     }
   }
   TSCD_CHECK_ARG(wg < (1L << 31) && rwg < (1L << 31), "wgrad_batch: grid too large");
