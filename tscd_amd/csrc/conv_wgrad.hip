@@ -528,29 +528,45 @@ extern "C" int tscd_conv_wgrad_nhwc_f16_ex(const void* x, const void* dy, float*
 struct WgradJobHost { const void* x; const void* dy; float* dw; int B, H, W, cin, cout, ksize, ldx, lddy, groups, pad_; };
 struct WgradRedJob { const float* part; float* dw; int S, Cout, Cin, K, G, wg_begin; };
 struct WgradRedTable { WgradRedJob job[WGRAD_MAX_JOBS]; int njobs; };
-// one job's slabs -> dw: a thread adds the S slabs of four consecutive input channels of one (cout, tap) -- 16-byte loads, coalesced
-// along the slab rows -- in slab order, and stores them at their places in the torch layout [cout][cin][k][k]
+// one job's slabs -> dw.  A thread adds the S slabs of four consecutive input channels of one (cout, tap) -- 16-byte loads, coalesced
+// along the slab rows -- in slab order.  1x1: the slab row IS the dw row.  3x3: a workgroup takes one cout and 64 input channels, stages
+// its 9 x 64 sums in LDS and writes them as the 576 contiguous floats they are in the torch layout [cout][cin][3][3].
 __global__ __launch_bounds__(256) void wgrad_jobs_reduce_kernel(WgradRedTable t) {
+  __shared__ float tr[64 * 9];
   const int bid = blockIdx.x;
   int j = 0;
   for (int i = 1; i < t.njobs; ++i) j = bid >= t.job[i].wg_begin ? i : j;
   const WgradRedJob q = t.job[j];
   const int taps = q.K * q.K, Ncols = taps * q.Cin;
-  const long total_g = (long)q.Cout * Ncols, total = total_g * q.G;
-  const long src = ((long)(bid - q.wg_begin) * 256 + threadIdx.x) * 4;       // Cin % 8 == 0: the four never straddle a tap or a row
-  if (src >= total) return;
-  const long grp = src / total_g, r = src - grp * total_g;
-  const float* pg = q.part + grp * q.S * total_g + r;
-  f32x4 a = *(const f32x4*)pg;
-  for (int s = 1; s < q.S; ++s) a += *(const f32x4*)(pg + (long)s * total_g);
-  const int co = (int)(r / Ncols), col = (int)(r - (long)co * Ncols);
-  const int tap = col / q.Cin, ci = col - tap * q.Cin;
-  float* d = q.dw + grp * total_g + ((long)co * q.Cin + ci) * taps + tap;
+  const long total_g = (long)q.Cout * Ncols;
+  const int lb = bid - q.wg_begin;
   if (taps == 1) {
-    *(f32x4*)d = a;
-  } else {
-    d[0] = a[0]; d[taps] = a[1]; d[2 * taps] = a[2]; d[3 * taps] = a[3];
+    const long total = total_g * q.G;
+    const long src = ((long)lb * 256 + threadIdx.x) * 4;
+    if (src >= total) return;
+    const long grp = src / total_g;
+    const float* pg = q.part + grp * (q.S - 1) * total_g + src;          // slab 0 of the group that owns element `src`
+    f32x4 a = *(const f32x4*)pg;
+    for (int s = 1; s < q.S; ++s) a += *(const f32x4*)(pg + (long)s * total_g);
+    *(f32x4*)(q.dw + src) = a;
+    return;
   }
+  // 3x3: workgroup = (group, cout, block of 64 input channels)
+  const int cblocks = (q.Cin + 63) / 64;
+  const int cb = lb % cblocks, row = lb / cblocks;                       // row = grp * Cout + co
+  const int grp = row / q.Cout, co = row - grp * q.Cout;
+  const int ci0 = cb * 64, nci = q.Cin - ci0 < 64 ? q.Cin - ci0 : 64;     // multiple of 8
+  const int tid = threadIdx.x;
+  const int tap = tid >> 4, c4 = (tid & 15) * 4;
+  if (tap < taps && c4 < nci) {
+    const float* pg = q.part + (long)grp * q.S * total_g + (long)co * Ncols + tap * q.Cin + ci0 + c4;
+    f32x4 a = *(const f32x4*)pg;
+    for (int s = 1; s < q.S; ++s) a += *(const f32x4*)(pg + (long)s * total_g);
+    tr[(c4 + 0) * 9 + tap] = a[0]; tr[(c4 + 1) * 9 + tap] = a[1]; tr[(c4 + 2) * 9 + tap] = a[2]; tr[(c4 + 3) * 9 + tap] = a[3];
+  }
+  __syncthreads();
+  float* d = q.dw + (long)grp * total_g + ((long)co * q.Cin + ci0) * 9;
+  for (int i = tid; i < nci * 9; i += 256) d[i] = tr[i];
 }
 // Splits of a job: none up to 80 k-tiles (2560 pixels); beyond, ~48 k-tiles per workgroup, but never more than ~512 workgroups per
 // job (the 72 x 72 level's convs: 7 slabs of 370 k-tiles instead of 54 -- their slab traffic would otherwise rival the operand reads).
@@ -630,7 +646,7 @@ extern "C" int tscd_wgrad_batch_f16(const void* jobs_host, int njobs, void* work
       ws += (4L * q.S * n + 255) / 256 * 256;
       WgradRedJob& rj = r.job[r.njobs++];
       rj.part = q.part; rj.dw = a.dw; rj.S = q.S; rj.Cout = a.cout; rj.Cin = a.cin; rj.K = a.ksize; rj.G = q.G; rj.wg_begin = (int)rwg;
-      rwg += (n / 4 + 255) / 256;
+      rwg += a.ksize == 1 ? (n / 4 + 255) / 256 : (long)q.G * a.cout * ((a.cin + 63) / 64);
     }
   }
   TSCD_CHECK_ARG(wg < (1L << 31) && rwg < (1L << 31), "wgrad_batch: grid too large");
