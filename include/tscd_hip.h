@@ -183,6 +183,9 @@ int tscd_wgrad_batch_max_jobs(void);
 int tscd_wgrad_batch_supported(int B, int H, int W, int cin, int cout, int ksize, int ldx, int lddy, int groups);
 long tscd_wgrad_batch_workspace_bytes(const void* jobs_host, int njobs);
 int tscd_wgrad_batch_f16(const void* jobs_host, int njobs, void* workspace, long workspace_bytes, void* stream);
+/* Bias gradients of several nn.Linear layers in one launch (the same deferred pass as tscd_wgrad_batch_f16): jobs = HOST array of njobs
+ * records {const void* dy [M][C] fp16; float* db [C]; int M, C (multiple of 8), lddy, pad}; db_j[c] = sum over the M rows, fp32, fixed order. */
+int tscd_colsum_batch_f16(const void* jobs_host, int njobs, void* stream);
 /* The step's gradients into one flat fp32 arena and / or their non-finite check, one launch: replaces the GradScaler's inf check
  * inside scaler.step (tscd_trainer.py:171-176; torch: 6 multi-tensor launches) and the flattening of gradients into all-reduce
  * buckets that DistributedDataParallel does per parameter (tscd_trainer.py:230-231).  table: device array of nrows records

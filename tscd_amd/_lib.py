@@ -35,6 +35,7 @@ SIGNATURES = {
     "tscd_sgd_ema_step_f32": [P, L, P, P, I, F, I, P, P, F, F, P],
     "tscd_grad_gather_check_f32": [P, L, P, F, P, P],
     "tscd_wgrad_batch_f16": [P, I, P, L, P],
+    "tscd_colsum_batch_f16": [P, I, P],
     "tscd_sgd_ema_step_indirect_f32": [P, L, P, P, P, I, F, I, P, P, F, F, P],
     "tscd_conv_bn_act_train_f16": [P, P, P, I, P, I, I, I, I, I, I, I, I, I, P, P, F, F, P, P, P, P, I, P, I, I, P],
     "tscd_decode_score": [P, P, P, P, P, P, I, I, P, P, P, P],

@@ -660,6 +660,59 @@ extern "C" int tscd_wgrad_batch_f16(const void* jobs_host, int njobs, void* work
   return TSCD_OK;
 }
 
+// Column sums of several dY matrices (the bias gradients of the pass's nn.Linear layers) in ONE launch: db_j[c] = sum_r dY_j[r][c].
+// Workgroup = (job, 64 columns): 32 row lanes x 8 column chunks of 16 bytes, fp32 partial sums combined through LDS in row-lane order
+// (deterministic).  jobs: host array of {dy [M][C] fp16 (row stride lddy), db [C] fp32, M, C, lddy}.
+struct ColsumJobHost { const void* dy; float* db; int M, C, lddy, pad_; };
+struct ColsumJob { const f16* dy; float* db; int M, C, lddy, wg_begin; };
+struct ColsumTable { ColsumJob job[WGRAD_MAX_JOBS]; int njobs; };
+__global__ __launch_bounds__(256) void colsum_jobs_kernel(ColsumTable t) {
+  __shared__ float red[32][65];
+  const int bid = blockIdx.x;
+  int j = 0;
+  for (int i = 1; i < t.njobs; ++i) j = bid >= t.job[i].wg_begin ? i : j;
+  const ColsumJob q = t.job[j];
+  const int c0 = (bid - q.wg_begin) * 64, chunk = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = c0 + chunk * 8;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (c < q.C) {                                   // C % 8 == 0: a chunk is inside or outside
+    const f16* p = q.dy + (long)rl * q.lddy + c;
+    for (int r = rl; r < q.M; r += 32, p += 32L * q.lddy) {
+      const f16x8 v = *(const f16x8*)p;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][chunk * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64 && c0 + threadIdx.x < q.C) {
+    float a = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) a += red[r][threadIdx.x];
+    q.db[c0 + threadIdx.x] = a;
+  }
+}
+extern "C" int tscd_colsum_batch_f16(const void* jobs_host, int njobs, void* stream) {
+  TSCD_CHECK_ARG(jobs_host && njobs > 0 && njobs <= WGRAD_MAX_JOBS, "colsum_batch: 1..%d jobs", WGRAD_MAX_JOBS);
+  const ColsumJobHost* h = (const ColsumJobHost*)jobs_host;
+  ColsumTable t;
+  int wg = 0;
+  for (int i = 0; i < njobs; ++i) {
+    TSCD_CHECK_ARG(h[i].dy && h[i].db && h[i].M > 0 && h[i].C > 0 && h[i].C % 8 == 0 && h[i].lddy % 8 == 0 && h[i].lddy >= h[i].C &&
+                   ((uintptr_t)h[i].dy & 15) == 0, "colsum_batch: job %d: bad pointer / shape", i);
+    t.job[i].dy = (const f16*)h[i].dy; t.job[i].db = h[i].db; t.job[i].M = h[i].M; t.job[i].C = h[i].C; t.job[i].lddy = h[i].lddy;
+    t.job[i].wg_begin = wg;
+    wg += cdiv(h[i].C, 64);
+  }
+  t.njobs = njobs;
+  hipLaunchKernelGGL(colsum_jobs_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
+  TSCD_CHECK_LAUNCH("colsum_batch");
+  return TSCD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- BN + SiLU backward
 #define BNB_ROWS 32
 // SiLU'(t) with the fast gate (see sigmoid_fast_)

@@ -67,6 +67,7 @@ class _MCAFunction(torch.autograd.Function):
             t_obj = ops.linear(cat3_r, w_obj, b_obj)
         if want:
             ctx.cfg = cfg
+            ctx.biases = (b_lin, b_linr, b_out, b_obj)     # parameter objects: name the bias gradients for the pass's batched launch
             ctx.save_for_backward(xc, xr, sc, q_c, kv_c, q_r, kv_r, tiles, stats, xcat_c, cat3_c, xcat_r, cat3_r, wq_c, wkv_c, wq_r, wkv_r,
                                   w_lin, w_linr, w_out, w_obj, fwd_ws)
         return (t_cls, t_obj) if need_reg else t_cls
@@ -80,18 +81,20 @@ class _MCAFunction(torch.autograd.Function):
         nl = q_c.shape[0]
         z16 = lambda *shape: ops.ztemp(shape, dtype=torch.float16, device=xc.device)
 
-        def head(g, cat3, xcat, w_o, w_l):
+        b_lin, b_linr, b_out, b_obj = ctx.biases
+
+        def head(g, cat3, xcat, w_o, w_l, b_o, b_l):
             """through linear(3W->4W) and mca.linear(2W->2W): -> d cat3 [nl,3W], d xcat [nl,2W], dW_o, db_o, dW_l, db_l"""
             if g is None:      # this output was not used downstream: no gradient for its two linears (SURVEY F5)
                 return z16(nl, 3 * W), z16(nl, 2 * W), None, None, None, None
             g = g.to(torch.float16).contiguous()
-            d_cat3, dw_o, db_o = ops.linear_bwd(cat3, g, w_o, True, True, True, grad_params=[w_o])
-            d_xcat, dw_l, db_l = ops.linear_bwd(xcat, d_cat3[:, W:], w_l, True, True, True, grad_params=[w_l])    # dY = a column slice of d_cat3
+            d_cat3, dw_o, db_o = ops.linear_bwd(cat3, g, w_o, True, True, True, grad_params=[w_o, b_o])
+            d_xcat, dw_l, db_l = ops.linear_bwd(xcat, d_cat3[:, W:], w_l, True, True, True, grad_params=[w_l, b_l])    # dY = a column slice of d_cat3
             return d_cat3, d_xcat, dw_o, db_o, dw_l, db_l
 
-        dc3_c, dxc_c, dw_out, db_out, dw_lin, db_lin = head(g_cls, cat3_c, xcat_c, w_out, w_lin)
+        dc3_c, dxc_c, dw_out, db_out, dw_lin, db_lin = head(g_cls, cat3_c, xcat_c, w_out, w_lin, b_out, b_lin)
         if need_reg:
-            dc3_r, dxc_r, dw_obj, db_obj, dw_linr, db_linr = head(g_obj, cat3_r, xcat_r, w_obj, w_linr)
+            dc3_r, dxc_r, dw_obj, db_obj, dw_linr, db_linr = head(g_obj, cat3_r, xcat_r, w_obj, w_linr, b_obj, b_linr)
         else:
             dc3_r = dxc_r = dw_obj = db_obj = dw_linr = db_linr = None
         dq_c, dkv_c, dq_r, dkv_r, dscore = ops.mca_backward(q_c, kv_c, q_r, kv_r, sc, tiles, N, nl, W, need_reg, scale, sim_thresh,

@@ -68,6 +68,7 @@ class _Linear(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.bias_param = b               # (the parameter object: names the bias gradient for the pass's batched launch)
         return ops.linear(x, w, b)
 
     @staticmethod
@@ -76,7 +77,7 @@ class _Linear(torch.autograd.Function):
         if g.dtype != torch.float16:
             g = g.to(torch.float16)
         need = ctx.needs_input_grad
-        dx, dw, db = ops.linear_bwd(x, g, w, need[0], need[1], ctx.has_bias and need[2], grad_params=[w])
+        dx, dw, db = ops.linear_bwd(x, g, w, need[0], need[1], ctx.has_bias and need[2], grad_params=[w, ctx.bias_param if ctx.has_bias and need[2] else None])
         if dw is not None and dw.dtype != w.dtype:
             dw = dw.to(w.dtype)
         if db is not None and db.dtype != w.dtype:
