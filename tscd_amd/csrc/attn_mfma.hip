@@ -53,6 +53,26 @@ __device__ __forceinline__ float load_row(const f16* __restrict__ row, bool ok, 
   ss += __shfl_xor(ss, 32, 64);
   return ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
 }
+// The same in two steps, so that a loop can FETCH the next tile's raw rows before the matrix products of the current one (the
+// one-wave workgroups of this file are latency-bound: a fetch that is waited for at once costs a full L2 round trip per tile)
+template <int KS>
+__device__ __forceinline__ void load_raw(const f16* __restrict__ row, bool ok, int half, f16x8 (&f)[KS]) {
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    f[s] = ok ? *(const f16x8*)(row + 16 * s + 8 * half) : z;
+  }
+}
+template <int KS>
+__device__ __forceinline__ float inv_norm(const f16x8 (&f)[KS]) {
+  float ss = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += (float)f[s][j] * (float)f[s][j];
+  ss += __shfl_xor(ss, 32, 64);
+  return ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
+}
 template <int KS>
 __device__ __forceinline__ void scale_row(f16x8 (&f)[KS], float inv) {
 #pragma unroll
@@ -87,16 +107,24 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_kernel(const f16* __restrict
     for (int e = 0; e < 16; ++e) oacc[m][e] = 0.f;
   float psum = 0.f;
 
+  f16x8 kn[KS], vn[KS];            // raw rows of the NEXT key tile, in flight under the current tile's products
+  {
+    const bool ok0 = t.key0 + col < t.key1;
+    const long r0 = t.key0 + (ok0 ? col : 0);
+    load_raw<KS>(k + r0 * C + h * D, ok0, half, kn);
+    load_raw<KS>(v + r0 * C + h * D, ok0, half, vn);
+  }
   for (int kb = t.key0; kb < t.key1; kb += 32) {
-    const bool kok = kb + col < t.key1;
-    const long krow = kb + (kok ? col : 0);
     f16x8 kf[KS], vf[KS];
-    scale_row<KS>(kf, load_row<KS>(k + krow * C + h * D, kok, half, kf));
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      vf[s] = kok ? *(const f16x8*)(v + krow * C + h * D + 16 * s + 8 * half) : z;
+    for (int s = 0; s < KS; ++s) { kf[s] = kn[s]; vf[s] = vn[s]; }
+    if (kb + 32 < t.key1) {
+      const bool okn = kb + 32 + col < t.key1;
+      const long rn = kb + 32 + (okn ? col : 0);
+      load_raw<KS>(k + rn * C + h * D, okn, half, kn);
+      load_raw<KS>(v + rn * C + h * D, okn, half, vn);
     }
+    scale_row<KS>(kf, inv_norm<KS>(kf));
     __syncthreads();   // single-wave workgroup: orders the previous tile's transposing reads before the overwrite
 #pragma unroll
     for (int s = 0; s < KS; ++s) *(f16x8*)(vt + col * P + 16 * s + 8 * half) = vf[s];
@@ -196,16 +224,24 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __rest
 #pragma unroll
     for (int e = 0; e < 16; ++e) dqacc[m][e] = 0.f;
 
+  f16x8 kn[KS], vn[KS];            // raw rows of the NEXT key tile (see the forward kernel)
+  {
+    const bool ok0 = t.key0 + col < t.key1;
+    const long r0 = t.key0 + (ok0 ? col : 0);
+    load_raw<KS>(k + r0 * C + h * D, ok0, half, kn);
+    load_raw<KS>(v + r0 * C + h * D, ok0, half, vn);
+  }
   for (int kb = t.key0; kb < t.key1; kb += 32) {
-    const bool kok = kb + col < t.key1;
-    const long krow = kb + (kok ? col : 0);
     f16x8 kf[KS], vf[KS];
-    scale_row<KS>(kf, load_row<KS>(k + krow * C + h * D, kok, half, kf));
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      vf[s] = kok ? *(const f16x8*)(v + krow * C + h * D + 16 * s + 8 * half) : z;
+    for (int s = 0; s < KS; ++s) { kf[s] = kn[s]; vf[s] = vn[s]; }
+    if (kb + 32 < t.key1) {
+      const bool okn = kb + 32 + col < t.key1;
+      const long rn = kb + 32 + (okn ? col : 0);
+      load_raw<KS>(k + rn * C + h * D, okn, half, kn);
+      load_raw<KS>(v + rn * C + h * D, okn, half, vn);
     }
+    scale_row<KS>(kf, inv_norm<KS>(kf));
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < KS; ++s) *(f16x8*)(kt + col * P + 16 * s + 8 * half) = kf[s];
@@ -347,18 +383,30 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kv_kernel(const f16* __r
 #pragma unroll
     for (int e = 0; e < 16; ++e) dkacc[m][e] = dvacc[m][e] = 0.f;
 
+  f16x8 qn[KS], gn[KS];            // raw rows (and row scalars) of the NEXT query tile, in flight under the current tile's products
+  float ln, dln;
+  {
+    const bool ok0 = t.key0 + col < t.key1;
+    const long r0 = t.key0 + (ok0 ? col : 0);
+    load_raw<KS>(q + r0 * C + h * D, ok0, half, qn);
+    load_raw<KS>(dO + r0 * C + h * D, ok0, half, gn);
+    ln = ok0 ? lsum[r0 * heads + h] : 0.f;
+    dln = ok0 ? delta[r0 * heads + h] : 0.f;
+  }
   for (int qb = t.key0; qb < t.key1; qb += 32) {
-    const bool qok = qb + col < t.key1;
-    const long qrow = qb + (qok ? col : 0);
     f16x8 qf[KS], gf[KS];
-    scale_row<KS>(qf, load_row<KS>(q + qrow * C + h * D, qok, half, qf));
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      gf[s] = qok ? *(const f16x8*)(dO + qrow * C + h * D + 16 * s + 8 * half) : z;
+    for (int s = 0; s < KS; ++s) { qf[s] = qn[s]; gf[s] = gn[s]; }
+    const float l = ln, dl = dln;
+    if (qb + 32 < t.key1) {
+      const bool okn = qb + 32 + col < t.key1;
+      const long rn = qb + 32 + (okn ? col : 0);
+      load_raw<KS>(q + rn * C + h * D, okn, half, qn);
+      load_raw<KS>(dO + rn * C + h * D, okn, half, gn);
+      ln = okn ? lsum[rn * heads + h] : 0.f;
+      dln = okn ? delta[rn * heads + h] : 0.f;
     }
-    const float l = qok ? lsum[qrow * heads + h] : 0.f;
-    const float dl = qok ? delta[qrow * heads + h] : 0.f;
+    scale_row<KS>(qf, inv_norm<KS>(qf));
     __syncthreads();   // single-wave workgroup: the previous tile's transposing reads are done
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
