@@ -221,12 +221,30 @@ def test_backbone_prefetch_in_assignment_window_is_exact(golden, model):
 
     a, b, c = fresh(), fresh(), fresh()
     # a: clip 1 with the prefetch of clip 2, then clip 2;  b: the same two clips back to back without it
+    from yolox.utils import ModelEMA
+    ema_a, ema_b = ModelEMA(a, 0.9998), ModelEMA(b, 0.9998)
+    ema_a.updates = ema_b.updates = 4000                   # a decay well away from 0 (0.9998 * (1 - e^-2))
     out_a1 = a(imgs, labels, temb, next_x=imgs2, **kw)
     assert id(a) in tscd_mod._PREFETCHED
     stash = [t.clone() for t in tscd_mod._PREFETCHED[id(a)][1]]
+    # EMA / checkpoint order (reference tscd_trainer.py:171-176, ema.py:48-60): after step 1 the EMA and a checkpoint must see the frozen
+    # front's running statistics with clip 1 ONLY, although the prefetched pass of clip 2 has already advanced the live buffers
+    ema_a.update(a)
+    ck_a = {k: v.clone() for k, v in a.step_state_dict().items()}
+    live_a = {k: v.clone() for k, v in a.state_dict().items()}
     out_a2 = a(imgs2, labels, temb, **kw)
     assert id(a) not in tscd_mod._PREFETCHED
     out_b1 = b(imgs, labels, temb, **kw)
+    ema_b.update(b)
+    torch.cuda.synchronize()
+    sd_b1 = b.state_dict()
+    moved = 0
+    for k, v in sd_b1.items():
+        assert torch.equal(ck_a[k], v), k                                   # the checkpoint view == the run without look-ahead after clip 1
+        moved += int(not torch.equal(live_a[k], v))
+    assert moved > 50                                                       # ... while the live buffers really are one clip ahead
+    for (k, va), (_, vb) in zip(ema_a.ema.state_dict().items(), ema_b.ema.state_dict().items()):
+        assert torch.equal(va, vb), k                                       # EMA(1) identical with and without the prefetched pass
     c(imgs, labels, temb, **kw)
     with torch.no_grad():
         direct = c.head.frozen_prefix(c.backbone(imgs2)).tensors()     # what an in-place pass of clip 2 produces at this point
