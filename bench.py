@@ -318,7 +318,12 @@ def parity_full_size(args, sd0, clip, gpu, oracle_free, simota, decisions):
             rel = rd(ref)
             out.update(oracle_forced={k: ref[k] for k in list(keys) + ["total_loss"]}, rel_diff=rel, max_rel_diff=max(rel.values()),
                        max_rel_diff_anchor_terms=max(rel[k] for k in keys if k in ("iou_loss", "conf_loss", "cls_loss")),
-                       forced_oracle_seconds=time.time() - t0)
+                       forced_oracle_seconds=time.time() - t0,
+                       reading="iou_loss: the benchmark's targets are the PRODUCT's own decoded boxes of six proposals per frame "
+                               "(targets_on_top_proposals), so any other evaluation of the network scores ~5 % worse against them -- the fp32 "
+                               "oracle and the oracle's ops in fp16 alike; tests/test_gpu_fullsize_c3.py::test_c3_conv_stack_against_the_oracle "
+                               "asserts that the boxes agree box for box within the fp16 noise floor and that the bias flips when the targets "
+                               "are read from the oracle instead; every other term is arithmetic (<= 1 %)")
         except Exception as ex:
             out["forced_error"] = repr(ex)
     free = rd(oracle_free)

@@ -109,3 +109,37 @@ def test_eager_class_branch_follows_the_loss_scale(golden):
     assert applied >= 4, (applied, scales)             # the scaler backed off until the eager branch stopped overflowing
     assert scales[-1] == scales[-2] == scales[-3]      # and settled
     assert torch.isfinite(m2.head.cls_pred.weight).all() and not torch.equal(w0, m2.head.cls_pred.weight.detach())
+
+
+def test_fused_towers_honour_the_batchnorm_mode(golden):
+    """Advisor r03: with the exps' fix_bn option (BatchNorms put in eval() inside a training model, ovis_tscd_large.py:153-160) the
+    trained towers must normalise with RUNNING statistics and leave them untouched.  The fused no-grad path follows the modules' own
+    mode (== the unfused BaseConv calls, bit for bit); mixed modes are not fused; gradients through an eval-mode BatchNorm are refused
+    (the running-statistics backward is not built) instead of silently taking batch statistics."""
+    from yolox.models import tower_fusion as TW
+    m, imgs, labels, temb, kw = _tiny(golden, train=True)
+    head = m.head
+    with torch.no_grad():
+        x = head.stems[0](m.backbone(imgs)[0].permute(0, 2, 3, 1).half())
+    t0, t1 = head.cls_convs2[0], head.reg_convs2[0]
+    convs = [t0[0], t1[0], t0[1], t1[1]]
+    for c in convs:
+        c.bn.eval()
+    assert TW.fusable(convs) and not TW.batch_stats(t0[0])
+    stats = [c.bn.running_mean.clone() for c in convs]
+    with torch.no_grad():
+        fused = TW.towers_nograd(x, [t0[0], t1[0]], [t0[1], t1[1]])
+        W = head.width
+        want_c, want_r = t0[1](t0[0](x)), t1[1](t1[0](x))
+    torch.cuda.synchronize()
+    assert torch.equal(fused[..., :W], want_c) and torch.equal(fused[..., W:], want_r)
+    assert all(torch.equal(s, c.bn.running_mean) for s, c in zip(stats, convs))          # running statistics untouched
+    t0[0].bn.train()                                                                       # mixed modes: one launch cannot serve both
+    assert not TW.fusable(convs)
+    t0[0].bn.eval()
+    with pytest.raises(NotImplementedError):
+        m(imgs, labels, temb, **kw)                                                        # training forward with gradients: refused, loudly
+    for c in convs:
+        c.bn.train()
+    out = m(imgs, labels, temb, **kw)
+    assert torch.isfinite(out["total_loss"])

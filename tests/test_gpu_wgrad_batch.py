@@ -68,8 +68,8 @@ def test_deferred_linear_weight_gradients_match_fp32_products(monkeypatch, twice
         assert float((dw - ref_w).abs().max()) <= 2e-3 * sw + 1e-5, (tuple(x.shape), float((dw - ref_w).abs().max()), sw)
         assert float((dw_i - ref_w).abs().max()) <= 2e-3 * sw + 1e-5
         assert float((db - ref_b).abs().max()) <= 2e-3 * sb + 1e-5
-        assert torch.equal(db, db_i)                                         # bias sums and data gradients take the same path either way
-        assert torch.equal(dx, dx_i)
+        assert float((db_i - ref_b).abs().max()) <= 2e-3 * sb + 1e-5        # (immediate: two-stage column sums; deferred: the batched launch)
+        assert torch.equal(dx, dx_i)                                         # data gradients take the same path either way
         assert lin.weight.grad.shape == lin.weight.shape and lin.weight.grad.is_contiguous()
 
 
@@ -81,7 +81,7 @@ def test_deferred_gradient_is_adopted_not_cloned(monkeypatch):
     real_compute = ops._WgradBatch.compute
 
     def compute(self):
-        seen.extend(dw for _, dw in self.check)
+        seen.extend(dw for prm, dw in self.check if prm.dim() == 2)            # the weights' entries (the biases are registered too)
         return real_compute(self)
 
     monkeypatch.setattr(ops._WgradBatch, "compute", compute)

@@ -1046,17 +1046,20 @@ def linear_bwd(x, dy, weight, need_dx=True, need_dw=True, need_db=False, grad_pa
     # the data-gradient copy of a PARAMETER is cached per version (and refreshed in the optimizer's batched re-pack): no pack launch here
     wdg = LINEAR_WEIGHTS.get(weight, mode=1) if need_dx and isinstance(weight, torch.nn.Parameter) and weight.is_contiguous() else None
     args = (x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), w.data_ptr(), int(w.dtype == torch.float32), _ptr(wdg), n, in_f, out_f, outp)
-    batch = _wgrad_batch([p_ for p_ in grad_params if p_ is not None]) if (need_dw and grad_params is not None and x.stride(1) == 1 and x.stride(0) % 8 == 0
+    bias_param = grad_params[1] if grad_params is not None and len(grad_params) > 1 else None
+    if grad_params is not None:
+        grad_params = [p_ for p_ in grad_params if p_ is not None]
+    batch = _wgrad_batch(grad_params) if (need_dw and grad_params is not None and x.stride(1) == 1 and x.stride(0) % 8 == 0
                                           and x.data_ptr() % 16 == 0 and in_f % 8 == 0) else None
     if batch is not None:
         # deferred: data gradient now, the weight-gradient GEMM with all the others at the end of the pass -- and the bias column sums
         # too when the caller named the bias parameter (grad_params = [weight, bias]); otherwise they are computed here
-        db_deferred = need_db and len(grad_params) > 1 and grad_params[1] is not None and grad_params[1].grad is None
+        db_deferred = need_db and bias_param is not None and bias_param.grad is None
         if need_dx or (need_db and not db_deferred):
             call("tscd_linear_bwd_packed_f16", *args, _ptr(dx), 0, 0 if db_deferred else _ptr(db), ws.data_ptr(), ws_bytes, _stream())
         if db_deferred:
             batch.db_jobs.append(_ColsumJobC(dy.data_ptr(), db.data_ptr(), n, outp, dy.stride(0), 0))
-            batch.check.append((grad_params[1], db[:out_f]))
+            batch.check.append((bias_param, db[:out_f]))
         batch.jobs.append(_WgradJobC(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 1, 1, n, in_f, outp, 1, x.stride(0), dy.stride(0), 1, 0))
         batch.keep.append((x, dy))
         batch.check.append((grad_params[0], dw[:out_f]))
