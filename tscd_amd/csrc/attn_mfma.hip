@@ -81,14 +81,22 @@ __device__ __forceinline__ void scale_row(f16x8 (&f)[KS], float inv) {
     for (int j = 0; j < 8; ++j) f[s][j] = (f16)((float)f[s][j] * inv);
 }
 
-template <int KS>
-__global__ __launch_bounds__(64) void cos_attn_mfma_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
-                                                          const f16* __restrict__ v, int C, int heads,
-                                                          const AttnTile* __restrict__ tiles, f16* __restrict__ out,
-                                                          float* __restrict__ lsum) {
-  constexpr int D = 16 * KS, MT = (KS + 1) / 2, P = tile_pitch(MT * 32);
-  __shared__ __attribute__((aligned(16))) f16 vt[32 * P];
-  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5, blk = (lane >> 4) & 1;
+// Waves per (query tile, head) task: the task's key tiles are dealt round-robin to NW waves (cos <= 1 needs no running maximum, so
+// the waves' partial sums simply add) and wave 0 adds the partials in wave order -- the one-wave loop over 16 key tiles was a pure
+// latency chain (a 32-row tile per microsecond).  Bounded by the 64 KB of static LDS: 4 waves up to head dim 32, 2 above.
+__host__ __device__ constexpr int attn_waves(int KS) { return KS <= 2 ? 4 : 2; }
+__host__ __device__ constexpr int attn_waves_kv(int KS) { return KS <= 2 ? 4 : 1; }      // the key-stationary kernel keeps two tiles per wave
+
+template <int KS, int NW>
+__global__ __launch_bounds__(64 * NW) void cos_attn_mfma_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                               const f16* __restrict__ v, int C, int heads,
+                                                               const AttnTile* __restrict__ tiles, f16* __restrict__ out,
+                                                               float* __restrict__ lsum) {
+  constexpr int D = 16 * KS, MT = (KS + 1) / 2, P = tile_pitch(MT * 32), RS = MT * 16 + 1;
+  __shared__ __attribute__((aligned(16))) f16 vt_all[NW][32 * P];
+  __shared__ float red[NW > 1 ? (NW - 1) * 64 * RS : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31, half = lane >> 5, blk = (lane >> 4) & 1;
+  f16* const vt = vt_all[wv];
   const AttnTile t = tiles[blockIdx.x / heads];
   const int h = blockIdx.x % heads;
   const bool qok = col < t.nrows;
@@ -107,25 +115,29 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_kernel(const f16* __restrict
     for (int e = 0; e < 16; ++e) oacc[m][e] = 0.f;
   float psum = 0.f;
 
-  f16x8 kn[KS], vn[KS];            // raw rows of the NEXT key tile, in flight under the current tile's products
+  f16x8 kn[KS], vn[KS];            // raw rows of this wave's NEXT key tile, in flight under the current tile's products
+  const int iters = ((t.key1 - t.key0 + 31) / 32 + NW - 1) / NW;       // the same count for every wave (the loop holds barriers)
   {
-    const bool ok0 = t.key0 + col < t.key1;
-    const long r0 = t.key0 + (ok0 ? col : 0);
+    const int kb0 = t.key0 + 32 * wv;
+    const bool ok0 = kb0 + col < t.key1;
+    const long r0 = ok0 ? kb0 + col : t.key0;
     load_raw<KS>(k + r0 * C + h * D, ok0, half, kn);
     load_raw<KS>(v + r0 * C + h * D, ok0, half, vn);
   }
-  for (int kb = t.key0; kb < t.key1; kb += 32) {
+  for (int it = 0; it < iters; ++it) {
+    const int kb = t.key0 + 32 * (it * NW + wv);
     f16x8 kf[KS], vf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) { kf[s] = kn[s]; vf[s] = vn[s]; }
-    if (kb + 32 < t.key1) {
-      const bool okn = kb + 32 + col < t.key1;
-      const long rn = kb + 32 + (okn ? col : 0);
+    if (it + 1 < iters) {
+      const int kbn = kb + 32 * NW;
+      const bool okn = kbn + col < t.key1;
+      const long rn = okn ? kbn + col : t.key0;
       load_raw<KS>(k + rn * C + h * D, okn, half, kn);
       load_raw<KS>(v + rn * C + h * D, okn, half, vn);
     }
     scale_row<KS>(kf, inv_norm<KS>(kf));
-    __syncthreads();   // single-wave workgroup: orders the previous tile's transposing reads before the overwrite
+    __syncthreads();   // orders the previous tile's transposing reads before the overwrite (each wave has its own tile)
 #pragma unroll
     for (int s = 0; s < KS; ++s) *(f16x8*)(vt + col * P + 16 * s + 8 * half) = vf[s];
     f32x16 st;
@@ -153,6 +165,27 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_kernel(const f16* __restrict
       }
   }
   psum += __shfl_xor(psum, 32, 64);
+  if (NW > 1) {                                  // partial sums of waves 1.. -> wave 0, added in wave order
+    if (wv > 0) {
+      float* r = red + ((wv - 1) * 64 + lane) * RS;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r[m * 16 + e] = oacc[m][e];
+      r[MT * 16] = psum;
+    }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) {
+      const float* r = red + ((ww - 1) * 64 + lane) * RS;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[m][e] += r[m * 16 + e];
+      psum += r[MT * 16];
+    }
+  }
   const float il = psum > 0.f ? 1.0f / psum : 0.f;
   if (qok) {
     if (half == 0) lsum[qrow * heads + h] = psum;
@@ -174,16 +207,19 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_kernel(const f16* __restrict
 // KV = true: the one-launch form -- dq written directly, dk^ / dv summed over query tiles by fp32 atomics into the workspace
 // (2 * nk * C floats, zeroed by the caller).  KV = false: dq only, and delta = dO.O per (query, head) to `delta_out` for the
 // key-stationary kernel below (dkn doubles as delta_out).
-template <int KS, bool KV>
-__global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
-                                                              const f16* __restrict__ v, const f16* __restrict__ dO,
-                                                              const f16* __restrict__ o, const float* __restrict__ lsum, int C,
-                                                              int heads, const AttnTile* __restrict__ tiles, f16* __restrict__ dq,
-                                                              float* __restrict__ dkn, float* __restrict__ dvacc) {
-  constexpr int D = 16 * KS, MT = (KS + 1) / 2, P = tile_pitch(MT * 32), TP = 32;
-  __shared__ __attribute__((aligned(16))) f16 qt[32 * P], gt[KV ? 32 * P : 8], kt[32 * P];
+template <int KS, bool KV, int NW>
+__global__ __launch_bounds__(64 * NW) void cos_attn_mfma_bwd_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                                   const f16* __restrict__ v, const f16* __restrict__ dO,
+                                                                   const f16* __restrict__ o, const float* __restrict__ lsum, int C,
+                                                                   int heads, const AttnTile* __restrict__ tiles, f16* __restrict__ dq,
+                                                                   float* __restrict__ dkn, float* __restrict__ dvacc) {
+  static_assert(!KV || NW == 1, "the one-launch (atomic) form runs one wave per task");
+  constexpr int D = 16 * KS, MT = (KS + 1) / 2, P = tile_pitch(MT * 32), TP = 32, RS = MT * 16 + 1;
+  __shared__ __attribute__((aligned(16))) f16 qt[32 * P], gt[KV ? 32 * P : 8], kt_all[NW][32 * P];
   __shared__ __attribute__((aligned(16))) f16 ts[KV ? 32 * TP : 8], tp[KV ? 32 * TP : 8];    // dS and P, [query][key]
-  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5, blk = (lane >> 4) & 1;
+  __shared__ float red[NW > 1 ? (NW - 1) * 64 * RS : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31, half = lane >> 5, blk = (lane >> 4) & 1;
+  f16* const kt = kt_all[wv];
   const AttnTile t = tiles[blockIdx.x / heads];
   const int h = blockIdx.x % heads;
   const bool qok = col < t.nrows;
@@ -204,17 +240,17 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __rest
   delta += __shfl_xor(delta, 32, 64);
   const float l = qok ? lsum[qrow * heads + h] : 0.f;
   const float il = l > 0.f ? 1.0f / l : 0.f;
-  if (!KV && qok && half == 0) dkn[qrow * heads + h] = delta;
-  // LDS copies of q^ and dO ([query][d], zero pad columns) for the transposed operands of dK^ / dV
+  if (!KV && qok && half == 0 && wv == 0) dkn[qrow * heads + h] = delta;
+  // LDS copies of q^ and dO ([query][d], zero pad columns) for the transposed operands of dK^ / dV (wave 0 writes the shared q^ copy)
   for (int i = lane; i < 32 * P; i += 64) {
-    qt[i] = (f16)0.f;
+    if (wv == 0) qt[i] = (f16)0.f;
     kt[i] = (f16)0.f;
     if (KV) gt[i] = (f16)0.f;
   }
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    *(f16x8*)(qt + col * P + 16 * s + 8 * half) = qf[s];
+    if (wv == 0) *(f16x8*)(qt + col * P + 16 * s + 8 * half) = qf[s];
     if (KV) *(f16x8*)(gt + col * P + 16 * s + 8 * half) = gf[s];
   }
 
@@ -224,20 +260,24 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __rest
 #pragma unroll
     for (int e = 0; e < 16; ++e) dqacc[m][e] = 0.f;
 
-  f16x8 kn[KS], vn[KS];            // raw rows of the NEXT key tile (see the forward kernel)
+  f16x8 kn[KS], vn[KS];            // raw rows of this wave's NEXT key tile (see the forward kernel)
+  const int iters = ((t.key1 - t.key0 + 31) / 32 + NW - 1) / NW;
   {
-    const bool ok0 = t.key0 + col < t.key1;
-    const long r0 = t.key0 + (ok0 ? col : 0);
+    const int kb0 = t.key0 + 32 * wv;
+    const bool ok0 = kb0 + col < t.key1;
+    const long r0 = ok0 ? kb0 + col : t.key0;
     load_raw<KS>(k + r0 * C + h * D, ok0, half, kn);
     load_raw<KS>(v + r0 * C + h * D, ok0, half, vn);
   }
-  for (int kb = t.key0; kb < t.key1; kb += 32) {
+  for (int it = 0; it < iters; ++it) {
+    const int kb = t.key0 + 32 * (it * NW + wv);
     f16x8 kf[KS], vf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) { kf[s] = kn[s]; vf[s] = vn[s]; }
-    if (kb + 32 < t.key1) {
-      const bool okn = kb + 32 + col < t.key1;
-      const long rn = kb + 32 + (okn ? col : 0);
+    if (it + 1 < iters) {
+      const int kbn = kb + 32 * NW;
+      const bool okn = kbn + col < t.key1;
+      const long rn = okn ? kbn + col : t.key0;
       load_raw<KS>(k + rn * C + h * D, okn, half, kn);
       load_raw<KS>(v + rn * C + h * D, okn, half, vn);
     }
@@ -313,6 +353,25 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __rest
       }
     }
   }
+  if (NW > 1) {                                  // partial dq^ of waves 1.. -> wave 0, added in wave order
+    if (wv > 0) {
+      float* r = red + ((wv - 1) * 64 + lane) * RS;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r[m * 16 + e] = dqacc[m][e];
+    }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) {
+      const float* r = red + ((ww - 1) * 64 + lane) * RS;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dqacc[m][e] += r[m * 16 + e];
+    }
+  }
   // q normalisation backward, per lane: dq = (dq^ - q^ (q^.dq^)) / ||q||; this lane's d set is m*32 + 8 g + 4 half + j
   float dot = 0.f;
 #pragma unroll
@@ -349,16 +408,21 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kernel(const f16* __rest
 //                                                              from the accumulators (query order permuted alike on both)
 // 1/l and delta = dO.O vary along the accumulator's rows here: the tile's 32 values are staged in LDS.
 // ktiles: (key row0, nkeys <= 32, query0, query1).  delta: [n][heads] fp32 written by cos_attn_mfma_bwd_kernel<KS, false>.
-template <int KS>
-__global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kv_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
-                                                                 const f16* __restrict__ v, const f16* __restrict__ dO,
-                                                                 const float* __restrict__ lsum, const float* __restrict__ delta,
-                                                                 int C, int heads, const AttnTile* __restrict__ ktiles,
-                                                                 f16* __restrict__ dk, f16* __restrict__ dv) {
-  constexpr int D = 16 * KS, MT = (KS + 1) / 2, P = tile_pitch(MT * 32);
-  __shared__ __attribute__((aligned(16))) f16 qt[32 * P], gt[32 * P], kt[32 * P];
-  __shared__ float ils[32], dls[32];
-  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5, blk = (lane >> 4) & 1;
+template <int KS, int NW>
+__global__ __launch_bounds__(64 * NW) void cos_attn_mfma_bwd_kv_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                                      const f16* __restrict__ v, const f16* __restrict__ dO,
+                                                                      const float* __restrict__ lsum, const float* __restrict__ delta,
+                                                                      int C, int heads, const AttnTile* __restrict__ ktiles,
+                                                                      f16* __restrict__ dk, f16* __restrict__ dv) {
+  constexpr int D = 16 * KS, MT = (KS + 1) / 2, P = tile_pitch(MT * 32), RS = 2 * MT * 16 + 1;
+  __shared__ __attribute__((aligned(16))) f16 qt_all[NW][32 * P], gt_all[NW][32 * P], kt[32 * P];
+  __shared__ float ils_all[NW][32], dls_all[NW][32];
+  __shared__ float red[NW > 1 ? (NW - 1) * 64 * RS : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31, half = lane >> 5, blk = (lane >> 4) & 1;
+  f16* const qt = qt_all[wv];
+  f16* const gt = gt_all[wv];
+  float* const ils = ils_all[wv];
+  float* const dls = dls_all[wv];
   const AttnTile t = ktiles[blockIdx.x / heads];
   const int h = blockIdx.x % heads;
   const bool kok = col < t.nrows;
@@ -372,10 +436,15 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kv_kernel(const f16* __r
     f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     vf[s] = kok ? *(const f16x8*)(v + krow * C + h * D + 16 * s + 8 * half) : z;
   }
-  for (int i = lane; i < 32 * P; i += 64) { qt[i] = (f16)0.f; gt[i] = (f16)0.f; kt[i] = (f16)0.f; }
+  for (int i = lane; i < 32 * P; i += 64) {
+    qt[i] = (f16)0.f;
+    gt[i] = (f16)0.f;
+    if (wv == 0) kt[i] = (f16)0.f;
+  }
   __syncthreads();
+  if (wv == 0)
 #pragma unroll
-  for (int s = 0; s < KS; ++s) *(f16x8*)(kt + col * P + 16 * s + 8 * half) = kf[s];
+    for (int s = 0; s < KS; ++s) *(f16x8*)(kt + col * P + 16 * s + 8 * half) = kf[s];
 
   f32x16 dkacc[MT], dvacc[MT];
 #pragma unroll
@@ -383,24 +452,28 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kv_kernel(const f16* __r
 #pragma unroll
     for (int e = 0; e < 16; ++e) dkacc[m][e] = dvacc[m][e] = 0.f;
 
-  f16x8 qn[KS], gn[KS];            // raw rows (and row scalars) of the NEXT query tile, in flight under the current tile's products
+  f16x8 qn[KS], gn[KS];            // raw rows (and row scalars) of this wave's NEXT query tile, in flight under the current tile's products
   float ln, dln;
+  const int iters = ((t.key1 - t.key0 + 31) / 32 + NW - 1) / NW;       // query tiles dealt round-robin to the NW waves
   {
-    const bool ok0 = t.key0 + col < t.key1;
-    const long r0 = t.key0 + (ok0 ? col : 0);
+    const int qb0 = t.key0 + 32 * wv;
+    const bool ok0 = qb0 + col < t.key1;
+    const long r0 = ok0 ? qb0 + col : t.key0;
     load_raw<KS>(q + r0 * C + h * D, ok0, half, qn);
     load_raw<KS>(dO + r0 * C + h * D, ok0, half, gn);
     ln = ok0 ? lsum[r0 * heads + h] : 0.f;
     dln = ok0 ? delta[r0 * heads + h] : 0.f;
   }
-  for (int qb = t.key0; qb < t.key1; qb += 32) {
+  for (int it = 0; it < iters; ++it) {
+    const int qb = t.key0 + 32 * (it * NW + wv);
     f16x8 qf[KS], gf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) { qf[s] = qn[s]; gf[s] = gn[s]; }
     const float l = ln, dl = dln;
-    if (qb + 32 < t.key1) {
-      const bool okn = qb + 32 + col < t.key1;
-      const long rn = qb + 32 + (okn ? col : 0);
+    if (it + 1 < iters) {
+      const int qbn = qb + 32 * NW;
+      const bool okn = qbn + col < t.key1;
+      const long rn = okn ? qbn + col : t.key0;
       load_raw<KS>(q + rn * C + h * D, okn, half, qn);
       load_raw<KS>(dO + rn * C + h * D, okn, half, gn);
       ln = okn ? lsum[rn * heads + h] : 0.f;
@@ -445,6 +518,25 @@ __global__ __launch_bounds__(64) void cos_attn_mfma_bwd_kv_kernel(const f16* __r
         dvacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ag, pb[s2], dvacc[m], 0, 0, 0);
       }
   }
+  if (NW > 1) {                                  // partial dk^ / dv of waves 1.. -> wave 0, added in wave order
+    if (wv > 0) {
+      float* r = red + ((wv - 1) * 64 + lane) * RS;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { r[m * 32 + e] = dkacc[m][e]; r[m * 32 + 16 + e] = dvacc[m][e]; }
+    }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) {
+      const float* r = red + ((ww - 1) * 64 + lane) * RS;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dkacc[m][e] += r[m * 32 + e]; dvacc[m][e] += r[m * 32 + 16 + e]; }
+    }
+  }
   // k normalisation backward, per lane: dk = (dk^ - k^ (k^.dk^)) / ||k||; this lane's d set is m*32 + 8 g + 4 half + j
   float dot = 0.f;
 #pragma unroll
@@ -485,12 +577,12 @@ extern "C" int tscd_cos_attn_mfma_f16(const void* q, const void* k, const void* 
   const int D = C / heads;
   TSCD_CHECK_ARG(tscd_cos_attn_mfma_supported(D) && C % 8 == 0, "cos_attn_mfma: head dim %d not supported", D);
   if (ntiles == 0) return TSCD_OK;
-  dim3 grid(ntiles * heads), block(64);
+  dim3 grid(ntiles * heads);
   hipStream_t st = (hipStream_t)stream;
 #define CAM(KSV)                                                                                                              \
   case KSV:                                                                                                                    \
-    hipLaunchKernelGGL((cos_attn_mfma_kernel<KSV>), grid, block, 0, st, (const f16*)q, (const f16*)k, (const f16*)v, C, heads, \
-                       (const AttnTile*)tiles, (f16*)out, lsum);                                                               \
+    hipLaunchKernelGGL((cos_attn_mfma_kernel<KSV, attn_waves(KSV)>), grid, dim3(64 * attn_waves(KSV)), 0, st, (const f16*)q,   \
+                       (const f16*)k, (const f16*)v, C, heads, (const AttnTile*)tiles, (f16*)out, lsum);                       \
     break
   switch (D / 16) {
     CAM(1); CAM(2); CAM(3); CAM(4); CAM(5); CAM(6); CAM(7); CAM(8); CAM(9); CAM(10);
@@ -518,7 +610,7 @@ extern "C" int tscd_cos_attn_mfma_bwd_f16(const void* q, const void* k, const vo
   dim3 grid(ntiles * heads), block(64);
 #define CAB(KSV)                                                                                                               \
   case KSV:                                                                                                                     \
-    hipLaunchKernelGGL((cos_attn_mfma_bwd_kernel<KSV, true>), grid, block, 0, st, (const f16*)q, (const f16*)k, (const f16*)v,   \
+    hipLaunchKernelGGL((cos_attn_mfma_bwd_kernel<KSV, true, 1>), grid, block, 0, st, (const f16*)q, (const f16*)k, (const f16*)v, \
                        (const f16*)dO, (const f16*)out, lsum, C, heads, (const AttnTile*)tiles, (f16*)dq, dkn, dva);             \
     break
   switch (D / 16) {
@@ -546,12 +638,12 @@ extern "C" int tscd_cos_attn_mfma_bwd2_f16(const void* q, const void* k, const v
   if (ntiles == 0 || nktiles == 0) return TSCD_OK;
 #define CAB2(KSV)                                                                                                                \
   case KSV:                                                                                                                      \
-    hipLaunchKernelGGL((cos_attn_mfma_bwd_kernel<KSV, false>), dim3(ntiles * heads), dim3(64), 0, st, (const f16*)q, (const f16*)k, \
-                       (const f16*)v, (const f16*)dO, (const f16*)out, lsum, C, heads, (const AttnTile*)tiles, (f16*)dq, delta_ws,  \
-                       (float*)nullptr);                                                                                         \
-    hipLaunchKernelGGL((cos_attn_mfma_bwd_kv_kernel<KSV>), dim3(nktiles * heads), dim3(64), 0, st, (const f16*)q, (const f16*)k,  \
-                       (const f16*)v, (const f16*)dO, lsum, (const float*)delta_ws, C, heads, (const AttnTile*)ktiles, (f16*)dk,  \
-                       (f16*)dv);                                                                                                \
+    hipLaunchKernelGGL((cos_attn_mfma_bwd_kernel<KSV, false, attn_waves(KSV)>), dim3(ntiles * heads), dim3(64 * attn_waves(KSV)), 0, st, \
+                       (const f16*)q, (const f16*)k, (const f16*)v, (const f16*)dO, (const f16*)out, lsum, C, heads,                  \
+                       (const AttnTile*)tiles, (f16*)dq, delta_ws, (float*)nullptr);                                                 \
+    hipLaunchKernelGGL((cos_attn_mfma_bwd_kv_kernel<KSV, attn_waves_kv(KSV)>), dim3(nktiles * heads), dim3(64 * attn_waves_kv(KSV)), 0, \
+                       st, (const f16*)q, (const f16*)k, (const f16*)v, (const f16*)dO, lsum, (const float*)delta_ws, C, heads,       \
+                       (const AttnTile*)ktiles, (f16*)dk, (f16*)dv);                                                                 \
     break
   switch (D / 16) {
     CAB2(1); CAB2(2); CAB2(3); CAB2(4); CAB2(5); CAB2(6); CAB2(7); CAB2(8); CAB2(9); CAB2(10);
