@@ -452,33 +452,29 @@ __global__ __launch_bounds__(64 * NW) void cos_attn_mfma_bwd_kv_kernel(const f16
 #pragma unroll
     for (int e = 0; e < 16; ++e) dkacc[m][e] = dvacc[m][e] = 0.f;
 
-  f16x8 qn[KS], gn[KS];            // raw rows (and row scalars) of this wave's NEXT query tile, in flight under the current tile's products
-  float ln, dln;
+  // raw rows (and row scalars) of this wave's NEXT query tile are fetched under the current tile's products -- up to head dim 64; above,
+  // the two extra fragment sets cost more (accumulator-file moves) than the latency they hide: there a tile is fetched when it is due
+  constexpr bool PF = KS <= 4;
+  f16x8 qn[KS], gn[KS];
+  float ln = 0.f, dln = 0.f;
   const int iters = ((t.key1 - t.key0 + 31) / 32 + NW - 1) / NW;       // query tiles dealt round-robin to the NW waves
-  {
-    const int qb0 = t.key0 + 32 * wv;
-    const bool ok0 = qb0 + col < t.key1;
-    const long r0 = ok0 ? qb0 + col : t.key0;
-    load_raw<KS>(q + r0 * C + h * D, ok0, half, qn);
-    load_raw<KS>(dO + r0 * C + h * D, ok0, half, gn);
-    ln = ok0 ? lsum[r0 * heads + h] : 0.f;
-    dln = ok0 ? delta[r0 * heads + h] : 0.f;
-  }
+  auto fetch = [&](int qb) {
+    const bool ok = qb + col < t.key1;
+    const long r = ok ? qb + col : t.key0;
+    load_raw<KS>(q + r * C + h * D, ok, half, qn);
+    load_raw<KS>(dO + r * C + h * D, ok, half, gn);
+    ln = ok ? lsum[r * heads + h] : 0.f;
+    dln = ok ? delta[r * heads + h] : 0.f;
+  };
+  if (PF) fetch(t.key0 + 32 * wv);
   for (int it = 0; it < iters; ++it) {
     const int qb = t.key0 + 32 * (it * NW + wv);
+    if (!PF) fetch(qb);
     f16x8 qf[KS], gf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) { qf[s] = qn[s]; gf[s] = gn[s]; }
     const float l = ln, dl = dln;
-    if (it + 1 < iters) {
-      const int qbn = qb + 32 * NW;
-      const bool okn = qbn + col < t.key1;
-      const long rn = okn ? qbn + col : t.key0;
-      load_raw<KS>(q + rn * C + h * D, okn, half, qn);
-      load_raw<KS>(dO + rn * C + h * D, okn, half, gn);
-      ln = okn ? lsum[rn * heads + h] : 0.f;
-      dln = okn ? delta[rn * heads + h] : 0.f;
-    }
+    if (PF && it + 1 < iters) fetch(qb + 32 * NW);
     scale_row<KS>(qf, inv_norm<KS>(qf));
     __syncthreads();   // single-wave workgroup: the previous tile's transposing reads are done
 #pragma unroll
