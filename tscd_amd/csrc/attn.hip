@@ -555,8 +555,24 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const f16* __res
 #pragma unroll
   for (int k = 0; k < LN_BWD_NC; ++k) ag[k] = ab[k] = 0.f;
   for (int row = blockIdx.x * 4 + wave; row < n; row += nwaves) {
+    // the row's first 1024 columns live in registers: x and dy are fetched ONCE (the three passes below were three dependent trips to
+    // L2 per row -- with one row per wave the whole launch was that latency chain)
+    float xr[LN_BWD_NC], dr[LN_BWD_NC];
+#pragma unroll
+    for (int k = 0; k < LN_BWD_NC; ++k) {
+      const int c = lane + 64 * k;
+      xr[k] = dr[k] = 0.f;
+      if (c < C) {
+        float x = (float)a[(long)row * C + c];
+        if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
+        xr[k] = x;
+        dr[k] = (float)dy[(long)row * C + c];
+      }
+    }
     float s = 0.f, s2 = 0.f;
-    for (int c = lane; c < C; c += 64) {
+#pragma unroll
+    for (int k = 0; k < LN_BWD_NC; ++k) { s += xr[k]; s2 += xr[k] * xr[k]; }
+    for (int c = lane + 64 * LN_BWD_NC; c < C; c += 64) {
       float x = (float)a[(long)row * C + c];
       if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
       s += x; s2 += x * x;
@@ -564,7 +580,15 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const f16* __res
     s = wave_sum(s); s2 = wave_sum(s2);
     float mean = s / C, var = fmaxf(s2 / C - mean * mean, 0.f), inv = 1.0f / sqrtf(var + eps);
     float m1 = 0.f, m2 = 0.f;
-    for (int c = lane; c < C; c += 64) {
+#pragma unroll
+    for (int k = 0; k < LN_BWD_NC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < C) {
+        const float g = dr[k] * gamma[c];
+        m1 += g; m2 += g * ((xr[k] - mean) * inv);
+      }
+    }
+    for (int c = lane + 64 * LN_BWD_NC; c < C; c += 64) {
       float x = (float)a[(long)row * C + c];
       if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
       float xh = (x - mean) * inv, g = (float)dy[(long)row * C + c] * gamma[c];
@@ -575,9 +599,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const f16* __res
     for (int k = 0; k < LN_BWD_NC; ++k) {
       const int c = lane + 64 * k;
       if (c < C) {
-        float x = (float)a[(long)row * C + c];
-        if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
-        float xh = (x - mean) * inv, d = (float)dy[(long)row * C + c];
+        const float xh = (xr[k] - mean) * inv, d = dr[k];
         dx[(long)row * C + c] = (f16)(inv * (d * gamma[c] - m1 - xh * m2));
         ag[k] += d * xh;
         ab[k] += d;
