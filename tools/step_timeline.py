@@ -67,6 +67,21 @@ from tscd_amd import functional as TF
 wrap(ops, "simota_assign", before="simota_in")
 wrap(TF, "dense_loss", before="dense_loss_in")
 wrap(tscd_mod.TSCD, "_prefetch", before="prefetch_in", after="prefetch_out")
+_orig_prefetch = tscd_mod.TSCD._prefetch
+
+
+def _prefetch_timed(self, next_x):
+    """... plus an event on the PREFETCH stream behind the replayed frozen front: when the next clip's pass really ends on the device
+    (device mark prefetch_done; the post segment shares the CUs with whatever of the pass is still running when the chain ends)."""
+    r = _orig_prefetch(self, next_x)
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(tscd_mod._prefetch_stream(next_x.device))
+    D["prefetch_done"] = e
+    H["prefetch_done"] = time.perf_counter()
+    return r
+
+
+tscd_mod.TSCD._prefetch = _prefetch_timed
 orig_chain = M.lap_chain_f16
 
 
@@ -119,7 +134,7 @@ for _ in range(N):
     step(rec)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t) / N * 1e3
-names = ["counts_on_host", "prepare_in", "costs_queued", "chain_start", "simota_in", "dense_loss_in", "prefetch_in", "prefetch_out", "finish_in", "chain_end", "finish_out", "forward_out", "backward_out", "step_out"]
+names = ["counts_on_host", "prepare_in", "costs_queued", "chain_start", "simota_in", "dense_loss_in", "prefetch_in", "prefetch_out", "prefetch_done", "finish_in", "chain_end", "finish_out", "forward_out", "backward_out", "step_out"]
 print(f"steady state after {PREROLL} steps: {ms:.2f} ms per step (no drains)")
 print("host clock, ms from the step's start (median of %d steps):" % N)
 M.AwarePositionRegMatcher._join_pending(model.head.local_reg_matcher)
