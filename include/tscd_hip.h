@@ -15,6 +15,7 @@
  */
 #ifndef TSCD_HIP_H
 #define TSCD_HIP_H
+#include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -294,6 +295,38 @@ int tscd_se_fuse_bwd_acc_f16(const void* reg, int ldr, const void* edge, int lde
 int tscd_add_layernorm_bwd_acc_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
                                    void* dx, float* dgamma, float* dbeta, void* stream);
 int tscd_row_normalize_f16(const void* x, int ldx, int n, int n_pad, int C, float eps, void* out, int ldo, void* stream);
+/* The CAFM frame chain's row addressing inside the four kernels above (tscd_matching.py:761-888: every frame's rows are re-ordered by
+ * its assignment before they meet the next frame's; the permuted reads / writes ride in the kernels that consume / produce the rows
+ * instead of index_select launches).  A row map sends row r (segment s = r / seg_rows, local l = r % seg_rows) to
+ * s * seg_rows + idx[off0 + s * off_stride + l]; idx null = identity. */
+typedef struct {
+  const int64_t* idx;
+  int seg_rows, off0, off_stride;
+} TscdRowMap;
+typedef struct {
+  TscdRowMap edge_map;       /* edge row of output row r; backward: also the row d edge of row r is written to */
+  int pos_seg_rows;          /* 0: one pos / d pos vector; else row r takes pos + (r / pos_seg_rows) * pos_stride floats */
+  int pos_stride;
+  const void* add_reg[3];    /* backward: d reg[r] = fp16(d reg + sum_k add_reg[k][r], r < add_reg_rows[k]) -- fp16 [rows, C] */
+  int add_reg_rows[3];
+  const void* add_edge[2];   /* the same for d edge */
+  int add_edge_rows[2];
+} TscdSeFuseEx;
+typedef struct {
+  TscdRowMap a_map;          /* row of `a` read for output row r */
+  const void* dy_add;        /* backward: dy row r = fp16(dy[r] + dy_add[r]) */
+  void* dx_mapped;           /* backward: a copy of dx row r at row a_map(r) of this buffer (dx itself may then be null) */
+} TscdLnEx;
+int tscd_se_fuse_ex_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
+                        const float* pos, long n, int C, void* out, const void* ex /* TscdSeFuseEx */, void* stream);
+int tscd_add_layernorm_ex_f16(const void* a, const void* b, const float* gamma, const float* beta, int n, int C, float eps,
+                              void* out, const void* ex /* TscdLnEx */, void* stream);
+/* backward forms: ADD into the fp32 accumulators (as the _acc entries) */
+int tscd_se_fuse_bwd_ex_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
+                            const void* dout, long n, int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2,
+                            const void* ex /* TscdSeFuseEx */, void* stream);
+int tscd_add_layernorm_bwd_ex_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
+                                  void* dx, float* dgamma, float* dbeta, const void* ex /* TscdLnEx */, void* stream);
 
 /* ---- eval tail: decode_reg_preds5 (tscd_head.py:914-949) + postprocess (post_process.py:9-85) +
  * torchvision.ops.batched_nms.  mode 0 = refined set, 1 = original detections, 2 = original detections with class-agnostic

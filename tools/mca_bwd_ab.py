@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""MCA backward timing at the bench clip's sizes (16 frames, 4 local, 500 / 50 proposals per frame, W 256), per call."""
+"""MCA forward and backward timing at the bench clip's sizes (16 frames, 4 local, 500 / 50 proposals per frame, W 256), per call."""
 import os
 import sys
 
@@ -29,6 +29,16 @@ for P in (500, 50):
         a = (g2(), g2() if need_reg else None, g3(), g3() if need_reg else None)
         f = lambda: ops.mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, 25.0, 0.75, 0.99, stats, a[0], a[1], a[2], a[3],
                                      cat3_c, cat3_r)
+        fw = lambda: ops.mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, 25.0, 0.75, 0.99, want_stats=True)
+        for _ in range(3):
+            fw()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            fw()
+        e.record()
+        torch.cuda.synchronize()
+        print(f"P {P} need_reg {need_reg} forward: {s.elapsed_time(e) / 10 * 1e3:8.1f} us per call", flush=True)
         for rnd in range(2):
             for _ in range(2):
                 f()

@@ -59,6 +59,10 @@ SIGNATURES = {
     "tscd_se_fuse_bwd_acc_f16": [P, I, P, I, P, P, P, L, I, P, P, P, P, P, P],
     "tscd_add_layernorm_bwd_acc_f16": [P, P, P, P, I, I, F, P, P, P, P],
     "tscd_row_normalize_f16": [P, I, I, I, I, F, P, I, P],
+    "tscd_se_fuse_ex_f16": [P, I, P, I, P, P, P, L, I, P, P, P],
+    "tscd_add_layernorm_ex_f16": [P, P, P, P, I, I, F, P, P, P],
+    "tscd_se_fuse_bwd_ex_f16": [P, I, P, I, P, P, P, L, I, P, P, P, P, P, P, P],
+    "tscd_add_layernorm_bwd_ex_f16": [P, P, P, P, I, I, F, P, P, P, P, P],
     "tscd_batched_nms": [P, I, P, I, P, P, P, I, F, F, I, I, I, I, P, L, P, P, P, P],
     "tscd_conv_wgrad_nhwc_f16": [P, P, P, I, I, I, I, I, I, I, I, P, L, P],
     "tscd_bn_silu_bwd_f16": [P, P, P, P, P, P, L, I, P, P, P, L, P],

@@ -130,10 +130,41 @@ extern "C" int tscd_cos_attn_f16(const void* q, const void* k, const void* v, in
   return TSCD_OK;
 }
 
+// ---- row addressing of the CAFM frame chain (yolox/models/tscd_matching.py::_CafmChain; reference tscd_matching.py:761-888: the rows of a
+// frame are re-ordered by its assignment before they meet the next frame's).  The permuted reads / writes ride in the kernels that
+// consume / produce the rows instead of separate gather launches.  Declared for callers in include/tscd_hip.h.
+struct RowMap {
+  const long* idx;       // null: identity
+  int seg_rows;          // rows per segment; row r -> segment s = r / seg_rows, local l = r % seg_rows
+  int off0, off_stride;  // mapped row = s * seg_rows + idx[off0 + s * off_stride + l]
+};
+__device__ __forceinline__ long map_row(const RowMap& m, long r) {
+  if (!m.idx) return r;
+  const long s = r / m.seg_rows, l = r - s * m.seg_rows;
+  return s * m.seg_rows + m.idx[m.off0 + s * m.off_stride + l];
+}
+struct SeFuseEx {
+  RowMap edge_map;       // edge row of output row r; backward: also the row d edge of row r is written to
+  int pos_seg_rows;      // 0: one pos / d pos vector; else row r takes pos + (r / pos_seg_rows) * pos_stride
+  int pos_stride;
+  // backward only: d reg[r] = fp16(d reg + sum_k add_reg[k][r] (r < add_reg_rows[k])), same for d edge (addend rows in OUTPUT order, pitch C)
+  const f16* add_reg[3];
+  int add_reg_rows[3];
+  const f16* add_edge[2];
+  int add_edge_rows[2];
+};
+struct LnEx {
+  RowMap a_map;          // row of `a` read for output row r
+  const f16* dy_add;     // backward: dy row r = fp16(dy[r] + dy_add[r])
+  f16* dx_mapped;        // backward: a copy of dx row r at row a_map(r) of this buffer
+};
+
 // out[n][c] = reg*g0 + edge*g1 + pos[c],  (g0,g1) = sigmoid(W2 relu(W0 [reg, edge])).  w0 [32][2], w2 [2][32] fp32.
+// (ONE instantiation serves the plain and the row-mapped entry points -- a zeroed `ex` is the identity: the per-op path and the fused
+// chain then run the same machine code and stay bit-identical, tests/test_gpu_head_stages.py; the same holds for the three kernels below.)
 __global__ __launch_bounds__(256) void se_fuse_kernel(const f16* __restrict__ reg, int ldr, const f16* __restrict__ edge, int lde,
                                const float* __restrict__ w0, const float* __restrict__ w2, const float* __restrict__ pos, long n,
-                               int C, f16* __restrict__ out) {
+                               int C, f16* __restrict__ out, SeFuseEx ex) {
   __shared__ float sw0[64], sw2[64];
   if (threadIdx.x < 64) { sw0[threadIdx.x] = w0[threadIdx.x]; sw2[threadIdx.x] = w2[threadIdx.x]; }
   __syncthreads();
@@ -141,7 +172,8 @@ __global__ __launch_bounds__(256) void se_fuse_kernel(const f16* __restrict__ re
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     long row = idx / C;
     int c = idx % C;
-    float a = (float)reg[row * ldr + c], b = (float)edge[row * lde + c];
+    const long erow = map_row(ex.edge_map, row);
+    float a = (float)reg[row * ldr + c], b = (float)edge[erow * lde + c];
     float g0 = 0.f, g1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
@@ -152,29 +184,49 @@ __global__ __launch_bounds__(256) void se_fuse_kernel(const f16* __restrict__ re
     g0 = (float)(f16)sigmoidf_((float)(f16)g0);
     g1 = (float)(f16)sigmoidf_((float)(f16)g1);
     float o = (float)(f16)((float)(f16)(a * g0) + (float)(f16)(b * g1));
-    out[idx] = (f16)(o + (pos ? pos[c] : 0.f));
+    const float* pv = pos;
+    if (pos && ex.pos_seg_rows > 0) pv = pos + (row / ex.pos_seg_rows) * ex.pos_stride;
+    out[idx] = (f16)(o + (pv ? pv[c] : 0.f));
   }
 }
-extern "C" int tscd_se_fuse_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
-                                const float* pos, long n, int C, void* out, void* stream) {
+static int se_fuse_launch(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2, const float* pos, long n,
+                          int C, void* out, const SeFuseEx* ex, void* stream) {
   TSCD_CHECK_ARG(reg && edge && w0 && w2 && out, "se_fuse: null pointer");
   if (n == 0) return TSCD_OK;
   long total = n * C;
   int grid = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(se_fuse_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, (hipStream_t)stream, (const f16*)reg, ldr,
-                     (const f16*)edge, lde, w0, w2, pos, n, C, (f16*)out);
+  if (grid > 2048) grid = 2048;
+  if (ex) {
+    TSCD_CHECK_ARG(!ex->edge_map.idx || ex->edge_map.seg_rows > 0, "se_fuse: row map without a segment length");
+    hipLaunchKernelGGL(se_fuse_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)reg, ldr, (const f16*)edge, lde, w0,
+                       w2, pos, n, C, (f16*)out, *ex);
+  } else {
+    hipLaunchKernelGGL(se_fuse_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)reg, ldr, (const f16*)edge, lde, w0,
+                       w2, pos, n, C, (f16*)out, SeFuseEx{});
+  }
   TSCD_CHECK_LAUNCH("se_fuse");
   return TSCD_OK;
+}
+extern "C" int tscd_se_fuse_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
+                                const float* pos, long n, int C, void* out, void* stream) {
+  return se_fuse_launch(reg, ldr, edge, lde, w0, w2, pos, n, C, out, nullptr, stream);
+}
+// ... with the chain's row addressing (struct TscdSeFuseEx of include/tscd_hip.h: permuted edge rows, one pos vector per row segment)
+extern "C" int tscd_se_fuse_ex_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
+                                   const float* pos, long n, int C, void* out, const void* ex, void* stream) {
+  TSCD_CHECK_ARG(ex, "se_fuse_ex: null extras");
+  return se_fuse_launch(reg, ldr, edge, lde, w0, w2, pos, n, C, out, (const SeFuseEx*)ex, stream);
 }
 
 // out = LayerNorm(a (+ b)) * gamma + beta, one wave per row, eps = 1e-5 (nn.LayerNorm default).
 __global__ void add_layernorm_kernel(const f16* __restrict__ a, const f16* __restrict__ b, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, int n, int C, float eps, f16* __restrict__ out) {
+                                     const float* __restrict__ beta, int n, int C, float eps, f16* __restrict__ out, LnEx ex) {
   int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (row >= n) return;
+  const long arow = map_row(ex.a_map, row);
   float s = 0.f, s2 = 0.f;
   for (int c = lane; c < C; c += 64) {
-    float x = (float)a[(long)row * C + c];
+    float x = (float)a[arow * C + c];
     if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
     s += x;
     s2 += x * x;
@@ -183,19 +235,35 @@ __global__ void add_layernorm_kernel(const f16* __restrict__ a, const f16* __res
   s2 = wave_sum(s2);
   float mean = s / C, var = fmaxf(s2 / C - mean * mean, 0.f), inv = 1.0f / sqrtf(var + eps);
   for (int c = lane; c < C; c += 64) {
-    float x = (float)a[(long)row * C + c];
+    float x = (float)a[arow * C + c];
     if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
     out[(long)row * C + c] = (f16)((x - mean) * inv * gamma[c] + beta[c]);
   }
 }
-extern "C" int tscd_add_layernorm_f16(const void* a, const void* b, const float* gamma, const float* beta, int n, int C,
-                                      float eps, void* out, void* stream) {
+static int add_layernorm_launch(const void* a, const void* b, const float* gamma, const float* beta, int n, int C, float eps, void* out,
+                                const LnEx* ex, void* stream) {
   TSCD_CHECK_ARG(a && gamma && beta && out && C > 0, "add_layernorm: bad args");
   if (n == 0) return TSCD_OK;
-  hipLaunchKernelGGL(add_layernorm_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const f16*)a,
-                     (const f16*)b, gamma, beta, n, C, eps, (f16*)out);
+  if (ex) {
+    TSCD_CHECK_ARG(!ex->a_map.idx || ex->a_map.seg_rows > 0, "add_layernorm: row map without a segment length");
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const f16*)a,
+                       (const f16*)b, gamma, beta, n, C, eps, (f16*)out, *ex);
+  } else {
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3((n * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const f16*)a,
+                       (const f16*)b, gamma, beta, n, C, eps, (f16*)out, LnEx{});
+  }
   TSCD_CHECK_LAUNCH("add_layernorm");
   return TSCD_OK;
+}
+extern "C" int tscd_add_layernorm_f16(const void* a, const void* b, const float* gamma, const float* beta, int n, int C,
+                                      float eps, void* out, void* stream) {
+  return add_layernorm_launch(a, b, gamma, beta, n, C, eps, out, nullptr, stream);
+}
+// ... reading the rows of `a` through a row map (struct TscdLnEx of include/tscd_hip.h)
+extern "C" int tscd_add_layernorm_ex_f16(const void* a, const void* b, const float* gamma, const float* beta, int n, int C,
+                                         float eps, void* out, const void* ex, void* stream) {
+  TSCD_CHECK_ARG(ex, "add_layernorm_ex: null extras");
+  return add_layernorm_launch(a, b, gamma, beta, n, C, eps, out, (const LnEx*)ex, stream);
 }
 
 // out[row][off : off+C] = x[row] / (||x[row]|| + eps); one wave per row; rows >= n (padding) are zero-filled.
@@ -436,8 +504,8 @@ extern "C" int tscd_cos_attn_bwd_finish_f16(const void* k, const void* workspace
 // se_fuse backward: d reg, d edge (fp16), d pos [C], d w0 [32][2], d w2 [2][32] (fp32 atomics; caller zeroes them).
 __global__ __launch_bounds__(256) void se_fuse_bwd_kernel(const f16* __restrict__ reg, int ldr, const f16* __restrict__ edge, int lde,
                                    const float* __restrict__ w0, const float* __restrict__ w2, const f16* __restrict__ dout, long n,
-                                   int C, f16* __restrict__ dreg, f16* __restrict__ dedge, float* __restrict__ dpos,
-                                   float* __restrict__ dw0, float* __restrict__ dw2) {
+                                   int C, f16* dreg, f16* dedge, float* __restrict__ dpos,
+                                   float* __restrict__ dw0, float* __restrict__ dw2, SeFuseEx ex) {
   __shared__ float sw0[64], sw2[64], acc[128];
   if (threadIdx.x < 64) { sw0[threadIdx.x] = w0[threadIdx.x]; sw2[threadIdx.x] = w2[threadIdx.x]; }
   if (threadIdx.x < 128) acc[threadIdx.x] = 0.f;
@@ -448,14 +516,16 @@ __global__ __launch_bounds__(256) void se_fuse_bwd_kernel(const f16* __restrict_
   for (int j = 0; j < 128; ++j) v[j] = 0.f;
   long total = n * C;
   // when the grid stride is a multiple of C a thread stays on one column: d pos accumulates in a register and costs one atomic per
-  // thread instead of one per element (n x C atomics on C addresses were most of this kernel's 18 us)
+  // thread (and row segment) instead of one per element (n x C atomics on C addresses were most of this kernel's 18 us)
   const bool fixed_col = ((long)gridDim.x * blockDim.x) % C == 0;
   float gsum = 0.f;
   int gcol = -1;
+  long gseg = 0;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     long row = idx / C;
     int c = idx % C;
-    float a = (float)reg[row * ldr + c], b = (float)edge[row * lde + c], go = (float)dout[idx];
+    const long erow = map_row(ex.edge_map, row);
+    float a = (float)reg[row * ldr + c], b = (float)edge[erow * lde + c], go = (float)dout[idx];
     float hid[32], z0 = 0.f, z1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
@@ -476,11 +546,25 @@ __global__ __launch_bounds__(256) void se_fuse_bwd_kernel(const f16* __restrict_
       v[64 + 2 * j] += dh * a;
       v[64 + 2 * j + 1] += dh * b;
     }
+    {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (ex.add_reg[k] && row < ex.add_reg_rows[k]) da += (float)ex.add_reg[k][idx];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (ex.add_edge[k] && row < ex.add_edge_rows[k]) db += (float)ex.add_edge[k][idx];
+    }
     dreg[idx] = (f16)da;
-    dedge[idx] = (f16)db;
-    if (fixed_col) { gsum += go; gcol = c; } else atomicAdd(dpos + c, go);
+    dedge[erow * C + c] = (f16)db;
+    const long seg = ex.pos_seg_rows > 0 ? row / ex.pos_seg_rows : 0;
+    if (fixed_col) {
+      if (gcol >= 0 && seg != gseg) { atomicAdd(dpos + gseg * ex.pos_stride + gcol, gsum); gsum = 0.f; }
+      gsum += go; gcol = c; gseg = seg;
+    } else {
+      atomicAdd(dpos + seg * ex.pos_stride + c, go);
+    }
   }
-  if (fixed_col && gcol >= 0) atomicAdd(dpos + gcol, gsum);
+  if (fixed_col && gcol >= 0) atomicAdd(dpos + gseg * ex.pos_stride + gcol, gsum);
   // wave reduce-scatter: at each step a lane keeps one half of its values and receives the partner's share of that half,
   // so the 128 column sums cost 126 shuffles instead of 128 x 6; afterwards lane l owns values base(l), base(l)+1
   const int lane = threadIdx.x & 63;
@@ -504,20 +588,29 @@ __global__ __launch_bounds__(256) void se_fuse_bwd_kernel(const f16* __restrict_
   else if (threadIdx.x < 128) atomicAdd(dw0 + threadIdx.x - 64, acc[threadIdx.x]);
 }
 static int se_fuse_bwd_launch(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2, const void* dout, long n,
-                              int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2, bool zero, void* stream);
+                              int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2, bool zero, const SeFuseEx* ex, void* stream);
 extern "C" int tscd_se_fuse_bwd_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
                                     const void* dout, long n, int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2,
                                     void* stream) {
-  return se_fuse_bwd_launch(reg, ldr, edge, lde, w0, w2, dout, n, C, dreg, dedge, dpos, dw0, dw2, true, stream);
+  return se_fuse_bwd_launch(reg, ldr, edge, lde, w0, w2, dout, n, C, dreg, dedge, dpos, dw0, dw2, true, nullptr, stream);
 }
 // The same ADDING into dpos / dw0 / dw2 (the caller cleared them, e.g. as parts of one arena zeroed once for a whole backward chain).
 extern "C" int tscd_se_fuse_bwd_acc_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
                                         const void* dout, long n, int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2,
                                         void* stream) {
-  return se_fuse_bwd_launch(reg, ldr, edge, lde, w0, w2, dout, n, C, dreg, dedge, dpos, dw0, dw2, false, stream);
+  return se_fuse_bwd_launch(reg, ldr, edge, lde, w0, w2, dout, n, C, dreg, dedge, dpos, dw0, dw2, false, nullptr, stream);
+}
+// The adding form with the chain's extras (struct TscdSeFuseEx): permuted edge rows (d edge is written to the row it was read from),
+// one d pos vector per row segment, and up to 3 / 2 fp16 addends summed into d reg / d edge before the single rounding (dreg / dedge
+// may BE one of their addends: every element is read and written by the same thread).
+extern "C" int tscd_se_fuse_bwd_ex_f16(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2,
+                                       const void* dout, long n, int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2,
+                                       const void* ex, void* stream) {
+  TSCD_CHECK_ARG(ex, "se_fuse_bwd_ex: null extras");
+  return se_fuse_bwd_launch(reg, ldr, edge, lde, w0, w2, dout, n, C, dreg, dedge, dpos, dw0, dw2, false, (const SeFuseEx*)ex, stream);
 }
 static int se_fuse_bwd_launch(const void* reg, int ldr, const void* edge, int lde, const float* w0, const float* w2, const void* dout, long n,
-                              int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2, bool zero, void* stream) {
+                              int C, void* dreg, void* dedge, float* dpos, float* dw0, float* dw2, bool zero, const SeFuseEx* ex, void* stream) {
   TSCD_CHECK_ARG(reg && edge && w0 && w2 && dout && dreg && dedge && dpos && dw0 && dw2, "se_fuse_bwd: null pointer");
   if (n == 0) return TSCD_OK;
   // dpos [C] | dw0 [64] | dw2 [64] are atomic accumulators: cleared here (callers pass them as one C+128 float block or apart)
@@ -533,8 +626,14 @@ static int se_fuse_bwd_launch(const void* reg, int ldr, const void* edge, int ld
   long total = n * C;
   int grid = (int)((total + 1023) / 1024);                 // ~4 elements per thread
   if (grid > 256) grid = 256;
-  hipLaunchKernelGGL(se_fuse_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)reg, ldr,
-                     (const f16*)edge, lde, w0, w2, (const f16*)dout, n, C, (f16*)dreg, (f16*)dedge, dpos, dw0, dw2);
+  if (ex) {
+    TSCD_CHECK_ARG(!ex->edge_map.idx || ex->edge_map.seg_rows > 0, "se_fuse_bwd: row map without a segment length");
+    hipLaunchKernelGGL(se_fuse_bwd_kernel, dim3(grid), dim3(256), 0, sst, (const f16*)reg, ldr, (const f16*)edge, lde, w0, w2,
+                       (const f16*)dout, n, C, (f16*)dreg, (f16*)dedge, dpos, dw0, dw2, *ex);
+  } else {
+    hipLaunchKernelGGL(se_fuse_bwd_kernel, dim3(grid), dim3(256), 0, sst, (const f16*)reg, ldr, (const f16*)edge, lde, w0, w2,
+                       (const f16*)dout, n, C, (f16*)dreg, (f16*)dedge, dpos, dw0, dw2, SeFuseEx{});
+  }
   TSCD_CHECK_LAUNCH("se_fuse_bwd");
   return TSCD_OK;
 }
@@ -547,7 +646,7 @@ static int se_fuse_bwd_launch(const void* reg, int ldr, const void* edge, int ld
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const f16* __restrict__ a, const f16* __restrict__ b,
                                                                 const float* __restrict__ gamma, const f16* __restrict__ dy, int n, int C,
                                                                 float eps, f16* __restrict__ dx, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta) {
+                                                                float* __restrict__ dbeta, LnEx ex) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = gridDim.x * 4;
@@ -555,6 +654,17 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const f16* __res
 #pragma unroll
   for (int k = 0; k < LN_BWD_NC; ++k) ag[k] = ab[k] = 0.f;
   for (int row = blockIdx.x * 4 + wave; row < n; row += nwaves) {
+    const long arow = map_row(ex.a_map, row);
+    // dy of the row: plus the second contribution where the caller has one (rounded to fp16 like the tensor add it replaces)
+    auto dyv = [&](int c) -> float {
+      float d = (float)dy[(long)row * C + c];
+      if (ex.dy_add) d = (float)(f16)(d + (float)ex.dy_add[(long)row * C + c]);
+      return d;
+    };
+    auto put = [&](int c, float v) {
+      if (dx) dx[(long)row * C + c] = (f16)v;
+      if (ex.dx_mapped) ex.dx_mapped[arow * C + c] = (f16)v;
+    };
     // the row's first 1024 columns live in registers: x and dy are fetched ONCE (the three passes below were three dependent trips to
     // L2 per row -- with one row per wave the whole launch was that latency chain)
     float xr[LN_BWD_NC], dr[LN_BWD_NC];
@@ -563,17 +673,17 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const f16* __res
       const int c = lane + 64 * k;
       xr[k] = dr[k] = 0.f;
       if (c < C) {
-        float x = (float)a[(long)row * C + c];
+        float x = (float)a[arow * C + c];
         if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
         xr[k] = x;
-        dr[k] = (float)dy[(long)row * C + c];
+        dr[k] = dyv(c);
       }
     }
     float s = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < LN_BWD_NC; ++k) { s += xr[k]; s2 += xr[k] * xr[k]; }
     for (int c = lane + 64 * LN_BWD_NC; c < C; c += 64) {
-      float x = (float)a[(long)row * C + c];
+      float x = (float)a[arow * C + c];
       if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
       s += x; s2 += x * x;
     }
@@ -589,9 +699,9 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const f16* __res
       }
     }
     for (int c = lane + 64 * LN_BWD_NC; c < C; c += 64) {
-      float x = (float)a[(long)row * C + c];
+      float x = (float)a[arow * C + c];
       if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
-      float xh = (x - mean) * inv, g = (float)dy[(long)row * C + c] * gamma[c];
+      float xh = (x - mean) * inv, g = dyv(c) * gamma[c];
       m1 += g; m2 += g * xh;
     }
     m1 = wave_sum(m1) / C; m2 = wave_sum(m2) / C;
@@ -600,16 +710,16 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const f16* __res
       const int c = lane + 64 * k;
       if (c < C) {
         const float xh = (xr[k] - mean) * inv, d = dr[k];
-        dx[(long)row * C + c] = (f16)(inv * (d * gamma[c] - m1 - xh * m2));
+        put(c, inv * (d * gamma[c] - m1 - xh * m2));
         ag[k] += d * xh;
         ab[k] += d;
       }
     }
     for (int c = lane + 64 * LN_BWD_NC; c < C; c += 64) {        // C > 1024: the tail falls back to per-element atomics
-      float x = (float)a[(long)row * C + c];
+      float x = (float)a[arow * C + c];
       if (b) x = (float)(f16)(x + (float)b[(long)row * C + c]);
-      float xh = (x - mean) * inv, d = (float)dy[(long)row * C + c];
-      dx[(long)row * C + c] = (f16)(inv * (d * gamma[c] - m1 - xh * m2));
+      float xh = (x - mean) * inv, d = dyv(c);
+      put(c, inv * (d * gamma[c] - m1 - xh * m2));
       atomicAdd(dgamma + c, d * xh);
       atomicAdd(dbeta + c, d);
     }
@@ -628,19 +738,26 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const f16* __res
   }
 }
 static int add_layernorm_bwd_launch(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps, void* dx,
-                                    float* dgamma, float* dbeta, bool zero, void* stream);
+                                    float* dgamma, float* dbeta, bool zero, const LnEx* ex, void* stream);
 extern "C" int tscd_add_layernorm_bwd_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
                                           void* dx, float* dgamma, float* dbeta, void* stream) {
-  return add_layernorm_bwd_launch(a, b, gamma, dy, n, C, eps, dx, dgamma, dbeta, true, stream);
+  return add_layernorm_bwd_launch(a, b, gamma, dy, n, C, eps, dx, dgamma, dbeta, true, nullptr, stream);
 }
 // The same ADDING into dgamma / dbeta (cleared by the caller).
 extern "C" int tscd_add_layernorm_bwd_acc_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
                                               void* dx, float* dgamma, float* dbeta, void* stream) {
-  return add_layernorm_bwd_launch(a, b, gamma, dy, n, C, eps, dx, dgamma, dbeta, false, stream);
+  return add_layernorm_bwd_launch(a, b, gamma, dy, n, C, eps, dx, dgamma, dbeta, false, nullptr, stream);
+}
+// The adding form with the chain's extras (struct TscdLnEx): `a` read through a row map, a second dy contribution, and dx also (or only:
+// dx may be null then) written to the mapped row of a second buffer.
+extern "C" int tscd_add_layernorm_bwd_ex_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
+                                             void* dx, float* dgamma, float* dbeta, const void* ex, void* stream) {
+  TSCD_CHECK_ARG(ex && (dx || ((const LnEx*)ex)->dx_mapped), "add_layernorm_bwd_ex: no extras / no destination");
+  return add_layernorm_bwd_launch(a, b, gamma, dy, n, C, eps, dx, dgamma, dbeta, false, (const LnEx*)ex, stream);
 }
 static int add_layernorm_bwd_launch(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps, void* dx,
-                                    float* dgamma, float* dbeta, bool zero, void* stream) {
-  TSCD_CHECK_ARG(a && gamma && dy && dx && dgamma && dbeta && C > 0, "add_layernorm_bwd: bad args");
+                                    float* dgamma, float* dbeta, bool zero, const LnEx* ex, void* stream) {
+  TSCD_CHECK_ARG(a && gamma && dy && (dx || ex) && dgamma && dbeta && C > 0, "add_layernorm_bwd: bad args");
   if (!zero) {
   } else if (dbeta == dgamma + C) {                                            // atomic accumulators
     (void)hipMemsetAsync(dgamma, 0, sizeof(float) * 2 * C, (hipStream_t)stream);
@@ -651,8 +768,14 @@ static int add_layernorm_bwd_launch(const void* a, const void* b, const float* g
   if (n == 0) return TSCD_OK;
   int grid = (n + 3) / 4;
   if (grid > 256) grid = 256;                      // >= 1 row per wave; at most one block per CU
-  hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)a,
-                     (const f16*)b, gamma, (const f16*)dy, n, C, eps, (f16*)dx, dgamma, dbeta);
+  if (ex) {
+    TSCD_CHECK_ARG(!ex->a_map.idx || ex->a_map.seg_rows > 0, "add_layernorm_bwd: row map without a segment length");
+    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)a, (const f16*)b, gamma,
+                       (const f16*)dy, n, C, eps, (f16*)dx, dgamma, dbeta, *ex);
+  } else {
+    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)a, (const f16*)b, gamma,
+                       (const f16*)dy, n, C, eps, (f16*)dx, dgamma, dbeta, LnEx{});
+  }
   TSCD_CHECK_LAUNCH("add_layernorm_bwd");
   return TSCD_OK;
 }

@@ -111,11 +111,12 @@ __global__ void mca_prep_kernel(const f16* __restrict__ q_c, const f16* __restri
 
 // -------------------------------------------------------------------------------------------------- pass A
 template <int DP, bool F16L>
-__global__ __launch_bounds__(256) void mca_stats_kernel(McaParams p) {
+__global__ __launch_bounds__(256) void mca_stats_kernel(McaParams p, int ntiles) {
   constexpr int KS = DP / 16;
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
-  const McaTile t = p.tiles[blockIdx.x];
-  const int s = blockIdx.y;
+  int s, tile;
+  if (!xcd_remap(blockIdx.x, p.S, ntiles, s, tile)) return;      // class = key split: its key fragments stay in one XCD's L2
+  const McaTile t = p.tiles[tile];
   const int n_local = ((t.loc_end + 31) >> 5) - (t.loc_start >> 5);
   const int n_glob = ((p.N + 31) >> 5) - (p.N_L >> 5);
   const int nblk = n_local + n_glob;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void mca_stats_kernel(McaParams p) {
 
 // -------------------------------------------------------------------------------------------------- pass B
 template <int DP, bool NEED_REG, bool F16L>
-__global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p) {
+__global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p, int ntiles) {
   constexpr int KS = DP / 16, NT = DP / 32;
   constexpr int PST = 33;   // fp32 tile row stride
   constexpr int HST = 40;   // fp16 tile row stride (80 B: conflict-free b128 rows)
@@ -194,8 +195,11 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p) {
   __shared__ float den[2][32];
 
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
-  const McaTile t = p.tiles[blockIdx.x];
-  const int s = blockIdx.y;
+  // class = key split (as the backward's passes, mca_common.h): the ~24 MB of key-side fragments of a 16 x 500 clip do not fit one
+  // XCD's 4 MB L2, the 1/8 a split class touches does -- with (tile, split) ids dealt round-robin every XCD streamed all of them
+  int s, tile;
+  if (!xcd_remap(blockIdx.x, p.S, ntiles, s, tile)) return;
+  const McaTile t = p.tiles[tile];
   const int n_local = ((t.loc_end + 31) >> 5) - (t.loc_start >> 5);
   const int n_glob = ((p.N + 31) >> 5) - (p.N_L >> 5);
   const int nblk = n_local + n_glob;
@@ -498,14 +502,14 @@ extern "C" int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q
   p.part_oc = part_oc; p.part_or = part_or; p.part_sc = part_sc; p.part_sr = part_sr; p.part_den = part_den;
   p.N = N; p.N_L = N_L; p.Npad = Npad; p.WP = WP; p.S = S;
   p.scale = scale; p.sim_thresh = sim_thresh; p.conf_thresh = conf_thresh;
-  dim3 grid(ntiles, S), block(256);
+  dim3 grid(xcd_grid(S, ntiles)), block(256);
 #define MCA_LAUNCH_L(DPV, FL)                                                                        \
   do {                                                                                              \
-    hipLaunchKernelGGL((mca_stats_kernel<DPV, FL>), grid, block, 0, st, p);                         \
+    hipLaunchKernelGGL((mca_stats_kernel<DPV, FL>), grid, block, 0, st, p, ntiles);                         \
     if (need_reg)                                                                                   \
-      hipLaunchKernelGGL((mca_aggregate_kernel<DPV, true, FL>), grid, block, 0, st, p);             \
+      hipLaunchKernelGGL((mca_aggregate_kernel<DPV, true, FL>), grid, block, 0, st, p, ntiles);             \
     else                                                                                            \
-      hipLaunchKernelGGL((mca_aggregate_kernel<DPV, false, FL>), grid, block, 0, st, p);            \
+      hipLaunchKernelGGL((mca_aggregate_kernel<DPV, false, FL>), grid, block, 0, st, p, ntiles);            \
   } while (0)
 #define MCA_LAUNCH(DPV)                                                                             \
   do {                                                                                              \

@@ -62,18 +62,6 @@ struct McaBwdParams {
   float scale, sim_thresh, conf_thresh;
 };
 
-// XCD-aware workgroup order.  Workgroup ids go round-robin over the 8 XCDs (each with its own 4 MB L2), so ids with the same
-// id % 8 share an L2: they take the affinity classes c = xcd, xcd + 8, ... (u = the units of a class, consecutive ids of the
-// XCD), and what a class shares -- the key fragments of a key split, the dM / A blocks of a (tile, key block) pair that all four
-// heads read -- is fetched from memory once per XCD instead of once per workgroup.  Grid = 8 * ceil(C / 8) * U; false = padding.
-__device__ __forceinline__ bool xcd_remap(int id, int C, int U, int& c, int& u) {
-  const int xcd = id & 7, k = id >> 3;
-  c = xcd + 8 * (k / U);
-  u = k % U;
-  return c < C;
-}
-static inline unsigned xcd_grid(int C, int U) { return 8u * ((C + 7) / 8) * U; }
-
 template <int DP>
 __device__ __forceinline__ long rowfrag(int rb, int h, int ks) { return ((((long)rb * MCA_HEADS + h) * (DP / 16) + ks) << 9); }
 template <int DP>

@@ -1294,6 +1294,94 @@ def add_layernorm_bwd(a, b, gamma, d_out, eps=1e-5, out=None, acc=None):
     return dx, acc[0], acc[1]
 
 
+# ---- the CAFM frame chain's row addressing inside se_fuse / add_layernorm (include/tscd_hip.h: TscdRowMap, TscdSeFuseEx, TscdLnEx) ----
+import ctypes as _CT
+
+
+class _RowMapC(_CT.Structure):
+    _fields_ = [("idx", _CT.c_void_p), ("seg_rows", _CT.c_int), ("off0", _CT.c_int), ("off_stride", _CT.c_int)]
+
+
+class _SeFuseExC(_CT.Structure):
+    _fields_ = [("edge_map", _RowMapC), ("pos_seg_rows", _CT.c_int), ("pos_stride", _CT.c_int),
+                ("add_reg", _CT.c_void_p * 3), ("add_reg_rows", _CT.c_int * 3),
+                ("add_edge", _CT.c_void_p * 2), ("add_edge_rows", _CT.c_int * 2)]
+
+
+class _LnExC(_CT.Structure):
+    _fields_ = [("a_map", _RowMapC), ("dy_add", _CT.c_void_p), ("dx_mapped", _CT.c_void_p)]
+
+
+def row_map(idx, seg_rows, off0, off_stride=0):
+    """Row r (segment s = r // seg_rows, local l) -> s * seg_rows + idx[off0 + s * off_stride + l]; idx: int64 device table."""
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and seg_rows > 0
+    return _RowMapC(idx.data_ptr(), seg_rows, off0, off_stride)
+
+
+def _rows16(t, C):
+    assert t.dtype == torch.float16 and t.is_contiguous() and t.shape[-1] == C
+    return t.data_ptr()
+
+
+def se_fuse_ex(reg, edge, w0, w2, pos, out, n, edge_map=None, pos_seg_rows=0, pos_stride=0):
+    """se_fuse over ``n`` rows into ``out`` with the edge rows read through ``edge_map`` and one fp32 pos vector per ``pos_seg_rows`` rows
+    (``pos`` then [segments, pos_stride])."""
+    C = reg.shape[1]
+    assert reg.stride(1) == 1 and edge.stride(1) == 1 and out.is_contiguous() and out.dtype == torch.float16 and out.shape[1] == C
+    ex = _SeFuseExC()
+    if edge_map is not None:
+        ex.edge_map = edge_map
+    ex.pos_seg_rows, ex.pos_stride = pos_seg_rows, pos_stride
+    call("tscd_se_fuse_ex_f16", reg.data_ptr(), reg.stride(0), edge.data_ptr(), edge.stride(0), w0.data_ptr(), w2.data_ptr(),
+         _ptr(pos), n, C, out.data_ptr(), _CT.addressof(ex), _stream())
+    return out
+
+
+def se_fuse_bwd_ex(reg, edge, w0, w2, d_out, d_reg, d_edge, n, dpos, dw0, dw2, edge_map=None, pos_seg_rows=0, pos_stride=0,
+                   add_reg=(), add_edge=()):
+    """se_fuse backward over ``n`` rows ADDING into the fp32 accumulators (dpos: one [C] vector per row segment, ``pos_stride`` floats
+    apart).  ``edge_map``: the edge rows are read -- and their gradient written -- through the map; ``add_reg`` / ``add_edge``: up to 3 / 2
+    (fp16 [rows, C] tensor, rows) addends summed into d_reg / d_edge before the one rounding (d_reg / d_edge may be one of them)."""
+    C = reg.shape[1]
+    assert reg.stride(1) == 1 and edge.stride(1) == 1 and d_out.is_contiguous() and d_out.dtype == torch.float16
+    assert len(add_reg) <= 3 and len(add_edge) <= 2
+    ex = _SeFuseExC()
+    if edge_map is not None:
+        ex.edge_map = edge_map
+    ex.pos_seg_rows, ex.pos_stride = pos_seg_rows, pos_stride
+    for k, (t, rows) in enumerate(add_reg):
+        ex.add_reg[k], ex.add_reg_rows[k] = _rows16(t, C), rows
+    for k, (t, rows) in enumerate(add_edge):
+        ex.add_edge[k], ex.add_edge_rows[k] = _rows16(t, C), rows
+    call("tscd_se_fuse_bwd_ex_f16", reg.data_ptr(), reg.stride(0), edge.data_ptr(), edge.stride(0), w0.data_ptr(), w2.data_ptr(),
+         d_out.data_ptr(), n, C, _rows16(d_reg, C), _rows16(d_edge, C), dpos.data_ptr(), dw0.data_ptr(), dw2.data_ptr(),
+         _CT.addressof(ex), _stream())
+
+
+def add_layernorm_ex(a, b, gamma, beta, eps, out, n, a_map):
+    """out[r] = LayerNorm(a[a_map(r)] (+ b[r])) over ``n`` rows."""
+    C = out.shape[1]
+    ex = _LnExC()
+    ex.a_map = a_map
+    call("tscd_add_layernorm_ex_f16", _rows16(a, C), None if b is None else _rows16(b, C), gamma.data_ptr(), beta.data_ptr(), n, C, eps,
+         _rows16(out, C), _CT.addressof(ex), _stream())
+    return out
+
+
+def add_layernorm_bwd_ex(a, b, gamma, d_out, eps, dx, n, acc, a_map=None, dy_add=None, dx_mapped=None):
+    """add_layernorm backward over ``n`` rows ADDING d_gamma / d_beta into ``acc`` [2, C]: ``a`` read through ``a_map``, dy = fp16(d_out +
+    dy_add), dx written to ``dx`` (may be None) and to row a_map(r) of ``dx_mapped``."""
+    C = d_out.shape[1]
+    assert acc.dtype == torch.float32 and acc.is_contiguous() and tuple(acc.shape) == (2, C)
+    ex = _LnExC()
+    if a_map is not None:
+        ex.a_map = a_map
+    ex.dy_add = None if dy_add is None else _rows16(dy_add, C)
+    ex.dx_mapped = None if dx_mapped is None else _rows16(dx_mapped, C)
+    call("tscd_add_layernorm_bwd_ex_f16", _rows16(a, C), None if b is None else _rows16(b, C), gamma.data_ptr(), _rows16(d_out, C), n, C,
+         eps, None if dx is None else _rows16(dx, C), acc[0].data_ptr(), acc[1].data_ptr(), _CT.addressof(ex), _stream())
+
+
 def match_costs_clip(reg, cls, pairs):
     """Every Hungarian cost matrix of a clip whose frames are matched against each other (no carried-over state): the [reg | cls]
     rows of ALL proposals are normalised once (two launches), each matrix is one GEMM over two row ranges of that buffer, written

@@ -336,12 +336,16 @@ class _CafmChain(torch.autograd.Function):
         nl = n * L
         temb16 = temb.to(torch.float16).contiguous()
         t_emb = ops.linear(temb16, w_pos, b_pos).float()                   # [L, W] fp32 rows (the SE gate takes fp32 position vectors)
-        # key side of every frame: k_in = SE(cur, cur_edge) + t_j, then ONE projection each for k and v over all local rows
+        # The row permutations (assignment order c_j, its inverse inv_j) are not materialised: the kernels that consume / produce the
+        # rows read / write them through a row map into the clip's index table (ops.row_map; 18 gather launches per step before).
+        c_off, inv_off = [sl[0] for sl in slots], [sl[1] for sl in slots]
+        inv_stride = inv_off[1] - inv_off[0] if L > 1 else 0
+        assert all(inv_off[j] == inv_off[0] + j * inv_stride for j in range(L)), "index table: the inverse permutations are not evenly spaced"
+        cmap = lambda j: ops.row_map(idx, n, c_off[j])
+        # key side of every frame: k_in = SE(cur, cur_edge) + t_j (one launch: a position vector per frame), then ONE projection each
+        # for k and v over all local rows
         k_in = ops.temp((nl, W), dtype=torch.float16, device=dev)
-        for j in range(L):
-            s0 = j * n
-            ops.call("tscd_se_fuse_f16", feat[s0:].data_ptr(), W, edge[s0:].data_ptr(), W, w0f.data_ptr(), w2f.data_ptr(), t_emb[j].data_ptr(),
-                     n, W, k_in[s0:].data_ptr(), ops._stream())
+        ops.se_fuse_ex(feat, edge, w0f, w2f, t_emb, k_in, nl, pos_seg_rows=n, pos_stride=W)
         k_all, v_all = ops.linear(k_in, wk), ops.linear(feat, wv)
         mfma = ops.cos_attn_uses_mfma(W, heads)
         tiles = ops.attn_tiles([(0, n, 0, n)], dev, rows=32 if mfma else 16)
@@ -349,82 +353,77 @@ class _CafmChain(torch.autograd.Function):
         q_in = ops.temp((nl, W), dtype=torch.float16, device=dev)
         q_all = ops.temp((nl, W), dtype=torch.float16, device=dev)
         t2_all = ops.temp((nl, W), dtype=torch.float16, device=dev)
-        idn_all = ops.temp((nl, W), dtype=torch.float16, device=dev)    # residual inputs: cur (first frame) / cur[c]
-        qedge_all = ops.temp((nl, W), dtype=torch.float16, device=dev)  # query-side edge rows: cur_edge (first) / previous frame's cur_edge[c]
         out_all = ops.temp((nl, W), dtype=torch.float16, device=dev)    # per-frame outputs in assignment order (= the next frame's tgt)
-        o = ops.temp((nl, W), dtype=torch.float16, device=dev)          # outputs back in proposal order
         lsums = []
         for j in range(L):
             s0, s1 = j * n, (j + 1) * n
-            cur, cur_edge = feat[s0:s1], edge[s0:s1]
             if feed is not None and j >= 1:
                 feed.wait(j)       # frame j's assignment order: the stream goes on as soon as ITS matrix is solved (frame 0 needs none)
-            c = idx[slots[j][0]:slots[j][0] + n] if slots[j][0] >= 0 else None
-            if j == 0:
-                tgt, qedge, idn, qpos = cur, cur_edge, cur, t_emb[0]
-            else:
-                torch.index_select(cur, 0, c, out=idn_all[s0:s1])
-                qedge = edge[:n] if j == 1 else qedge_all[s0:s1]
-                tgt, idn, qpos = out_all[s0 - n:s0], idn_all[s0:s1], t_emb[j - 1]
-            ops.call("tscd_se_fuse_f16", tgt.data_ptr(), W, qedge.data_ptr(), W, w0f.data_ptr(), w2f.data_ptr(), qpos.data_ptr(), n, W,
-                     q_in[s0:].data_ptr(), ops._stream())
+            # query side: tgt = the previous frame's output (assignment order), its edge rows = the previous frame's in ITS assignment
+            # order (frame 1 reads frame 0's in place: frame 0 keeps its own order)
+            tgt = feat[:n] if j == 0 else out_all[s0 - n:s0]
+            qedge = edge[:n] if j <= 1 else edge[s0 - n:s0]
+            ops.se_fuse_ex(tgt, qedge, w0f, w2f, t_emb[max(j - 1, 0)], q_in[s0:s1], n, edge_map=cmap(j - 1) if j >= 2 else None)
             ops.linear(q_in[s0:s1], wq, out=q_all[s0:s1])
             if mfma:
                 lsums.append(ops.cos_attn_mfma(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], heads, tiles, True, out=t2_all[s0:s1])[1])
             else:
                 t2_all[s0:s1].copy_(ops.cos_attn(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], heads, tiles))
-            ops.call("tscd_add_layernorm_f16", idn.data_ptr(), t2_all[s0:].data_ptr(), g_ln.data_ptr(), b_ln.data_ptr(), n, W, eps_ln,
-                     out_all[s0:].data_ptr(), ops._stream())
-            if 0 < j < L - 1:  # the next frame's query-side edge rows = this frame's edge rows in assignment order (frame 1 reads frame 0's in place)
-                torch.index_select(cur_edge, 0, c, out=qedge_all[s1:s1 + n])
+            # residual input: cur (first frame) / cur[c_j]
+            if j == 0:
+                ops.call("tscd_add_layernorm_f16", feat.data_ptr(), t2_all.data_ptr(), g_ln.data_ptr(), b_ln.data_ptr(), n, W, eps_ln,
+                         out_all.data_ptr(), ops._stream())
+            else:
+                ops.add_layernorm_ex(feat[s0:s1], t2_all[s0:s1], g_ln, b_ln, eps_ln, out_all[s0:s1], n, cmap(j))
         if feed is not None and L == 1:
             feed.wait(0)
-        for j in range(L):     # back to proposal order (after the loop: frame 0 then never waits for its own self-assignment)
-            s0, s1 = j * n, (j + 1) * n
-            torch.index_select(out_all[s0:s1], 0, idx[slots[j][1]:slots[j][1] + n], out=o[s0:s1])
-        matched = ops.add_layernorm(o, None, g_dec, b_dec, eps_dec)
+        # back to proposal order inside the decoder norm (row-wise, so it commutes with the permutation): row i of frame j reads
+        # out_j[inv_j[i]] (after the loop: frame 0 then never waits for its own self-assignment)
+        matched = ops.temp((nl, W), dtype=torch.float16, device=dev)
+        ops.add_layernorm_ex(out_all, None, g_dec, b_dec, eps_dec, matched, nl, ops.row_map(idx, n, inv_off[0], inv_stride))
         ctx.meta = meta[:6]
         ctx.mfma = mfma
         ctx.dtypes = (w_pos.dtype, se_w0.dtype, wq.dtype, ln_g.dtype, dec_g.dtype)
         ctx.save_for_backward(idx, feat, edge, temb16, t_emb, w_pos, w0f, w2f, wq, wk, wv, g_ln, g_dec, k_in, k_all, v_all, q_in, q_all,
-                              t2_all, idn_all, qedge_all, out_all, o, tiles, *lsums)
+                              t2_all, out_all, tiles, *lsums)
         return matched
 
     @staticmethod
     def backward(ctx, d_matched):
         n, L, heads, slots, eps_ln, eps_dec = ctx.meta
-        (idx, feat, edge, temb16, t_emb, w_pos, w0f, w2f, wq, wk, wv, g_ln, g_dec, k_in, k_all, v_all, q_in, q_all, t2_all, idn_all, qedge_all,
-         out_all, o, tiles, *lsums) = ctx.saved_tensors
+        (idx, feat, edge, temb16, t_emb, w_pos, w0f, w2f, wq, wk, wv, g_ln, g_dec, k_in, k_all, v_all, q_in, q_all, t2_all,
+         out_all, tiles, *lsums) = ctx.saved_tensors
         W = feat.shape[1]
         dev = feat.device
         nl = n * L
+        c_off, inv_off = [sl[0] for sl in slots], [sl[1] for sl in slots]
+        inv_stride = inv_off[1] - inv_off[0] if L > 1 else 0
+        cmap = lambda j: ops.row_map(idx, n, c_off[j])
         h16 = lambda t: t if t.dtype == torch.float16 else t.to(torch.float16)
-        d_o, dg_dec, db_dec = ops.add_layernorm_bwd(o, None, g_dec, h16(d_matched).contiguous(), eps_dec)
         mk = lambda: ops.temp((nl, W), dtype=torch.float16, device=dev)
         dk_all, dv_all, dq_all = mk(), mk(), mk()
+        d_out_all = mk()                                     # d loss / d out_j of every frame, in assignment order
         d_idn = mk()                                         # gradient of the residual inputs, in proposal order (added to d_feat at the end)
         d_edge = mk()                                        # query-side contributions to the edge rows, in proposal order
-        d_mem_all, d_ed_all = mk(), mk()                     # key-side gate: d cur, d cur_edge of every frame
         # ONE zeroed arena for every fp32 parameter-gradient accumulator of the chain (the kernels ADD into their part): per frame the
-        # query-side gate's [d pos | d w0 | d w2], the key-side gate's, and the residual LayerNorm's [d gamma, d beta]
+        # query-side gate's [d pos | d w0 | d w2], the key-side gate's, the residual LayerNorm's [d gamma, d beta]; the decoder norm's
         SW = W + 128
-        arena = ops.ztemp((2 * L * SW + L * 2 * W,), dtype=torch.float32, device=dev)
+        arena = ops.ztemp((2 * L * SW + (L + 1) * 2 * W,), dtype=torch.float32, device=dev)
         A, K = arena[:L * SW].view(L, SW), arena[L * SW:2 * L * SW].view(L, SW)
-        ln_acc = arena[2 * L * SW:].view(L, 2, W)
+        ln_acc = arena[2 * L * SW:].view(L + 1, 2, W)
+        # decoder norm: matched[i of frame j] = LN(out_j[inv_j[i]]) -- dx goes straight back to row inv_j[i] of frame j
+        ops.add_layernorm_bwd_ex(out_all, None, g_dec, h16(d_matched).contiguous(), eps_dec, None, nl, ln_acc[L],
+                                 a_map=ops.row_map(idx, n, inv_off[0], inv_stride), dx_mapped=d_out_all)
+        dg_dec, db_dec = ln_acc[L, 0], ln_acc[L, 1]
         carry_out = None        # d loss / d out_j (assignment order) arriving from frame j+1's query path
         d_tgt0 = d_qedge0 = None
         for j in range(L - 1, -1, -1):
             s0, s1 = j * n, (j + 1) * n
-            c = idx[slots[j][0]:slots[j][0] + n] if slots[j][0] >= 0 else None
-            inv = idx[slots[j][1]:slots[j][1] + n]
-            # o[s0:s1] = out_j[inv]  =>  d out_j = d_o[s0:s1][inverse of inv]; that inverse is c for the matched frames
-            cinv = c if c is not None else torch.argsort(inv)
-            d_out = d_o[s0:s1].index_select(0, cinv)
-            if carry_out is not None:
-                d_out += carry_out
-            idn = feat[:n] if j == 0 else idn_all[s0:s1]
-            # residual input: cur (first frame: its gradient is already in proposal order) or cur[c]
-            dx, _, _ = ops.add_layernorm_bwd(idn, t2_all[s0:s1], g_ln, d_out, eps_ln, out=d_idn[s0:s1] if j == 0 else None, acc=ln_acc[j])
+            # residual input: cur (first frame: its gradient is already in proposal order) or cur[c_j] (dx also lands at row c_j[r] of d_idn);
+            # d out_j = the decoder norm's part + what frame j+1's query path sent back
+            dx = d_idn[s0:s1] if j == 0 else ops.temp((n, W), dtype=torch.float16, device=dev)
+            ops.add_layernorm_bwd_ex(feat[s0:s1], t2_all[s0:s1], g_ln, d_out_all[s0:s1], eps_ln, dx, n, ln_acc[j],
+                                     a_map=cmap(j) if j > 0 else None, dy_add=carry_out, dx_mapped=d_idn[s0:s1] if j > 0 else None)
             if ctx.mfma:
                 ops.cos_attn_mfma_bwd(q_all[s0:s1], k_all[s0:s1], v_all[s0:s1], dx, t2_all[s0:s1], lsums[j], heads, tiles, True,
                                       outs=(dq_all[s0:s1], dk_all[s0:s1], dv_all[s0:s1]), ktiles32=ctx.ktiles, keys_full=True)
@@ -433,44 +432,36 @@ class _CafmChain(torch.autograd.Function):
                 dq_all[s0:s1].copy_(dq)
                 dk_all[s0:s1].copy_(dk)
                 dv_all[s0:s1].copy_(dv)
-            if j > 0:
-                torch.index_select(dx, 0, inv, out=d_idn[s0:s1])         # back to proposal order
             # query path: q = Wq q_in, q_in = SE(tgt, qedge) + qpos  (Wq's own gradient is one GEMM over all frames below)
             dq_in = ops.linear_dgrad(dq_all[s0:s1], wq)
             tgt = feat[:n] if j == 0 else out_all[s0 - n:s0]
-            qedge = edge[:n] if j <= 1 else qedge_all[s0:s1]
-            # frame 1's query-side edge rows are frame 0's in place: their gradient goes straight to its destination
-            d_tgt, d_qedge, _, _, _ = ops.se_fuse_bwd(tgt, qedge, w0f, w2f, dq_in, acc=A[j],
-                                                      outs=(ops.temp((n, W), dtype=torch.float16, device=dev), d_edge[0:n]) if j == 1 else None)
+            d_tgt = ops.temp((n, W), dtype=torch.float16, device=dev)
             if j == 0:
-                d_tgt0, d_qedge0 = d_tgt, d_qedge
-                carry_out = None
+                d_qedge0 = ops.temp((n, W), dtype=torch.float16, device=dev)
+                ops.se_fuse_bwd_ex(tgt, edge[:n], w0f, w2f, dq_in, d_tgt, d_qedge0, n, A[0], A[0, W:], A[0, W + 64:])
+                d_tgt0, carry_out = d_tgt, None
             else:
+                # frame j's query-side edge rows are frame j-1's in assignment order (frame 0 keeps its own): their gradient goes
+                # straight to its rows of d_edge
+                ops.se_fuse_bwd_ex(tgt, edge[s0 - n:s0], w0f, w2f, dq_in, d_tgt, d_edge[s0 - n:s0], n, A[j], A[j, W:], A[j, W + 64:],
+                                   edge_map=cmap(j - 1) if j >= 2 else None)
                 carry_out = d_tgt
-                # frame j's query-side edge rows are frame j-1's edge rows in assignment order (frame 0 keeps its own order)
-                if j > 1:
-                    torch.index_select(d_qedge, 0, idx[slots[j - 1][1]:slots[j - 1][1] + n], out=d_edge[s0 - n:s0])
-        d_edge[nl - n:nl].zero_()                                    # the last frame's edge rows feed no later query gate
         # key / value side of all frames at once
         dk_in, dwk, _ = ops.linear_bwd(k_in, dk_all, wk, True, True, False, grad_params=[wk])
         d_feat, dwv, _ = ops.linear_bwd(feat, dv_all, wv, True, True, False, grad_params=[wv])
         _, dwq, _ = ops.linear_bwd(q_in, dq_all, wq, False, True, False, grad_params=[wq])
-        for j in range(L):
-            s0, s1 = j * n, (j + 1) * n
-            ops.se_fuse_bwd(feat[s0:s1], edge[s0:s1], w0f, w2f, dk_in[s0:s1], outs=(d_mem_all[s0:s1], d_ed_all[s0:s1]), acc=K[j])
-        # fp16 sums over [nl, W] (the per-op path accumulates in fp16 too): 3 + 2 launches instead of a dozen per-frame ones
-        d_feat += d_idn
-        d_feat += d_mem_all
-        d_feat[:n] += d_tgt0
-        d_edge += d_ed_all
-        d_edge[:n] += d_qedge0
+        # key-side gate of all frames in ONE launch (a d pos vector per frame), which also sums up d feat and d edge: value path +
+        # residual inputs + key-side gate (+ frame 0's query-side gate); the last frame's edge rows feed no later query gate
+        ops.se_fuse_bwd_ex(feat, edge, w0f, w2f, dk_in, d_feat, d_edge, nl, K, K[0, W:], K[0, W + 64:], pos_seg_rows=n, pos_stride=SW,
+                           add_reg=[(d_feat, nl), (d_idn, nl), (d_tgt0, n)],
+                           add_edge=([(d_edge, (L - 1) * n)] if L > 1 else []) + [(d_qedge0, n)])
         d_temb = K[:, :W].clone()                                   # key-side gate of frame j adds t_j
         d_temb[0] += A[0, :W]                                       # query-side gate: t_0 for the first frame, t_{j-1} for frame j
         if L > 1:
             d_temb[:L - 1] += A[1:, :W]
         dse = (A[:, W:] + K[:, W:]).sum(0)
         dw0, dw2 = dse[:64].view(32, 2), dse[64:].view(2, 32)
-        ln_sum = ln_acc.sum(0)
+        ln_sum = ln_acc[:L].sum(0)
         dg_ln, db_ln = ln_sum[0], ln_sum[1]
         _, dw_pos, db_pos = ops.linear_bwd(temb16, d_temb.to(torch.float16), w_pos, False, True, True)
         dt_pos, dt_se, dt_q, dt_ln, dt_dec = ctx.dtypes
