@@ -231,9 +231,11 @@ __global__ void gather_rows_kernel(MapTable t, const int* __restrict__ sel_idx, 
   for (int c = lane * 8; c < W; c += 512) *(f16x8*)(dst + c) = *(const f16x8*)(src + c);
 }
 
+// addmask bit f: feature f's rows are ADDED to what its maps hold (a gradient map another consumer of the same feature map has
+// already written; proposals are distinct anchors of a frame, so no two rows meet) instead of written into a zeroed map
 __global__ void scatter_rows_kernel(MapTable t, const int* __restrict__ sel_idx, int cap, const int* __restrict__ frame_off,
                                     int B, int N, int W, int ld, int nmaps, const f16* __restrict__ g0, const f16* __restrict__ g1,
-                                    const f16* __restrict__ g2) {
+                                    const f16* __restrict__ g2, int addmask) {
   int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   int n = wave / nmaps, f = wave % nmaps;
   if (n >= N) return;
@@ -243,7 +245,17 @@ __global__ void scatter_rows_kernel(MapTable t, const int* __restrict__ sel_idx,
   int k = a >= t.a0[2] ? 2 : (a >= t.a0[1] ? 1 : 0);
   f16* dst = t.gmap[f][k] + ((long)b * t.hw[k] + (a - t.a0[k])) * ld;
   const f16* src = (f == 0 ? g0 : (f == 1 ? g1 : g2)) + (long)n * W;
-  for (int c = lane * 8; c < W; c += 512) *(f16x8*)(dst + c) = *(const f16x8*)(src + c);
+  if ((addmask >> f) & 1) {
+    for (int c = lane * 8; c < W; c += 512) {
+      f16x8 v = *(const f16x8*)(dst + c);
+      const f16x8 g = *(const f16x8*)(src + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)g[e]);        // one rounding, as the tensor add it replaces
+      *(f16x8*)(dst + c) = v;
+    }
+  } else {
+    for (int c = lane * 8; c < W; c += 512) *(f16x8*)(dst + c) = *(const f16x8*)(src + c);
+  }
 }
 
 // maps: 9 pointers [feature 0..2][level 0..2]; features beyond nmaps may be null.  map_ld: pixel stride of every map in elements (W
@@ -251,6 +263,7 @@ __global__ void scatter_rows_kernel(MapTable t, const int* __restrict__ sel_idx,
 extern "C" int tscd_gather_rows(const void* const* maps, const int* hw3, const int* sel_idx, int cap, const int* frame_off,
                                 int B, int N, int W, int map_ld, int nmaps, void* out0, void* out1, void* out2, int scatter,
                                 void* stream) {
+  // scatter: 0 gather; bit 0 set: scatter out0..2 into the maps, bits 1..3: feature 0..2 ADDS to its maps instead of overwriting
   TSCD_CHECK_ARG(maps && hw3 && sel_idx && frame_off && N >= 0 && W % 8 == 0 && map_ld % 8 == 0 && map_ld >= W && nmaps >= 1 && nmaps <= 3,
                  "gather_rows: bad args");
   if (N == 0) return TSCD_OK;
@@ -265,12 +278,12 @@ extern "C" int tscd_gather_rows(const void* const* maps, const int* hw3, const i
     }
   long waves = (long)N * nmaps;
   dim3 grid((unsigned)((waves * 64 + 255) / 256)), block(256);
-  if (!scatter)
+  if (!(scatter & 1))
     hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, (hipStream_t)stream, t, sel_idx, cap, frame_off, B, N, W, map_ld, nmaps,
                        (f16*)out0, (f16*)out1, (f16*)out2);
   else
     hipLaunchKernelGGL(scatter_rows_kernel, grid, block, 0, (hipStream_t)stream, t, sel_idx, cap, frame_off, B, N, W, map_ld, nmaps,
-                       (const f16*)out0, (const f16*)out1, (const f16*)out2);
+                       (const f16*)out0, (const f16*)out1, (const f16*)out2, (scatter >> 1) & 7);
   TSCD_CHECK_LAUNCH("gather_rows");
   return TSCD_OK;
 }

@@ -793,14 +793,19 @@ def gather_rows(maps_per_feature, geo, sel_idx, frame_off, N, W):
     return outs
 
 
-def scatter_rows(grads, grad_maps_per_feature, geo, sel_idx, frame_off, N, W):
-    """Adjoint of gather_rows: writes grads[f][n] into the (pre-zeroed) grad maps."""
+def scatter_rows(grads, grad_maps_per_feature, geo, sel_idx, frame_off, N, W, add=None):
+    """Adjoint of gather_rows: writes grads[f][n] into the (pre-zeroed) grad maps; ``add[f]``: feature f's rows are ADDED to what its
+    maps already hold (another consumer's gradient of the same feature maps) -- no zero fill and no tensor add for that feature."""
     nm = len(grads)
     B = grad_maps_per_feature[0][0].shape[0]
     gs = [g.contiguous() for g in grads]
     ld = _maps_ld(grad_maps_per_feature, W)
+    mode = 1
+    for f in range(nm):
+        if add is not None and add[f]:
+            mode |= 2 << f
     call("tscd_gather_rows", _map_table(grad_maps_per_feature), geo.c_hw, sel_idx.data_ptr(), sel_idx.shape[1],
-         frame_off.data_ptr(), B, N, W, ld, nm, _ptr(gs[0]), _ptr(gs[1] if nm > 1 else None), _ptr(gs[2] if nm > 2 else None), 1,
+         frame_off.data_ptr(), B, N, W, ld, nm, _ptr(gs[0]), _ptr(gs[1] if nm > 1 else None), _ptr(gs[2] if nm > 2 else None), mode,
          _stream())
 
 

@@ -53,6 +53,33 @@ class _GatherRows(torch.autograd.Function):
         return (None,) * 6 + tuple(zeros)
 
 
+class _TapGather(torch.autograd.Function):
+    """The row gather of the trained towers' outputs (find_feature_score) TOGETHER with the regression maps' other consumer: returns
+    (f_cls, f_reg, reg_tap[0..2]) where reg_tap[k] aliases reg_maps[k] and feeds the edge block.  Backward then receives the edge
+    block's gradient of reg_maps[k] and the gathered rows' gradient in ONE call and adds the rows into the former in place (distinct
+    anchors: no two rows meet) -- the separate path zero-filled a map per level, scattered into it and left the sum to a tensor add."""
+
+    @staticmethod
+    def forward(ctx, geo, sel_idx, frame_off, N, W, *maps):
+        cls_maps, reg_maps = list(maps[:3]), list(maps[3:6])
+        f_cls, f_reg = ops.gather_rows([cls_maps, reg_maps], geo, sel_idx, frame_off, N, W)
+        ctx.geo, ctx.sel_idx, ctx.frame_off, ctx.N, ctx.W = geo, sel_idx, frame_off, N, W
+        ctx.shapes = [m.shape for m in maps]
+        return (f_cls, f_reg) + tuple(m.view(m.shape) for m in reg_maps)
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg, *g_taps):
+        dev = ctx.sel_idx.device
+        zc = [ops.ztemp(s, dtype=torch.float16, device=dev) for s in ctx.shapes[:3]]
+        ok = all(g is not None and g.dtype == torch.float16 and g.is_contiguous() and g.shape == s for g, s in zip(g_taps, ctx.shapes[3:]))
+        zr = list(g_taps) if ok else [ops.ztemp(s, dtype=torch.float16, device=dev) for s in ctx.shapes[3:]]
+        rows = [g.to(torch.float16) if g is not None else ops.ztemp((ctx.N, ctx.W), dtype=torch.float16, device=dev) for g in (g_cls, g_reg)]
+        ops.scatter_rows(rows, [zc, zr], ctx.geo, ctx.sel_idx, ctx.frame_off, ctx.N, ctx.W, add=(False, ok))
+        if not ok:
+            zr = [z if g is None else z + g.to(torch.float16) for z, g in zip(zr, g_taps)]
+        return (None,) * 5 + tuple(zc) + tuple(zr)
+
+
 class HeadPrefix:
     """The part of the head that depends on nothing the optimizer steps (reference: ovis_tscd_large.py:141-149 freezes ``stems``,
     ``reg_convs``, ``cls_convs`` and ``reg_preds``): per pyramid level (x = stem output [B,h,w,W], fz = [reg_feat | cls_feat]
@@ -84,6 +111,9 @@ LEVEL_STREAMS = LEVEL_STREAM_LAYOUT != "0"
 FUSE_TOWERS = os.environ.get("TSCD_FUSE_TOWERS", "1") != "0"
 EAGER_CLASS_BRANCH = os.environ.get("TSCD_EAGER_CLASS_BRANCH", "1") != "0"
 HOOK_EARLY = os.environ.get("TSCD_PREFETCH_EARLY", "1") != "0"      # the next clip's frozen pass right behind the cost matrices' copy
+# the trained towers' row gather and the edge block share ONE autograd node on the regression maps (_TapGather: the rows are added into the
+# edge block's gradient map in place); "0" = separate gather (zero-filled maps + a tensor add per level)
+TAP_GATHER = os.environ.get("TSCD_TAP_GATHER", "1") != "0"
 
 
 _SIDE_STREAMS = {}      # device -> [torch.cuda.Stream]; process-wide (module attributes must stay deep-copyable for ModelEMA)
@@ -340,7 +370,11 @@ class TSCDHead(nn.Module):
                 return _GatherRows.apply(geo, sel_idx, frame_off, N, W, nf, *maps)
             return ops.gather_rows([maps[3 * f:3 * f + 3] for f in range(nf)], geo, sel_idx, frame_off, N, W)
 
-        f_cls, f_reg = gather(cls_maps + reg_maps)
+        if grad and TAP_GATHER and len(cls_maps) == 3 and all(m.requires_grad for m in cls_maps + reg_maps):
+            tapped = _TapGather.apply(geo, sel_idx, frame_off, N, W, *cls_maps, *reg_maps)
+            f_cls, f_reg, reg_maps = tapped[0], tapped[1], list(tapped[2:])      # the edge block reads the taps
+        else:
+            f_cls, f_reg = gather(cls_maps + reg_maps)
         if training:
             raw_all = torch.cat([r.reshape(B, -1, nch) for r in raw_levels], 1)              # [B,A,5+NC] logits with grad
         if grad:
