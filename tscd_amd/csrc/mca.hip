@@ -218,10 +218,7 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p, int 
   // DP >= 64: the local-row v^ fragments are re-read (L1-hot, 2 KB per head) in every key block instead of living in registers --
   // 128 accumulator + 64 fragment + 32 score registers do not fit the 256 of an occupancy-2 wave
   // (DP >= 96, both branches: 192 accumulator registers -- the q fragments are re-read as well)
-  constexpr bool VL_RELOAD = NEED_REG ? DP >= 64 : DP >= 96;
-  // (DP = 64, both branches: the q fragments are re-read too -- L1-hot, ~4x shorter than the L2 trip of the key fragments that take
-  // their 32 registers one block ahead, below)
-  constexpr bool Q_RELOAD = DP >= 64 && NEED_REG;
+  constexpr bool VL_RELOAD = NEED_REG ? DP >= 64 : DP >= 96, Q_RELOAD = DP >= 96 && NEED_REG;
   f16x8 qc[Q_RELOAD ? 1 : KS], qr[Q_RELOAD ? 1 : KS], vlc[VL_RELOAD ? 1 : KS], vlr[VL_RELOAD ? 1 : KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
@@ -242,26 +239,6 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p, int 
     for (int e = 0; e < 16; ++e) oc[n][e] = orr[n][e] = sfc[n][e] = sfr[n][e] = 0.f;
   __syncthreads();
 
-  // The key fragments of a block's FIRST product are fetched one block ahead, during the previous block's aggregations (the three
-  // phases of a block each began with a load -> wait -> MFMA sequence whose L2 latency two waves per SIMD do not hide; DP <= 64: the
-  // 32 registers fit next to the accumulators)
-  constexpr bool K_AHEAD = DP <= 64;
-  f16x8 kc_n[K_AHEAD ? KS : 1], kr_n[K_AHEAD ? KS : 1];
-  auto fetch_k = [&](int jj) __attribute__((always_inline)) {
-    if constexpr (K_AHEAD) {
-      if (jj < nblk) {
-        int k0, l0, h0;
-        block_range(t, p.N_L, p.N, jj, k0, l0, h0, n_local);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const long of = ((((long)(k0 >> 5) * MCA_HEADS + h) * KS + ks) * 64 + lane) * 8;
-          kc_n[ks] = *(const f16x8*)(p.kF_c + of);
-          kr_n[ks] = *(const f16x8*)(p.kF_r + of);
-        }
-      }
-    }
-  };
-  fetch_k(s);
   for (int j = s; j < nblk; j += p.S) {
     int key0, lo, hi;
     block_range(t, p.N_L, p.N, j, key0, lo, hi, n_local);
@@ -278,9 +255,8 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p, int 
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const long of = ((((long)(key0 >> 5) * MCA_HEADS + h) * KS + ks) * 64 + lane) * 8;
-        f16x8 kc, kr;
-        if constexpr (K_AHEAD) { kc = kc_n[ks]; kr = kr_n[ks]; }
-        else { kc = *(const f16x8*)(p.kF_c + of); kr = *(const f16x8*)(p.kF_r + of); }
+        f16x8 kc = *(const f16x8*)(p.kF_c + of);
+        f16x8 kr = *(const f16x8*)(p.kF_r + of);
         if constexpr (Q_RELOAD) {
           const long oq = (long)qrow * p.WP + h * DP + ks * 16 + (lane >> 5) * 8;
           sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(p.qn_c + oq), kc, sc, 0, 0, 0);
@@ -355,7 +331,6 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p, int 
       }
     }
     __syncthreads();
-    fetch_k(j + p.S);                                    // the next block's k^ fragments travel under the aggregations
     // aggregations: [32 rows x 32 keys] @ V^T-stored values of this head
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
