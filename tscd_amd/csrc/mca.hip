@@ -269,8 +269,13 @@ __global__ __launch_bounds__(256, 2) void mca_aggregate_kernel(McaParams p, int 
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        float pc = valid ? __expf(mca_logit_cls<F16L>(sc[e], kscore, p.scale) - p.scale) * invl[h][0][row] : 0.f;
-        float pr = valid ? __expf(mca_logit_reg<F16L>(sr[e], p.scale) - p.scale) * invl[h][1][row] : 0.f;
+        // (the LDS reads stand OUTSIDE the select: a load under the condition is not speculated, and the 32 selects of a block became
+        // 32 exec-mask branch pairs -- 11.5 M VALU + 3 M SALU instructions per launch next to 0.85 M MFMAs, rocprofv3 SQ_INSTS_*)
+        const float il_c = invl[h][0][row], il_r = invl[h][1][row];
+        const float ec = __expf(mca_logit_cls<F16L>(sc[e], kscore, p.scale) - p.scale) * il_c;
+        const float er = __expf(mca_logit_reg<F16L>(sr[e], p.scale) - p.scale) * il_r;
+        float pc = valid ? ec : 0.f;
+        float pr = valid ? er : 0.f;
         float pp = 0.5f * (pc + pr);
         Pf[h][row][col] = pp;
         Ph[h][row][col] = (f16)pp;
