@@ -142,6 +142,9 @@ def conv_bn_silu(x, weight, gamma, beta, running_mean, running_var, stride, trai
     if residual is None:
         y, _ = ops.conv2d(x, wpk, cout, k, stride, ops.EPI_BN_SILU, scale_shift=ss, out=out)
         return y
+    if out is not None and out.data_ptr() == residual.data_ptr():      # writing back over the residual: raw output in its own buffer
+        y, _ = ops.conv2d(x, wpk, cout, k, stride, ops.EPI_RAW)
+        return ops.bn_act(y, ss, ops.ACT_SILU, residual=residual, out=out)
     y, _ = ops.conv2d(x, wpk, cout, k, stride, ops.EPI_RAW, out=out)
     return ops.bn_act(y, ss, ops.ACT_SILU, residual=residual)
 

@@ -464,7 +464,11 @@ def bn_finalize(partial, count, gamma, beta, running_mean, running_var, eps=BN_E
 def conv_bn_act_train(x, wpk, cout, ksize, stride, gamma, beta, running_mean, running_var, eps=BN_EPS, momentum=BN_MOMENTUM,
                       act=ACT_SILU, residual=None, out=None, keep_raw=False):
     """BaseConv in training mode in one host call (conv + batch statistics + apply): -> (out, raw, scale_shift [2,C], mean, invstd).
-    keep_raw: raw conv output in its own buffer (the backward needs it); otherwise the apply pass runs in place on ``out``."""
+    keep_raw: raw conv output in its own buffer (the backward needs it); otherwise the apply pass runs in place on ``out``.
+    ``out`` may BE ``residual`` (a bottleneck writing back over its own input): the raw output then takes a buffer of its own and
+    the apply pass reads and writes each element of ``out`` in place."""
+    if out is not None and residual is not None and out.data_ptr() == residual.data_ptr():
+        keep_raw = True
     if CONV_PROFILE is not None:            # roofline instrumentation brackets the conv launch alone: separate calls
         raw, part = conv2d(x, wpk, cout, ksize, stride, EPI_RAW, out=None if keep_raw else out, want_stats=True)
         B, Ho, Wo, _ = raw.shape

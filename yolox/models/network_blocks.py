@@ -24,6 +24,9 @@ def get_activation(name="silu", inplace=True):
     raise AttributeError("Unsupported act type: {}".format(name))
 
 
+# CSPLayer's conv1 || conv2 as one launch on the gradient-free path (TSCD_FUSE_CSP=0: two launches)
+import os as _os
+FUSE_CSP = _os.environ.get("TSCD_FUSE_CSP", "1") != "0"
 _DEFERRED_TICKS = None     # list of num_batches_tracked buffers while a defer_bn_ticks() scope is open
 
 
@@ -167,9 +170,19 @@ class CSPLayer(nn.Module):
             return self.conv3(torch.cat([x1, self.conv2(x)], dim=-1))
         B, H, W, _ = x.shape
         h = self.conv1.conv.out_channels
+        n = len(self.m)
+        if FUSE_CSP and x.is_cuda:
+            from . import tower_fusion as TW
+            if TW.fusable([self.conv1, self.conv2]):
+                # conv1 || conv2 read the same input: ONE launch over the 2h concatenated output channels, straight into the concat
+                # buffer [conv1(x) | conv2(x)]; the bottlenecks then run on its first half and the last one writes back into it
+                cat = TW.shared_input_pair_nograd(x, self.conv1, self.conv2)
+                x1 = cat[..., :h]
+                for i, blk in enumerate(self.m):
+                    x1 = blk(x1, out=cat[..., :h] if i == n - 1 else None)
+                return self.conv3(cat, out=out)
         cat = ops.empty_nhwc(B, H, W, 2 * h, x.device)      # [m(conv1(x)) | conv2(x)]
         self.conv2(x, out=cat[..., h:])
-        n = len(self.m)
         x1 = self.conv1(x, out=cat[..., :h] if n == 0 else None)
         for i, blk in enumerate(self.m):
             x1 = blk(x1, out=cat[..., :h] if i == n - 1 else None)

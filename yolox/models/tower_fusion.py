@@ -162,6 +162,21 @@ def towers_nograd(x, firsts, seconds):
     return b
 
 
+def shared_input_pair_nograd(x, c0, c1):
+    """Two 1x1 / 3x3 BaseConvs of one width on the SAME input, without autograd, as ONE conv launch over the concatenated output channels
+    (+ one statistics and one apply launch in training mode): CSPLayer's conv1 || conv2 (network_blocks.py:163-176 / reference
+    network_blocks.py:134-165).  -> [B,h,w,2*Cout]: c0's output in channels [0, Cout), c1's in [Cout, 2*Cout).  Bit-identical to the two
+    separate launches (every output channel sums its K in the same order)."""
+    C = c0.conv.out_channels
+    wa = _fused_weights([c0.conv.weight, c1.conv.weight], 0, "dense")
+    k = c0.conv.kernel_size[0]
+    if batch_stats(c0):
+        _tick([c0, c1])
+        return ops.conv_bn_act_train_multi(x, wa, C, [_bn_tuple(c0), _bn_tuple(c1)], k, 1, c0.bn.eps, c0.bn.momentum)[0]
+    out, _ = ops.conv2d(x, wa, 2 * C, k, 1, ops.EPI_BN_SILU, scale_shift=_folded([c0, c1]))
+    return out
+
+
 class _TowerPairTrain(torch.autograd.Function):
     """Two trainable towers on the (gradient-free) stem output, training mode.  Inputs after x: the 4 conv weights, 4 gammas, 4 betas
     (first convs, then second convs); ``mods`` carries the BatchNorm buffers.  Returns the two towers' outputs (views of one buffer)."""
