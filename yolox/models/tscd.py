@@ -77,6 +77,11 @@ class _FrozenFront(nn.Module):
         object.__setattr__(self, "_head", head)
 
     def forward(self, x):
+        # (One in-order pass.  Forking the stride-8 level's head prefix onto a second stream next to the neck's bottom-up half -- its
+        # large launches beside the small levels' underfilled ones -- was built and measured in round 4: 13.48 vs 12.36 ms per step in
+        # the same process, because the extra stream lands on a hardware queue that another stream of the step already parks on the
+        # assignment latch, and the two-ranks-on-one-GPU rehearsal deadlocked.  yolo_pafpn.top_down_nhwc / bottom_up_nhwc and
+        # TSCDHead.frozen_prefix_level keep the split for a runtime that gives the branch a queue of its own.)
         return self._head.frozen_prefix(self.backbone(x)).tensors()
 
 

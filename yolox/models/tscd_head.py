@@ -226,23 +226,23 @@ class TSCDHead(nn.Module):
         """stems + the base towers (+ the box prediction convs when they are frozen too) of every level, without autograd -- the
         reference's frozen half of tscd_head.py:315-373 (its BatchNorms still take batch statistics in training mode).  xin: the
         pyramid as NCHW-logical maps.  The two base towers run as fused launches (tower_fusion.py)."""
+        return HeadPrefix([self.frozen_prefix_level(k, xf.permute(0, 2, 3, 1)) for k, xf in enumerate(xin)])
+
+    def frozen_prefix_level(self, k, f):
+        """Level k of frozen_prefix on its NHWC pyramid map -> (stem output, [reg_feat | cls_feat], box logits or None)."""
         W = self.width
-        levels = []
-        for k, xf in enumerate(xin):
-            f = xf.permute(0, 2, 3, 1)
-            f = f if f.dtype == torch.float16 else f.half()
-            x = self.stems[k](f)
-            firsts, seconds = [self.reg_convs[k][0], self.cls_convs[k][0]], [self.reg_convs[k][1], self.cls_convs[k][1]]
-            if FUSE_TOWERS and TW.fusable(firsts + seconds):
-                fz = TW.towers_nograd(x, firsts, seconds)                 # [reg_feat | cls_feat]
-            else:
-                fz = ops.empty_nhwc(x.shape[0], x.shape[1], x.shape[2], 2 * W, x.device)
-                self.reg_convs[k][1](self.reg_convs[k][0](x), out=fz[..., :W])
-                self.cls_convs[k][1](self.cls_convs[k][0](x), out=fz[..., W:])
-            rp = self.reg_preds[k]
-            reg_o = None if rp.weight.requires_grad else TF.conv_bias(fz[..., :W], rp.weight, rp.bias)
-            levels.append((x, fz, reg_o))
-        return HeadPrefix(levels)
+        f = f if f.dtype == torch.float16 else f.half()
+        x = self.stems[k](f)
+        firsts, seconds = [self.reg_convs[k][0], self.cls_convs[k][0]], [self.reg_convs[k][1], self.cls_convs[k][1]]
+        if FUSE_TOWERS and TW.fusable(firsts + seconds):
+            fz = TW.towers_nograd(x, firsts, seconds)                 # [reg_feat | cls_feat]
+        else:
+            fz = ops.empty_nhwc(x.shape[0], x.shape[1], x.shape[2], 2 * W, x.device)
+            self.reg_convs[k][1](self.reg_convs[k][0](x), out=fz[..., :W])
+            self.cls_convs[k][1](self.cls_convs[k][0](x), out=fz[..., W:])
+        rp = self.reg_preds[k]
+        reg_o = None if rp.weight.requires_grad else TF.conv_bias(fz[..., :W], rp.weight, rp.bias)
+        return (x, fz, reg_o)
 
     def prefix_modules(self):
         """The modules frozen_prefix runs (what a captured graph of it depends on)."""

@@ -34,6 +34,12 @@ class YOLOPAFPN(nn.Module):
         self._c = (c0, c1, c2)
 
     def forward_nhwc(self, img):
+        p2, carry = self.top_down_nhwc(img)
+        return (p2,) + self.bottom_up_nhwc(p2, carry)
+
+    def top_down_nhwc(self, img):
+        """Backbone + the top-down half of the neck: -> (pan_out2, carry) -- the stride-8 output is complete here, before the bottom-up
+        half (``bottom_up_nhwc(pan_out2, carry)`` -> pan_out1, pan_out0), so a caller can start that level's head next to it."""
         ops.require_gpu(img, "input image")
         c0, c1, c2 = self._c
         B, _, H, W = img.shape
@@ -52,11 +58,16 @@ class YOLOPAFPN(nn.Module):
         fpn_out1 = self.reduce_conv1(f_out0, out=n16[..., c0:])
         ops.copy_slice(fpn_out1, cat8[..., :c0], upsample=True)
         pan_out2 = self.C3_p3(cat8)
+        return pan_out2, (n16, n32)
+
+    def bottom_up_nhwc(self, pan_out2, carry):
+        c0, c1, c2 = self._c
+        n16, n32 = carry
         self.bu_conv2(pan_out2, out=n16[..., :c0])
         pan_out1 = self.C3_n3(n16)
         self.bu_conv1(pan_out1, out=n32[..., :c1])
         pan_out0 = self.C3_n4(n32)
-        return pan_out2, pan_out1, pan_out0
+        return pan_out1, pan_out0
 
     def forward_nhwc_grad(self, img):
         """The same network on the autograd path (the base detector trains backbone and neck): every block returns
