@@ -18,3 +18,5 @@ cp gpurun_out/final/pmc/pmc_mfma.json gpurun_out/final/summary/r04_pmc_mfma.json
 cp gpurun_out/final/pmc/pmc_hbm.json gpurun_out/final/summary/r04_pmc_hbm.json
 grep steady gpurun_out/final/summary/r04_step_timeline_final.txt gpurun_out/final/summary/r04_step_timeline_ddp_final.txt
 head -c 700 gpurun_out/final/bench_line.json; echo; tail -16 gpurun_out/final/pmc.log
+bash tools/lap_ab/run.sh > gpurun_out/final/summary/r04_lap_ns_per_pass.txt 2>&1; tail -3 gpurun_out/final/summary/r04_lap_ns_per_pass.txt
+timeout -k 10 120 python tools/mca_bwd_ab.py > gpurun_out/final/summary/r04_mca_call_times.txt 2>&1; grep "P 500" gpurun_out/final/summary/r04_mca_call_times.txt
