@@ -173,3 +173,30 @@ def test_backbone_and_neck_backward_vs_oracle_autograd(golden):
     mean_hip, mean_floor = sum(1 - r[0] for r in rows) / len(rows), sum(1 - r[1] for r in rows) / len(rows)
     print("mean 1 - cos: HIP", mean_hip, "fp16 oracle run", mean_floor)
     assert mean_hip <= 1.5 * mean_floor + 1e-3
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_csp_conv1_conv2_as_one_launch_is_bit_identical(golden, training):
+    """CSPLayer's conv1 || conv2 as ONE launch over the concatenated output channels (network_blocks.FUSE_CSP, tower_fusion.
+    shared_input_pair_nograd) against the two separate launches: every output channel sums its K in the same order, so the pyramid --
+    and in training mode the BatchNorm running statistics -- are bit-identical."""
+    from yolox.models import network_blocks as nb
+    cfg, sd, vec, meta = golden
+    imgs = torch.from_numpy(vec["evalA_imgs"]).float().cuda()
+    res = {}
+    for fuse in (True, False):
+        nb.FUSE_CSP = fuse
+        try:
+            m = load_backbone(sd, cfg)
+            m = m.train() if training else m.eval()
+            with torch.no_grad():
+                outs = [o.clone() for o in m(imgs)]
+            torch.cuda.synchronize()
+            res[fuse] = (outs, {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+        finally:
+            nb.FUSE_CSP = True
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    for k in res[True][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+

@@ -316,6 +316,39 @@ def test_train_step_is_the_same_under_every_stream_layout(golden, model, monkeyp
         assert float((g0[n] - g1[n]).abs().max()) <= 2e-2 * scale, (n, float((g0[n] - g1[n]).abs().max()), scale)
 
 
+def test_train_step_with_and_without_the_tap_gather(golden, model, monkeypatch):
+    """_TapGather (the trained towers' row gather and the edge block as ONE autograd node on the regression maps, the rows' gradient added
+    into the edge block's map in place) against the separate gather (zero-filled maps + a tensor add per level): same losses, gradients
+    equal up to the single rounding of the folded sum."""
+    cfg, sd, vec, meta = golden
+    import copy
+    import yolox.models.tscd_head as head_mod
+    imgs = torch.from_numpy(vec["evalA_imgs"]).float().cuda().half()
+    labels = torch.from_numpy(vec["train_labels"]).cuda().half()
+    temb = torch.from_numpy(vec["time_embedding"]).cuda().half()
+    kw = dict(lframe=int(meta["lframe"]), gframe=int(meta["gframe"]), resume=False)
+
+    def run(tap):
+        monkeypatch.setattr(head_mod, "TAP_GATHER", tap)
+        m = copy.deepcopy(model).train()
+        for mod in (m.backbone, m.head.stems, m.head.reg_convs, m.head.cls_convs, m.head.reg_preds):
+            for p in mod.parameters():
+                p.requires_grad = False
+        out = m(imgs, labels, temb, **kw)
+        out["total_loss"].backward()
+        torch.cuda.synchronize()
+        return ({k: float(v) for k, v in out.items() if torch.is_tensor(v)},
+                {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None})
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert o0 == o1, (o0, o1)
+    assert set(g0) == set(g1) and len(g0) > 40
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-12
+        assert float((g0[n] - g1[n]).abs().max()) <= 2e-2 * scale, (n, float((g0[n] - g1[n]).abs().max()), scale)
+
+
 def test_train_with_the_reference_assignment_and_proposal_sets_is_tight(golden, model, monkeypatch):
     """with the label assignment (SimOTA foreground anchors, matched boxes, matched IoUs) AND the proposal sets forced to
     the reference's -- both are integer decisions that fp16 noise upstream can flip, and both are bit-exact on identical inputs

@@ -837,3 +837,78 @@ def test_nms_more_candidates_than_one_lds_sort_chunk():
         assert out[i].shape[0] == len(k) == len(ref_keep[i]), (i, len(k), len(ref_keep[i]))
         sc = (out[i][:, 4].float() * out[i][:, 5].float()).half().float().cpu()
         assert torch.all(sc[:-1] >= sc[1:])
+
+
+@pytest.mark.parametrize("n,L,W", [(96, 4, 256), (40, 3, 64)])
+def test_row_mapped_se_fuse_and_layernorm_equal_gather_then_plain(n, L, W):
+    """The CAFM chain's row maps (ops.row_map into the clip's index table): the row-mapped entry points against materialised gathers /
+    scatters around the plain ones -- forward bit-identical (one machine code for both), backward bit-identical in dx / d edge and equal in
+    the fp32 accumulators up to the order of the atomic adds."""
+    from tscd_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n * L + W)
+    nl = n * L
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    reg, edge, dout, b = (rnd(nl, W).half().to(dev) for _ in range(4))
+    w0, w2 = (rnd(32, 2) * 0.5).to(dev).contiguous(), (rnd(2, 32) * 0.5).to(dev).contiguous()
+    pos = rnd(L, W).to(dev).contiguous()
+    gamma, beta = (1 + 0.1 * rnd(W)).to(dev), (0.1 * rnd(W)).to(dev)
+    # index table [inv_0 | c_1 | inv_1 | ...] of random permutations
+    perms = [torch.randperm(n, generator=g) for _ in range(2 * L - 1)]
+    idx = torch.cat(perms).to(dev)
+    c_off = [-1] + [(2 * j - 1) * n for j in range(1, L)]
+    inv_off = [2 * j * n for j in range(L)]
+    # --- se_fuse: all frames in one launch with a position vector per frame == per-frame plain launches
+    out_seg = torch.empty(nl, W, dtype=torch.float16, device=dev)
+    ops.se_fuse_ex(reg, edge, w0, w2, pos, out_seg, nl, pos_seg_rows=n, pos_stride=W)
+    for j in range(L):
+        want = ops.se_fuse(reg[j * n:(j + 1) * n], edge[j * n:(j + 1) * n], w0, w2, pos[j])
+        assert torch.equal(out_seg[j * n:(j + 1) * n], want), j
+    # --- se_fuse with permuted edge rows (frame j reads frame j-1's edge rows in assignment order)
+    j = 2
+    c = idx[c_off[j - 1]:c_off[j - 1] + n]
+    tgt, e_prev = reg[j * n:(j + 1) * n], edge[(j - 1) * n:j * n]
+    got = torch.empty(n, W, dtype=torch.float16, device=dev)
+    ops.se_fuse_ex(tgt, e_prev, w0, w2, pos[j - 1], got, n, edge_map=ops.row_map(idx, n, c_off[j - 1]))
+    assert torch.equal(got, ops.se_fuse(tgt, e_prev[c].contiguous(), w0, w2, pos[j - 1]))
+    # backward of the same: d edge lands at the permuted rows; addends folded in
+    add1, add2 = rnd(n, W).half().to(dev), rnd(n, W).half().to(dev)
+    d_reg, d_edge = torch.empty(n, W, dtype=torch.float16, device=dev), torch.zeros(n, W, dtype=torch.float16, device=dev)
+    acc = torch.zeros(W + 128, device=dev)
+    ops.se_fuse_bwd_ex(tgt, e_prev, w0, w2, dout[:n].contiguous(), d_reg, d_edge, n, acc, acc[W:], acc[W + 64:],
+                       edge_map=ops.row_map(idx, n, c_off[j - 1]), add_reg=[(add1, n), (add2, n // 2)])
+    r_reg, r_edge, r_pos, r_w0, r_w2 = ops.se_fuse_bwd(tgt, e_prev[c].contiguous(), w0, w2, dout[:n].contiguous())
+    want_reg = r_reg.float() + add1.float()
+    want_reg[:n // 2] += add2[:n // 2].float()
+    # (the plain entry rounds d reg to fp16 before the adds the caller does; the folded form rounds once: within one fp16 ulp)
+    assert (d_reg.float() - want_reg).abs().max().item() <= 2e-3 * want_reg.abs().max().item() + 1e-3
+    want_edge = torch.zeros_like(d_edge)
+    want_edge[c] = r_edge
+    assert torch.equal(d_edge, want_edge)
+    assert torch.allclose(acc[:W], r_pos, rtol=1e-4, atol=1e-4) and torch.allclose(acc[W:W + 64].view(32, 2), r_w0, rtol=1e-3, atol=1e-3)
+    # --- add_layernorm through a row map: residual rows gathered by c_j; the decoder norm's un-permute by the segmented inverse map
+    a_perm = reg[j * n:(j + 1) * n][idx[c_off[j]:c_off[j] + n]].contiguous()
+    out_m = torch.empty(n, W, dtype=torch.float16, device=dev)
+    ops.add_layernorm_ex(reg[j * n:(j + 1) * n], b[:n].contiguous(), gamma, beta, 1e-5, out_m, n, ops.row_map(idx, n, c_off[j]))
+    assert torch.equal(out_m, ops.add_layernorm(a_perm, b[:n].contiguous(), gamma, beta, 1e-5))
+    inv_all = torch.cat([j2 * n + idx[inv_off[j2]:inv_off[j2] + n] for j2 in range(L)])
+    out_d = torch.empty(nl, W, dtype=torch.float16, device=dev)
+    ops.add_layernorm_ex(reg, None, gamma, beta, 1e-5, out_d, nl, ops.row_map(idx, n, inv_off[0], inv_off[1] - inv_off[0]))
+    assert torch.equal(out_d, ops.add_layernorm(reg[inv_all].contiguous(), None, gamma, beta, 1e-5))
+    # backward: dx scattered back through the same map (no dx in output order), d gamma / d beta added into the accumulator
+    acc2 = torch.zeros(2, W, device=dev)
+    dx_m = torch.zeros(nl, W, dtype=torch.float16, device=dev)
+    ops.add_layernorm_bwd_ex(reg, None, gamma, dout, 1e-5, None, nl, acc2, a_map=ops.row_map(idx, n, inv_off[0], inv_off[1] - inv_off[0]),
+                             dx_mapped=dx_m)
+    r_dx, r_dg, r_db = ops.add_layernorm_bwd(reg[inv_all].contiguous(), None, gamma, dout, 1e-5)
+    want_dx = torch.zeros_like(dx_m)
+    want_dx[inv_all] = r_dx
+    assert torch.equal(dx_m, want_dx)
+    assert torch.allclose(acc2[0], r_dg, rtol=1e-3, atol=1e-2) and torch.allclose(acc2[1], r_db, rtol=1e-3, atol=1e-2)
+    # a second dy contribution is added in fp16 first
+    carry = rnd(n, W).half().to(dev)
+    acc3, dx3 = torch.zeros(2, W, device=dev), torch.empty(n, W, dtype=torch.float16, device=dev)
+    ops.add_layernorm_bwd_ex(reg[:n].contiguous(), b[:n].contiguous(), gamma, dout[:n].contiguous(), 1e-5, dx3, n, acc3, dy_add=carry)
+    r3, _, _ = ops.add_layernorm_bwd(reg[:n].contiguous(), b[:n].contiguous(), gamma, (dout[:n] + carry).contiguous(), 1e-5)
+    assert torch.equal(dx3, r3)
+

@@ -145,6 +145,21 @@ def test_gather_rows_scatter_adjoint_and_gather_det(B, S, W, nf):
         lhs = (outs[f].cpu().double() * grads[f].double()).sum()
         rhs = (x * got.double()).sum()
         assert lhs == rhs                                                               # <G x, g> == <x, G^T g>, exactly
+    # the adding form (one feature's rows land in maps that already hold another consumer's gradient): == map + scattered rows, rounded once
+    base = [[torch.randn(B, h, w, W, generator=g).half() for (h, w) in hw] for _ in range(nf)]
+    amaps = [[m.clone().cuda() for m in f] for f in base]
+    add = tuple(f % 2 == 0 for f in range(nf))
+    ops.scatter_rows([x.cuda() for x in grads], amaps, geo, sel_d, frame_off, N, W, add=add)
+    torch.cuda.synchronize()
+    for f in range(nf):
+        b0 = torch.cat([m.reshape(B, -1, W) for m in base[f]], 1)
+        want = b0.clone()
+        if add[f]:
+            want[b_idx, a_idx] = (b0[b_idx, a_idx].float() + grads[f].float()).half()
+        else:
+            want[b_idx, a_idx] = grads[f]
+        got = torch.cat([m.reshape(B, -1, W) for m in amaps[f]], 1).cpu()
+        assert torch.equal(got, want), ("add", f)
     det = torch.randn(B, A, 7 + 25, generator=g).half()
     rows = ops.gather_det(det.cuda().contiguous(), sel_d, frame_off, N)
     torch.cuda.synchronize()

@@ -4,7 +4,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
-timeout -k 10 500 python bench.py > gpurun_out/final/bench_line.json 2> gpurun_out/final/bench.err && echo "bench ok" &&
+timeout -k 10 500 python bench.py --steps 20 --warmup 5 > gpurun_out/final/bench_line.json 2> gpurun_out/final/bench.err && echo "bench ok" &&
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/final/stats.log 2>&1 && echo "stats ok"
 if [ "$1" != "stats-only" ]; then
 set -e

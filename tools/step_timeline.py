@@ -134,8 +134,12 @@ for _ in range(N):
     step(rec)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t) / N * 1e3
+_gaps = np.diff([h["start"] for h, _ in rec]) * 1e3
+_dev = [rec[i][1]["start"].elapsed_time(rec[i + 1][1]["start"]) for i in range(len(rec) - 1)]
 names = ["counts_on_host", "prepare_in", "costs_queued", "chain_start", "simota_in", "dense_loss_in", "prefetch_in", "prefetch_out", "prefetch_done", "finish_in", "chain_end", "finish_out", "forward_out", "backward_out", "step_out"]
 print(f"steady state after {PREROLL} steps: {ms:.2f} ms per step (no drains)")
+print("start-to-start, ms: host median %.2f max %.2f; device median %.2f max %.2f; the 3 longest device steps %s" %
+      (np.median(_gaps), _gaps.max(), np.median(_dev), max(_dev), np.round(sorted(_dev)[-3:], 2).tolist()))
 print("host clock, ms from the step's start (median of %d steps):" % N)
 M.AwarePositionRegMatcher._join_pending(model.head.local_reg_matcher)
 k0 = len(STARTS) - N
