@@ -253,3 +253,32 @@ def test_chain_with_index_table_and_latch():
     assert latch.wait(gen3, 10)
     assert np.array_equal(table, np.arange(len(table)) % n)           # ... and no stale table is handed to the device
     assert not latch.wait(gen3 + 1, 5) and latch.timeouts == 1
+
+
+def test_lap_fixed_point_on_tie_heavy_matrices_matches_scipy():
+    """Matrices with massive exact ties -- quarter-integer costs, constant matrices, rows / columns drawn with replacement from the device
+    cost sample of tests/golden (the random-init regime: ~8 columns tied at the minimum of a pass) -- through the fixed-point solver:
+    rows and columns identical to scipy's.  The plateau pass (lap.cpp: relax_row_plateau) takes the tie rule from the same sweep as the
+    relaxation on 9 passes of 10 here."""
+    import os
+    from tscd_amd._host import lap_f16
+    rng = np.random.default_rng(123)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cafm_cost_device_sample.npz"))
+    crop = z["cost_f16_bits"].view(np.float16).astype(np.float64)
+    for t in range(200):
+        nr, nc = int(rng.integers(1, 140)), int(rng.integers(1, 140))
+        kind = t % 5
+        if kind == 0:
+            c = rng.integers(0, 4, (nr, nc)).astype(np.float64) * 0.25
+        elif kind == 1:
+            c = crop[np.ix_(rng.integers(0, crop.shape[0], nr), rng.integers(0, crop.shape[1], nc))]
+        elif kind == 2:
+            c = np.round(rng.random((nr, nc)) * 8) / 8
+        elif kind == 3:
+            c = np.full((nr, nc), 0.5)
+        else:
+            c = crop[np.ix_(rng.integers(0, crop.shape[0], nr), rng.integers(0, crop.shape[1], nc))] + 0.01 * rng.standard_normal((nr, nc))
+        m = np.ascontiguousarray(c.astype(np.float16).view(np.uint16))
+        r, cc = lap_f16(m)
+        r0, c0 = linear_sum_assignment(m.view(np.float16).astype(np.float64))
+        assert np.array_equal(r, r0) and np.array_equal(cc, c0), (t, kind, nr, nc)
