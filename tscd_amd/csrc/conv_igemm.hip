@@ -506,7 +506,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (BM == 64 ? 3 : 2)) void conv_igemm_
 // BK 32 / 64, 128- or 256-wide tiles): the limit is the volume that has to come in through the per-CU LDS-DMA path, ~42 GB/s
 // per CU as used here (24 KB per 128x256x32 step: A 8 KB gathered again for every tap + B 16 KB).  An implicit GEMM fetches
 // each input pixel 9 times (once per tap) and each weight row once per 128 output pixels.  Here
-//   * the tile is 256 consecutive output pixels x 256 channels: weights are fetched once per 256 pixels (half the B volume);
+//   * the tile is 192 / 224 / 256 consecutive output pixels x 256 channels: weights are fetched once per 256 pixels (half the B volume);
 //   * per 32-channel chunk the 256 + 2W + 2 input pixels the 9 taps touch (flattened pixel range [m0 - W - 1, m0 + 256 + W])
 //     are staged ONCE (26 KB at W = 72, double-buffered) and tap (kh, kw) reads its A fragments at a row shift of kh*W + kw:
 //     A volume / 4.5.  Taps that fall outside the image (left / right / top / bottom edge, other frame) are handled at
@@ -530,15 +530,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_v5() {
   else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 }
 
-// TM = 32-row MFMA tiles per wave: 3 -> 192-pixel tiles, 4 -> 256-pixel tiles (the host picks whichever leaves the smaller
-// idle tail for the launch's M).  The tap loop is unrolled (tap is a compile-time constant in every step: shifts, validity
+// TM16 = 16-row MFMA tiles per wave: 6 -> 192-pixel tiles, 7 -> 224, 8 -> 256 (the host picks whichever needs the fewest rounds x rows
+// for the launch's M: 224 for the 72x72 level's 512-channel launches -- 742 workgroups in 3 rounds where 192-row tiles take 4).  The tap loop is unrolled (tap is a compile-time constant in every step: shifts, validity
 // bits and the halo issue slots fold) and every channel chunk but the last runs without tail logic (fixed DMA distance,
 // fixed vmcnt): the L segment's instruction count, not the MFMAs, bounded the first version of this loop.
-template <int TM>
+template <int TM16>
 __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, int HRP) {
   constexpr int MAXP = 4;                                // A pieces per wave: halo of <= 512 rows
-  constexpr int BM = 64 * TM, BN = 256, NS = 6, WAVES_M = 2, WAVES_N = 4, WM = 32 * TM, WN = 64;
-  constexpr int TM16 = 2 * TM, TN16 = 4;                 // 16 x 16 tiles per wave: v_mfma_f32_16x16x32_f16, one MFMA per (tile, 32-channel step)
+  constexpr int BM = 32 * TM16, BN = 256, NS = 6, WAVES_M = 2, WAVES_N = 4, WM = 16 * TM16, WN = 64;
+  constexpr int TN16 = 4;                                // TM16 x 4 tiles of 16 x 16 per wave: v_mfma_f32_16x16x32_f16, one MFMA per (tile, 32-channel step)
   constexpr int B_BYTES = BN * 64;                       // 16 KB per k-step
   constexpr int SMEM_BYTES = 2 * (1024 + 480 * 64) + NS * B_BYTES;         // HRP <= 480; also >= the epilogue's staging tile
   __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
@@ -623,8 +623,8 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_halo_kernel(ConvParams p, i
   // a_pre[tap][i]: byte offset inside an A buffer of this lane's fragment for row-tile i at tap `tap` -- the halo row, or the
   // zero block when the tap falls outside the image for this lane's output pixel (9 x TM registers, computed once)
   // (TM = 4, 256-pixel tiles: two 16-bit offsets per register -- 72 offsets next to 128 accumulator registers would spill)
-  constexpr bool PACKED = TM >= 4;
-  constexpr int NTAB = PACKED ? TM16 / 2 : TM16;
+  constexpr bool PACKED = TM16 >= 7;
+  constexpr int NTAB = PACKED ? (TM16 + 1) / 2 : TM16;
   int a_pre[9][NTAB];
 #pragma unroll
   for (int i = 0; i < TM16; ++i) {
@@ -750,7 +750,7 @@ extern "C" int tscd_conv_tile_n(int cout) { return pick_bn(cout); }
 extern "C" int tscd_conv_tile_m(void) { return 128; }
 
 // Per-call plan overrides (tests and A/B timing only; the product passes the automatic values): there is no process-global state.
-//   variant  -1 automatic; 0 register-staged loop; 1 LDS-DMA 128-wide tiles only; 5 / 6 halo-staged 256- / 192-pixel tiles wherever
+//   variant  -1 automatic; 0 register-staged loop; 1 LDS-DMA 128-wide tiles only; 5 / 6 / 7 halo-staged 256- / 192- / 224-pixel tiles wherever
 //            their shape allows
 //   korder   1 = chunk-major k order in the register-staged loop (the halo variant's order; Cin % 32 == 0)
 //   tile_m   64 / 128 / 192: tile height of the LDS-DMA 128-wide variant; 0 automatic
@@ -761,15 +761,16 @@ struct ConvPlan { int variant, korder, tile_m; };
 // selection: only when the launch has enough tiles to give every CU one (its 1-workgroup-per-CU tiles cannot share a CU with
 // anything), and then the height (192 / 256) whose last round leaves fewer CUs idle.
 static int halo_tile_m(const ConvPlan& pl, long M, int W, int Cin, int Cout, int ksize, int stride, int G) {
-  if (pl.variant != -1 && pl.variant != 5 && pl.variant != 6) return 0;
+  if (pl.variant != -1 && pl.variant != 5 && pl.variant != 6 && pl.variant != 7) return 0;
   if (ksize != 3 || stride != 1 || Cin % 32 != 0 || Cout % 256 != 0) return 0;
   auto fits = [&](int bm) { return (bm + 2 * W + 2 + 15) / 16 * 16 <= 480; };
   if (pl.variant == 5) return fits(256) ? 256 : 0;
   if (pl.variant == 6) return fits(192) ? 192 : 0;
+  if (pl.variant == 7) return fits(224) ? 224 : 0;
   const long nt = (long)(Cout / 256) * G;
   int best = 0;
   double best_cost = 1e30;
-  for (int bm : {192, 256}) {
+  for (int bm : {192, 224, 256}) {
     if (!fits(bm)) continue;
     const long tiles = (M + bm - 1) / bm * nt;
     if (tiles < 200) continue;                               // clearly fewer tiles than CUs: the 128-row variants' finer grain wins
@@ -826,7 +827,7 @@ static int conv_launch(const void* x, const void* wpk, void* y, const float* bia
   TSCD_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d: ksize %d not supported", ksize);
   TSCD_CHECK_ARG(stride == 1 || stride == 2, "conv2d: stride %d not supported", stride);
   TSCD_CHECK_ARG(epilogue >= 0 && epilogue <= 5, "conv2d: bad epilogue %d", epilogue);
-  TSCD_CHECK_ARG(pl.variant == -1 || pl.variant == 0 || pl.variant == 1 || pl.variant == 5 || pl.variant == 6, "conv2d: variant %d", pl.variant);
+  TSCD_CHECK_ARG(pl.variant == -1 || pl.variant == 0 || pl.variant == 1 || (pl.variant >= 5 && pl.variant <= 7), "conv2d: variant %d", pl.variant);
   if (epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU) TSCD_CHECK_ARG(bias, "conv2d: bias epilogue without bias");
   if (epilogue == EPI_BN_SILU || epilogue == EPI_BN) TSCD_CHECK_ARG(scale && shift, "conv2d: BN epilogue without scale/shift");
   ConvParams p;
@@ -861,9 +862,11 @@ static int conv_launch(const void* x, const void* wpk, void* y, const float* bia
     p.ntiles_g = cdiv(Cout, 256);
     p.ntiles = p.ntiles_g * G;
     if (v5_tm == 192)
-      hipLaunchKernelGGL((conv_igemm_halo_kernel<3>), dim3(p.mtiles * p.ntiles), dim3(512), 0, s, p, hrp);
+      hipLaunchKernelGGL((conv_igemm_halo_kernel<6>), dim3(p.mtiles * p.ntiles), dim3(512), 0, s, p, hrp);
+    else if (v5_tm == 224)
+      hipLaunchKernelGGL((conv_igemm_halo_kernel<7>), dim3(p.mtiles * p.ntiles), dim3(512), 0, s, p, hrp);
     else
-      hipLaunchKernelGGL((conv_igemm_halo_kernel<4>), dim3(p.mtiles * p.ntiles), dim3(512), 0, s, p, hrp);
+      hipLaunchKernelGGL((conv_igemm_halo_kernel<8>), dim3(p.mtiles * p.ntiles), dim3(512), 0, s, p, hrp);
     TSCD_CHECK_LAUNCH("conv2d (halo)");
     return TSCD_OK;
   }

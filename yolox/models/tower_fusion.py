@@ -165,8 +165,9 @@ def towers_nograd(x, firsts, seconds):
 def shared_input_pair_nograd(x, c0, c1):
     """Two 1x1 / 3x3 BaseConvs of one width on the SAME input, without autograd, as ONE conv launch over the concatenated output channels
     (+ one statistics and one apply launch in training mode): CSPLayer's conv1 || conv2 (network_blocks.py:163-176 / reference
-    network_blocks.py:134-165).  -> [B,h,w,2*Cout]: c0's output in channels [0, Cout), c1's in [Cout, 2*Cout).  Bit-identical to the two
-    separate launches (every output channel sums its K in the same order)."""
+    network_blocks.py:134-165).  -> [B,h,w,2*Cout]: c0's output in channels [0, Cout), c1's in [Cout, 2*Cout).  The conv outputs are the two separate
+    launches' bits (every output channel sums its K in the same order); in training mode the batch statistics are summed over the wider
+    launch's M-tiles (another tile height), so they agree to fp32 rounding, not bit for bit."""
     C = c0.conv.out_channels
     wa = _fused_weights([c0.conv.weight, c1.conv.weight], 0, "dense")
     k = c0.conv.kernel_size[0]
