@@ -33,7 +33,7 @@ dk = [k for k in fd if "halo" in k[0] and k[1] == 432 * 512]
 dd = None
 if dk:
     k = dk[0]; fdv = fd[k][1] / fd[k][0]; wdv = wd[k][1] / wd[k][0]
-    dd = {"shape": "B16 72x72 256->256 3x3 (conv_igemm_halo_kernel<3>, 432 workgroups)", "launches": fd[k][0], "fetch_size_kib_raw": fdv,
+    dd = {"shape": "B16 72x72 256->256 3x3 (conv_igemm_halo_kernel<6>: 192-row tiles, 432 workgroups)", "launches": fd[k][0], "fetch_size_kib_raw": fdv,
           "write_size_kib": wdv, "bytes_per_launch": (2 * fdv + wdv) * 1024, "algorithmic_bytes": 82944 * 256 * 2 * 2 + 256 * 2304 * 2}
 out = {"what": "HBM-side traffic per launch of the LDS-DMA implicit-GEMM conv kernels (conv_igemm_glds_kernel<*,128,2> + conv_igemm_halo_kernel + conv_igemm_v3_kernel), rocprofv3 PMC counters (MI355X)",
        "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --preroll 0 --no-cpu-baseline",
