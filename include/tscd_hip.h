@@ -295,6 +295,10 @@ int tscd_se_fuse_bwd_acc_f16(const void* reg, int ldr, const void* edge, int lde
 int tscd_add_layernorm_bwd_acc_f16(const void* a, const void* b, const float* gamma, const void* dy, int n, int C, float eps,
                                    void* dx, float* dgamma, float* dbeta, void* stream);
 int tscd_row_normalize_f16(const void* x, int ldx, int n, int n_pad, int C, float eps, void* out, int ldo, void* stream);
+/* Every Hungarian cost matrix of a clip in one launch (double_match_embds, tscd_matching.py:912-937): pairs = npairs x (r0, nr, c0, nc)
+ * row ranges of the normalised [reg | cls] rows; matrix p = 1 - rows[r0..r0+nr) . rows[c0..c0+nc)^T / 2 (NaN -> 0), fp16 row-major [nr][nc],
+ * written back to back into `out`.  K % 16 == 0, ld >= K, at most 16 pairs. */
+int tscd_match_cost_pairs_f16(const void* rows, int ld, int K, const int* pairs, int npairs, void* out, void* stream);
 /* The CAFM frame chain's row addressing inside the four kernels above (tscd_matching.py:761-888: every frame's rows are re-ordered by
  * its assignment before they meet the next frame's; the permuted reads / writes ride in the kernels that consume / produce the rows
  * instead of index_select launches).  A row map sends row r (segment s = r / seg_rows, local l = r % seg_rows) to

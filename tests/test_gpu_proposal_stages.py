@@ -238,3 +238,30 @@ def test_device_hungarian_cost_and_assignment_chain(golden):
     assert len(got_cols) == len(want_cols)
     for fi, (a, b) in enumerate(zip(got_cols, want_cols)):
         assert np.array_equal(a, b), fi
+
+
+@pytest.mark.parametrize("n_per,L,C", [(500, 4, 1024), (37, 3, 64), (130, 2, 256)])
+def test_cost_matrices_in_one_launch_are_the_per_matrix_launches_bits(n_per, L, C, monkeypatch):
+    """ops.match_costs_clip: every cost matrix of a clip from ONE launch (tscd_match_cost_pairs_f16: a wave per 32 x 32 tile) against one
+    implicit-GEMM launch per matrix (the EPI_COST epilogue): the same MFMA chain over ascending k, so the fp16 costs -- which decide
+    exact ties in the assignment -- are bit-identical; and both within fp16 of 1 - (cos_reg + cos_cls) / 2."""
+    from tscd_amd import ops
+    g = torch.Generator().manual_seed(n_per + L)
+    n = n_per * L
+    reg = torch.randn(n, C, generator=g).half().cuda()
+    cls = torch.randn(n, C, generator=g).half().cuda()
+    pairs = [(0, n_per, 0, n_per)] + [((j - 1) * n_per, j * n_per, j * n_per, (j + 1) * n_per) for j in range(1, L)]
+    monkeypatch.setattr(ops, "COST_PAIRS_ONE_LAUNCH", True)
+    flat1, shapes1 = ops.match_costs_clip(reg, cls, pairs)
+    monkeypatch.setattr(ops, "COST_PAIRS_ONE_LAUNCH", False)
+    flat0, shapes0 = ops.match_costs_clip(reg, cls, pairs)
+    torch.cuda.synchronize()
+    assert shapes0 == shapes1 and torch.equal(flat0, flat1)
+    nrm = lambda t: torch.nn.functional.normalize(t.float(), dim=1)
+    o = 0
+    for (r0, r1, c0, c1) in pairs:
+        want = 1 - 0.5 * (nrm(reg[r0:r1]) @ nrm(reg[c0:c1]).T + nrm(cls[r0:r1]) @ nrm(cls[c0:c1]).T)
+        got = flat1[o:o + (r1 - r0) * (c1 - c0)].view(r1 - r0, c1 - c0).float()
+        assert (got - want).abs().max().item() <= 3e-3
+        o += (r1 - r0) * (c1 - c0)
+

@@ -59,6 +59,7 @@ SIGNATURES = {
     "tscd_se_fuse_bwd_acc_f16": [P, I, P, I, P, P, P, L, I, P, P, P, P, P, P],
     "tscd_add_layernorm_bwd_acc_f16": [P, P, P, P, I, I, F, P, P, P, P],
     "tscd_row_normalize_f16": [P, I, I, I, I, F, P, I, P],
+    "tscd_match_cost_pairs_f16": [P, I, I, P, I, P, P],
     "tscd_se_fuse_ex_f16": [P, I, P, I, P, P, P, L, I, P, P, P],
     "tscd_add_layernorm_ex_f16": [P, P, P, P, I, I, F, P, P, P],
     "tscd_se_fuse_bwd_ex_f16": [P, I, P, I, P, P, P, L, I, P, P, P, P, P, P, P],

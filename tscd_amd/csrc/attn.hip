@@ -294,6 +294,73 @@ extern "C" int tscd_row_normalize_f16(const void* x, int ldx, int n, int n_pad, 
   return TSCD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Every Hungarian cost matrix of a clip in ONE launch (double_match_embds, tscd_matching.py:912-937): matrix p = 1 - rows[r0_p ..]
+// . rows[c0_p ..]^T / 2 over the normalised [reg | cls] rows (K = 2C), NaN -> 0, fp16.  One wave per 32 x 32 output tile; the same
+// v_mfma_f32_32x32x16_f16 chain over ascending k as the conv kernel's EPI_COST launch it replaces (one launch per matrix: 4 x 23 us of 32
+// workgroups each on the step's critical path) -- bit-identical costs.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define COST_MAX_PAIRS 16
+struct CostPair { int r0, nr, c0, nc, tile0, tn; long out_off; };
+struct CostPairs { CostPair p[COST_MAX_PAIRS]; int n; };
+__global__ __launch_bounds__(256) void match_cost_pairs_kernel(const f16* __restrict__ rows, int ld, int K, CostPairs t, f16* __restrict__ out,
+                                                               int ntiles) {
+  const int lane = threadIdx.x & 63;
+  const int tile = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (tile >= ntiles) return;
+  int pi = 0;
+  for (int i = 1; i < t.n; ++i) pi = tile >= t.p[i].tile0 ? i : pi;          // wave-uniform
+  const CostPair q = t.p[pi];
+  const int lt = tile - q.tile0, mt = lt / q.tn, nt = lt - mt * q.tn;
+  // fragment rows: lane l holds row (l & 31), k = 16 ks + 8 (l >> 5) .. + 7.  Rows past the matrix read the last valid row (masked at the store).
+  const int ra = min(mt * 32 + (lane & 31), q.nr - 1), rb = min(nt * 32 + (lane & 31), q.nc - 1);
+  const f16* pa = rows + (long)(q.r0 + ra) * ld + (lane >> 5) * 8;
+  const f16* pb = rows + (long)(q.c0 + rb) * ld + (lane >> 5) * 8;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < K; k += 16)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)(pa + k), *(const f16x8*)(pb + k), acc, 0, 0, 0);
+  const int col = nt * 32 + (lane & 31);
+  if (col < q.nc) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      if (row < q.nr) {
+        const float c = 1.0f - 0.5f * (float)(f16)acc[e];
+        out[q.out_off + (long)row * q.nc + col] = (c != c) ? (f16)0.f : (f16)c;
+      }
+    }
+  }
+}
+// pairs: npairs x (r0, nr, c0, nc) row ranges of `rows` [*, ld] (fp16, K <= ld, K % 16 == 0, 16-byte aligned); matrix p is written row-major
+// [nr][nc] at out + the sum of the earlier matrices' sizes.
+extern "C" int tscd_match_cost_pairs_f16(const void* rows, int ld, int K, const int* pairs, int npairs, void* out, void* stream) {
+  TSCD_CHECK_ARG(rows && pairs && out && npairs > 0 && npairs <= COST_MAX_PAIRS, "match_cost_pairs: 1..%d pairs", COST_MAX_PAIRS);
+  TSCD_CHECK_ARG(K > 0 && K % 16 == 0 && ld >= K && ld % 8 == 0 && ((uintptr_t)rows & 15) == 0, "match_cost_pairs: K=%d ld=%d", K, ld);
+  CostPairs t;
+  t.n = npairs;
+  int tiles = 0;
+  long off = 0;
+  for (int i = 0; i < npairs; ++i) {
+    CostPair& q = t.p[i];
+    q.r0 = pairs[4 * i]; q.nr = pairs[4 * i + 1]; q.c0 = pairs[4 * i + 2]; q.nc = pairs[4 * i + 3];
+    TSCD_CHECK_ARG(q.r0 >= 0 && q.c0 >= 0 && q.nr >= 0 && q.nc >= 0, "match_cost_pairs: bad range in pair %d", i);
+    q.tn = (q.nc + 31) / 32;
+    q.tile0 = tiles;
+    q.out_off = off;
+    tiles += ((q.nr + 31) / 32) * q.tn;
+    off += (long)q.nr * q.nc;
+  }
+  if (tiles == 0) return TSCD_OK;
+  hipLaunchKernelGGL(match_cost_pairs_kernel, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)rows, ld, K, t, (f16*)out,
+                     tiles);
+  TSCD_CHECK_LAUNCH("match_cost_pairs");
+  return TSCD_OK;
+}
+
+
 // ====================================================================================================================
 // Backward kernels (autograd of the modules above under tscd_trainer.py:171-176).
 // ====================================================================================================================

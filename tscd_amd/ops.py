@@ -1391,6 +1391,9 @@ def add_layernorm_bwd_ex(a, b, gamma, d_out, eps, dx, n, acc, a_map=None, dy_add
          eps, None if dx is None else _rows16(dx, C), acc[0].data_ptr(), acc[1].data_ptr(), _CT.addressof(ex), _stream())
 
 
+COST_PAIRS_ONE_LAUNCH = _os.environ.get("TSCD_COST_PAIRS_ONE_LAUNCH", "1") != "0"
+
+
 def match_costs_clip(reg, cls, pairs):
     """Every Hungarian cost matrix of a clip whose frames are matched against each other (no carried-over state): the [reg | cls]
     rows of ALL proposals are normalised once (two launches), each matrix is one GEMM over two row ranges of that buffer, written
@@ -1405,6 +1408,13 @@ def match_costs_clip(reg, cls, pairs):
     call("tscd_row_normalize_f16", cls.data_ptr(), cls.stride(0), n, n + pad, C, 1e-6, norm[:, C:].data_ptr(), 2 * C, _stream())
     shapes = [(r1 - r0, c1 - c0) for (r0, r1, c0, c1) in pairs]
     flat = temp((sum(a * b for a, b in shapes),), dtype=torch.float16, device=dev)
+    if COST_PAIRS_ONE_LAUNCH and len(pairs) <= 16:
+        # all matrices in ONE launch of 32 x 32 tiles (a launch per matrix was 4 x 23 us of 32 workgroups each, on the step's critical
+        # path in front of the assignment chain); the same MFMA chain per output element: bit-identical costs
+        import ctypes as C_
+        tab = (C_.c_int * (4 * len(pairs)))(*[v for (r0, r1, c0, c1) in pairs for v in (r0, r1 - r0, c0, c1 - c0)])
+        call("tscd_match_cost_pairs_f16", norm.data_ptr(), 2 * C, 2 * C, C_.cast(tab, C_.c_void_p), len(pairs), flat.data_ptr(), _stream())
+        return flat, shapes
     o = 0
     for (r0, r1, c0, c1), (nr, nc) in zip(pairs, shapes):
         if nr * nc:
