@@ -20,10 +20,10 @@ for i in range(N):
     out = model(imgs, targets, temb, lframe=args.lframe, gframe=args.frames - args.lframe, resume=False, next_x=imgs)
     opt.zero_grad(set_to_none=True)
     scaler.scale(out["total_loss"]).backward()
+    model.check_assignments()
     scaler.step(opt)
     scaler.update()
-    model.join_prefetch()
-    ema.update()
+    ema.update()              # reads the pre-prefetch BatchNorm snapshot (no join with the prefetched pass)
     if i % 500 == 499:
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / 500 * 1e3
