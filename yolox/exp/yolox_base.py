@@ -5,8 +5,10 @@ get_trainer, eval) and their defaults.
 
 MI355X specifics: the optimizer is tscd_amd.optim.FusedSGD (one launch for the three parameter groups + the EMA of the stepped
 parameters); ``get_data_loader`` takes any dataset with the ``pull_item / load_anno / input_dim`` contract through ``self.dataset_fn``
--- COCO itself (a pycocotools JSON index + cv2 decode) is absent from this image, the default is the seeded synthetic stand-in of
-yolox/data/mosaic.py, wrapped in the same MosaicDetection -> TrainTransform chain the reference builds (:138-165)."""
+-- with ``data_dir`` set it is yolox.data.COCODataset over the COCO-format JSON there (own index, PIL decode: no pycocotools / cv2 in
+this image) and ``get_evaluator`` is COCOEvaluator on csrc_host/cocoeval.cpp; without a data set (none ships here) the default is the
+seeded synthetic stand-in of yolox/data/mosaic.py.  Either way the loader is the MosaicDetection -> TrainTransform chain the reference
+builds (:138-165)."""
 import os
 import random
 
@@ -62,8 +64,14 @@ class Exp(BaseExp):
         the per-rank share of ``batch_size`` (yolox_base.py:138-196)."""
         from yolox.data import TrainTransform
         from yolox.data.mosaic import InfiniteSampler, MosaicDetection, SyntheticDetectionDataset, YoloBatchLoader
-        base = self.dataset_fn() if self.dataset_fn is not None else SyntheticDetectionDataset(
-            self.synthetic_len, self.num_classes, self.input_size, seed=self.seed or 0)
+        if self.dataset_fn is not None:
+            base = self.dataset_fn()
+        elif self.data_dir is not None:
+            from yolox.data import COCODataset
+            base = COCODataset(data_dir=self.data_dir, json_file=self.train_ann, name=self.train_name, img_size=self.input_size,
+                               preproc=None, cache=cache_img)
+        else:
+            base = SyntheticDetectionDataset(self.synthetic_len, self.num_classes, self.input_size, seed=self.seed or 0)
         self.dataset = MosaicDetection(base, mosaic=not no_aug, img_size=self.input_size,
                                        preproc=TrainTransform(max_labels=120, flip_prob=self.flip_prob, hsv_prob=self.hsv_prob),
                                        degrees=self.degrees, translate=self.translate, mosaic_scale=self.mosaic_scale,
@@ -73,7 +81,7 @@ class Exp(BaseExp):
         rank = dist.get_rank() if is_distributed else 0
         sampler = InfiniteSampler(len(self.dataset), seed=self.seed or 0, rank=rank, world_size=world)
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
-        return YoloBatchLoader(self.dataset, max(1, batch_size // world), sampler, workers=0 if self.dataset_fn is None else self.data_num_workers,
+        return YoloBatchLoader(self.dataset, max(1, batch_size // world), sampler, workers=0 if (self.dataset_fn is None and self.data_dir is None) else self.data_num_workers,
                                device=device)
 
     def random_resize(self, data_loader, epoch, rank, is_distributed):
@@ -130,10 +138,27 @@ class Exp(BaseExp):
                            warmup_lr_start=self.warmup_lr, no_aug_epochs=self.no_aug_epochs, min_lr_ratio=self.min_lr_ratio)
 
     # ------------------------------------------------------------------ evaluation
+    def get_eval_loader(self, batch_size, is_distributed, testdev=False, legacy=False):
+        """COCODataset(val / test annotations, ValTransform) read in order, each rank its contiguous share (:261-291)."""
+        from yolox.data import COCODataset, ValTransform
+        valdataset = COCODataset(data_dir=self.data_dir, json_file=self.val_ann if not testdev else self.test_ann,
+                                 name=self.val_name if not testdev else "test2017", img_size=self.test_size, preproc=ValTransform(legacy=legacy))
+        world = dist.get_world_size() if is_distributed else 1
+        rank = dist.get_rank() if is_distributed else 0
+        per = max(1, batch_size // world)
+        sampler = (torch.utils.data.distributed.DistributedSampler(valdataset, num_replicas=world, rank=rank, shuffle=False)
+                   if is_distributed else torch.utils.data.SequentialSampler(valdataset))
+        return torch.utils.data.DataLoader(valdataset, batch_size=per, sampler=sampler, num_workers=0 if self.data_num_workers == 0 else
+                                           min(self.data_num_workers, 4), pin_memory=True)
+
     def get_evaluator(self, batch_size, is_distributed, testdev=False, legacy=False):
-        """COCO evaluation needs the data set and its annotation index (absent here): an exp with a real ``dataset_fn`` overrides this;
-        the default returns None and the trainer then skips the evaluation epochs."""
-        return None
+        """COCOEvaluator over get_eval_loader (:293-306); None without a data set (``data_dir`` unset: the trainer then skips the
+        evaluation epochs)."""
+        if self.data_dir is None:
+            return None
+        from yolox.evaluators import COCOEvaluator
+        return COCOEvaluator(dataloader=self.get_eval_loader(batch_size, is_distributed, testdev, legacy), img_size=self.test_size,
+                             confthre=self.test_conf, nmsthre=self.nmsthre, num_classes=self.num_classes, testdev=testdev)
 
     def get_trainer(self, args):
         from yolox.core import BaseTrainer
