@@ -76,6 +76,10 @@ class FusedSGD(torch.optim.SGD):
             raise NotImplementedError("FusedSGD: at most 8 parameter groups")
         # the chunk table names parameters, momentum buffers and EMA copies (stable addresses); gradients are re-allocated by
         # zero_grad(set_to_none=True) every step and reach the kernel through a per-step array of ~150 pointers
+        # (checked once per step: check_finite and step share it -- _gbase is this step's marker; the walk over ~150 parameters is 0.3 ms
+        # of host time)
+        if self._table is not None and self._gbase is not None and self._table[4] == len(self.param_groups):
+            return self._table
         if self._table is None or self._table[0] != self._signature() or self._table[4] != len(self.param_groups):
             self._build()
         return self._table
@@ -105,6 +109,7 @@ class FusedSGD(torch.optim.SGD):
         the check runs on the all-reduced arena, so every rank takes the same skip decision."""
         if self._reducer is not None:
             self._reducer.finish()
+        self._gbase = None               # a new step begins here (a previous one whose step() never ran must not lend its pointers)
         sig, table, n, params, _, chk = self._ensure_table()
         if n == 0:
             return
