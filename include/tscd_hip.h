@@ -248,6 +248,15 @@ int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const void* q_r, co
                           const void* soft_r, int ld_soft, void* workspace, long workspace_bytes, void* dq_c, void* dkv_c,
                           void* dq_r, void* dkv_r, float* dscore, const void* fwd_rows, long fwd_rows_bytes, void* stream);
 
+/* Several independent stride-1 GEMM-shaped convs (1x1 / nn.Linear as 1 x n images) in ONE launch of the 64 x 128 LDS-DMA tile: the
+ * proposal stage's mutually independent linears (post_trans.py:640-660 q / kv projections, tscd_matching.py:31-60 q / k / v).  jobs = njobs
+ * records {x, wpk, y, bias (fp32 or NULL), B, H, W, Cin, Cout, ldx, ldy, epilogue (0 raw, 1 bias, 2 bias + ReLU)}; each job needs
+ * tscd_conv2d_jobs_supported(Cin, Cout); at most tscd_conv2d_jobs_max() jobs.  Same bits as one tscd_conv2d_nhwc_f16 call per job. */
+typedef struct { const void* x; const void* wpk; void* y; const float* bias; int B, H, W, Cin, Cout, ldx, ldy, epilogue; } TscdConvJob;
+int tscd_conv2d_jobs_max(void);
+int tscd_conv2d_jobs_supported(int Cin, int Cout);
+int tscd_conv2d_jobs_nhwc_f16(const void* jobs /* TscdConvJob[njobs] */, int njobs, void* stream);
+
 /* ---- CAFM / TaskAligned pieces: PositionMHAttention / MHAttention (tscd_matching.py:31-60,140-181), SEModule
  * (:264-283), LayerNorm of forward_post (:566-589,:394-458), cosine normalisation of double_match_embds (:912-937).
  * tiles: device int[ntiles][4] = (row0, nrows, key0, key1). */

@@ -447,3 +447,28 @@ def test_grouped_wgrad_and_two_segment_bn_backward(case):
     draw2, dg2, db2 = ops.bn_silu_bwd_multi([torch.cat((d0, d1), -1).contiguous()], raw, ss, mean, invstd, gam)
     torch.cuda.synchronize()
     assert torch.equal(draw2, draw_r) and torch.equal(dg2, dg_r) and torch.equal(db2, db_r)
+
+
+def test_linear_jobs_one_launch_equals_separate_launches():
+    """ops.linear_jobs: several independent nn.Linear GEMMs as ONE job-table launch of the 64 x 128 LDS-DMA tile (tscd_conv2d_jobs_nhwc_f16)
+    -- the separate launches' bits (an element's K-sum does not depend on which workgroup computes it), with and without bias, into an
+    output slice of a wider buffer; a job outside the form (30 outputs) sends the whole call down the one-launch-each path."""
+    from tscd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    dev = torch.device("cuda:0")
+    mk = lambda *s: torch.randn(*s, generator=g)
+    x1, x2, x3 = mk(2000, 256).half().to(dev), mk(8000, 256).half().to(dev), mk(500, 1024).half().to(dev)
+    w1, w2, w3 = (mk(256, 256) * 0.05).to(dev), (mk(512, 256) * 0.05).to(dev), (mk(1024, 1024) * 0.03).to(dev)
+    b2, b3 = mk(512).to(dev), mk(1024).half().to(dev)
+    wide = torch.zeros(500, 2048, dtype=torch.float16, device=dev)
+    jobs = [(x1, w1, None, None), (x2, w2, b2, None), (x3, w3, b3, wide[:, 1024:])]
+    got = ops.linear_jobs(jobs)
+    want = [ops.linear(x1, w1), ops.linear(x2, w2, b2), ops.linear(x3, w3, b3)]
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert torch.equal(wide[:, 1024:], want[2]) and float(wide[:, :1024].abs().max()) == 0.0
+    # a job outside the 128-wide form: every job takes its own launch, same results
+    w4 = (mk(30, 256) * 0.05).to(dev)
+    got = ops.linear_jobs([(x1, w1, None, None), (x1, w4, None, None)])
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], ops.linear(x1, w4))

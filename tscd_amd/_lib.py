@@ -59,6 +59,7 @@ SIGNATURES = {
     "tscd_se_fuse_bwd_acc_f16": [P, I, P, I, P, P, P, L, I, P, P, P, P, P, P],
     "tscd_add_layernorm_bwd_acc_f16": [P, P, P, P, I, I, F, P, P, P, P],
     "tscd_row_normalize_f16": [P, I, I, I, I, F, P, I, P],
+    "tscd_conv2d_jobs_nhwc_f16": [P, I, P],
     "tscd_match_cost_pairs_f16": [P, I, I, P, I, P, P],
     "tscd_se_fuse_ex_f16": [P, I, P, I, P, P, P, L, I, P, P, P],
     "tscd_add_layernorm_ex_f16": [P, P, P, P, I, I, F, P, P, P],
@@ -82,7 +83,7 @@ SIGNATURES = {
     "tscd_loss_dense_reg_f16": [P, P, P, P, P, P, I, I, I, I, P, P, P, L, P, P, P, P],
     "tscd_loss_rows_f16": [P, P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, L, P, P, P, P, P],
 }
-PLAIN = {"tscd_wgrad_batch_max_jobs": ([], I), "tscd_wgrad_batch_workspace_bytes": ([P, I], L), "tscd_wgrad_batch_supported": ([I] * 9, I), "tscd_pred_grad_split_workspace_bytes": ([L, I], L), "tscd_ema_chunk_elems": ([], I), "tscd_pack_block_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
+PLAIN = {"tscd_conv2d_jobs_max": ([], I), "tscd_conv2d_jobs_supported": ([I, I], I), "tscd_wgrad_batch_max_jobs": ([], I), "tscd_wgrad_batch_workspace_bytes": ([P, I], L), "tscd_wgrad_batch_supported": ([I] * 9, I), "tscd_pred_grad_split_workspace_bytes": ([L, I], L), "tscd_ema_chunk_elems": ([], I), "tscd_pack_block_elems": ([], I), "tscd_bias_relu_bwd_workspace_bytes": ([L, I], L), "tscd_conv_wgrad_splits": ([L, I, I, I], I), "tscd_conv_wgrad_workspace_bytes": ([L, I, I, I], L),
          "tscd_bn_silu_bwd_workspace_bytes": ([L, I], L), "tscd_linear_bwd_workspace_bytes": ([I, I, I], L),
          "tscd_mca_dp": ([I], I), "tscd_mca_workspace_bytes": ([I, I, I, I], L), "tscd_mca_rows_bytes": ([I, I, I], L),
          "tscd_mca_backward_workspace_bytes": ([I, I, I, I, I], L),

@@ -342,7 +342,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // Tile height BM: 128 by default; 192 x 128 when that puts one workgroup on most CUs in a single round (36x36 level: 216
 // workgroups instead of 324 half-filling a second round), 64 x 128 when 128-row tiles leave most CUs empty (18x18 level).
 template <int BM, int BN, int WAVES_N>
-__global__ __launch_bounds__(128 * WAVES_N, (BM == 64 ? 3 : 2)) void conv_igemm_glds_kernel(ConvParams p) {
+__device__ __forceinline__ void conv_igemm_glds_tile(const ConvParams& p, const int bid, const int nblk) {
   constexpr int NS = 4, WAVES_M = 2, NW = WAVES_M * WAVES_N, NT = 64 * NW;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
@@ -354,7 +354,6 @@ __global__ __launch_bounds__(128 * WAVES_N, (BM == 64 ? 3 : 2)) void conv_igemm_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int nblk = gridDim.x, bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int nta = lid % p.ntiles, mt = lid / p.ntiles;
@@ -495,6 +494,23 @@ __global__ __launch_bounds__(128 * WAVES_N, (BM == 64 ? 3 : 2)) void conv_igemm_
     mfmas(std::integral_constant<int, 0>{});
   }
   conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN>(p, acc, (f16*)smem, m0, n0, mt, tid, lane, wm, wn, gv.cbase, gv.sbase);
+}
+template <int BM, int BN, int WAVES_N>
+__global__ __launch_bounds__(128 * WAVES_N, (BM == 64 ? 3 : 2)) void conv_igemm_glds_kernel(ConvParams p) {
+  conv_igemm_glds_tile<BM, BN, WAVES_N>(p, blockIdx.x, gridDim.x);
+}
+// Job-table form: SEVERAL independent GEMMs of this variant (the nn.Linear layers of the proposal stage that do not depend on each other:
+// MCA's four input projections, its two output pairs, TaskAligned's / CAFM's q / k / v) in ONE launch -- each alone is a few dozen
+// workgroups and a launch of its own on a latency-bound stretch.  A workgroup finds its job by its index (uniform scalar compares).
+#define CONV_MAX_JOBS 8
+struct ConvJobTable { ConvParams job[CONV_MAX_JOBS]; int wg_begin[CONV_MAX_JOBS + 1]; int njobs; };
+template <int BM, int BN, int WAVES_N>
+__global__ __launch_bounds__(128 * WAVES_N, (BM == 64 ? 3 : 2)) void conv_igemm_glds_jobs_kernel(ConvJobTable t) {
+  const int bid = blockIdx.x;
+  int j = 0;
+  for (int i = 1; i < t.njobs; ++i) j = bid >= t.wg_begin[i] ? i : j;
+  const ConvParams p = t.job[j];
+  conv_igemm_glds_tile<BM, BN, WAVES_N>(p, bid - t.wg_begin[j], t.wg_begin[j + 1] - t.wg_begin[j]);
 }
 
 // ====================================================================================================================
@@ -907,4 +923,44 @@ extern "C" int tscd_conv2d_nhwc_f16_ex(const void* x, const void* wpk, void* y, 
                                        void* stream) {
   return conv_launch(x, wpk, y, bias, scale, shift, bn_partial, B, H, W, Cin, Cout, ksize, stride, ldx, ldy, epilogue, groups,
                      ConvPlan{variant, korder, tile_m}, stream);
+}
+
+// Several independent stride-1 GEMM-shaped launches (1x1 convs / nn.Linear as 1 x n images) in one launch of the 64 x 128 LDS-DMA tile:
+// jobs[i] = {x, wpk, y, bias (fp32 or null), B, H, W, Cin, Cout, ldx, ldy, epilogue (EPI_RAW / EPI_BIAS / EPI_BIAS_RELU)}; every job needs
+// Cin % 32 == 0 and Cout > 64 (the 128-wide tile).  Results are the single launches' bits (the tile height does not enter an element's sum).
+struct ConvJobHost { const void* x; const void* wpk; void* y; const float* bias; int B, H, W, Cin, Cout, ldx, ldy, epilogue; };
+extern "C" int tscd_conv2d_jobs_max(void) { return CONV_MAX_JOBS; }
+extern "C" int tscd_conv2d_jobs_supported(int Cin, int Cout) { return (Cin % 32 == 0 && Cin >= 32 && pick_bn(Cout) == 128) ? 1 : 0; }
+extern "C" int tscd_conv2d_jobs_nhwc_f16(const void* jobs_host, int njobs, void* stream) {
+  TSCD_CHECK_ARG(jobs_host && njobs > 0 && njobs <= CONV_MAX_JOBS, "conv2d_jobs: 1..%d jobs", CONV_MAX_JOBS);
+  const ConvJobHost* h = (const ConvJobHost*)jobs_host;
+  ConvJobTable t;
+  t.njobs = njobs;
+  int wg = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const ConvJobHost& a = h[i];
+    TSCD_CHECK_ARG(a.x && a.wpk && a.y && a.B > 0 && a.H > 0 && a.W > 0, "conv2d_jobs: job %d: bad pointers / shape", i);
+    TSCD_CHECK_ARG(tscd_conv2d_jobs_supported(a.Cin, a.Cout), "conv2d_jobs: job %d: Cin=%d Cout=%d not of the 128-wide LDS-DMA form", i, a.Cin, a.Cout);
+    TSCD_CHECK_ARG(a.ldx % 8 == 0 && a.ldx >= a.Cin && a.ldy >= a.Cout && ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.wpk & 15) == 0,
+                   "conv2d_jobs: job %d: strides / alignment", i);
+    TSCD_CHECK_ARG(a.epilogue == EPI_RAW || ((a.epilogue == EPI_BIAS || a.epilogue == EPI_BIAS_RELU) && a.bias), "conv2d_jobs: job %d: epilogue", i);
+    ConvParams& p = t.job[i];
+    p.x = (const f16*)a.x; p.w = (const f16*)a.wpk; p.y = (f16*)a.y;
+    p.bias = a.bias; p.scale = nullptr; p.shift = nullptr; p.bn_partial = nullptr;
+    p.B = a.B; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+    p.Ho = a.H; p.Wo = a.W; p.ldx = a.ldx; p.ldy = a.ldy;
+    p.K = a.Cin; p.Kpad = (a.Cin + 31) / 32 * 32;
+    const long M = (long)a.B * a.H * a.W;
+    TSCD_CHECK_ARG(M < (1L << 31), "conv2d_jobs: M too large");
+    p.M = (int)M; p.epilogue = a.epilogue;
+    p.korder = 0; p.G = 1;
+    p.cstride = cdiv(a.Cout, 128) * 128; p.wrows_g = p.cstride;
+    p.mtiles = cdiv(M, 64); p.ntiles_g = cdiv(a.Cout, 128); p.ntiles = p.ntiles_g;
+    t.wg_begin[i] = wg;
+    wg += p.mtiles * p.ntiles;
+  }
+  t.wg_begin[njobs] = wg;
+  hipLaunchKernelGGL((conv_igemm_glds_jobs_kernel<64, 128, 2>), dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
+  TSCD_CHECK_LAUNCH("conv2d_jobs");
+  return TSCD_OK;
 }

@@ -691,6 +691,49 @@ def linear(x, weight, bias=None, out=None, wpk=None):
     return out
 
 
+import ctypes as _C
+
+
+class _ConvJobC(_C.Structure):
+    _fields_ = [("x", _C.c_void_p), ("wpk", _C.c_void_p), ("y", _C.c_void_p), ("bias", _C.c_void_p), ("B", _C.c_int), ("H", _C.c_int),
+                ("W", _C.c_int), ("Cin", _C.c_int), ("Cout", _C.c_int), ("ldx", _C.c_int), ("ldy", _C.c_int), ("epilogue", _C.c_int)]
+
+
+LINEAR_JOBS = _os.environ.get("TSCD_LINEAR_JOBS", "1") != "0"
+
+
+def linear_jobs(jobs):
+    """Several INDEPENDENT ``linear`` calls -- jobs = [(x, weight, bias or None, out or None)] -- as ONE launch where every job is of the
+    128-wide LDS-DMA form (K % 32 == 0, more than 64 outputs); otherwise (or with TSCD_LINEAR_JOBS=0) one launch each.  -> list of outputs,
+    the separate launches' bits."""
+    outs, recs, keep = [], [], []
+    ok = LINEAR_JOBS and CONV_PROFILE is None and 2 <= len(jobs) <= lib.tscd_conv2d_jobs_max()
+    for (x, weight, bias, out) in jobs:
+        n, K = x.shape
+        nout = weight.shape[0]
+        if out is None:
+            out = temp((n, nout), dtype=torch.float16, device=x.device)
+        outs.append(out)
+        if not ok:
+            continue
+        wpk = LINEAR_WEIGHTS.get(weight)
+        if not (n > 0 and x.is_cuda and x.dtype == torch.float16 and x.stride(1) == 1 and out.stride(1) == 1 and wpk.shape[1] == K
+                and wpk.shape[0] >= nout and lib.tscd_conv2d_jobs_supported(K, nout)):
+            ok = False
+            continue
+        b32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
+        keep.append((wpk, b32))
+        recs.append(_ConvJobC(x.data_ptr(), wpk.data_ptr(), out.data_ptr(), None if b32 is None else b32.data_ptr(), 1, 1, n, K, nout,
+                              x.stride(0), out.stride(0), EPI_RAW if b32 is None else EPI_BIAS))
+    if ok:
+        arr = (_ConvJobC * len(recs))(*recs)
+        call("tscd_conv2d_jobs_nhwc_f16", _C.cast(arr, _C.c_void_p), len(recs), _stream())
+        return outs
+    for (x, weight, bias, _), out in zip(jobs, outs):
+        linear(x, weight, bias, out=out)
+    return outs
+
+
 # ----------------------------------------------------------------------------------------------------
 # proposal stage
 # ----------------------------------------------------------------------------------------------------

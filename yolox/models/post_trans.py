@@ -49,8 +49,9 @@ class _MCAFunction(torch.autograd.Function):
         N, W = x_cls.shape
         nl = sum(ppf[:lframe])
         xc, xr, sc = x_cls.contiguous(), x_reg.contiguous(), score.to(torch.float16).contiguous()
-        q_c, kv_c = ops.linear(xc[:nl], wq_c), ops.linear(xc, wkv_c)
-        q_r, kv_r = ops.linear(xr[:nl], wq_r), ops.linear(xr, wkv_r)
+        # the four input projections do not depend on each other: one job-table launch (ops.linear_jobs)
+        q_c, kv_c, q_r, kv_r = ops.linear_jobs([(xc[:nl], wq_c, None, None), (xc, wkv_c, None, None), (xr[:nl], wq_r, None, None),
+                                                (xr, wkv_r, None, None)])
         tiles = ops.mca_tiles(ppf, lframe, xc.device)
         want = any(ctx.needs_input_grad)
         # with a backward to come the forward's workspace stays alive: its normalised q / k / v rows are what the backward's first launch
@@ -59,12 +60,13 @@ class _MCAFunction(torch.autograd.Function):
                                 keep_workspace=want, fp16_logits=f16l)
         xcat_c, cat3_c, xcat_r, cat3_r, stats = res[:5]
         fwd_ws = res[5] if want else None
-        ops.linear(xcat_c, w_lin, b_lin, out=cat3_c[:, W:])
-        t_cls = ops.linear(cat3_c, w_out, b_out)
         t_obj = None
-        if need_reg:
-            ops.linear(xcat_r, w_linr, b_linr, out=cat3_r[:, W:])
-            t_obj = ops.linear(cat3_r, w_obj, b_obj)
+        if need_reg:       # the class and the regression branch run side by side: two launches of two jobs instead of four
+            ops.linear_jobs([(xcat_c, w_lin, b_lin, cat3_c[:, W:]), (xcat_r, w_linr, b_linr, cat3_r[:, W:])])
+            t_cls, t_obj = ops.linear_jobs([(cat3_c, w_out, b_out, None), (cat3_r, w_obj, b_obj, None)])
+        else:
+            ops.linear(xcat_c, w_lin, b_lin, out=cat3_c[:, W:])
+            t_cls = ops.linear(cat3_c, w_out, b_out)
         if want:
             ctx.cfg = cfg
             ctx.biases = (b_lin, b_linr, b_out, b_obj)     # parameter objects: name the bias gradients for the pass's batched launch

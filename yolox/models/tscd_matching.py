@@ -85,6 +85,49 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LinearJobs(torch.autograd.Function):
+    """Several independent nn.Linear calls (x_i, w_i, b_i) whose forward GEMMs run as ONE job-table launch (ops.linear_jobs); the backward
+    is each layer's own (the weight / bias gradients join the pass's batched launch as for _Linear)."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        xs = [a.contiguous() for a in args[:n]]
+        ws, bs = args[n:2 * n], args[2 * n:3 * n]
+        ctx.n = n
+        ctx.bias_params = bs
+        ctx.save_for_backward(*xs, *ws)
+        return tuple(ops.linear_jobs([(x, w, b, None) for x, w, b in zip(xs, ws, bs)]))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = ctx.n
+        xs, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        need = ctx.needs_input_grad
+        dxs, dws, dbs = [], [], []
+        for i in range(n):
+            g, x, w, b = gs[i], xs[i], ws[i], ctx.bias_params[i]
+            if g is None:
+                dxs.append(None); dws.append(None); dbs.append(None)
+                continue
+            if g.dtype != torch.float16:
+                g = g.to(torch.float16)
+            want_b = b is not None and need[1 + 2 * n + i]
+            dx, dw, db = ops.linear_bwd(x, g.contiguous(), w, need[1 + i], need[1 + n + i], want_b, grad_params=[w, b if want_b else None])
+            dxs.append(dx)
+            dws.append(dw if dw is None or dw.dtype == w.dtype else dw.to(w.dtype))
+            dbs.append(db if db is None or db.dtype == w.dtype else db.to(w.dtype))
+        return (None, *dxs, *dws, *dbs)
+
+
+def linears(pairs):
+    """[(x, nn.Linear)] -> outputs; independent layers, one forward launch where the shapes allow (ops.linear_jobs)."""
+    n = len(pairs)
+    xs, ws, bs = [x for x, _ in pairs], [l.weight for _, l in pairs], [l.bias for _, l in pairs]
+    if torch.is_grad_enabled() and any(t.requires_grad for t in xs + ws):
+        return _LinearJobs.apply(n, *xs, *ws, *bs)
+    return tuple(ops.linear_jobs([(x.contiguous(), w, b, None) for x, w, b in zip(xs, ws, bs)]))
+
+
 def linear(x, lin):
     """nn.Linear on the MFMA GEMM (fp16 in/out)."""
     w, b = lin.weight, lin.bias
@@ -198,8 +241,8 @@ class MHAttention(nn.Module):
         self.attn_drop = nn.Dropout(dropout)
 
     def attend(self, q_in, k_in, v_in, segments):
-        return cos_attention(linear(q_in, self.q_reg), linear(k_in, self.k_reg), linear(v_in, self.v_reg), self.num_heads,
-                             segments)
+        q, k, v = linears([(q_in, self.q_reg), (k_in, self.k_reg), (v_in, self.v_reg)])
+        return cos_attention(q, k, v, self.num_heads, segments)
 
 
 class PositionMHAttention(MHAttention):
@@ -346,7 +389,7 @@ class _CafmChain(torch.autograd.Function):
         # for k and v over all local rows
         k_in = ops.temp((nl, W), dtype=torch.float16, device=dev)
         ops.se_fuse_ex(feat, edge, w0f, w2f, t_emb, k_in, nl, pos_seg_rows=n, pos_stride=W)
-        k_all, v_all = ops.linear(k_in, wk), ops.linear(feat, wv)
+        k_all, v_all = ops.linear_jobs([(k_in, wk, None, None), (feat, wv, None, None)])
         mfma = ops.cos_attn_uses_mfma(W, heads)
         tiles = ops.attn_tiles([(0, n, 0, n)], dev, rows=32 if mfma else 16)
         ctx.ktiles = ops.attn_key_tiles([(0, n, 0, n)], dev) if mfma and KEY_STATIONARY_BWD else None
