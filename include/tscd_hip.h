@@ -232,7 +232,10 @@ int tscd_mca_forward(const void* q_c, const void* kv_c, const void* q_r, const v
  * projected q / (k|v) rows and the key scores.  stats = stats_out of the forward call; dxcat_* [N_L,2W], dsoft_* / soft_* the
  * first W columns of the [N_L,3W] concat (row strides ld_dsoft / ld_soft). */
 long tscd_mca_backward_workspace_bytes(int N, int N_L, int W, int S, int ntiles);
-/* Three passes without atomics (delta + dM/Ac/Ar blocks; dq per query tile; dk/dv/dscore per key block): deterministic. */
+/* Three passes without atomics (delta + dM/Ac/Ar blocks; dq per query tile; dk/dv/dscore per key block): deterministic.
+ * dxcat_c = dsoft_c = NULL (need_reg only): no gradient reaches the class branch's attention outputs -- agg_iou, whose class output
+ * feeds the assignment cost detached (tscd_head.py:480-483,491-500; tscd_matching.py:919-926).  The passes leave out everything
+ * that would only carry those zeros (12 of 32 MFMAs per tile pair in the first pass, dvc, Ac): same bits as zero tensors. */
 int tscd_mca_backward(const void* q_c, const void* kv_c, const void* q_r, const void* kv_r, const void* score,
                       const int* tiles, int ntiles, int N, int N_L, int W, int S, int need_reg, float scale, float sim_thresh,
                       float conf_thresh, const float* stats, const void* dxcat_c, const void* dxcat_r, const void* dsoft_c,

@@ -435,6 +435,77 @@ def test_mca_backward_reads_the_forward_workspace_or_rederives_it_bit_for_bit():
             assert torch.isfinite(x.float()).all() and torch.equal(x, y)
 
 
+@pytest.mark.parametrize("W,ppf,L", [(256, [70, 33, 150, 97], 2), (128, [200, 180, 150, 170, 31], 3), (320, [40, 25, 90], 1)])
+def test_mca_backward_without_class_branch_gradient_equals_zero_tensors_bit_for_bit(W, ppf, L):
+    """agg_iou's class output only feeds the assignment cost, detached: no gradient reaches the class branch's attention
+    outputs.  ops.mca_backward(dxcat_c=None, dcat3_c=None) runs the passes that leave the zeros' arithmetic out (CLS_G = false in
+    mca_bwd.hip): every result equals the one zero tensors give, bit for bit."""
+    from tscd_amd import ops
+    d = torch.device("cuda")
+    g = torch.Generator().manual_seed(17)
+    N, N_L = sum(ppf), sum(ppf[:L])
+    tiles = ops.mca_tiles(ppf, L, d)
+    centers = torch.randn(8, W, generator=g)
+    lab = torch.randint(0, 8, (N,), generator=g)
+    rows = lambda n, c, s: (centers[lab[:n]].repeat(1, c // W) + s * torch.randn(n, c, generator=g)).half().to(d).contiguous()
+    q_c, q_r, kv_c, kv_r = rows(N_L, W, 0.2), rows(N_L, W, 0.05), rows(N, 2 * W, 0.2), rows(N, 2 * W, 0.05)
+    score = torch.rand(N, generator=g).half().to(d)
+    mk = lambda n, c: torch.randn(n, c, generator=g).half().to(d).contiguous()
+    xcat_c, cat3_c, xcat_r, cat3_r, stats, ws = ops.mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, True, 25.0, 0.75, 0.99,
+                                                                  want_stats=True, keep_workspace=True)
+    dx_r, dc3_r = mk(N_L, 2 * W), mk(N_L, 3 * W)
+    z = lambda c: torch.zeros(N_L, c, dtype=torch.float16, device=d)
+    head = (q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, True, 25.0, 0.75, 0.99, stats)
+    r0 = ops.mca_backward(*head, z(2 * W), dx_r, z(3 * W), dc3_r, cat3_c, cat3_r, fwd_ws=ws)
+    r1 = ops.mca_backward(*head, None, dx_r, None, dc3_r, cat3_c, cat3_r, fwd_ws=ws)
+    r2 = ops.mca_backward(*head, None, dx_r, None, dc3_r, cat3_c, cat3_r)
+    torch.cuda.synchronize()
+    for name, x, y, y2 in zip(("dq_c", "dkv_c", "dq_r", "dkv_r", "dscore"), r0, r1, r2):
+        assert torch.isfinite(x.float()).all() and x.float().abs().max() > 0, name
+        assert torch.equal(x, y) and torch.equal(x, y2), (name, (x.float() - y.float()).abs().max().item())
+    assert torch.count_nonzero(r1[1][:, W:]) == 0        # d(value rows) of the class branch: exactly zero
+    with pytest.raises(ValueError):
+        ops.mca_backward(*head, None, dx_r, z(3 * W), dc3_r, cat3_c, cat3_r)
+
+
+def test_mca_module_with_only_the_objectness_output_used_matches_oracle_autograd():
+    """The module as agg_iou is used in the train step: the class output feeds nothing with a gradient.  Gradients of the inputs and of
+    the parameters that get one vs the oracle's fp32 autograd; the class head's linears get none."""
+    from yolox.models.post_trans import MCA_tscd_g2l_reg
+    W, ppf, L = 128, [200, 180, 150, 170], 3
+    g = torch.Generator().manual_seed(4)
+    cfg = O.TSCDConfig()
+    mod = MCA_tscd_g2l_reg(W, 4 * W, num_heads=4, reconf=True)
+    N = sum(ppf)
+    centers = torch.randn(8, W, generator=g)
+    lab = torch.randint(0, 8, (N,), generator=g)
+    xc = (centers[lab] + 0.2 * torch.randn(N, W, generator=g)).half()
+    xr = (centers[lab] + 0.05 * torch.randn(N, W, generator=g)).half()
+    sc = torch.rand(N, generator=g).half()
+    go = torch.randn(sum(ppf[:L]), 4 * W, generator=g)
+    sd = {"m." + k: v.detach().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+    xc32, xr32, sc32 = xc.float().requires_grad_(True), xr.float().requires_grad_(True), sc.float().requires_grad_(True)
+    rc, ro = O.mca_tscd_g2l_reg(sd, "m", xc32, xr32, sc32, ppf, L, cfg)
+    (ro * go).sum().backward()
+    mod = mod.cuda()
+    xcg, xrg, scg = xc.cuda().requires_grad_(True), xr.cuda().requires_grad_(True), sc.cuda().requires_grad_(True)
+    c, o = mod(xcg, xrg, scg, None, sim_thresh=0.75, preds_per_frame=ppf, lframe=L, conf_sim_thresh=0.99)
+    (o.float() * go.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    checks = [(xcg.grad, xc32.grad, "x_cls"), (xrg.grad, xr32.grad, "x_reg"), (scg.grad, sc32.grad, "score")]
+    for k, p in mod.named_parameters():
+        ref = sd["m." + k].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            checks.append((p.grad, ref, k))
+    assert len(checks) >= 9
+    for got, ref, name in checks:
+        cos = torch.nn.functional.cosine_similarity(got.float().cpu().flatten(), ref.flatten(), dim=0).item()
+        ratio = (got.float().cpu().norm() / ref.norm()).item()
+        assert cos > 0.999 and abs(ratio - 1) < 0.01, (name, cos, ratio)
+
+
 def _cos(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))

@@ -39,6 +39,18 @@ for P in (500, 50):
         e.record()
         torch.cuda.synchronize()
         print(f"P {P} need_reg {need_reg} forward: {s.elapsed_time(e) / 10 * 1e3:8.1f} us per call", flush=True)
+        if need_reg:      # agg_iou as the train step calls it: no gradient reaches the class branch's outputs (CLS_G = false passes)
+            fn = lambda: ops.mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, True, 25.0, 0.75, 0.99, stats, None, a[1], None, a[3],
+                                          cat3_c, cat3_r)
+            for _ in range(2):
+                fn()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(5):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            print(f"P {P} need_reg True, no class-branch gradient: {s.elapsed_time(e) / 5 * 1e3:8.1f} us per call", flush=True)
         for rnd in range(2):
             for _ in range(2):
                 f()

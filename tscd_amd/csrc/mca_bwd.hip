@@ -118,14 +118,17 @@ __global__ __launch_bounds__(256) void mca_bwd_layout_kernel(const f16* __restri
 
 // Query side: one workgroup per (query tile, array).  Arrays 0..7 = row fragments of q^c q^r v^c v^r dOc dOr dsoftc dsoftr,
 // 8..13 = col fragments of q^c q^r dOc dOr dsoftc dsoftr (rows beyond the tile are zero); array 14 = gdot = dsoft . soft.
+// cls_grad = 0 (dO_c = dS_c = null: no gradient reaches the class branch's outputs): the arrays only the zeros would fill -- v^c,
+// dOc, dsoftc in either form -- are not written (the CLS_G = false passes do not read them) and gdot_c = 0.
 __global__ __launch_bounds__(256) void mca_bwd_tiles_kernel(const McaTile* __restrict__ tiles, const f16* __restrict__ qn_c,
                                                             const f16* __restrict__ qn_r, const f16* __restrict__ vn_c,
                                                             const f16* __restrict__ vn_r, const f16* __restrict__ dO_c, int ld_dO,
                                                             const f16* __restrict__ dO_r, const f16* __restrict__ dS_c, int ld_dS,
                                                             const f16* __restrict__ dS_r, const f16* __restrict__ soft_c,
                                                             const f16* __restrict__ soft_r, int ld_soft, int N_L, int W, int d,
-                                                            int DP, int need_reg, McaBwdParams p, float* gdot) {
+                                                            int DP, int need_reg, int cls_grad, McaBwdParams p, float* gdot) {
   const int t = blockIdx.x, arr = blockIdx.y, tid = threadIdx.x;
+  if (!cls_grad && (arr == 2 || arr == 4 || arr == 6 || arr == 10 || arr == 12)) return;
   const McaTile tl = tiles[t];
   const int WP = MCA_HEADS * DP, KS = DP / 16, NT = DP / 32;
   const int nchunk = MCA_HEADS * KS * 64;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void mca_bwd_tiles_kernel(const McaTile* __res
       const long row = tl.row0 + j;
       float gc = 0.f, gr = 0.f;
       for (int c = lane; c < W; c += 64) {
-        gc += (float)dS_c[row * ld_dS + c] * (float)soft_c[row * ld_soft + c];
+        if (cls_grad) gc += (float)dS_c[row * ld_dS + c] * (float)soft_c[row * ld_soft + c];
         if (need_reg) gr += (float)dS_r[row * ld_dS + c] * (float)soft_r[row * ld_soft + c];
       }
       gc = wave_sum(gc); gr = wave_sum(gr);
@@ -181,11 +184,20 @@ __global__ __launch_bounds__(256) void mca_bwd_tiles_kernel(const McaTile* __res
 }
 
 // ------------------------------------------------------------------------------------------------ pass 1: delta, dM, Ac, Ar
-template <int DP, bool NEED_REG>
+// CLS_G = false: no gradient reaches the class branch's attention outputs (dOc = dsoftc = 0 -- agg_iou, whose class output is only
+// used detached as assignment cost).  Everything that only carries those zeros is left out: the v^c.v^c similarity
+// (its mask only gates Ac), dOc.vc, dsoftc.Vc, their fragments and Ac -- 20 of 32 MFMAs per visit remain, the query-side fragments fit
+// the register file again (the full form spills 48 VGPRs at DP 64), and the result is bit for bit what the zeros would have given.
+// With ONE branch carrying sim_round2 weights (CLS_G != NEED_REG) its similarity and its dA travel in the exchange's 2nd and 3rd
+// array at once: 3 barriers per visit instead of 5.
+template <int DP, bool NEED_REG, bool CLS_G>
 __global__ __launch_bounds__(256, 2) void mca_bwd_delta_kernel(McaBwdParams p, int ntiles) {
+  static_assert(NEED_REG || CLS_G, "mca_bwd_delta_kernel: no upstream gradient at all");
   constexpr int KS = DP / 16;
   constexpr int PST = 33;
-  __shared__ float X[3][MCA_HEADS][32][PST];          // cross-head exchange (round 1: P, Rc, Rr; round 2: dM, dAc, dAr)
+  constexpr bool BOTH = NEED_REG && CLS_G;            // both branches carry sim_round2 weights: two exchange rounds
+  constexpr int BR = NEED_REG ? 1 : 0;                // the one branch that does, otherwise
+  __shared__ float X[3][MCA_HEADS][32][PST];          // cross-head exchange (BOTH: round 1 P, Rc, Rr; round 2 dM, dAc, dAr.  else P, R, dA)
   __shared__ float A32[2][32][PST];                   // Ac, Ar
   __shared__ float invl[MCA_HEADS][2][32];
   __shared__ float dinv[2][32];
@@ -215,9 +227,11 @@ __global__ __launch_bounds__(256, 2) void mca_bwd_delta_kernel(McaBwdParams p, i
     const long o = rowfrag<DP>(tile, h, ks) + lane * 8;
     qc[ks] = *(const f16x8*)(p.qF_c + o);
     qr[ks] = *(const f16x8*)(p.qF_r + o);
-    vlc[ks] = *(const f16x8*)(p.vlF_c + o);
-    gOc[ks] = *(const f16x8*)(p.gOF_c + o);
-    gSc[ks] = *(const f16x8*)(p.gSF_c + o);
+    if (CLS_G) {
+      vlc[ks] = *(const f16x8*)(p.vlF_c + o);
+      gOc[ks] = *(const f16x8*)(p.gOF_c + o);
+      gSc[ks] = *(const f16x8*)(p.gSF_c + o);
+    }
     if (NEED_REG) {
       vlr[ks] = *(const f16x8*)(p.vlF_r + o);
       gOr[ks] = *(const f16x8*)(p.gOF_r + o);
@@ -244,12 +258,14 @@ __global__ __launch_bounds__(256, 2) void mca_bwd_delta_kernel(McaBwdParams p, i
     for (int ks = 0; ks < KS; ++ks) {
       const long o = rowfrag<DP>(kb, h, ks) + lane * 8;
       const f16x8 kc = *(const f16x8*)(p.kF_c + o), kr = *(const f16x8*)(p.kF_r + o);
-      const f16x8 vnc = *(const f16x8*)(p.vnF_c + o), vrc = *(const f16x8*)(p.vrF_c + o);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qc[ks], kc, sc, 0, 0, 0);
       sr = __builtin_amdgcn_mfma_f32_32x32x16_f16(qr[ks], kr, sr, 0, 0, 0);
-      rc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlc[ks], vnc, rc, 0, 0, 0);
-      gv = __builtin_amdgcn_mfma_f32_32x32x16_f16(gOc[ks], vrc, gv, 0, 0, 0);       // (dOc.vc + dOr.vr) / 2 in one accumulator
-      gac = __builtin_amdgcn_mfma_f32_32x32x16_f16(gSc[ks], vrc, gac, 0, 0, 0);
+      if (CLS_G) {
+        const f16x8 vnc = *(const f16x8*)(p.vnF_c + o), vrc = *(const f16x8*)(p.vrF_c + o);
+        rc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlc[ks], vnc, rc, 0, 0, 0);
+        gv = __builtin_amdgcn_mfma_f32_32x32x16_f16(gOc[ks], vrc, gv, 0, 0, 0);       // (dOc.vc + dOr.vr) / 2 in one accumulator
+        gac = __builtin_amdgcn_mfma_f32_32x32x16_f16(gSc[ks], vrc, gac, 0, 0, 0);
+      }
       if (NEED_REG) {
         const f16x8 vnr = *(const f16x8*)(p.vnF_r + o), vrr = *(const f16x8*)(p.vrF_r + o);
         rr = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlr[ks], vnr, rr, 0, 0, 0);
@@ -264,44 +280,67 @@ __global__ __launch_bounds__(256, 2) void mca_bwd_delta_kernel(McaBwdParams p, i
       pc[e] = __builtin_amdgcn_exp2f(a_c * sc[e] - bias) * invl[h][0][row];
       pr[e] = __builtin_amdgcn_exp2f(sc2 * sr[e] - bias) * invl[h][1][row];
       X[0][h][row][col] = 0.5f * (pc[e] + pr[e]);
-      X[1][h][row][col] = valid ? rc[e] : -2.f;
-      X[2][h][row][col] = (valid && NEED_REG) ? rr[e] : -2.f;
-    }
-    __syncthreads();
-    {
-      const int row = tid >> 3, c0 = (tid & 7) * 4;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int cc = c0 + c;
-        const float mp = 0.25f * (X[0][0][row][cc] + X[0][1][row][cc] + X[0][2][row][cc] + X[0][3][row][cc]);
-        const float mc = 0.25f * (X[1][0][row][cc] + X[1][1][row][cc] + X[1][2][row][cc] + X[1][3][row][cc]);
-        const float mr = 0.25f * (X[2][0][row][cc] + X[2][1][row][cc] + X[2][2][row][cc] + X[2][3][row][cc]);
-        const float ex = __expf(mp);
-        A32[0][row][cc] = mc > p.sim_thresh ? ex * dinv[0][row] : 0.f;
-        A32[1][row][cc] = (NEED_REG && mr > p.conf_thresh) ? ex * dinv[1][row] : 0.f;
+      if (BOTH) {
+        X[1][h][row][col] = valid ? rc[e] : -2.f;
+        X[2][h][row][col] = valid ? rr[e] : -2.f;
+      } else {
+        X[1][h][row][col] = valid ? (NEED_REG ? rr[e] : rc[e]) : -2.f;
+        X[2][h][row][col] = NEED_REG ? gar[e] : gac[e];
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-      X[1][h][row][col] = gac[e];
-      X[2][h][row][col] = NEED_REG ? gar[e] : 0.f;
-    }
-    __syncthreads();
     const long blk = ((long)tile * p.maxblk + j) * 1024;
-    {
+    if (BOTH) {
+      {
+        const int row = tid >> 3, c0 = (tid & 7) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int cc = c0 + c;
+          const float mp = 0.25f * (X[0][0][row][cc] + X[0][1][row][cc] + X[0][2][row][cc] + X[0][3][row][cc]);
+          const float mc = 0.25f * (X[1][0][row][cc] + X[1][1][row][cc] + X[1][2][row][cc] + X[1][3][row][cc]);
+          const float mr = 0.25f * (X[2][0][row][cc] + X[2][1][row][cc] + X[2][2][row][cc] + X[2][3][row][cc]);
+          const float ex = __expf(mp);
+          A32[0][row][cc] = mc > p.sim_thresh ? ex * dinv[0][row] : 0.f;
+          A32[1][row][cc] = mr > p.conf_thresh ? ex * dinv[1][row] : 0.f;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+        X[1][h][row][col] = gac[e];
+        X[2][h][row][col] = gar[e];
+      }
+      __syncthreads();
+      {
+        const int row = tid >> 3, c0 = (tid & 7) * 4;
+        f32x4 dm;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int cc = c0 + c;
+          const float dac = X[1][0][row][cc] + X[1][1][row][cc] + X[1][2][row][cc] + X[1][3][row][cc];
+          const float dar = X[2][0][row][cc] + X[2][1][row][cc] + X[2][2][row][cc] + X[2][3][row][cc];
+          dm[c] = 0.125f * (A32[0][row][cc] * (dac - gdt[0][row]) + A32[1][row][cc] * (dar - gdt[1][row]));     // dM / 8
+          X[0][0][row][cc] = dm[c];
+        }
+        // query on the lane axis: keys c0 .. c0+3 = 8 i + 4 half + j  ->  [i][lane = 32 half + row][j]
+        *(f32x4*)(p.dMq + blk + (((tid & 7) >> 1) * 64 + (tid & 1) * 32 + row) * 4) = dm;
+      }
+    } else {      // one branch: mean probability, similarity and dA of a (row, key) are all there after the one exchange
       const int row = tid >> 3, c0 = (tid & 7) * 4;
+      const float thr = NEED_REG ? p.conf_thresh : p.sim_thresh;
       f32x4 dm;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int cc = c0 + c;
-        const float dac = X[1][0][row][cc] + X[1][1][row][cc] + X[1][2][row][cc] + X[1][3][row][cc];
-        const float dar = X[2][0][row][cc] + X[2][1][row][cc] + X[2][2][row][cc] + X[2][3][row][cc];
-        dm[c] = 0.125f * (A32[0][row][cc] * (dac - gdt[0][row]) + A32[1][row][cc] * (dar - gdt[1][row]));     // dM / 8
-        X[0][0][row][cc] = dm[c];
+        const float mp = 0.25f * (X[0][0][row][cc] + X[0][1][row][cc] + X[0][2][row][cc] + X[0][3][row][cc]);
+        const float mb = 0.25f * (X[1][0][row][cc] + X[1][1][row][cc] + X[1][2][row][cc] + X[1][3][row][cc]);
+        const float da = X[2][0][row][cc] + X[2][1][row][cc] + X[2][2][row][cc] + X[2][3][row][cc];
+        const float a = mb > thr ? __expf(mp) * dinv[BR][row] : 0.f;
+        A32[BR][row][cc] = a;
+        dm[c] = 0.125f * (a * (da - gdt[BR][row]));                                                               // dM / 8
+        X[0][0][row][cc] = dm[c];      // (this thread's own element: nobody else reads X[0][.][row][cc] in this phase)
       }
-      // query on the lane axis: keys c0 .. c0+3 = 8 i + 4 half + j  ->  [i][lane = 32 half + row][j]
       *(f32x4*)(p.dMq + blk + (((tid & 7) >> 1) * 64 + (tid & 1) * 32 + row) * 4) = dm;
     }
     __syncthreads();
@@ -309,7 +348,8 @@ __global__ __launch_bounds__(256, 2) void mca_bwd_delta_kernel(McaBwdParams p, i
       const int kk = tid >> 3, q0 = (tid & 7) * 4;
       const long o = blk + (((tid & 7) >> 1) * 64 + (tid & 1) * 32 + kk) * 4;
       *(f32x4*)(p.dMk + o) = f32x4{X[0][0][q0][kk], X[0][0][q0 + 1][kk], X[0][0][q0 + 2][kk], X[0][0][q0 + 3][kk]};
-      *(f16x4*)(p.Ack + o) = f16x4{(f16)A32[0][q0][kk], (f16)A32[0][q0 + 1][kk], (f16)A32[0][q0 + 2][kk], (f16)A32[0][q0 + 3][kk]};
+      if (CLS_G)
+        *(f16x4*)(p.Ack + o) = f16x4{(f16)A32[0][q0][kk], (f16)A32[0][q0 + 1][kk], (f16)A32[0][q0 + 2][kk], (f16)A32[0][q0 + 3][kk]};
       if (NEED_REG)
         *(f16x4*)(p.Ark + o) = f16x4{(f16)A32[1][q0][kk], (f16)A32[1][q0 + 1][kk], (f16)A32[1][q0 + 2][kk], (f16)A32[1][q0 + 3][kk]};
     }
@@ -375,8 +415,8 @@ __device__ __forceinline__ f16x8 lds_frag(const char* base, int lane) { return *
 // Workgroup = 4 consecutive query tiles (one per wave) x one head x one split of the key blocks.  Per visited key block the
 // key-side fragments (k^c k^r vc vr rows, k^c k^r columns: 24 KB at DP 64) are staged ONCE for the four waves, double
 // buffered, one barrier per visit; each wave adds its own dM block (4 KB).  A wave whose tile does not see the block (local
-// blocks of another frame) skips the arithmetic but keeps the barriers.
-template <int DP, bool NEED_REG>
+// blocks of another frame) skips the arithmetic but keeps the barriers.  CLS_G = false (see pass 1): dOc = 0, so dOc.vc and the vc rows are left out.
+template <int DP, bool NEED_REG, bool CLS_G>
 __global__ __launch_bounds__(256) void mca_bwd_dq_kernel(McaBwdParams p, int ntiles) {
   constexpr int KS = DP / 16, NT = DP / 32;
   constexpr int A_BYTES = 4 * KS * 1024, C_BYTES = 4 * NT * 1024, W_OFF = A_BYTES + C_BYTES, STAGE = W_OFF + 4 * 4096;
@@ -403,7 +443,7 @@ __global__ __launch_bounds__(256) void mca_bwd_dq_kernel(McaBwdParams p, int nti
     const long o = rowfrag<DP>(tsafe, h, ks) + lane * 8;
     qc[ks] = *(const f16x8*)(p.qF_c + o);
     qr[ks] = *(const f16x8*)(p.qF_r + o);
-    gOc[ks] = *(const f16x8*)(p.gOF_c + o);
+    if (CLS_G) gOc[ks] = *(const f16x8*)(p.gOF_c + o);
     if (NEED_REG) gOr[ks] = *(const f16x8*)(p.gOF_r + o);
   }
   f32x16 dqc[NT], dqr[NT];
@@ -424,7 +464,7 @@ __global__ __launch_bounds__(256) void mca_bwd_dq_kernel(McaBwdParams p, int nti
     const f16* rows[4] = {p.kF_c, p.kF_r, p.vrF_c, p.vrF_r};
 #pragma unroll
     for (int a = 0; a < 4; ++a)
-      if (a < 3 || NEED_REG)
+      if (a < 2 || (a == 2 && CLS_G) || (a == 3 && NEED_REG))
         for (int f = w; f < KS; f += 4) dma_1k(rows[a] + rowfrag<DP>(kb, h, f), sb + (a * KS + f) * 1024, lane);
     const f16* cols[2] = {p.kT_c, p.kT_r};
 #pragma unroll
@@ -461,7 +501,8 @@ __global__ __launch_bounds__(256) void mca_bwd_dq_kernel(McaBwdParams p, int nti
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int a = 0; a < (NEED_REG ? 4 : 3); ++a) fa[buf][u][a] = lds_frag(sb + (a * KS + 2 * g + u) * 1024, lane);
+          for (int a = 0; a < (NEED_REG ? 4 : 3); ++a)
+            if (a != 2 || CLS_G) fa[buf][u][a] = lds_frag(sb + (a * KS + 2 * g + u) * 1024, lane);
       };
       rd(0, 0);
       MCA_SCHED_FENCE();
@@ -473,7 +514,7 @@ __global__ __launch_bounds__(256) void mca_bwd_dq_kernel(McaBwdParams p, int nti
           const int ks = 2 * g + u;
           sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][u][0], qc[ks], sc, 0, 0, 0);
           sr = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][u][1], qr[ks], sr, 0, 0, 0);
-          gv = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][u][2], gOc[ks], gv, 0, 0, 0);
+          if (CLS_G) gv = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][u][2], gOc[ks], gv, 0, 0, 0);
           if (NEED_REG) gv = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][u][3], gOr[ks], gv, 0, 0, 0);
         }
         MCA_SCHED_FENCE();
@@ -538,8 +579,10 @@ __global__ __launch_bounds__(256) void mca_bwd_dq_kernel(McaBwdParams p, int nti
 // Workgroup = 4 consecutive key blocks (one per wave) x one head x one split of the query tiles.  A visit is (query tile,
 // kind): kind 0 = the tile's own frame (local keys), kind 1 = the global keys; the tile's fragments (q^ / dO rows, q^ / dO /
 // dsoft columns: 40 KB at DP 64) and its row statistics are staged once for the four waves, each wave adds its own dM / Ac /
-// Ar block (8 KB).  Double buffered at DP <= 64 (146 KB of LDS), single buffered above.
-template <int DP, bool NEED_REG>
+// Ar block (8 KB).  Double buffered at DP <= 64 (146 KB of LDS), single buffered above.  CLS_G = false (see pass 1): dOc = dsoftc = 0,
+// so dvc = P^T dOc + Ac^T dsoftc = 0 is neither computed nor written (the finish kernel is told), and dOc.vc, the vc rows, the dOc /
+// dsoftc fragments and Ac are left out.
+template <int DP, bool NEED_REG, bool CLS_G>
 __global__ __launch_bounds__(256) void mca_bwd_dkv_kernel(McaBwdParams p, int ntiles) {
   constexpr int KS = DP / 16, NT = DP / 32;
   constexpr int NSTAGE = DP <= 64 ? 2 : 1;
@@ -565,7 +608,7 @@ __global__ __launch_bounds__(256) void mca_bwd_dkv_kernel(McaBwdParams p, int nt
     const long o = rowfrag<DP>(bs, h, ks) + lane * 8;
     kc[ks] = *(const f16x8*)(p.kF_c + o);
     kr[ks] = *(const f16x8*)(p.kF_r + o);
-    vc[ks] = *(const f16x8*)(p.vrF_c + o);
+    if (CLS_G) vc[ks] = *(const f16x8*)(p.vrF_c + o);
     if (NEED_REG) vr[ks] = *(const f16x8*)(p.vrF_r + o);
   }
   f32x16 akc[NT], akr[NT], avc[NT], avr[NT];
@@ -599,12 +642,12 @@ __global__ __launch_bounds__(256) void mca_bwd_dkv_kernel(McaBwdParams p, int nt
     const f16* rows[4] = {p.qF_c, p.qF_r, p.gOF_c, p.gOF_r};
 #pragma unroll
     for (int a = 0; a < 4; ++a)
-      if (a < 3 || NEED_REG)
+      if (a < 2 || (a == 2 && CLS_G) || (a == 3 && NEED_REG))
         for (int f = w; f < KS; f += 4) dma_1k(rows[a] + rowfrag<DP>(tt, h, f), sb + (a * KS + f) * 1024, lane);
     const f16* cols[6] = {p.qT_c, p.qT_r, p.gOT_c, p.gST_c, p.gOT_r, p.gST_r};
 #pragma unroll
     for (int a = 0; a < 6; ++a)
-      if (a < 4 || NEED_REG)
+      if (a < 2 || (a < 4 && CLS_G) || (a >= 4 && NEED_REG))
         for (int f = w; f < 2 * NT; f += 4) dma_1k(cols[a] + colfrag<DP>(tt, h, 0, 0) + f * 512, sb + A_BYTES + (a * 2 * NT + f) * 1024, lane);
     if (w == 0) dma_1k(p.rowstat + ((long)tt * MCA_HEADS + h) * 256, sb + RS_OFF, lane);
     // a wave that does not take part stages block 0 of the tile (finite numbers) and masks its keys and A weights below
@@ -615,7 +658,8 @@ __global__ __launch_bounds__(256) void mca_bwd_dkv_kernel(McaBwdParams p, int nt
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_1k(p.dMk + blk + i * 256, wb + i * 1024, lane);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma_1k(p.Ack + blk + i * 512, wb + 4096 + i * 1024, lane);
+    for (int i = 0; i < 2; ++i)
+      if (CLS_G) dma_1k(p.Ack + blk + i * 512, wb + 4096 + i * 1024, lane);
     if (NEED_REG)
 #pragma unroll
       for (int i = 0; i < 2; ++i) dma_1k(p.Ark + blk + i * 512, wb + 6144 + i * 1024, lane);
@@ -645,7 +689,8 @@ __global__ __launch_bounds__(256) void mca_bwd_dkv_kernel(McaBwdParams p, int nt
 #pragma unroll
           for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int a = 0; a < (NEED_REG ? 4 : 3); ++a) fa[fbuf][u][a] = lds_frag(sb + (a * KS + 2 * g + u) * 1024, lane);
+            for (int a = 0; a < (NEED_REG ? 4 : 3); ++a)
+              if (a != 2 || CLS_G) fa[fbuf][u][a] = lds_frag(sb + (a * KS + 2 * g + u) * 1024, lane);
         };
         rd(0, 0);
         MCA_SCHED_FENCE();
@@ -657,7 +702,7 @@ __global__ __launch_bounds__(256) void mca_bwd_dkv_kernel(McaBwdParams p, int nt
             const int ks = 2 * g + u;
             sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][u][0], kc[ks], sc, 0, 0, 0);
             sr = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][u][1], kr[ks], sr, 0, 0, 0);
-            gv = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][u][2], vc[ks], gv, 0, 0, 0);
+            if (CLS_G) gv = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][u][2], vc[ks], gv, 0, 0, 0);
             if (NEED_REG) gv = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][u][3], vr[ks], gv, 0, 0, 0);
           }
           MCA_SCHED_FENCE();
@@ -670,7 +715,7 @@ __global__ __launch_bounds__(256) void mca_bwd_dkv_kernel(McaBwdParams p, int nt
         const int r0 = 8 * i + 4 * half;
         const f32x4 dm = *(const f32x4*)(wb + (i * 64 + lane) * 16);
         const f16x4 zero4 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-        const f16x4 a_c = mine ? *(const f16x4*)(wb + 4096 + (i * 64 + lane) * 8) : zero4;
+        const f16x4 a_c = (CLS_G && mine) ? *(const f16x4*)(wb + 4096 + (i * 64 + lane) * 8) : zero4;
         const f16x4 a_r = (NEED_REG && mine) ? *(const f16x4*)(wb + 6144 + (i * 64 + lane) * 8) : zero4;
         const f32x4 il_c = *(const f32x4*)(rs + r0), il_r = *(const f32x4*)(rs + 32 + r0);
         const f32x4 dl_c = *(const f32x4*)(rs + 64 + r0), dl_r = *(const f32x4*)(rs + 96 + r0);
@@ -695,7 +740,8 @@ __global__ __launch_bounds__(256) void mca_bwd_dkv_kernel(McaBwdParams p, int nt
         auto rd = [&](int q, int fbuf) __attribute__((always_inline)) {
           const int f = (q % NT) * 2 + q / NT;      // q = m * NT + n
 #pragma unroll
-          for (int a = 0; a < (NEED_REG ? 6 : 4); ++a) fb[fbuf][a] = lds_frag(cb + (a * 2 * NT + f) * 1024, lane);
+          for (int a = 0; a < (NEED_REG ? 6 : 4); ++a)
+            if (a < 2 || a >= 4 || CLS_G) fb[fbuf][a] = lds_frag(cb + (a * 2 * NT + f) * 1024, lane);
         };
         rd(0, 0);
         MCA_SCHED_FENCE();
@@ -705,8 +751,10 @@ __global__ __launch_bounds__(256) void mca_bwd_dkv_kernel(McaBwdParams p, int nt
           if (q + 1 < 2 * NT) rd(q + 1, (q + 1) & 1);
           akc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tc[m], fb[q & 1][0], akc[n], 0, 0, 0);
           akr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tr[m], fb[q & 1][1], akr[n], 0, 0, 0);
-          avc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pp[m], fb[q & 1][2], avc[n], 0, 0, 0);
-          avc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ac[m], fb[q & 1][3], avc[n], 0, 0, 0);
+          if (CLS_G) {
+            avc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pp[m], fb[q & 1][2], avc[n], 0, 0, 0);
+            avc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ac[m], fb[q & 1][3], avc[n], 0, 0, 0);
+          }
           if (NEED_REG) {
             avr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pp[m], fb[q & 1][4], avr[n], 0, 0, 0);
             avr[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[m], fb[q & 1][5], avr[n], 0, 0, 0);
@@ -737,7 +785,7 @@ __global__ __launch_bounds__(256) void mca_bwd_dkv_kernel(McaBwdParams p, int nt
       const long o = (long)(key0 + (e & 3) + 8 * (e >> 2) + 4 * half) * p.WP + h * DP + n * 32 + col;
       okc[o] = akc[n][e];
       okr[o] = akr[n][e];
-      ovc[o] = avc[n][e];
+      if (CLS_G) ovc[o] = avc[n][e];
       if (NEED_REG) ovr[o] = avr[n][e];
     }
 }
@@ -752,7 +800,7 @@ __global__ void mca_bwd_finish_kernel(const f16* __restrict__ q_c, const f16* __
                                       int ld_dvloc, int N, int N_L, int W, int d, int DP, int need_reg, f16* dq_c, f16* dkv_c,
                                       f16* dq_r, f16* dkv_r, int nsq, long dq_stride, int nsk, long dk_stride,
                                       const float* __restrict__ dscore_part, int nds, int Npad, float* __restrict__ dscore,
-                                      const f16* __restrict__ score, float scale) {
+                                      const f16* __restrict__ score, float scale, int cls_grad) {
   int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   int n = wave >> 1, br = wave & 1;
   if (n >= N) return;
@@ -772,7 +820,7 @@ __global__ void mca_bwd_finish_kernel(const f16* __restrict__ q_c, const f16* __
   const f16* dvloc = br ? dvloc_r : dvloc_c;
   f16* dq = br ? dq_r : dq_c;
   f16* dkv = br ? dkv_r : dkv_c;
-  const bool vgrad = (br == 0) || need_reg;
+  const bool vgrad = br == 0 ? cls_grad != 0 : need_reg != 0;      // (no class-branch gradient: dvc = 0 and dv_c / dvloc_c are not read)
   for (int h = 0; h < MCA_HEADS; ++h) {
     float kx[2] = {0.f, 0.f}, qx[2] = {0.f, 0.f}, dk[2] = {0.f, 0.f}, dqq[2] = {0.f, 0.f};
     float sk = 0.f, sq = 0.f, kd = 0.f, qd = 0.f;
@@ -873,9 +921,14 @@ extern "C" int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const vo
                                      const void* dxcat_r, const void* dsoft_c, const void* dsoft_r, int ld_dsoft, const void* soft_c,
                                      const void* soft_r, int ld_soft, void* workspace, long workspace_bytes, void* dq_c, void* dkv_c,
                                      void* dq_r, void* dkv_r, float* dscore, const void* fwd_rows, long fwd_rows_bytes, void* stream) {
-  TSCD_CHECK_ARG(q_c && kv_c && q_r && kv_r && score && tiles && stats && dxcat_c && dsoft_c && soft_c && workspace && dq_c &&
-                     dkv_c && dq_r && dkv_r && dscore, "mca_backward: null pointer");
+  TSCD_CHECK_ARG(q_c && kv_c && q_r && kv_r && score && tiles && stats && soft_c && workspace && dq_c && dkv_c && dq_r && dkv_r && dscore,
+                 "mca_backward: null pointer");
   TSCD_CHECK_ARG(!need_reg || (dxcat_r && dsoft_r && soft_r), "mca_backward: reg gradients missing");
+  // dxcat_c = dsoft_c = null: no gradient reaches the class branch's outputs (agg_iou: its class output is only used detached);
+  // the passes then leave out what would only carry zeros -- same results as zero tensors, bit for bit
+  const int cls_grad = (dxcat_c || dsoft_c) ? 1 : 0;
+  TSCD_CHECK_ARG(cls_grad ? (dxcat_c && dsoft_c) : need_reg != 0,
+                 "mca_backward: class-branch gradients must be both given or (with need_reg) both null");
   TSCD_CHECK_ARG(W % MCA_HEADS == 0 && W % 8 == 0 && N_L > 0 && N >= N_L && ntiles > 0 && S > 0 && S <= 64, "mca_backward: bad sizes");
   const int d = W / MCA_HEADS, DP = (d + 31) / 32 * 32, WP = MCA_HEADS * DP;
   TSCD_CHECK_ARG(DP <= 96, "mca_backward: head dim %d not supported (max 96)", d);
@@ -931,19 +984,21 @@ extern "C" int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const vo
                      (const f16*)kv_r, N, Npad, W, d, DP, kF_c, kF_r, vnF_c, vnF_r, vrF_c, vrF_r, kT_c, kT_r, (const f16*)score, score_pad, scale);
   hipLaunchKernelGGL(mca_bwd_tiles_kernel, dim3(ntiles, 15), dim3(256), 0, st, (const McaTile*)tiles, qn_c, qn_r, vn_c, vn_r,
                      (const f16*)dxcat_c, 2 * W, (const f16*)dxcat_r, (const f16*)dsoft_c, ld_dsoft, (const f16*)dsoft_r,
-                     (const f16*)soft_c, (const f16*)soft_r, ld_soft, N_L, W, d, DP, need_reg, p, gdot);
+                     (const f16*)soft_c, (const f16*)soft_r, ld_soft, N_L, W, d, DP, need_reg, cls_grad, p, gdot);
   TSCD_CHECK_LAUNCH("mca_backward layouts");
   dim3 block(256);
-#define MCAS(DPV, REG)                                                                                                   \
-  do {                                                                                                                   \
-    hipLaunchKernelGGL((mca_bwd_delta_kernel<DPV, REG>), dim3(xcd_grid(S, ntiles)), block, 0, st, p, ntiles);            \
-    hipLaunchKernelGGL(mca_bwd_rowstat_kernel, dim3(ntiles), block, 0, st, p.tiles, stats, delta_part, S, N_L, rowstat); \
-    hipLaunchKernelGGL((mca_bwd_dq_kernel<DPV, REG>), dim3(xcd_grid((ntiles + 3) / 4 * pl.S2, MCA_HEADS)), block, 0, st, p, ntiles);  \
-    hipLaunchKernelGGL((mca_bwd_dkv_kernel<DPV, REG>), dim3(xcd_grid((pl.nkb + 3) / 4 * pl.S3, MCA_HEADS)), block, 0, st, p, ntiles); \
+#define MCAS(DPV, REG, CLS)                                                                                                   \
+  do {                                                                                                                        \
+    hipLaunchKernelGGL((mca_bwd_delta_kernel<DPV, REG, CLS>), dim3(xcd_grid(S, ntiles)), block, 0, st, p, ntiles);            \
+    hipLaunchKernelGGL(mca_bwd_rowstat_kernel, dim3(ntiles), block, 0, st, p.tiles, stats, delta_part, S, N_L, rowstat);      \
+    hipLaunchKernelGGL((mca_bwd_dq_kernel<DPV, REG, CLS>), dim3(xcd_grid((ntiles + 3) / 4 * pl.S2, MCA_HEADS)), block, 0, st, p, ntiles);  \
+    hipLaunchKernelGGL((mca_bwd_dkv_kernel<DPV, REG, CLS>), dim3(xcd_grid((pl.nkb + 3) / 4 * pl.S3, MCA_HEADS)), block, 0, st, p, ntiles); \
   } while (0)
-#define MCAB(DPV)                                          \
-  do {                                                     \
-    if (need_reg) MCAS(DPV, true); else MCAS(DPV, false);  \
+#define MCAB(DPV)                                              \
+  do {                                                         \
+    if (!need_reg) MCAS(DPV, false, true);                     \
+    else if (cls_grad) MCAS(DPV, true, true);                  \
+    else MCAS(DPV, true, false);                               \
   } while (0)
   if (DP == 32) MCAB(32);
   else if (DP == 64) MCAB(64);
@@ -955,9 +1010,10 @@ extern "C" int tscd_mca_backward_fws(const void* q_c, const void* kv_c, const vo
     long waves = 2L * N;
     hipLaunchKernelGGL(mca_bwd_finish_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st, (const f16*)q_c,
                        (const f16*)kv_c, (const f16*)q_r, (const f16*)kv_r, dqn_c, dqn_r, dkn_c, dkn_r, dv_c, dv_r,
-                       (const f16*)dxcat_c + W, need_reg ? (const f16*)dxcat_r + W : (const f16*)dxcat_c + W, 2 * W, N, N_L, W, d, DP,
+                       cls_grad ? (const f16*)dxcat_c + W : (const f16*)dxcat_r + W,
+                       need_reg ? (const f16*)dxcat_r + W : (const f16*)dxcat_c + W, 2 * W, N, N_L, W, d, DP,
                        need_reg, (f16*)dq_c, (f16*)dkv_c, (f16*)dq_r, (f16*)dkv_r, pl.S2, dq_stride, pl.S3, dk_stride, dscore_part,
-                       pl.S3 * MCA_HEADS, Npad, dscore, (const f16*)score, scale);
+                       pl.S3 * MCA_HEADS, Npad, dscore, (const f16*)score, scale, cls_grad);
     TSCD_CHECK_LAUNCH("mca_backward finish");
   }
   return TSCD_OK;

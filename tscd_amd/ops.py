@@ -922,10 +922,14 @@ def mca_attention(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale
 def mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale, sim_thresh, conf_thresh, stats, dxcat_c, dxcat_r,
                  dcat3_c, dcat3_r, cat3_c, cat3_r, fwd_ws=None):
     """Gradients of the fused attention w.r.t. the projected rows: -> (dq_c [N_L,W], dkv_c [N,2W], dq_r, dkv_r, dscore [N]).
-    dxcat_* [N_L,2W] contiguous fp16; dcat3_* / cat3_* [N_L,3W] (only their first W columns are read)."""
+    dxcat_* [N_L,2W] contiguous fp16; dcat3_* / cat3_* [N_L,3W] (only their first W columns are read).  ``dxcat_c = dcat3_c = None``
+    (with need_reg): no gradient reaches the class branch's outputs (agg_iou, whose class output is only used detached); the passes leave
+    out what would only carry zeros -- the results are those of zero tensors, bit for bit."""
     dev = q_c.device
     nt = tiles.shape[0]
     S = mca_splits(nt)
+    if (dxcat_c is None) != (dcat3_c is None) or (dxcat_c is None and not need_reg):
+        raise ValueError("mca_backward: the class branch's gradients are both given or, with need_reg, both None")
     ws_bytes = lib.tscd_mca_backward_workspace_bytes(N, N_L, W, S, nt)
     ws = temp((ws_bytes,), dtype=torch.uint8, device=dev)
     dq_c = temp((N_L, W), dtype=torch.float16, device=dev)
@@ -933,11 +937,11 @@ def mca_backward(q_c, kv_c, q_r, kv_r, score, tiles, N, N_L, W, need_reg, scale,
     dkv_c = temp((N, 2 * W), dtype=torch.float16, device=dev)
     dkv_r = temp((N, 2 * W), dtype=torch.float16, device=dev)
     dscore = temp((N,), dtype=torch.float32, device=dev)
-    for t in (dxcat_c, dcat3_c, cat3_c) + ((dxcat_r, dcat3_r, cat3_r) if need_reg else ()):
+    for t in ((dxcat_c, dcat3_c) if dxcat_c is not None else ()) + (cat3_c,) + ((dxcat_r, dcat3_r, cat3_r) if need_reg else ()):
         assert t.is_contiguous() and t.dtype == torch.float16
     call("tscd_mca_backward_fws", q_c.data_ptr(), kv_c.data_ptr(), q_r.data_ptr(), kv_r.data_ptr(), score.data_ptr(), tiles.data_ptr(), nt,
-         N, N_L, W, S, int(need_reg), float(scale), float(sim_thresh), float(conf_thresh), stats.data_ptr(), dxcat_c.data_ptr(),
-         _ptr(dxcat_r), dcat3_c.data_ptr(), _ptr(dcat3_r), 3 * W, cat3_c.data_ptr(), _ptr(cat3_r), 3 * W, ws.data_ptr(), ws_bytes,
+         N, N_L, W, S, int(need_reg), float(scale), float(sim_thresh), float(conf_thresh), stats.data_ptr(), _ptr(dxcat_c),
+         _ptr(dxcat_r), _ptr(dcat3_c), _ptr(dcat3_r), 3 * W, cat3_c.data_ptr(), _ptr(cat3_r), 3 * W, ws.data_ptr(), ws_bytes,
          dq_c.data_ptr(), dkv_c.data_ptr(), dq_r.data_ptr(), dkv_r.data_ptr(), dscore.data_ptr(), _ptr(fwd_ws),
          0 if fwd_ws is None else fwd_ws.numel(), _stream())
     return dq_c, dkv_c, dq_r, dkv_r, dscore

@@ -88,6 +88,8 @@ class _MCAFunction(torch.autograd.Function):
         def head(g, cat3, xcat, w_o, w_l, b_o, b_l):
             """through linear(3W->4W) and mca.linear(2W->2W): -> d cat3 [nl,3W], d xcat [nl,2W], dW_o, db_o, dW_l, db_l"""
             if g is None:      # this output was not used downstream: no gradient for its two linears (SURVEY F5)
+                if need_reg and g_obj is not None and cat3 is cat3_c:
+                    return None, None, None, None, None, None      # ... and none for its attention outputs: mca_backward leaves it out
                 return z16(nl, 3 * W), z16(nl, 2 * W), None, None, None, None
             g = g.to(torch.float16).contiguous()
             d_cat3, dw_o, db_o = ops.linear_bwd(cat3, g, w_o, True, True, True, grad_params=[w_o, b_o])
