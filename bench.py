@@ -288,7 +288,8 @@ def cpu_baseline(args, state_dict, clip):
     if div == 1 and train:      # whole clip, same weights and inputs as the GPU's first step: keep the losses as a full-size parity signal
         losses = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in out.items() if k in ("total_loss", "iou_loss", "conf_loss", "cls_loss", "num_fg",
                                                                 "loss_matched_cls", "loss_matched_obj", "loss_matched_iou")}
-    return {"value": 1.0 / dt, "unit": "clips/s", "cores": ncores, "kind": "port", "losses_step0": losses,
+    return {"value": 1.0 / dt, "unit": "clips/s", "cores": ncores, "host_cores_available": len(os.sched_getaffinity(0)),
+            "kind": "port", "losses_step0": losses,
             "sample": f"{nf} of {args.frames} frames ({nl} local + {nf - nl} global) @{args.size}^2, TSCD d{args.depth}/w{args.width}, "
                       f"{'fwd+bwd' if train else 'eval fwd'}, {args.props} props/frame, measured {dt / div:.1f} s x{div} = {dt:.1f} s per clip; "
                       f"oracle/tscd_oracle.py, torch {torch.__version__} fp32, {ncores} threads"}
