@@ -5,7 +5,7 @@ import os
 import torch  # noqa: F401  -- load PyTorch-ROCm's bundled libamdhip64.so.7 FIRST so this library binds to the same HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtscd_hip.so")
+LIB_PATH = os.environ.get("TSCD_HIP_LIB") or os.path.join(_HERE, "lib", "libtscd_hip.so")      # (TSCD_HIP_LIB: A/B builds of the timing tools)
 
 P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 
