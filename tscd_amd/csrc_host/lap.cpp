@@ -253,6 +253,20 @@ static inline void set_lane(int32_t* arr, int64_t j, int32_t val) {     // arr 6
   int32_t* blk = arr + (j & ~(int64_t)15);
   _mm512_store_si512(blk, _mm512_mask_mov_epi32(_mm512_load_si512(blk), (__mmask16)(1u << (j & 15)), _mm512_set1_epi32(val)));
 }
+// positions in `remaining` order as 16-bit lanes (nc < 32000): 32 columns per op in the tie rule, ONE array.  pos16[j] = position of
+// column j, bit 15 set while the column has no row (padding: 0x7fff).  Smallest position among the ties = min of (pos16 & 0x7fff);
+// LARGEST position among the ties without a row = 0x7fff - min of (pos16 ^ 0xffff) (>= 0x8000 for a column that has a row).
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static inline void set_lane16(uint16_t* arr, int64_t j, uint16_t val) {     // arr 64-byte aligned
+  uint16_t* blk = arr + (j & ~(int64_t)31);
+  _mm512_store_si512(blk, _mm512_mask_mov_epi16(_mm512_load_si512(blk), (__mmask32)(1u << (j & 31)), _mm512_set1_epi16((short)val)));
+}
+__attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
+static inline uint32_t hmin_epu16(__m512i v) {
+  const __m256i a = _mm256_min_epu16(_mm512_castsi512_si256(v), _mm512_extracti64x4_epi64(v, 1));
+  const __m128i b = _mm_min_epu16(_mm256_castsi256_si128(a), _mm256_extracti128_si256(a, 1));
+  return (uint32_t)_mm_extract_epi16(_mm_minpos_epu16(b), 0) & 0xffffu;
+}
 template <typename CT>
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
 static inline __m512i load16(const CT* p) {
@@ -287,16 +301,18 @@ static int32_t relax_row_q(const CT* crow, const int32_t* veff, int32_t* spc, in
 // CAFM at random initialisation 93 % of the passes stay on their plateau (8 tied columns on average); the others (no column at
 // `level`: first_pos stays INT32_MAX) take the minimum and the tie rule in two further sweeps, as every pass did before (one relaxing
 // sweep, a reduction, one tie sweep that waited for it, two reductions: 55 ns per pass on the box's EPYC 9575F, of which the tie sweep
-// and its reductions were 45 %).
+// and its reductions were 45 %).  Second half of round 4: the positions as 16-bit lanes in ONE array (32 columns per masked min, both
+// reductions through phminposuw; four loads and two reductions per 32 columns less) 50.7 -> 48.0 ns, and the next pass's cost row
+// prefetched as soon as its index is known -> 45.5 ns (same-box A/B against the previous file, results scipy-checked).
 template <typename CT>
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
-static inline void relax_row_plateau(const CT* crow, const int32_t* veff, int32_t* spc, int16_t* path, const int32_t* pos,
-                                     const int32_t* posfree, int64_t ncp, int32_t base, int16_t id, int32_t level, int32_t& first_pos,
+static inline void relax_row_plateau(const CT* crow, const int32_t* veff, int32_t* spc, int16_t* path, const uint16_t* pos16,
+                                     int64_t ncp, int32_t base, int16_t id, int32_t level, int32_t& first_pos,
                                      int32_t& last_free_pos) {
   const __m512i vbase = _mm512_set1_epi32(base), vlevel = _mm512_set1_epi32(level);
   const __m512i vid = _mm512_set1_epi16(id);
-  __m512i pmin0 = _mm512_set1_epi32(std::numeric_limits<int32_t>::max()), pmin1 = pmin0;
-  __m512i pmax0 = _mm512_set1_epi32(-1), pmax1 = pmax0;
+  const __m512i v7fff = _mm512_set1_epi16(0x7fff), vffff = _mm512_set1_epi16((short)0xffff);
+  __m512i pmin = vffff, imin = vffff;
   for (int64_t j = 0; j < ncp; j += 32) {
     __m512i r0 = _mm512_sub_epi32(_mm512_add_epi32(load16<CT>(crow + j), vbase), _mm512_loadu_si512(veff + j));
     __m512i r1 = _mm512_sub_epi32(_mm512_add_epi32(load16<CT>(crow + j + 16), vbase), _mm512_loadu_si512(veff + j + 16));
@@ -308,13 +324,14 @@ static inline void relax_row_plateau(const CT* crow, const int32_t* veff, int32_
     _mm512_storeu_si512(spc + j + 16, s1);
     _mm512_mask_storeu_epi16(path + j, (__mmask32)m0 | ((__mmask32)m1 << 16), vid);
     const __mmask16 e0 = _mm512_cmpeq_epi32_mask(s0, vlevel), e1 = _mm512_cmpeq_epi32_mask(s1, vlevel);
-    pmin0 = _mm512_mask_min_epi32(pmin0, e0, pmin0, _mm512_load_si512(pos + j));
-    pmin1 = _mm512_mask_min_epi32(pmin1, e1, pmin1, _mm512_load_si512(pos + j + 16));
-    pmax0 = _mm512_mask_max_epi32(pmax0, e0, pmax0, _mm512_load_si512(posfree + j));
-    pmax1 = _mm512_mask_max_epi32(pmax1, e1, pmax1, _mm512_load_si512(posfree + j + 16));
+    const __mmask32 e = (__mmask32)e0 | ((__mmask32)e1 << 16);
+    const __m512i pf = _mm512_load_si512(pos16 + j);
+    pmin = _mm512_mask_min_epu16(pmin, e, pmin, _mm512_and_si512(pf, v7fff));
+    imin = _mm512_mask_min_epu16(imin, e, imin, _mm512_xor_si512(pf, vffff));      // free: 0x7fff - pos; with a row: >= 0x8000
   }
-  first_pos = _mm512_reduce_min_epi32(_mm512_min_epi32(pmin0, pmin1));
-  last_free_pos = _mm512_reduce_max_epi32(_mm512_max_epi32(pmax0, pmax1));
+  const uint32_t fp = hmin_epu16(pmin), fi = hmin_epu16(imin);
+  first_pos = fp >= 0x7fffu ? std::numeric_limits<int32_t>::max() : (int32_t)fp;
+  last_free_pos = fi >= 0x8000u ? -1 : (int32_t)(0x7fffu - fi);
 }
 template <typename CT>
 __attribute__((target("avx512f,avx512bw,avx512vl,f16c")))
@@ -444,23 +461,24 @@ static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, 
   }
   struct { CT* p; CT* data() { return p; } } c32{c_buf};
   convert_q<CT>(cost, c32.data(), nr * ncp, E);
-  AlignedBuf<int32_t> veff(ncp, QDEADV), spc(ncp), pos(ncp, -1), posfree(ncp, -1);
+  AlignedBuf<int32_t> veff(ncp, QDEADV), spc(ncp);
+  AlignedBuf<uint16_t> pos(ncp, (uint16_t)0x7fff);      // pos16 of the tie rule (see set_lane16)
   AlignedBuf<int16_t> path(ncp, -1);
   std::vector<int32_t> u(nr, 0), v(ncp, 0), spcsave(ncp, 0), col4row(nr, -1), row4col(ncp, -1);
-  std::vector<int32_t> remaining(nc), remaining0(nc), pos0(ncp, -1), posfree0(ncp, -1);
+  std::vector<int32_t> remaining(nc), remaining0(nc);
+  std::vector<uint16_t> pos0(ncp, (uint16_t)0x7fff);
   std::vector<int32_t> sr_list, dead_list;
   sr_list.reserve(nr); dead_list.reserve(nc);
   for (int64_t it = 0; it < nc; ++it) {
     remaining0[it] = (int32_t)(nc - it - 1);       // reversed start: a constant matrix solves to the identity (scipy #11602)
-    pos0[nc - it - 1] = posfree0[nc - it - 1] = (int32_t)it;
+    pos0[nc - it - 1] = (uint16_t)(it | 0x8000);
     veff[it] = 0;
   }
   for (int64_t curRow = 0; curRow < nr; ++curRow) {
     int32_t minVal = 0;
     int64_t i = curRow, num_remaining = nc, sink = -1;
     std::memcpy(remaining.data(), remaining0.data(), sizeof(int32_t) * nc);
-    std::memcpy(pos.data(), pos0.data(), sizeof(int32_t) * ncp);
-    std::memcpy(posfree.data(), posfree0.data(), sizeof(int32_t) * ncp);   // -1 where the column already has a row
+    std::memcpy(pos.data(), pos0.data(), sizeof(uint16_t) * ncp);          // bit 15 cleared where the column already has a row
     std::fill(spc.begin(), spc.end(), QINF);
     sr_list.clear();
     dead_list.clear();
@@ -472,7 +490,7 @@ static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, 
       int32_t lowest, first_pos32 = std::numeric_limits<int32_t>::max(), last_free32 = -1;
       const bool on_plateau = sr_list.size() > 1;      // the first pass of an augmentation starts from path length 0: no plateau yet
       if (on_plateau) {
-        relax_row_plateau<CT>(c32.data() + i * ncp, veff.data(), spc.data(), path.data(), pos.data(), posfree.data(), ncp, minVal - u[i],
+        relax_row_plateau<CT>(c32.data() + i * ncp, veff.data(), spc.data(), path.data(), pos.data(), ncp, minVal - u[i],
                               (int16_t)i, minVal, first_pos32, last_free32);
         lowest = minVal;
       }
@@ -483,24 +501,29 @@ static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, 
         if (lowest == QINF) return 2;
         if (lowest >= QLIM || lowest <= -QLIM) return 3;
         const __m512i vlow = _mm512_set1_epi32(lowest);
-        __m512i pmin = _mm512_set1_epi32(std::numeric_limits<int32_t>::max()), pmax = _mm512_set1_epi32(-1);
-        __m512i pmin1 = pmin, pmax1 = pmax;
-        for (int64_t j = 0; j < ncp; j += 32) {      // two independent accumulator chains
-          __mmask16 m0 = _mm512_cmpeq_epi32_mask(_mm512_load_si512(spc.data() + j), vlow);
-          __mmask16 m1 = _mm512_cmpeq_epi32_mask(_mm512_load_si512(spc.data() + j + 16), vlow);
-          pmin = _mm512_mask_min_epi32(pmin, m0, pmin, _mm512_load_si512(pos.data() + j));
-          pmin1 = _mm512_mask_min_epi32(pmin1, m1, pmin1, _mm512_load_si512(pos.data() + j + 16));
-          pmax = _mm512_mask_max_epi32(pmax, m0, pmax, _mm512_load_si512(posfree.data() + j));
-          pmax1 = _mm512_mask_max_epi32(pmax1, m1, pmax1, _mm512_load_si512(posfree.data() + j + 16));
+        const __m512i v7fff = _mm512_set1_epi16(0x7fff), vffff = _mm512_set1_epi16((short)0xffff);
+        __m512i pmin = vffff, imin = vffff;
+        for (int64_t j = 0; j < ncp; j += 32) {
+          const __mmask16 m0 = _mm512_cmpeq_epi32_mask(_mm512_load_si512(spc.data() + j), vlow);
+          const __mmask16 m1 = _mm512_cmpeq_epi32_mask(_mm512_load_si512(spc.data() + j + 16), vlow);
+          const __mmask32 m = (__mmask32)m0 | ((__mmask32)m1 << 16);
+          const __m512i pf = _mm512_load_si512(pos.data() + j);
+          pmin = _mm512_mask_min_epu16(pmin, m, pmin, _mm512_and_si512(pf, v7fff));
+          imin = _mm512_mask_min_epu16(imin, m, imin, _mm512_xor_si512(pf, vffff));
         }
-        first_pos32 = _mm512_reduce_min_epi32(_mm512_min_epi32(pmin, pmin1));
-        last_free32 = _mm512_reduce_max_epi32(_mm512_max_epi32(pmax, pmax1));
+        const uint32_t fp = hmin_epu16(pmin), fi = hmin_epu16(imin);
+        first_pos32 = fp >= 0x7fffu ? std::numeric_limits<int32_t>::max() : (int32_t)fp;
+        last_free32 = fi >= 0x8000u ? -1 : (int32_t)(0x7fffu - fi);
       }
       const int64_t first_pos = first_pos32, last_free_pos = last_free32;
       const int64_t index = (last_free_pos > first_pos) ? last_free_pos : first_pos;
       minVal = lowest;
       const int64_t j = remaining[index];
       if (row4col[j] == -1) sink = j; else i = row4col[j];
+      if (sink == -1) {      // the next pass's cost row (L2-resident): every line on its way before the bookkeeping below
+        const char* nrow = (const char*)(c32.data() + i * ncp);
+        for (int64_t b = 0; b < (int64_t)(ncp * sizeof(CT)); b += 64) _mm_prefetch(nrow + b, _MM_HINT_T0);
+      }
       spcsave[j] = spc[j];
       // single-lane updates of arrays the vector passes re-read right away: write the whole 64-byte block (a 4-byte store
       // followed by an overlapping 64-byte load cannot be store-forwarded and stalls until the store retires)
@@ -510,8 +533,7 @@ static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, 
       --num_remaining;
       const int32_t moved = remaining[num_remaining];
       remaining[index] = moved;
-      set_lane(pos.data(), moved, (int32_t)index);
-      set_lane(posfree.data(), moved, row4col[moved] == -1 ? (int32_t)index : -1);
+      set_lane16(pos.data(), moved, (uint16_t)(index | (row4col[moved] == -1 ? 0x8000 : 0)));
     }
     bool over = false;
     u[curRow] += minVal;
@@ -531,7 +553,7 @@ static int solve_q_t(int64_t nr, int64_t nc, int64_t ncp, const uint16_t* cost, 
     while (true) {
       const int64_t r = path[j];
       row4col[j] = (int32_t)r;
-      posfree0[j] = -1;
+      pos0[j] &= (uint16_t)0x7fff;
       const int32_t t = col4row[r];
       col4row[r] = (int32_t)j;
       j = t;
