@@ -282,3 +282,22 @@ def test_lap_fixed_point_on_tie_heavy_matrices_matches_scipy():
         r, cc = lap_f16(m)
         r0, c0 = linear_sum_assignment(m.view(np.float16).astype(np.float64))
         assert np.array_equal(r, r0) and np.array_equal(cc, c0), (t, kind, nr, nc)
+
+
+@pytest.mark.parametrize("nr,nc", [(60, 2600), (2600, 60), (300, 700), (1100, 1100)])
+def test_lap_fixed_point_wide_matrices_with_ties_match_scipy(nr, nc):
+    """The tie rule keeps the columns' positions as 16-bit lanes (lap.cpp: pos16, bit 15 = "no row yet"): matrices whose positions need
+    more than 8 and 11 bits, rectangular both ways (the transposed orientation included), with exact ties -- scipy's rows and columns."""
+    from tscd_amd._host import lap_f16
+    rng = np.random.default_rng(nr * 7 + nc)
+    for kind in range(3):
+        if kind == 0:
+            c = rng.integers(0, 3, (nr, nc)).astype(np.float64) * 0.25          # massive ties: free columns at high positions decide
+        elif kind == 1:
+            c = np.round(rng.random((nr, nc)) * 16) / 16
+        else:
+            c = np.full((nr, nc), 0.75)
+        m = np.ascontiguousarray(c.astype(np.float16).view(np.uint16))
+        r, cc = lap_f16(m)
+        r0, c0 = linear_sum_assignment(m.view(np.float16).astype(np.float64))
+        assert np.array_equal(r, r0) and np.array_equal(cc, c0), (kind, nr, nc)
