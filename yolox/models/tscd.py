@@ -107,7 +107,7 @@ class TSCD(nn.Module):
         front = hit[1]
         # frozen as the exps freeze them (ovis_tscd_large.py:116-117,141-149): the backbone, and the box prediction convs (whose output
         # is part of the prefix); stems and base towers run without autograd whatever their flags say, exactly as TSCDHead always has
-        if any(p.requires_grad for p in graphs.parameters_of(self.backbone)) or any(p.requires_grad for p in self.head.reg_preds.parameters()):
+        if any(p.requires_grad for p in graphs.parameters_of(self.backbone)) or any(p.requires_grad for p in graphs.parameters_of(self.head.reg_preds)):
             return None
         front.training = self.training          # the graph key carries the mode; the children keep their own flags
         return front

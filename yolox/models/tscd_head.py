@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from tscd_amd import functional as TF
-from tscd_amd import ops
+from tscd_amd import graphs, ops
 from tscd_amd.autograd import eager_branch
 
 from . import tower_fusion as TW
@@ -267,7 +267,7 @@ class TSCDHead(nn.Module):
             x = pre.levels[k][0]
             t0, t1 = self.cls_convs2[k], self.reg_convs2[k]
             fus = FUSE_TOWERS and not x.requires_grad and TW.fusable([t0[0], t1[0], t0[1], t1[1]])
-            if fus and grad and TW.batch_stats(t0[0]) and all(p.requires_grad for p in list(t0.parameters()) + list(t1.parameters())):
+            if fus and grad and TW.batch_stats(t0[0]) and all(p.requires_grad for p in graphs.parameters_of(t0) + graphs.parameters_of(t1)):
                 cls_maps[k], reg_maps[k] = TW.tower_pair_train(x, t0, t1)
             elif fus and not grad:                   # (towers_nograd follows the modules' own BatchNorm mode)
                 b2 = TW.towers_nograd(x, [t0[0], t1[0]], [t0[1], t1[1]])
@@ -441,7 +441,7 @@ class TSCDHead(nn.Module):
                 if seed is None:
                     seed, track = _eager_seed(dev), True
                 loss_r_cls, features_cls_matched, cls_preds = eager_branch(
-                    branch, [f_cls, f_reg, cls_scores], list(self.agg.parameters()) + list(self.cls_pred.parameters()), seed, track)
+                    branch, [f_cls, f_reg, cls_scores], list(graphs.parameters_of(self.agg) + graphs.parameters_of(self.cls_pred)), seed, track)
             else:
                 loss_r_cls = class_loss(cls_preds)
         if hook is not None:          # queued behind the window's own work: the next clip's frozen backbone pass (tscd.py)
